@@ -1,0 +1,156 @@
+/*
+ * newsreclib_amd.h -- C ABI of the MI355X (gfx950) NRMS hot path.
+ *
+ * This is the drop-in boundary under the reference's operator API (plug point 3):
+ * the Python modules `news_encoder` / `user_encoder` / `click_predictor` of
+ * `newsreclib_amd.nrms_module.NRMSModule` call these entry points through ctypes
+ * (newsreclib_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - C linkage, plain pointers and sizes; no C++ or torch types cross the boundary.
+ *   - every pointer except NrlBlockParams/NrlBlockGrads structs themselves is a DEVICE pointer on
+ *     the current device; the caller (PyTorch's caching allocator) owns every buffer incl. the
+ *     workspace; the library never allocates device memory and never synchronises.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it.
+ *   - return value 0 = success, negative = error (NRL_E_*); nrl_last_error() returns a
+ *     thread-local message.  Nothing throws.
+ *   - all floating point is IEEE fp32 ("dtype": "f32"); token ids / offsets are int64.
+ *   - reference citations are relative to andreeaiana/newsreclib.
+ */
+#ifndef NEWSRECLIB_AMD_H
+#define NEWSRECLIB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRL_ABI_VERSION 1
+
+#define NRL_OK 0
+#define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
+#define NRL_E_WORKSPACE (-2) /* workspace too small */
+#define NRL_E_HIP (-3)       /* a HIP runtime call failed */
+
+/* One "multi-head self-attention + additive attention" block.  Field <-> reference state_dict key
+ * (prefix `news_encoder.text_encoders.title.` or `user_encoder.`):
+ *   in_proj_weight  multihead_attention.in_proj_weight   (3D, D) rows [Wq; Wk; Wv]
+ *   in_proj_bias    multihead_attention.in_proj_bias     (3D)
+ *   out_proj_weight multihead_attention.out_proj.weight  (D, D)
+ *   out_proj_bias   multihead_attention.out_proj.bias    (D)
+ *   att_weight      additive_attention.linear.weight     (Q, D)
+ *   att_bias        additive_attention.linear.bias       (Q)
+ *   att_query       additive_attention.query             (Q)
+ * PyTorch Linear layout (out, in) row-major, used in place (no re-layout, no copies).
+ * Replaces: nn.MultiheadAttention + AdditiveAttention as wired in text.py:199-220 (MHSAAddAtt)
+ * and user/nrms.py:23-30 (UserEncoder). */
+typedef struct NrlBlockParams {
+  const float* in_proj_weight;
+  const float* in_proj_bias;
+  const float* out_proj_weight;
+  const float* out_proj_bias;
+  const float* att_weight;
+  const float* att_bias;
+  const float* att_query;
+  int32_t embed_dim;  /* D, multiple of 4 */
+  int32_t num_heads;  /* D / num_heads in {16, 20, 32, 48, 64} */
+  int32_t query_dim;  /* Q, multiple of 4 */
+  int32_t reserved;
+} NrlBlockParams;
+
+/* Gradient accumulators, same shapes as NrlBlockParams; kernels ADD into them (callers zero
+ * them, or pass the persistent .grad / flat DP gradient buffer to accumulate in place). */
+typedef struct NrlBlockGrads {
+  float* in_proj_weight;
+  float* in_proj_bias;
+  float* out_proj_weight;
+  float* out_proj_bias;
+  float* att_weight;
+  float* att_bias;
+  float* att_query;
+} NrlBlockGrads;
+
+int nrl_abi_version(void);
+const char* nrl_last_error(void);
+
+/* ---- dropout keep-mask specification (normative statement: oracle/nrms_oracle.py) ----------
+ * keep(i) = lowbias32(i * 0x9E3779B1 + key) >= floor(p * 2^32), i = row * D + col (32-bit).
+ * Replaces nn.Dropout at text.py:220,225,230 (torch's RNG stream is not reproducible on device). */
+uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream);
+int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, uint32_t stream,
+                     void* stream_handle);
+
+/* ---- news encoder: MHSAAddAtt.forward, text.py:222-236 (behind NewsEncoder.forward,
+ * news.py:134-160) ------------------------------------------------------------------------------
+ * ids (N, L) int64 -> out (N, D).  Embedding gather (bit-exact; id 0 is an ordinary row,
+ * text.py:215-217) fused into the in-projection GEMM's A-tile loader; dropout stream `stream0`
+ * after the gather and `stream0 + 1` after the attention out-projection when p_drop > 0.
+ * `save_for_backward` != 0 keeps activations in `ws` for nrl_news_encoder_bwd. */
+size_t nrl_news_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t embed_dim,
+                                        int32_t num_heads, int32_t query_dim);
+int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_t vocab,
+                         const int64_t* ids, int64_t n_news, int32_t seq_len, double p_drop,
+                         uint64_t seed, uint32_t stream0, int32_t save_for_backward, float* out,
+                         void* ws, size_t ws_bytes, void* stream);
+/* Backward of the above (autograd of text.py:222-236 incl. embedding_dense_backward with
+ * padding_idx=0: rows of id 0 receive no gradient).  d_out (N, D).  Adds into `g` and into
+ * d_emb_table (vocab, D).  `ws` must be the workspace the forward filled. */
+int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
+                         int64_t vocab, const int64_t* ids, int64_t n_news, int32_t seq_len,
+                         double p_drop, uint64_t seed, uint32_t stream0, const float* d_out,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- user encoder: nrms UserEncoder.forward, user/nrms.py:32-41 --------------------------------
+ * hist (B, H, D) -> out (B, D).  Reproduces the reference's seq-first nn.MultiheadAttention call:
+ * attention runs across the B users for each history slot (SURVEY.md headline fact 3). */
+size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t embed_dim,
+                                        int32_t num_heads, int32_t query_dim);
+int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t batch,
+                         int64_t hist_len, int32_t save_for_backward, float* out, void* ws,
+                         size_t ws_bytes, void* stream);
+int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
+                         int64_t batch, int64_t hist_len, const float* d_out, float* d_hist,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- to_dense_batch (torch_geometric 2.3.0; call sites nrms_module.py:233,237,277-284) ---------
+ * x (N, D) + offsets (B+1) int64 (prefix sums of the sorted assignment vector) ->
+ * dense (B, max_len, D), zero-filled past each group's length.  _bwd is the adjoint gather. */
+int nrl_to_dense_batch_fwd(const float* x, const int64_t* offsets, int64_t batch, int64_t max_len,
+                           int32_t dim, float* dense, void* stream);
+int nrl_to_dense_batch_bwd(const float* d_dense, const int64_t* offsets, int64_t batch,
+                           int64_t max_len, int32_t dim, int64_t n_rows, float* d_x, void* stream);
+
+/* ---- click predictor: DotProduct.forward, click_predictor.py:9-11 as called at
+ * nrms_module.py:251-253: user (B, D), cand (B, C, D) -> scores (B, C) -------------------------- */
+int nrl_dot_scores_fwd(const float* user, const float* cand, int64_t batch, int64_t n_cand,
+                       int32_t dim, float* scores, void* stream);
+int nrl_dot_scores_bwd(const float* d_scores, const float* user, const float* cand, int64_t batch,
+                       int64_t n_cand, int32_t dim, float* d_user, float* d_cand, void* stream);
+
+/* ---- loss: CrossEntropyLoss()(scores, y_true) with float targets, nrms_module.py:287-288 --------
+ * loss = mean_b(-sum_c y * log_softmax(scores)_c); also writes d_scores = grad_scale * dloss/dscores
+ * (pass grad_scale = 1 for plain backward, 1/world_size to pre-average for data parallel). */
+int nrl_ce_loss_fwd_bwd(const float* scores, const float* y_true, int64_t batch, int64_t n_cand,
+                        float grad_scale, float* loss, float* d_scores, void* stream);
+
+/* ---- optimizer: torch.optim.Adam(lr) dense step over a flat buffer, configs/model/nrms.yaml:49-52,
+ * abstract_recommender.py:96.  `step` is the 1-based step count.  grad_scale multiplies g first
+ * (1/world_size after a sum all-reduce).  zero_grad != 0 clears g after use. */
+int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  double lr, double beta1, double beta2, double eps, int64_t step, float grad_scale,
+                  int32_t zero_grad, void* stream);
+
+/* ---- building blocks exported for unit parity tests and reuse ------------------------------- */
+/* nn.Embedding lookup alone (bit-exact), text.py:224. */
+int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,
+                         float* out, void* stream);
+/* C(M,N) = A(M,K) * W(N,K)^T + bias  (nn.Linear), exact-fp32 MFMA. */
+int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n,
+                   int32_t k, float* c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEWSRECLIB_AMD_H */

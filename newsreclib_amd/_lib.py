@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI declared in include/newsreclib_amd.h.
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a
+``RuntimeError`` is raised (a silent PyTorch/eager path would void every parity claim).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
+ABI_VERSION = 1
+
+
+class NrlBlockParams(ctypes.Structure):
+    _fields_ = [
+        ("in_proj_weight", c_void_p), ("in_proj_bias", c_void_p),
+        ("out_proj_weight", c_void_p), ("out_proj_bias", c_void_p),
+        ("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p),
+        ("embed_dim", c_int32), ("num_heads", c_int32), ("query_dim", c_int32), ("reserved", c_int32),
+    ]
+
+
+class NrlBlockGrads(ctypes.Structure):
+    _fields_ = [
+        ("in_proj_weight", c_void_p), ("in_proj_bias", c_void_p),
+        ("out_proj_weight", c_void_p), ("out_proj_bias", c_void_p),
+        ("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/newsreclib_amd.h one to one
+SIGNATURES = {
+    "nrl_abi_version": (c_int32, []),
+    "nrl_last_error": (c_char_p, []),
+    "nrl_dropout_key": (c_uint32, [c_uint64, c_uint32]),
+    "nrl_dropout_mask": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_uint32, c_void_p]),
+    "nrl_news_encoder_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
+    "nrl_news_encoder_fwd": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                       c_double, c_uint64, c_uint32, c_int32, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
+    "nrl_news_encoder_bwd": (c_int32, [POINTER(NrlBlockParams), POINTER(NrlBlockGrads), c_void_p, c_int64,
+                                       c_void_p, c_int64, c_int32, c_double, c_uint64, c_uint32, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
+    "nrl_user_encoder_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32, c_int32]),
+    "nrl_user_encoder_fwd": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_int64, c_int32, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
+    "nrl_user_encoder_bwd": (c_int32, [POINTER(NrlBlockParams), POINTER(NrlBlockGrads), c_void_p, c_int64,
+                                       c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nrl_to_dense_batch_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
+    "nrl_to_dense_batch_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_void_p,
+                                         c_void_p]),
+    "nrl_dot_scores_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
+    "nrl_dot_scores_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
+                                     c_void_p, c_void_p]),
+    "nrl_ce_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
+                                      c_void_p]),
+    "nrl_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
+                                c_double, c_int64, c_float, c_int32, c_void_p]),
+    "nrl_embedding_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "nrl_linear_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension was not built (run `python -m newsreclib_amd._build` "
+            "or `__graft_entry__.build()`); newsreclib_amd has no CPU/PyTorch fallback by design.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    got = lib.nrl_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"ABI version mismatch: library {got}, binding {ABI_VERSION} (rebuild)")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().nrl_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

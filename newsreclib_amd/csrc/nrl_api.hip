@@ -1,0 +1,325 @@
+// C ABI of the gfx950 NRMS hot path (declarations + contract: include/newsreclib_amd.h).
+//
+// Both encoders are the same "MHSA + additive attention" block (text.py:218-219 /
+// user/nrms.py:27-30); they differ in how the block's input rows are produced (embedding gather
+// with dropout vs. a dense history tensor), in which axis the tiny attentions run over, and in
+// where the input gradient goes (scatter-add into the table vs. a dense d_hist).
+#include <stdarg.h>
+#include <string.h>
+
+#include "nrl_gemm.h"
+#include "nrl_kernels.h"
+
+namespace nrl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// tile shape used by every projection GEMM: 2x2 waves, 4x4 MFMA blocks each -> 128 x 128
+#define NRL_TILE 2, 2, 4, 4
+
+static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K) {
+  const int64_t tiles = ceil_div(rows_out, 128) * ceil_div(cols_out, 128);
+  int64_t s = ceil_div(2048, tiles);
+  const int64_t max_s = ceil_div(K, 8 * GEMM_BK);
+  if (s > max_s) s = max_s;
+  return (int)(s < 1 ? 1 : s);
+}
+
+struct BlockShape {
+  int64_t M;       // rows entering the block (N*L for news, B*H for the user encoder)
+  int D, Q, heads, dh;
+  int64_t pool_groups;  // output rows
+  int pool_len;         // rows per output row
+  AttnGeom geom;
+};
+
+struct BlockWs {
+  float *x, *qkv, *o, *y, *t, *w, *lse, *dy, *dqkv;
+};
+
+static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
+  auto al = [](size_t n) { return align_up(n, 64); };
+  size_t n = 0;
+  if (with_x) n += al((size_t)M * D);
+  n += al((size_t)M * 3 * D) * 2;  // qkv, dqkv
+  n += al((size_t)M * D) * 3;      // o, y, dy
+  n += al((size_t)M * Q);          // t / d_pre
+  n += al((size_t)M);              // w
+  n += al((size_t)M * heads);      // lse
+  return n;
+}
+
+static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x, BlockWs* out) {
+  NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+  if (ws_bytes < block_ws_floats(s.M, s.D, s.Q, s.heads, with_x) * sizeof(float)) {
+    set_error("workspace too small: %zu < %zu bytes", ws_bytes,
+              block_ws_floats(s.M, s.D, s.Q, s.heads, with_x) * sizeof(float));
+    return NRL_E_WORKSPACE;
+  }
+  float* p = (float*)ws;
+  auto take = [&](size_t n) { float* r = p; p += align_up(n, 64); return r; };
+  out->x = with_x ? take((size_t)s.M * s.D) : nullptr;
+  out->qkv = take((size_t)s.M * 3 * s.D);
+  out->dqkv = take((size_t)s.M * 3 * s.D);
+  out->o = take((size_t)s.M * s.D);
+  out->y = take((size_t)s.M * s.D);
+  out->dy = take((size_t)s.M * s.D);
+  out->t = take((size_t)s.M * s.Q);
+  out->w = take((size_t)s.M);
+  out->lse = take((size_t)s.M * s.heads);
+  return NRL_OK;
+}
+
+static int check_params(const NrlBlockParams* p) {
+  NRL_REQUIRE(p != nullptr, "params struct is null");
+  NRL_REQUIRE(p->in_proj_weight && p->in_proj_bias && p->out_proj_weight && p->out_proj_bias &&
+                  p->att_weight && p->att_bias && p->att_query, "null parameter pointer");
+  NRL_REQUIRE(p->embed_dim > 0 && p->embed_dim % 4 == 0, "embed_dim must be a positive multiple of 4");
+  NRL_REQUIRE(p->query_dim > 0 && p->query_dim % 4 == 0, "query_dim must be a positive multiple of 4");
+  NRL_REQUIRE(p->num_heads > 0 && p->embed_dim % p->num_heads == 0, "embed_dim must be divisible by num_heads");
+  NRL_REQUIRE(attn_head_dim_supported(p->embed_dim / p->num_heads),
+              "head dim %d unsupported (16, 20, 32, 48, 64)", p->embed_dim / p->num_heads);
+  NRL_REQUIRE((((uintptr_t)p->in_proj_weight | (uintptr_t)p->out_proj_weight | (uintptr_t)p->att_weight) & 15) == 0,
+              "weight matrices must be 16-byte aligned");
+  return NRL_OK;
+}
+
+// forward of the shared block given an A-operand accessor for the in-projection
+template <class AOp>
+static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape& s, const BlockWs& w,
+                     Dropout drop2, bool save, float* out, hipStream_t st) {
+  const int D = s.D, Q = s.Q;
+  const Dropout nodrop = make_dropout(0.0, 0, 0);
+  // q|k|v = x W_in^T + b_in           (text.py:229 / user/nrms.py:34; torch in-projection)
+  NRL_TRY((launch_gemm<NRL_TILE>(a_in, KCPlain{P->in_proj_weight, D, 3 * D},
+                                 EpiLinear{w.qkv, 3 * D, P->in_proj_bias, 0, nodrop, 3 * D}, s.M, 3 * D,
+                                 D, 1, st)));
+  // per (group, head): softmax(q k^T / sqrt(dh)) v
+  NRL_TRY(attn_fwd(w.qkv, w.o, save ? w.lse : nullptr, s.geom, st));
+  // y = dropout(o W_o^T + b_o)        (out-projection, text.py:229-230)
+  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.o, D, s.M}, KCPlain{P->out_proj_weight, D, D},
+                                 EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, 1, st)));
+  // t = tanh(y W_a^T + b_a)           (attention.py:34)
+  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.y, D, s.M}, KCPlain{P->att_weight, D, Q},
+                                 EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q}, s.M, Q, D, 1, st)));
+  // w = softmax(t . q_a); out = sum w y   (attention.py:37-40)
+  NRL_TRY(pool_fwd(w.t, P->att_query, w.y, s.pool_groups, s.pool_len, Q, D, w.w, out, st));
+  return NRL_OK;
+}
+
+// backward of the shared block up to d(qkv); the caller finishes with the in-projection dgrad
+static int block_bwd_to_dqkv(const NrlBlockParams* P, const NrlBlockGrads* G, const float* x_rows,
+                             const BlockShape& s, const BlockWs& w, Dropout drop2, const float* d_out,
+                             hipStream_t st) {
+  const int D = s.D, Q = s.Q;
+  // additive attention backward: t -> d_pre in place, dq_a
+  NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st));
+  // dy = (d_pre W_a + w * d_out) * dropout2
+  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.t, Q, s.M}, RCPlain{P->att_weight, D, D, 0},
+                                 EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, D, Q, 1, st)));
+  // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
+  NRL_TRY((launch_gemm<NRL_TILE>(RCPlain{w.t, Q, Q, 0}, RCPlain{w.y, D, D, 1},
+                                 EpiAtomicWB{G->att_weight, D, G->att_bias, D}, Q, D + 1, s.M,
+                                 wgrad_splits(Q, D + 1, s.M), st)));
+  // d_o = dy W_o  (written over y, which is dead from here on)
+  float* d_o = w.y;
+  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.dy, D, s.M}, RCPlain{P->out_proj_weight, D, D, 0},
+                                 EpiStore{d_o, D}, s.M, D, D, 1, st)));
+  // dW_o += dy^T o ; db_o += colsum(dy)
+  NRL_TRY((launch_gemm<NRL_TILE>(RCPlain{w.dy, D, D, 0}, RCPlain{w.o, D, D, 1},
+                                 EpiAtomicWB{G->out_proj_weight, D, G->out_proj_bias, D}, D, D + 1, s.M,
+                                 wgrad_splits(D, D + 1, s.M), st)));
+  // attention backward -> dqkv
+  NRL_TRY(attn_bwd(w.qkv, w.o, d_o, w.lse, w.dqkv, s.geom, st));
+  // dW_in += dqkv^T x ; db_in += colsum(dqkv)
+  NRL_TRY((launch_gemm<NRL_TILE>(RCPlain{w.dqkv, 3 * D, 3 * D, 0}, RCPlain{x_rows, D, D, 1},
+                                 EpiAtomicWB{G->in_proj_weight, D, G->in_proj_bias, D}, 3 * D, D + 1, s.M,
+                                 wgrad_splits(3 * D, D + 1, s.M), st)));
+  return NRL_OK;
+}
+
+static int check_grads(const NrlBlockGrads* g) {
+  NRL_REQUIRE(g != nullptr && g->in_proj_weight && g->in_proj_bias && g->out_proj_weight &&
+                  g->out_proj_bias && g->att_weight && g->att_bias && g->att_query,
+              "null gradient pointer");
+  return NRL_OK;
+}
+
+static BlockShape news_shape(const NrlBlockParams* p, int64_t n_news, int L) {
+  BlockShape s;
+  s.D = p->embed_dim; s.Q = p->query_dim; s.heads = p->num_heads; s.dh = s.D / s.heads;
+  s.M = n_news * L;
+  s.pool_groups = n_news; s.pool_len = L;
+  s.geom.q_outer = (int64_t)L * 3 * s.D; s.geom.q_seq = 3 * s.D;
+  s.geom.o_outer = (int64_t)L * s.D; s.geom.o_seq = s.D;
+  s.geom.groups = n_news * s.heads; s.geom.heads = s.heads; s.geom.S = L; s.geom.D = s.D;
+  s.geom.dh = s.dh; s.geom.scale = 1.0f / sqrtf((float)s.dh);
+  return s;
+}
+
+static BlockShape user_shape(const NrlBlockParams* p, int64_t B, int64_t H) {
+  BlockShape s;
+  s.D = p->embed_dim; s.Q = p->query_dim; s.heads = p->num_heads; s.dh = s.D / s.heads;
+  s.M = B * H;
+  s.pool_groups = B; s.pool_len = (int)H;
+  // seq-first quirk: the "sequence" is the user axis (stride H rows), the "batch" the slot axis
+  s.geom.q_outer = 3 * s.D; s.geom.q_seq = H * 3 * s.D;
+  s.geom.o_outer = s.D; s.geom.o_seq = H * s.D;
+  s.geom.groups = H * s.heads; s.geom.heads = s.heads; s.geom.S = (int)B; s.geom.D = s.D;
+  s.geom.dh = s.dh; s.geom.scale = 1.0f / sqrtf((float)s.dh);
+  return s;
+}
+
+}  // namespace nrl
+
+using namespace nrl;
+
+extern "C" {
+
+int nrl_abi_version(void) { return NRL_ABI_VERSION; }
+const char* nrl_last_error(void) { return g_err; }
+
+uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream) { return dropout_key(seed, stream); }
+
+int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, uint32_t stream,
+                     void* stream_handle) {
+  NRL_REQUIRE(keep != nullptr && n_elems >= 0 && p >= 0.0 && p < 1.0, "dropout_mask: bad arguments");
+  return dropout_mask(keep, n_elems, make_dropout(p, seed, stream), (hipStream_t)stream_handle);
+}
+
+size_t nrl_news_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t embed_dim,
+                                        int32_t num_heads, int32_t query_dim) {
+  return block_ws_floats(n_news * seq_len, embed_dim, query_dim, num_heads, true) * sizeof(float);
+}
+
+int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_t vocab,
+                         const int64_t* ids, int64_t n_news, int32_t seq_len, double p_drop,
+                         uint64_t seed, uint32_t stream0, int32_t save_for_backward, float* out,
+                         void* ws, size_t ws_bytes, void* stream) {
+  NRL_TRY(check_params(p));
+  NRL_REQUIRE(emb_table && ids && out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_fwd: bad arguments");
+  NRL_REQUIRE(((uintptr_t)emb_table & 15) == 0, "embedding table must be 16-byte aligned");
+  NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
+  if (n_news == 0) return NRL_OK;
+  const BlockShape s = news_shape(p, n_news, seq_len);
+  NRL_REQUIRE(s.M * s.D < (1LL << 32), "activation too large for the 32-bit dropout index space");
+  BlockWs w;
+  NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
+  const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
+  KCGather a_in{emb_table, ids, s.M, s.D, d1, save_for_backward ? w.x : nullptr};
+  return block_fwd(p, a_in, s, w, d2, save_for_backward != 0, out, (hipStream_t)stream);
+}
+
+int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
+                         int64_t vocab, const int64_t* ids, int64_t n_news, int32_t seq_len,
+                         double p_drop, uint64_t seed, uint32_t stream0, const float* d_out, void* ws,
+                         size_t ws_bytes, void* stream) {
+  NRL_TRY(check_params(p));
+  NRL_TRY(check_grads(g));
+  NRL_REQUIRE(d_emb_table && ids && d_out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_bwd: bad arguments");
+  if (n_news == 0) return NRL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const BlockShape s = news_shape(p, n_news, seq_len);
+  BlockWs w;
+  NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
+  const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
+  NRL_TRY(block_bwd_to_dqkv(p, g, w.x, s, w, d2, d_out, st));
+  // dx = dqkv W_in, times dropout1, scatter-added into the table rows (embedding_dense_backward)
+  return launch_gemm<NRL_TILE>(KCPlain{w.dqkv, 3 * s.D, s.M}, RCPlain{p->in_proj_weight, s.D, s.D, 0},
+                               EpiScatter{d_emb_table, ids, s.D, d1}, s.M, s.D, 3 * s.D, 1, st);
+}
+
+size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t embed_dim,
+                                        int32_t num_heads, int32_t query_dim) {
+  return block_ws_floats(batch * hist_len, embed_dim, query_dim, num_heads, false) * sizeof(float);
+}
+
+int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t batch, int64_t hist_len,
+                         int32_t save_for_backward, float* out, void* ws, size_t ws_bytes,
+                         void* stream) {
+  NRL_TRY(check_params(p));
+  NRL_REQUIRE(hist && out && batch > 0 && hist_len > 0, "user_encoder_fwd: bad arguments");
+  NRL_REQUIRE(((uintptr_t)hist & 15) == 0, "hist must be 16-byte aligned");
+  const BlockShape s = user_shape(p, batch, hist_len);
+  BlockWs w;
+  NRL_TRY(carve_ws(ws, ws_bytes, s, false, &w));
+  return block_fwd(p, KCPlain{hist, s.D, s.M}, s, w, make_dropout(0.0, 0, 0), save_for_backward != 0, out,
+                   (hipStream_t)stream);
+}
+
+int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
+                         int64_t batch, int64_t hist_len, const float* d_out, float* d_hist, void* ws,
+                         size_t ws_bytes, void* stream) {
+  NRL_TRY(check_params(p));
+  NRL_TRY(check_grads(g));
+  NRL_REQUIRE(hist && d_out && d_hist && batch > 0 && hist_len > 0, "user_encoder_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const BlockShape s = user_shape(p, batch, hist_len);
+  BlockWs w;
+  NRL_TRY(carve_ws(ws, ws_bytes, s, false, &w));
+  NRL_TRY(block_bwd_to_dqkv(p, g, hist, s, w, make_dropout(0.0, 0, 0), d_out, st));
+  return launch_gemm<NRL_TILE>(KCPlain{w.dqkv, 3 * s.D, s.M}, RCPlain{p->in_proj_weight, s.D, s.D, 0},
+                               EpiStore{d_hist, s.D}, s.M, s.D, 3 * s.D, 1, st);
+}
+
+int nrl_to_dense_batch_fwd(const float* x, const int64_t* offsets, int64_t batch, int64_t max_len,
+                           int32_t dim, float* dense, void* stream) {
+  NRL_REQUIRE(offsets && dense && batch >= 0 && max_len >= 0 && dim > 0, "to_dense_batch_fwd: bad arguments");
+  return to_dense_fwd(x, offsets, batch, max_len, dim, dense, (hipStream_t)stream);
+}
+
+int nrl_to_dense_batch_bwd(const float* d_dense, const int64_t* offsets, int64_t batch,
+                           int64_t max_len, int32_t dim, int64_t n_rows, float* d_x, void* stream) {
+  NRL_REQUIRE(offsets && d_dense && batch >= 0 && max_len >= 0 && dim > 0, "to_dense_batch_bwd: bad arguments");
+  return to_dense_bwd(d_dense, offsets, batch, max_len, dim, n_rows, d_x, (hipStream_t)stream);
+}
+
+int nrl_dot_scores_fwd(const float* user, const float* cand, int64_t batch, int64_t n_cand,
+                       int32_t dim, float* scores, void* stream) {
+  NRL_REQUIRE(user && cand && scores && batch >= 0 && n_cand >= 0 && dim > 0, "dot_scores_fwd: bad arguments");
+  return dot_scores_fwd(user, cand, batch, n_cand, dim, scores, (hipStream_t)stream);
+}
+
+int nrl_dot_scores_bwd(const float* d_scores, const float* user, const float* cand, int64_t batch,
+                       int64_t n_cand, int32_t dim, float* d_user, float* d_cand, void* stream) {
+  NRL_REQUIRE(d_scores && user && cand && d_user && d_cand && dim > 0, "dot_scores_bwd: bad arguments");
+  return dot_scores_bwd(d_scores, user, cand, batch, n_cand, dim, d_user, d_cand, (hipStream_t)stream);
+}
+
+int nrl_ce_loss_fwd_bwd(const float* scores, const float* y_true, int64_t batch, int64_t n_cand,
+                        float grad_scale, float* loss, float* d_scores, void* stream) {
+  NRL_REQUIRE(scores && y_true && loss, "ce_loss: bad arguments");
+  return ce_loss_fwd_bwd(scores, y_true, batch, n_cand, grad_scale, loss, d_scores, (hipStream_t)stream);
+}
+
+int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                  double beta1, double beta2, double eps, int64_t step, float grad_scale,
+                  int32_t zero_grad, void* stream) {
+  NRL_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0, "adam_step: bad arguments");
+  return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, zero_grad,
+                   (hipStream_t)stream);
+}
+
+int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,
+                         float* out, void* stream) {
+  NRL_REQUIRE(table && ids && out && n_ids >= 0 && dim > 0, "embedding_gather: bad arguments");
+  return embedding_gather(table, ids, n_ids, dim, out, (hipStream_t)stream);
+}
+
+int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k,
+                   float* c, void* stream) {
+  NRL_REQUIRE(a && w && c && m >= 0 && n > 0 && k > 0 && k % 4 == 0, "linear_fwd: bad arguments (k % 4 == 0)");
+  NRL_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0, "linear_fwd: operands must be 16-byte aligned");
+  return launch_gemm<NRL_TILE>(KCPlain{a, k, m}, KCPlain{w, k, n},
+                               EpiLinear{c, n, bias, 0, make_dropout(0.0, 0, 0), n}, m, n, k, 1,
+                               (hipStream_t)stream);
+}
+
+}  // extern "C"

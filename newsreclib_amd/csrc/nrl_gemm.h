@@ -1,0 +1,378 @@
+// Exact-fp32 MFMA GEMM for gfx950 (v_mfma_f32_16x16x4_f32), LDS-tiled, double-buffered.
+//
+//   C(m, n) = sum_k A(m, k) * B(k, n)      ->   epi(m, n, value)
+//
+// One kernel template serves every projection of the NRMS hot path (forward NT, dgrad NN, wgrad
+// TN) through three pluggable pieces:
+//   * operand accessors (how a tile is fetched from HBM): k-contiguous rows (optionally GATHERED
+//     through token ids with the dropout mask applied = the fused embedding lookup), or k-major
+//     ("row-contiguous") matrices;
+//   * an epilogue functor applied to every valid output element (bias / tanh / dropout / pooled
+//     gradient / atomic accumulate / embedding scatter-add);
+//   * the tile shape: WM x WN waves, each owning TM x TN MFMA blocks of 16x16.
+//
+// LDS image: both operands are stored k-major, As[k][BM + pad], Bs[k][BN + pad], pad chosen so the
+// per-MFMA fragment read (lanes 0-15 -> k, lanes 16-31 -> k+1, ...) is a conflict-free ds_read_b32.
+// Fragment maps (cdna_hip_programming.md section 3): A lane l holds A[i = l&15][k = l>>4], B holds
+// B[k = l>>4][j = l&15], C/D: col = l&15, row = 4*(l>>4) + reg.
+//
+// Why 16x16x4 and not 32x32x2: same 64 FLOP/clk/SIMD, but N in {900, 300, 200} pads to
+// {912, 304, 208} with 16-wide blocks vs {928, 320, 224} with 32-wide ones.
+#pragma once
+#include <type_traits>
+
+#include "nrl_common.h"
+
+namespace nrl {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int GEMM_BK = 16;
+enum { SRC_KC = 0, SRC_RC = 1 };
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---------------------------------------------------------------------------------------------
+// operand accessors
+// ---------------------------------------------------------------------------------------------
+// rows x K matrix, K contiguous (row-major activations, nn.Linear weights)
+struct KCPlain {
+  static constexpr int kLayout = SRC_KC;
+  const float* p;
+  int64_t ld;
+  int64_t rows;
+  struct State {
+    const float* ptr;
+  };
+  __device__ __forceinline__ State init(int64_t r) const { return State{r < rows ? p + r * ld : nullptr}; }
+  __device__ __forceinline__ float4 load(const State& s, int64_t /*r*/, int k, int kend, bool /*primary*/) const {
+    return (s.ptr != nullptr && k < kend) ? *reinterpret_cast<const float4*>(s.ptr + k) : f4zero();
+  }
+};
+
+// rows gathered from an embedding table through int64 ids (nn.Embedding, text.py:224), times the
+// dropout multiplier of text.py:225; the tile column 0 workgroup also saves the post-dropout row
+// (needed by the in-projection weight gradient).
+struct KCGather {
+  static constexpr int kLayout = SRC_KC;
+  const float* table;
+  const int64_t* ids;
+  int64_t rows;
+  int dim;
+  Dropout drop;
+  float* save;  // (rows, dim) or nullptr
+  struct State {
+    const float* ptr;
+  };
+  __device__ __forceinline__ State init(int64_t r) const {
+    return State{r < rows ? table + ids[r] * (int64_t)dim : nullptr};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int64_t r, int k, int kend, bool primary) const {
+    if (s.ptr == nullptr || k >= kend) return f4zero();
+    float4 v = *reinterpret_cast<const float4*>(s.ptr + k);
+    if (drop.thresh != 0u) {
+      const uint32_t idx = (uint32_t)r * (uint32_t)dim + (uint32_t)k;
+      v.x *= drop.mult(idx);
+      v.y *= drop.mult(idx + 1);
+      v.z *= drop.mult(idx + 2);
+      v.w *= drop.mult(idx + 3);
+    }
+    if (save != nullptr && primary) *reinterpret_cast<float4*>(save + r * (int64_t)dim + k) = v;
+    return v;
+  }
+};
+
+// K x rows matrix, rows contiguous (element (k, r) at p[k * ld + r]); `ones` appends a virtual
+// column r == rows that reads 1.0 (turns a weight-gradient GEMM into weight + bias gradient).
+struct RCPlain {
+  static constexpr int kLayout = SRC_RC;
+  const float* p;
+  int64_t ld;
+  int64_t rows;
+  int ones;
+  struct State {};  // no per-row state (keeps the kernel's staging arrays uniform)
+  __device__ __forceinline__ float4 load(int64_t k, int64_t r, int64_t kend) const {
+    if (k >= kend) return f4zero();
+    if (r < rows) return *reinterpret_cast<const float4*>(p + k * ld + r);
+    if (ones && r == rows) return make_float4(1.f, 0.f, 0.f, 0.f);
+    return f4zero();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// epilogues
+// ---------------------------------------------------------------------------------------------
+// C = act(v + bias[n]) * dropout(m, n)      (nn.Linear + optional tanh + optional nn.Dropout)
+struct EpiLinear {
+  float* c;
+  int64_t ldc;
+  const float* bias;  // may be null
+  int act_tanh;
+  Dropout drop;
+  int n_cols;  // logical row width for the dropout flat index
+  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
+    if (bias != nullptr) v += bias[n];
+    if (act_tanh) v = tanhf(v);
+    if (drop.thresh != 0u) v *= drop.mult((uint32_t)m * (uint32_t)n_cols + (uint32_t)n);
+    c[m * ldc + n] = v;
+  }
+};
+
+// dgrad into a plain buffer
+struct EpiStore {
+  float* c;
+  int64_t ldc;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const { c[m * ldc + n] = v; }
+};
+
+// additive-attention backward, fused: dy = (v + w[m] * d_out[group(m)][n]) * dropout(m, n)
+// (v = d_pre * W_a is the tanh-branch gradient, w * d_out the weighted-sum branch,
+// attention.py:34-40; the multiplier undoes text.py:230).
+struct EpiPoolBwd {
+  float* c;
+  int64_t ldc;
+  const float* w;      // (M) softmax weights
+  const float* d_out;  // (groups, N)
+  int group_len;       // rows per group
+  Dropout drop;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
+    v += w[m] * d_out[(m / group_len) * ldc + n];
+    if (drop.thresh != 0u) v *= drop.mult((uint32_t)m * (uint32_t)ldc + (uint32_t)n);
+    c[m * ldc + n] = v;
+  }
+};
+
+// split-K weight gradient: dW[m][n] += v for n < n_w, bias gradient db[m] += v for n == n_w
+struct EpiAtomicWB {
+  float* dw;
+  int64_t ldc;
+  float* db;  // may be null
+  int n_w;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
+    if (n < n_w)
+      atomicAdd(dw + m * ldc + n, v);
+    else if (n == n_w && db != nullptr)
+      atomicAdd(db + m, v);
+  }
+};
+
+// embedding_dense_backward fused into the in-projection dgrad: d_table[ids[m]][n] += v * dropout
+// (padding_idx = 0 rows receive nothing, text.py:215-217)
+struct EpiScatter {
+  float* d_table;
+  const int64_t* ids;
+  int dim;
+  Dropout drop;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
+    const int64_t id = ids[m];
+    if (id == 0) return;
+    if (drop.thresh != 0u) v *= drop.mult((uint32_t)m * (uint32_t)dim + (uint32_t)n);
+    atomicAdd(d_table + id * (int64_t)dim + n, v);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------
+template <int ROWS>
+struct LdsLd {
+  static constexpr int value = (ROWS + 31) / 32 * 32 + 16;  // == 16 (mod 32): conflict-free b32 reads
+};
+
+template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
+__global__ void __launch_bounds__(WM* WN * 64)
+    gemm_f32_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N,
+                    const int64_t K, const int tiles_n, const int64_t tiles_total,
+                    const int64_t k_per_split) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = GEMM_BK;
+  constexpr int LDA = LdsLd<BM>::value, LDB = LdsLd<BN>::value;
+  constexpr int NCH_A = (BM * BK / 4 + NT - 1) / NT;
+  constexpr int NCH_B = (BN * BK / 4 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  float* const As = smem;
+  float* const Bs = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // XCD-aware tile order: workgroups that land on one XCD (blockIdx % 8) walk consecutive tiles,
+  // so the n-tiles that share an A row-panel hit the same private L2 (bijective remap).
+  int64_t t;
+  {
+    const int64_t bid = blockIdx.x;
+    const int64_t q = tiles_total / 8, rem = tiles_total % 8;
+    const int64_t xcd = bid % 8, local = bid / 8;
+    t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+  }
+  const int64_t m0 = (t / tiles_n) * BM;
+  const int n0 = (int)(t % tiles_n) * BN;
+  const bool primary = (n0 == 0);
+  const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  if (kbeg >= kend) return;
+  const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
+
+  // which of this wave's 16x16 blocks hold any valid output (wave-uniform)
+  int nvi = 0, nvj = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) nvi += (m0 + (wm * TM + i) * 16 < M) ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) nvj += (n0 + (wn * TN + j) * 16 < N) ? 1 : 0;
+
+  // per-thread staging assignment (fixed across k-tiles)
+  typename AOp::State sa[NCH_A];
+  typename BOp::State sb[NCH_B];
+  if constexpr (AOp::kLayout == SRC_KC) {
+#pragma unroll
+    for (int c = 0; c < NCH_A; ++c) {
+      const int ch = tid + c * NT;
+      sa[c] = A.init(ch < BM * 4 ? m0 + (ch >> 2) : (int64_t)1 << 60);
+    }
+  }
+  if constexpr (BOp::kLayout == SRC_KC) {
+#pragma unroll
+    for (int c = 0; c < NCH_B; ++c) {
+      const int ch = tid + c * NT;
+      sb[c] = B.init(ch < BN * 4 ? (int64_t)n0 + (ch >> 2) : (int64_t)1 << 60);
+    }
+  }
+
+  float4 ra[NCH_A], rb[NCH_B];
+  auto load_tiles = [&](int64_t k0) {
+#pragma unroll
+    for (int c = 0; c < NCH_A; ++c) {
+      const int ch = tid + c * NT;
+      if constexpr (AOp::kLayout == SRC_KC) {
+        ra[c] = A.load(sa[c], m0 + (ch >> 2), (int)(k0 + 4 * (ch & 3)), (int)kend, primary);
+      } else {
+        constexpr int CPR = BM / 4;
+        ra[c] = (ch < BK * CPR) ? A.load(k0 + ch / CPR, m0 + 4 * (ch % CPR), kend) : f4zero();
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH_B; ++c) {
+      const int ch = tid + c * NT;
+      if constexpr (BOp::kLayout == SRC_KC) {
+        rb[c] = B.load(sb[c], (int64_t)n0 + (ch >> 2), (int)(k0 + 4 * (ch & 3)), (int)kend, false);
+      } else {
+        constexpr int CPR = BN / 4;
+        rb[c] = (ch < BK * CPR) ? B.load(k0 + ch / CPR, (int64_t)n0 + 4 * (ch % CPR), kend) : f4zero();
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* as = As + buf * BK * LDA;
+    float* bs = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int c = 0; c < NCH_A; ++c) {
+      const int ch = tid + c * NT;
+      if constexpr (AOp::kLayout == SRC_KC) {
+        if (ch < BM * 4) {
+          const int row = ch >> 2, kc = (ch & 3) * 4;
+          as[(kc + 0) * LDA + row] = ra[c].x;
+          as[(kc + 1) * LDA + row] = ra[c].y;
+          as[(kc + 2) * LDA + row] = ra[c].z;
+          as[(kc + 3) * LDA + row] = ra[c].w;
+        }
+      } else {
+        constexpr int CPR = BM / 4;
+        if (ch < BK * CPR) *reinterpret_cast<float4*>(as + (ch / CPR) * LDA + 4 * (ch % CPR)) = ra[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH_B; ++c) {
+      const int ch = tid + c * NT;
+      if constexpr (BOp::kLayout == SRC_KC) {
+        if (ch < BN * 4) {
+          const int row = ch >> 2, kc = (ch & 3) * 4;
+          bs[(kc + 0) * LDB + row] = rb[c].x;
+          bs[(kc + 1) * LDB + row] = rb[c].y;
+          bs[(kc + 2) * LDB + row] = rb[c].z;
+          bs[(kc + 3) * LDB + row] = rb[c].w;
+        }
+      } else {
+        constexpr int CPR = BN / 4;
+        if (ch < BK * CPR) *reinterpret_cast<float4*>(bs + (ch / CPR) * LDB + 4 * (ch % CPR)) = rb[c];
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(kbeg);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int tt = 0; tt < ntiles; ++tt) {
+    const int buf = tt & 1;
+    const int64_t k0 = kbeg + (int64_t)tt * BK;
+    if (tt + 1 < ntiles) load_tiles(k0 + BK);  // global loads in flight under the MFMAs below
+
+    const float* as = As + buf * BK * LDA + (wm * TM * 16 + l15);
+    const float* bs = Bs + buf * BK * LDB + (wn * TN * 16 + l15);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      if (k0 + 4 * ks < kend) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = as[(4 * ks + g) * LDA + i * 16];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = bs[(4 * ks + g) * LDB + j * 16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (i < nvi) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (j < nvj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    if (tt + 1 < ntiles) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds C[row = 4g + r][col = l15] of each block
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + r;
+        if (m < M && n < N) epi(m, n, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// host launcher.  `splits` > 1 partitions K over blockIdx.y (epilogue must accumulate atomically).
+template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
+int launch_gemm(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, int64_t K, int splits,
+                hipStream_t stream) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
+  const int64_t tiles_m = ceil_div(M, BM);
+  const int tiles_n = (int)ceil_div(N, BN);
+  const int64_t tiles_total = tiles_m * tiles_n;
+  if (splits < 1) splits = 1;
+  int64_t kps = ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK;
+  splits = (int)ceil_div(K, kps);
+  NRL_REQUIRE(tiles_total < (1LL << 31) && splits < 65536, "gemm grid too large");
+  dim3 grid((unsigned)tiles_total, (unsigned)splits, 1);
+  hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AOp, BOp, Epi>), grid, dim3(WM * WN * 64), 0,
+                     stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+}  // namespace nrl

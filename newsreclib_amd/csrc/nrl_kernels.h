@@ -1,0 +1,56 @@
+// Host-callable launchers of the non-GEMM kernels (wavefront-level attention, additive-attention
+// pooling, dense batching, scorer, loss, Adam).  Definitions in nrl_kernels.hip.
+#pragma once
+#include "nrl_common.h"
+
+namespace nrl {
+
+// Addressing of one family of tiny attentions inside a packed (rows, 3D) q|k|v buffer.
+// group = outer * heads + head; element (group, s, d) of q lives at
+//   qkv[outer * q_outer + s * q_seq + head * dh + d],   k at + D, v at + 2D
+// and of the output at o[outer * o_outer + s * o_seq + head * dh + d].
+// News encoder (text.py:228-229): outer = news row, s = token.  User encoder (user/nrms.py:34-36,
+// seq-first quirk): outer = history slot, s = USER index.
+struct AttnGeom {
+  int64_t q_outer, q_seq, o_outer, o_seq;
+  int64_t groups;
+  int heads, S, D, dh;
+  float scale;  // 1/sqrt(dh), applied to q before QK^T as torch does
+};
+
+bool attn_head_dim_supported(int dh);
+// o (rows, D); lse (groups, S) may be null in inference
+int attn_fwd(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream);
+// dqkv (rows, 3D) fully overwritten
+int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+             const AttnGeom& G, hipStream_t stream);
+
+// additive attention tail (attention.py:37-40): a = t . q_a; w = softmax_S(a); out = sum w y.
+// rows of group g are [g*S, (g+1)*S).  w (M) is saved for backward.
+int pool_fwd(const float* t, const float* q_a, const float* y, int64_t groups, int S, int Q, int D,
+             float* w, float* out, hipStream_t stream);
+// turns t (tanh outputs) IN PLACE into d_pre = da * q_a * (1 - t^2) and adds dq_a
+int pool_bwd_pre(const float* d_out, const float* y, const float* w, float* t_dpre,
+                 const float* q_a, float* dq_a, int64_t groups, int S, int Q, int D,
+                 hipStream_t stream);
+
+int to_dense_fwd(const float* x, const int64_t* offsets, int64_t B, int64_t max_len, int D,
+                 float* dense, hipStream_t stream);
+int to_dense_bwd(const float* d_dense, const int64_t* offsets, int64_t B, int64_t max_len, int D,
+                 int64_t n_rows, float* d_x, hipStream_t stream);
+
+int dot_scores_fwd(const float* user, const float* cand, int64_t B, int64_t C, int D, float* scores,
+                   hipStream_t stream);
+int dot_scores_bwd(const float* d_scores, const float* user, const float* cand, int64_t B, int64_t C,
+                   int D, float* d_user, float* d_cand, hipStream_t stream);
+int ce_loss_fwd_bwd(const float* scores, const float* y, int64_t B, int64_t C, float grad_scale,
+                    float* loss, float* d_scores, hipStream_t stream);
+
+int adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
+              double eps, int64_t step, float grad_scale, int zero_grad, hipStream_t stream);
+
+int embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int D, float* out,
+                     hipStream_t stream);
+int dropout_mask(uint8_t* keep, int64_t n, Dropout d, hipStream_t stream);
+
+}  // namespace nrl

@@ -1,0 +1,739 @@
+// Non-GEMM kernels of the NRMS hot path for gfx950 (wave64).
+//
+//  * attn_*: the (news x head) L x L and (slot x head) B x B attentions.  d_h = 20 and L = 30 are
+//    far too small/odd for MFMA tiles to pay (a 30x30x20 product fills 2x2 16x16 blocks at 5 k-steps
+//    with 12 % padding, and the softmax between the two products needs the scores in a per-row
+//    layout anyway), so they run on the vector ALU: one lane owns one query row, K/V of the group
+//    sit in LDS and are read as wave-wide broadcasts, softmax is online and in registers.  The
+//    scores (N*h*L*L, 380 MB at B=128 in the reference) never exist in memory.
+//  * pool_*: additive-attention softmax + weighted sum and its backward.
+//  * dense batching, dot-product scorer, probability-target cross entropy, dense Adam.
+#include <math.h>
+
+#include "nrl_kernels.h"
+
+namespace nrl {
+
+// =============================================================================================
+// attention
+// =============================================================================================
+template <int DH>
+__device__ __forceinline__ float dot_row(const float (&q)[DH], const float* row) {
+  const float4* r4 = reinterpret_cast<const float4*>(row);
+  float acc = 0.f;
+#pragma unroll
+  for (int d4 = 0; d4 < DH / 4; ++d4) {
+    const float4 kv = r4[d4];
+    acc = fmaf(q[4 * d4 + 0], kv.x, acc);
+    acc = fmaf(q[4 * d4 + 1], kv.y, acc);
+    acc = fmaf(q[4 * d4 + 2], kv.z, acc);
+    acc = fmaf(q[4 * d4 + 3], kv.w, acc);
+  }
+  return acc;
+}
+
+template <int DH>
+__device__ __forceinline__ void axpy_row(float a, const float* row, float (&o)[DH]) {
+  const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+  for (int d4 = 0; d4 < DH / 4; ++d4) {
+    const float4 vv = r4[d4];
+    o[4 * d4 + 0] = fmaf(a, vv.x, o[4 * d4 + 0]);
+    o[4 * d4 + 1] = fmaf(a, vv.y, o[4 * d4 + 1]);
+    o[4 * d4 + 2] = fmaf(a, vv.z, o[4 * d4 + 2]);
+    o[4 * d4 + 3] = fmaf(a, vv.w, o[4 * d4 + 3]);
+  }
+}
+
+template <int DH>
+__device__ __forceinline__ void load_row(const float* src, float (&r)[DH], float mul) {
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+  for (int d4 = 0; d4 < DH / 4; ++d4) {
+    const float4 v = s4[d4];
+    r[4 * d4 + 0] = v.x * mul;
+    r[4 * d4 + 1] = v.y * mul;
+    r[4 * d4 + 2] = v.z * mul;
+    r[4 * d4 + 3] = v.w * mul;
+  }
+}
+
+template <int DH>
+__device__ __forceinline__ void store_row(float* dst, const float (&r)[DH], float mul) {
+  float4* d4p = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int d4 = 0; d4 < DH / 4; ++d4)
+    d4p[d4] = make_float4(r[4 * d4] * mul, r[4 * d4 + 1] * mul, r[4 * d4 + 2] * mul, r[4 * d4 + 3] * mul);
+}
+
+// online-softmax accumulation of one query row against `nrows` keys/values held in LDS
+template <int DH>
+__device__ __forceinline__ void attend_rows(const float (&q)[DH], const float* Ks, const float* Vs,
+                                            int nrows, float& m, float& l, float (&o)[DH]) {
+  for (int cb = 0; cb < nrows; cb += 8) {
+    float s[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = cb + u;
+      const float acc = dot_row<DH>(q, Ks + (c < nrows ? c : 0) * DH);
+      s[u] = c < nrows ? acc : -INFINITY;
+      mx = fmaxf(mx, s[u]);
+    }
+    const float m_new = fmaxf(m, mx);
+    const float alpha = expf(m - m_new);  // m = -inf on the first block -> 0
+    l *= alpha;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = cb + u;
+      const float p = expf(s[u] - m_new);  // padded slots: exp(-inf) = 0
+      l += p;
+      axpy_row<DH>(p, Vs + (c < nrows ? c : 0) * DH, o);
+    }
+    m = m_new;
+  }
+}
+
+// cooperative copy of `nrows` rows of DH floats (row stride `stride` elements) into LDS
+template <int DH>
+__device__ __forceinline__ void stage_rows(const float* src, int64_t stride, int nrows, float* dst,
+                                           int tid, int nthreads, float mul = 1.0f) {
+  constexpr int C4 = DH / 4;
+  for (int idx = tid; idx < nrows * C4; idx += nthreads) {
+    const int row = idx / C4, c4 = idx % C4;
+    float4 v = *reinterpret_cast<const float4*>(src + row * stride + 4 * c4);
+    v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+    reinterpret_cast<float4*>(dst)[row * C4 + c4] = v;
+  }
+}
+
+// ---- S <= 32: two groups per wavefront (one per 32-lane half), GPW groups per workgroup ----------
+template <int DH, int GPW>
+__global__ void __launch_bounds__(GPW * 32)
+    attn_fwd_small(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
+                   const AttnGeom G) {
+  __shared__ float4 smem4[GPW * 2 * 32 * DH / 4];
+  const int tid = threadIdx.x, li = tid & 31, grp = tid >> 5;
+  const int64_t g = (int64_t)blockIdx.x * GPW + grp;
+  const bool gvalid = g < G.groups;
+  float* Ks = reinterpret_cast<float*>(smem4) + grp * (2 * 32 * DH);
+  float* Vs = Ks + 32 * DH;
+  const int64_t outer = gvalid ? g / G.heads : 0;
+  const int head = gvalid ? (int)(g % G.heads) : 0;
+  const float* qb = qkv + outer * G.q_outer + head * DH;
+  if (gvalid) {
+    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ks, li, 32);
+    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Vs, li, 32);
+  }
+  __syncthreads();
+  if (gvalid && li < G.S) {
+    float q[DH], acc[DH];
+    load_row<DH>(qb + li * G.q_seq, q, G.scale);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    attend_rows<DH>(q, Ks, Vs, G.S, m, l, acc);
+    store_row<DH>(o + outer * G.o_outer + li * G.o_seq + head * DH, acc, 1.0f / l);
+    if (lse != nullptr) lse[g * G.S + li] = m + logf(l);
+  }
+}
+
+template <int DH, int GPW>
+__global__ void __launch_bounds__(GPW * 32)
+    attn_bwd_small(const float* __restrict__ qkv, const float* __restrict__ o,
+                   const float* __restrict__ d_o, const float* __restrict__ lse,
+                   float* __restrict__ dqkv, const AttnGeom G) {
+  __shared__ float4 smem4[GPW * (4 * 32 * DH + 64) / 4];
+  const int tid = threadIdx.x, li = tid & 31, grp = tid >> 5;
+  const int64_t g = (int64_t)blockIdx.x * GPW + grp;
+  const bool gvalid = g < G.groups;
+  float* Ks = reinterpret_cast<float*>(smem4) + grp * (4 * 32 * DH + 64);
+  float* Vs = Ks + 32 * DH;
+  float* Qs = Vs + 32 * DH;   // scaled q rows
+  float* Ds = Qs + 32 * DH;   // dO rows
+  float* lse_s = Ds + 32 * DH;
+  float* dl_s = lse_s + 32;
+  const int64_t outer = gvalid ? g / G.heads : 0;
+  const int head = gvalid ? (int)(g % G.heads) : 0;
+  const float* qb = qkv + outer * G.q_outer + head * DH;
+  const float* ob = o + outer * G.o_outer + head * DH;
+  const float* dob = d_o + outer * G.o_outer + head * DH;
+  float* dqb = dqkv + outer * G.q_outer + head * DH;
+  if (gvalid) {
+    stage_rows<DH>(qb, G.q_seq, G.S, Qs, li, 32, G.scale);
+    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ks, li, 32);
+    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Vs, li, 32);
+    stage_rows<DH>(dob, G.o_seq, G.S, Ds, li, 32);
+  }
+  __syncthreads();
+  const bool active = gvalid && li < G.S;
+  // phase 1: lane = query row -> dq, and the row statistics phase 2 needs
+  if (active) {
+    float q[DH], dout[DH], dq[DH];
+    load_row<DH>(Qs + li * DH, q, 1.0f);
+    load_row<DH>(Ds + li * DH, dout, 1.0f);
+    const float dl = dot_row<DH>(dout, ob + li * G.o_seq);  // rowsum(dO * O) = rowsum(P * dP)
+    const float ls = lse[g * G.S + li];
+    lse_s[li] = ls;
+    dl_s[li] = dl;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+    for (int c = 0; c < G.S; ++c) {
+      const float p = expf(dot_row<DH>(q, Ks + c * DH) - ls);
+      const float dp = dot_row<DH>(dout, Vs + c * DH);
+      axpy_row<DH>(p * (dp - dl), Ks + c * DH, dq);
+    }
+    store_row<DH>(dqb + li * G.q_seq, dq, G.scale);
+  }
+  __syncthreads();
+  // phase 2: lane = key row -> dk, dv
+  if (active) {
+    float k[DH], v[DH], dk[DH], dv[DH];
+    load_row<DH>(Ks + li * DH, k, 1.0f);
+    load_row<DH>(Vs + li * DH, v, 1.0f);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int r = 0; r < G.S; ++r) {
+      const float p = expf(dot_row<DH>(k, Qs + r * DH) - lse_s[r]);
+      const float dp = dot_row<DH>(v, Ds + r * DH);
+      axpy_row<DH>(p * (dp - dl_s[r]), Qs + r * DH, dk);
+      axpy_row<DH>(p, Ds + r * DH, dv);
+    }
+    store_row<DH>(dqb + li * G.q_seq + G.D, dk, 1.0f);
+    store_row<DH>(dqb + li * G.q_seq + 2 * G.D, dv, 1.0f);
+  }
+}
+
+// ---- any S: one group per 256-thread workgroup, keys (or queries) streamed through LDS chunks ----
+constexpr int ATT_CHUNK = 128;
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+    attn_fwd_general(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
+                     const AttnGeom G) {
+  __shared__ float4 smem4[2 * ATT_CHUNK * DH / 4];
+  float* Ks = reinterpret_cast<float*>(smem4);
+  float* Vs = Ks + ATT_CHUNK * DH;
+  const int tid = threadIdx.x;
+  const int64_t g = blockIdx.x;
+  const int64_t outer = g / G.heads;
+  const int head = (int)(g % G.heads);
+  const float* qb = qkv + outer * G.q_outer + head * DH;
+  for (int q0 = 0; q0 < G.S; q0 += 256) {
+    const int qi = q0 + tid;
+    const bool active = qi < G.S;
+    float q[DH], acc[DH];
+    if (active) load_row<DH>(qb + (int64_t)qi * G.q_seq, q, G.scale);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int c0 = 0; c0 < G.S; c0 += ATT_CHUNK) {
+      const int nrows = min(ATT_CHUNK, G.S - c0);
+      __syncthreads();
+      stage_rows<DH>(qb + G.D + (int64_t)c0 * G.q_seq, G.q_seq, nrows, Ks, tid, 256);
+      stage_rows<DH>(qb + 2 * G.D + (int64_t)c0 * G.q_seq, G.q_seq, nrows, Vs, tid, 256);
+      __syncthreads();
+      if (active) attend_rows<DH>(q, Ks, Vs, nrows, m, l, acc);
+    }
+    if (active) {
+      store_row<DH>(o + outer * G.o_outer + (int64_t)qi * G.o_seq + head * DH, acc, 1.0f / l);
+      if (lse != nullptr) lse[g * G.S + qi] = m + logf(l);
+    }
+  }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+    attn_bwd_general(const float* __restrict__ qkv, const float* __restrict__ o,
+                     const float* __restrict__ d_o, const float* __restrict__ lse,
+                     float* __restrict__ dqkv, const AttnGeom G) {
+  __shared__ float4 smem4[(2 * ATT_CHUNK * DH + 2 * ATT_CHUNK) / 4];
+  float* As = reinterpret_cast<float*>(smem4);  // K chunk (phase 1) / scaled-Q chunk (phase 2)
+  float* Bs = As + ATT_CHUNK * DH;              // V chunk (phase 1) / dO chunk (phase 2)
+  float* lse_s = Bs + ATT_CHUNK * DH;
+  float* dl_s = lse_s + ATT_CHUNK;
+  const int tid = threadIdx.x;
+  const int64_t g = blockIdx.x;
+  const int64_t outer = g / G.heads;
+  const int head = (int)(g % G.heads);
+  const float* qb = qkv + outer * G.q_outer + head * DH;
+  const float* ob = o + outer * G.o_outer + head * DH;
+  const float* dob = d_o + outer * G.o_outer + head * DH;
+  float* dqb = dqkv + outer * G.q_outer + head * DH;
+
+  // phase 1: thread = query row
+  for (int q0 = 0; q0 < G.S; q0 += 256) {
+    const int qi = q0 + tid;
+    const bool active = qi < G.S;
+    float q[DH], dout[DH], dq[DH];
+    float ls = 0.f, dl = 0.f;
+    if (active) {
+      load_row<DH>(qb + (int64_t)qi * G.q_seq, q, G.scale);
+      load_row<DH>(dob + (int64_t)qi * G.o_seq, dout, 1.0f);
+      dl = dot_row<DH>(dout, ob + (int64_t)qi * G.o_seq);
+      ls = lse[g * G.S + qi];
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+    for (int c0 = 0; c0 < G.S; c0 += ATT_CHUNK) {
+      const int nrows = min(ATT_CHUNK, G.S - c0);
+      __syncthreads();
+      stage_rows<DH>(qb + G.D + (int64_t)c0 * G.q_seq, G.q_seq, nrows, As, tid, 256);
+      stage_rows<DH>(qb + 2 * G.D + (int64_t)c0 * G.q_seq, G.q_seq, nrows, Bs, tid, 256);
+      __syncthreads();
+      if (active) {
+        for (int c = 0; c < nrows; ++c) {
+          const float p = expf(dot_row<DH>(q, As + c * DH) - ls);
+          const float dp = dot_row<DH>(dout, Bs + c * DH);
+          axpy_row<DH>(p * (dp - dl), As + c * DH, dq);
+        }
+      }
+    }
+    if (active) store_row<DH>(dqb + (int64_t)qi * G.q_seq, dq, G.scale);
+  }
+  // phase 2: thread = key row
+  for (int k0 = 0; k0 < G.S; k0 += 256) {
+    const int ki = k0 + tid;
+    const bool active = ki < G.S;
+    float k[DH], v[DH], dk[DH], dv[DH];
+    if (active) {
+      load_row<DH>(qb + G.D + (int64_t)ki * G.q_seq, k, 1.0f);
+      load_row<DH>(qb + 2 * G.D + (int64_t)ki * G.q_seq, v, 1.0f);
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int r0 = 0; r0 < G.S; r0 += ATT_CHUNK) {
+      const int nrows = min(ATT_CHUNK, G.S - r0);
+      __syncthreads();
+      stage_rows<DH>(qb + (int64_t)r0 * G.q_seq, G.q_seq, nrows, As, tid, 256, G.scale);
+      stage_rows<DH>(dob + (int64_t)r0 * G.o_seq, G.o_seq, nrows, Bs, tid, 256);
+      if (tid < nrows) lse_s[tid] = lse[g * G.S + r0 + tid];
+      __syncthreads();
+      if (tid < nrows) {
+        float dout[DH];
+        load_row<DH>(Bs + tid * DH, dout, 1.0f);
+        dl_s[tid] = dot_row<DH>(dout, ob + (int64_t)(r0 + tid) * G.o_seq);
+      }
+      __syncthreads();
+      if (active) {
+        for (int r = 0; r < nrows; ++r) {
+          const float p = expf(dot_row<DH>(k, As + r * DH) - lse_s[r]);
+          const float dp = dot_row<DH>(v, Bs + r * DH);
+          axpy_row<DH>(p * (dp - dl_s[r]), As + r * DH, dk);
+          axpy_row<DH>(p, Bs + r * DH, dv);
+        }
+      }
+    }
+    if (active) {
+      store_row<DH>(dqb + (int64_t)ki * G.q_seq + G.D, dk, 1.0f);
+      store_row<DH>(dqb + (int64_t)ki * G.q_seq + 2 * G.D, dv, 1.0f);
+    }
+  }
+}
+
+bool attn_head_dim_supported(int dh) { return dh == 16 || dh == 20 || dh == 32 || dh == 48 || dh == 64; }
+
+#define NRL_DISPATCH_DH(dh, ...)                         \
+  switch (dh) {                                          \
+    case 16: { constexpr int DH = 16; __VA_ARGS__; } break; \
+    case 20: { constexpr int DH = 20; __VA_ARGS__; } break; \
+    case 32: { constexpr int DH = 32; __VA_ARGS__; } break; \
+    case 48: { constexpr int DH = 48; __VA_ARGS__; } break; \
+    case 64: { constexpr int DH = 64; __VA_ARGS__; } break; \
+    default: set_error("unsupported head dim %d", dh); return NRL_E_INVALID; \
+  }
+
+static int check_geom(const AttnGeom& G) {
+  NRL_REQUIRE(G.S > 0 && G.groups >= 0 && G.heads > 0, "bad attention geometry");
+  NRL_REQUIRE(G.D % 4 == 0 && G.q_seq % 4 == 0 && G.q_outer % 4 == 0 && G.o_seq % 4 == 0 &&
+                  G.o_outer % 4 == 0, "attention strides must be multiples of 4 floats");
+  NRL_REQUIRE(G.groups < (1LL << 31), "too many attention groups");
+  return NRL_OK;
+}
+
+int attn_fwd(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream) {
+  NRL_TRY(check_geom(G));
+  if (G.groups == 0) return NRL_OK;
+  NRL_DISPATCH_DH(G.dh, {
+    if (G.S <= 32) {
+      constexpr int GPW = DH <= 32 ? 8 : 4;
+      hipLaunchKernelGGL((attn_fwd_small<DH, GPW>), dim3((unsigned)ceil_div(G.groups, GPW)),
+                         dim3(GPW * 32), 0, stream, qkv, o, lse, G);
+    } else {
+      hipLaunchKernelGGL((attn_fwd_general<DH>), dim3((unsigned)G.groups), dim3(256), 0, stream, qkv,
+                         o, lse, G);
+    }
+  });
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+             const AttnGeom& G, hipStream_t stream) {
+  NRL_TRY(check_geom(G));
+  NRL_REQUIRE(lse != nullptr, "attention backward needs the saved log-sum-exp");
+  if (G.groups == 0) return NRL_OK;
+  NRL_DISPATCH_DH(G.dh, {
+    if (G.S <= 32) {
+      constexpr int GPW = DH <= 32 ? 4 : 2;
+      hipLaunchKernelGGL((attn_bwd_small<DH, GPW>), dim3((unsigned)ceil_div(G.groups, GPW)),
+                         dim3(GPW * 32), 0, stream, qkv, o, d_o, lse, dqkv, G);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_general<DH>), dim3((unsigned)G.groups), dim3(256), 0, stream, qkv,
+                         o, d_o, lse, dqkv, G);
+    }
+  });
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =============================================================================================
+// additive-attention pooling
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+    pool_fwd_kernel(const float* __restrict__ t, const float* __restrict__ q_a,
+                    const float* __restrict__ y, int S, int Q, int D, float* __restrict__ w,
+                    float* __restrict__ out) {
+  extern __shared__ float sm[];  // a[S] then w[S]
+  float* a_s = sm;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g = blockIdx.x;
+  const int64_t row0 = g * S;
+  for (int l = wave; l < S; l += 4) {
+    const float* tr = t + (row0 + l) * Q;
+    float part = 0.f;
+    for (int n = lane; n < Q; n += 64) part = fmaf(tr[n], q_a[n], part);
+    part = wave_sum(part);
+    if (lane == 0) a_s[l] = part;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float mx = -INFINITY;
+    for (int l = lane; l < S; l += 64) mx = fmaxf(mx, a_s[l]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int l = lane; l < S; l += 64) sum += expf(a_s[l] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int l = lane; l < S; l += 64) {
+      const float wl = expf(a_s[l] - mx) * inv;
+      a_s[l] = wl;
+      w[row0 + l] = wl;
+    }
+  }
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < S; ++l) acc = fmaf(a_s[l], y[(row0 + l) * D + d], acc);
+    out[g * D + d] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    pool_bwd_pre_kernel(const float* __restrict__ d_out, const float* __restrict__ y,
+                        const float* __restrict__ w, float* __restrict__ t_dpre,
+                        const float* __restrict__ q_a, float* __restrict__ dq_a, int S, int Q, int D) {
+  extern __shared__ float sm[];  // c[S] -> da[S]
+  float* c_s = sm;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g = blockIdx.x;
+  const int64_t row0 = g * S;
+  const float* dr = d_out + g * D;
+  for (int l = wave; l < S; l += 4) {
+    const float* yr = y + (row0 + l) * D;
+    float part = 0.f;
+    for (int d = lane; d < D; d += 64) part = fmaf(dr[d], yr[d], part);
+    part = wave_sum(part);
+    if (lane == 0) c_s[l] = part;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float dbar = 0.f;
+    for (int l = lane; l < S; l += 64) dbar = fmaf(w[row0 + l], c_s[l], dbar);
+    dbar = wave_sum(dbar);
+    for (int l = lane; l < S; l += 64) c_s[l] = w[row0 + l] * (c_s[l] - dbar);  // da_l
+  }
+  __syncthreads();
+  for (int n = tid; n < Q; n += 256) {
+    const float qn = q_a[n];
+    float accq = 0.f;
+    for (int l = 0; l < S; ++l) {
+      const int64_t idx = (row0 + l) * Q + n;
+      const float tv = t_dpre[idx];
+      const float da = c_s[l];
+      accq = fmaf(da, tv, accq);
+      t_dpre[idx] = da * qn * (1.0f - tv * tv);
+    }
+    atomicAdd(dq_a + n, accq);
+  }
+}
+
+int pool_fwd(const float* t, const float* q_a, const float* y, int64_t groups, int S, int Q, int D,
+             float* w, float* out, hipStream_t stream) {
+  if (groups == 0) return NRL_OK;
+  NRL_REQUIRE(S > 0 && S <= 8192 && groups < (1LL << 31), "pool_fwd: bad shape");
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)groups), dim3(256), S * sizeof(float), stream, t,
+                     q_a, y, S, Q, D, w, out);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int pool_bwd_pre(const float* d_out, const float* y, const float* w, float* t_dpre, const float* q_a,
+                 float* dq_a, int64_t groups, int S, int Q, int D, hipStream_t stream) {
+  if (groups == 0) return NRL_OK;
+  NRL_REQUIRE(S > 0 && S <= 8192 && groups < (1LL << 31), "pool_bwd_pre: bad shape");
+  hipLaunchKernelGGL(pool_bwd_pre_kernel, dim3((unsigned)groups), dim3(256), S * sizeof(float), stream,
+                     d_out, y, w, t_dpre, q_a, dq_a, S, Q, D);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =============================================================================================
+// dense batching (to_dense_batch as an index map) -- float4 granularity, D % 4 == 0
+// =============================================================================================
+__global__ void to_dense_fwd_kernel(const float4* __restrict__ x, const int64_t* __restrict__ offsets,
+                                    int64_t total4, int64_t max_len, int D4, float4* __restrict__ dense) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % D4);
+    const int64_t slot = i / D4;
+    const int64_t b = slot / max_len, h = slot % max_len;
+    const int64_t beg = offsets[b], cnt = offsets[b + 1] - beg;
+    dense[i] = h < cnt ? x[(beg + h) * D4 + d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+__global__ void to_dense_bwd_kernel(const float4* __restrict__ d_dense,
+                                    const int64_t* __restrict__ offsets, int64_t total4,
+                                    int64_t max_len, int D4, float4* __restrict__ d_x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % D4);
+    const int64_t slot = i / D4;
+    const int64_t b = slot / max_len, h = slot % max_len;
+    const int64_t beg = offsets[b], cnt = offsets[b + 1] - beg;
+    if (h < cnt) d_x[(beg + h) * D4 + d4] = d_dense[i];
+  }
+}
+
+static unsigned grid_for(int64_t n, int block) {
+  int64_t b = ceil_div(n, block);
+  return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+int to_dense_fwd(const float* x, const int64_t* offsets, int64_t B, int64_t max_len, int D,
+                 float* dense, hipStream_t stream) {
+  NRL_REQUIRE(D % 4 == 0, "to_dense: dim must be a multiple of 4");
+  const int64_t total4 = B * max_len * (D / 4);
+  if (total4 == 0) return NRL_OK;
+  hipLaunchKernelGGL(to_dense_fwd_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, stream,
+                     (const float4*)x, offsets, total4, max_len, D / 4, (float4*)dense);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int to_dense_bwd(const float* d_dense, const int64_t* offsets, int64_t B, int64_t max_len, int D,
+                 int64_t /*n_rows*/, float* d_x, hipStream_t stream) {
+  NRL_REQUIRE(D % 4 == 0, "to_dense: dim must be a multiple of 4");
+  const int64_t total4 = B * max_len * (D / 4);
+  if (total4 == 0) return NRL_OK;
+  hipLaunchKernelGGL(to_dense_bwd_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, stream,
+                     (const float4*)d_dense, offsets, total4, max_len, D / 4, (float4*)d_x);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =============================================================================================
+// scorer + loss
+// =============================================================================================
+// one wavefront per (b, c): scores[b, c] = <user[b], cand[b, c]>
+__global__ void __launch_bounds__(256)
+    dot_scores_fwd_kernel(const float* __restrict__ user, const float* __restrict__ cand, int64_t BC,
+                          int64_t C, int D, float* __restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= BC) return;
+  const float* u = user + (pair / C) * D;
+  const float* cv = cand + pair * D;
+  float part = 0.f;
+  for (int d = lane; d < D; d += 64) part = fmaf(u[d], cv[d], part);
+  part = wave_sum(part);
+  if (lane == 0) scores[pair] = part;
+}
+
+// thread per (b, d): d_user = sum_c ds * cand; d_cand = ds * user
+__global__ void dot_scores_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ user,
+                                      const float* __restrict__ cand, int64_t B, int64_t C, int D,
+                                      float* __restrict__ d_user, float* __restrict__ d_cand) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int64_t b = i / D;
+  const int d = (int)(i % D);
+  const float u = user[i];
+  float acc = 0.f;
+  for (int64_t c = 0; c < C; ++c) {
+    const float s = ds[b * C + c];
+    const int64_t idx = (b * C + c) * D + d;
+    acc = fmaf(s, cand[idx], acc);
+    d_cand[idx] = s * u;
+  }
+  d_user[i] = acc;
+}
+
+// CrossEntropyLoss with probability targets, mean over rows; one workgroup, deterministic sum
+__global__ void __launch_bounds__(256)
+    ce_kernel(const float* __restrict__ scores, const float* __restrict__ y, int64_t B, int64_t C,
+              float grad_scale, float* __restrict__ loss, float* __restrict__ d_scores) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float local = 0.f;
+  const float invB = 1.0f / (float)B;
+  for (int64_t b = tid; b < B; b += 256) {
+    const float* s = scores + b * C;
+    const float* yy = y + b * C;
+    float mx = -INFINITY;
+    for (int64_t c = 0; c < C; ++c) mx = fmaxf(mx, s[c]);
+    float sum = 0.f, ysum = 0.f;
+    for (int64_t c = 0; c < C; ++c) { sum += expf(s[c] - mx); ysum += yy[c]; }
+    const float lse = mx + logf(sum);
+    float lb = 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      const float logp = s[c] - lse;
+      lb -= yy[c] * logp;
+      if (d_scores != nullptr) d_scores[b * C + c] = (expf(logp) * ysum - yy[c]) * invB * grad_scale;
+    }
+    local += lb;
+  }
+  local = wave_sum(local);
+  if ((tid & 63) == 0) red[tid >> 6] = local;
+  __syncthreads();
+  if (tid == 0) *loss = (red[0] + red[1] + red[2] + red[3]) * invB;
+}
+
+int dot_scores_fwd(const float* user, const float* cand, int64_t B, int64_t C, int D, float* scores,
+                   hipStream_t stream) {
+  const int64_t BC = B * C;
+  if (BC == 0) return NRL_OK;
+  hipLaunchKernelGGL(dot_scores_fwd_kernel, dim3((unsigned)ceil_div(BC, 4)), dim3(256), 0, stream, user,
+                     cand, BC, C, D, scores);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int dot_scores_bwd(const float* d_scores, const float* user, const float* cand, int64_t B, int64_t C,
+                   int D, float* d_user, float* d_cand, hipStream_t stream) {
+  if (B * D == 0) return NRL_OK;
+  hipLaunchKernelGGL(dot_scores_bwd_kernel, dim3((unsigned)ceil_div(B * D, 256)), dim3(256), 0, stream,
+                     d_scores, user, cand, B, C, D, d_user, d_cand);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int ce_loss_fwd_bwd(const float* scores, const float* y, int64_t B, int64_t C, float grad_scale,
+                    float* loss, float* d_scores, hipStream_t stream) {
+  NRL_REQUIRE(B > 0 && C > 0, "ce: empty batch");
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, stream, scores, y, B, C, grad_scale, loss,
+                     d_scores);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =============================================================================================
+// dense Adam (torch _single_tensor_adam arithmetic), HBM-bound: 4 reads + 4 writes per element
+// =============================================================================================
+struct AdamConst {
+  float b1, b2, one_m_b1, one_m_b2, step_size, inv_sqrt_bc2, eps, grad_scale;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, const AdamConst& k) {
+  const float gg = g * k.grad_scale;
+  m = m * k.b1 + k.one_m_b1 * gg;
+  v = v * k.b2 + k.one_m_b2 * gg * gg;
+  const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
+  p = p - k.step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256)
+    adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                float* __restrict__ v, int64_t n, AdamConst k, int zero_grad) {
+  const int64_t n4 = n / 4;
+  float4* p4 = (float4*)p; float4* g4 = (float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    adam_elem(pp.x, gg.x, mm.x, vv.x, k);
+    adam_elem(pp.y, gg.y, mm.y, vv.y, k);
+    adam_elem(pp.z, gg.z, mm.z, vv.z, k);
+    adam_elem(pp.w, gg.w, mm.w, vv.w, k);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+      adam_elem(pp, gg, mm, vv, k);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+      if (zero_grad) g[i] = 0.f;
+    }
+  }
+}
+
+int adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
+              double eps, int64_t step, float grad_scale, int zero_grad, hipStream_t stream) {
+  if (n == 0) return NRL_OK;
+  NRL_REQUIRE(step >= 1, "adam: step is 1-based");
+  NRL_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+              "adam: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  AdamConst k;
+  k.b1 = (float)b1; k.b2 = (float)b2;
+  k.one_m_b1 = (float)(1.0 - b1); k.one_m_b2 = (float)(1.0 - b2);
+  k.step_size = (float)(lr / bc1);
+  k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  k.eps = (float)eps; k.grad_scale = grad_scale;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, stream, p, g, m, v, n, k,
+                     zero_grad);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =============================================================================================
+// embedding gather (bit-exact copy of table rows) and the dropout-mask probe
+// =============================================================================================
+__global__ void gather_kernel(const float4* __restrict__ table, const int64_t* __restrict__ ids,
+                              int64_t total4, int D4, float4* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D4;
+    out[i] = table[ids[row] * D4 + (i % D4)];
+  }
+}
+
+int embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int D, float* out,
+                     hipStream_t stream) {
+  NRL_REQUIRE(D % 4 == 0, "embedding dim must be a multiple of 4");
+  const int64_t total4 = n_ids * (D / 4);
+  if (total4 == 0) return NRL_OK;
+  hipLaunchKernelGGL(gather_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, stream,
+                     (const float4*)table, ids, total4, D / 4, (float4*)out);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+__global__ void dropout_mask_kernel(uint8_t* keep, int64_t n, Dropout d) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    keep[i] = d.mult((uint32_t)i) != 0.0f ? 1 : 0;
+}
+
+int dropout_mask(uint8_t* keep, int64_t n, Dropout d, hipStream_t stream) {
+  if (n == 0) return NRL_OK;
+  NRL_REQUIRE(n < (1LL << 32), "dropout index space is 32-bit");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, keep, n, d);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+}  // namespace nrl

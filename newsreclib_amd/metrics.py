@@ -1,0 +1,54 @@
+"""Epoch-end ranking metrics (AUC, MRR, nDCG@k) over concatenated per-impression scores.
+
+The reference wires torchmetrics ``AUROC``/``RetrievalMRR``/``RetrievalNormalizedDCG`` grouped by an
+``indexes`` vector (nrms_module.py:182-195,380-396).  These run once per epoch, outside the timed
+step, on small vectors; they are host-side bookkeeping in plain torch, vectorised over queries."""
+from typing import Dict, Sequence
+
+import torch
+
+
+def _dense(preds, targets, sizes):
+    B, C = sizes.numel(), int(sizes.max()) if sizes.numel() else 0
+    mask = torch.arange(C, device=preds.device)[None, :] < sizes[:, None]
+    p = preds.new_full((B, C), float("-inf"))
+    t = targets.new_zeros((B, C))
+    p[mask], t[mask] = preds, targets
+    return p, t, mask
+
+
+def ranking_metrics(preds: torch.Tensor, targets: torch.Tensor, cand_news_size: torch.Tensor,
+                    top_k_list: Sequence[int] = (5, 10)) -> Dict[str, float]:
+    sizes = cand_news_size.to(preds.device)
+    p, t, mask = _dense(preds.float(), targets.float(), sizes)
+    order = torch.argsort(p, dim=1, descending=True, stable=True)
+    t_sorted = torch.gather(t, 1, order)
+    ranks = torch.arange(1, p.shape[1] + 1, device=p.device, dtype=torch.float32)[None, :]
+    has_pos = t.sum(1) > 0
+    # MRR: reciprocal rank of the first relevant item, mean over queries with a positive
+    first = torch.where(t_sorted > 0, ranks, torch.full_like(ranks, float("inf"))).min(1).values
+    mrr = (1.0 / first)[has_pos].mean() if has_pos.any() else preds.new_tensor(0.0)
+    out = {"mrr": float(mrr)}
+    disc = 1.0 / torch.log2(ranks + 1.0)
+    ideal = torch.sort(t, dim=1, descending=True).values
+    for k in top_k_list:
+        dcg = (t_sorted[:, :k] * disc[:, :k]).sum(1)
+        idcg = (ideal[:, :k] * disc[:, :k]).sum(1)
+        ndcg = torch.where(idcg > 0, dcg / idcg.clamp_min(1e-12), torch.zeros_like(dcg))
+        out[f"ndcg@{k}"] = float(ndcg[has_pos].mean()) if has_pos.any() else 0.0
+    # global AUROC over all (score, label) pairs, as torchmetrics' binary AUROC without indexes
+    pos, neg = preds[targets > 0], preds[targets <= 0]
+    if pos.numel() and neg.numel():
+        allv = torch.cat([pos, neg])
+        r = torch.empty_like(allv)
+        srt, idx = torch.sort(allv)
+        # average ranks for ties
+        uniq, inv, cnt = torch.unique_consecutive(srt, return_inverse=True, return_counts=True)
+        ends = torch.cumsum(cnt, 0).float()
+        avg_rank = ends - (cnt.float() - 1) / 2
+        r[idx] = avg_rank[inv]
+        auc = (r[: pos.numel()].sum() - pos.numel() * (pos.numel() + 1) / 2) / (pos.numel() * neg.numel())
+        out["auc"] = float(auc)
+    else:
+        out["auc"] = 0.0
+    return out

@@ -1,0 +1,288 @@
+"""``torch.autograd.Function`` wrappers around the C ABI (include/newsreclib_amd.h).
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd tape; every FLOP of the
+path runs in the HIP library.  There is deliberately no eager fallback.
+
+Parameter-gradient convention: when a ``grad_bufs`` tuple is supplied (the persistent ``.grad`` /
+flat data-parallel gradient buffer of each parameter, see ``trainer.FlatParams``), the kernels
+accumulate straight into those buffers and autograd receives ``None`` for the parameters --
+no 84 MB zero-fill + add per encoder call.  Without it the functions return ordinary gradients.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import NrlBlockGrads, NrlBlockParams
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"newsreclib_amd: `{name}` must live on the GPU (got {t.device}); "
+                           "there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"newsreclib_amd: `{name}` must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _block_params(tensors: Sequence[torch.Tensor], heads: int) -> NrlBlockParams:
+    w_in, b_in, w_o, b_o, w_a, b_a, q_a = tensors
+    D, Q = w_o.shape[0], w_a.shape[0]
+    if w_in.shape != (3 * D, D) or b_in.shape != (3 * D,) or b_o.shape != (D,) or \
+            w_a.shape != (Q, D) or b_a.shape != (Q,) or q_a.shape != (Q,):
+        raise ValueError("newsreclib_amd: inconsistent MHSA/additive-attention parameter shapes")
+    return NrlBlockParams(w_in.data_ptr(), b_in.data_ptr(), w_o.data_ptr(), b_o.data_ptr(),
+                          w_a.data_ptr(), b_a.data_ptr(), q_a.data_ptr(), D, heads, Q, 0)
+
+
+def _block_grads(bufs: Sequence[torch.Tensor]) -> NrlBlockGrads:
+    return NrlBlockGrads(*[b.data_ptr() for b in bufs])
+
+
+def _grad_targets(params: Sequence[torch.Tensor], grad_bufs: Optional[Sequence[Optional[torch.Tensor]]]):
+    """-> (buffers the kernels add into, gradients to hand back to autograd)."""
+    bufs, rets = [], []
+    for i, p in enumerate(params):
+        gb = grad_bufs[i] if grad_bufs is not None else None
+        if gb is not None:
+            if gb.shape != p.shape or not gb.is_contiguous() or gb.dtype != torch.float32:
+                raise ValueError("newsreclib_amd: bad grad buffer")
+            bufs.append(gb)
+            rets.append(None)
+        else:
+            z = torch.zeros_like(p)
+            bufs.append(z)
+            rets.append(z)
+    return bufs, rets
+
+
+class NewsEncoderFn(torch.autograd.Function):
+    """``MHSAAddAtt.forward`` (reference text.py:222-236): ids (N, L) -> (N, D)."""
+
+    @staticmethod
+    def forward(ctx, ids, emb, w_in, b_in, w_o, b_o, w_a, b_a, q_a, heads, p_drop, seed, stream0,
+                grad_bufs):
+        lib = _lib.load()
+        ids = _chk(ids, torch.int64, "ids")
+        params = [_chk(t, torch.float32, n) for t, n in zip(
+            (emb, w_in, b_in, w_o, b_o, w_a, b_a, q_a),
+            ("embedding", "in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias",
+             "linear.weight", "linear.bias", "query"))]
+        emb = params[0]
+        if ids.dim() != 2:
+            raise ValueError("newsreclib_amd: token ids must be (num_news, num_tokens)")
+        N, L = ids.shape
+        V, D = emb.shape
+        bp = _block_params(params[1:], heads)
+        save = any(ctx.needs_input_grad)
+        ws_bytes = lib.nrl_news_encoder_workspace_bytes(N, L, D, heads, bp.query_dim)
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=ids.device)
+        out = torch.empty((N, D), dtype=torch.float32, device=ids.device)
+        _lib.check(lib.nrl_news_encoder_fwd(ctypes.byref(bp), emb.data_ptr(), V, ids.data_ptr(), N, L,
+                                            float(p_drop), int(seed), int(stream0), int(save),
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "nrl_news_encoder_fwd")
+        if save:
+            ctx.save_for_backward(ids, *params)
+            ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        ids, *params = ctx.saved_tensors
+        emb = params[0]
+        heads, p_drop, seed, stream0 = ctx.cfg
+        N, L = ids.shape
+        V, D = emb.shape
+        d_out = _chk(d_out, torch.float32, "d_out")
+        bp = _block_params(params[1:], heads)
+        bufs, rets = _grad_targets(params, ctx.grad_bufs)
+        bg = _block_grads(bufs[1:])
+        ws = ctx.ws
+        _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), bufs[0].data_ptr(), V,
+                                            ids.data_ptr(), N, L, p_drop, seed, stream0,
+                                            d_out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "nrl_news_encoder_bwd")
+        ctx.ws = None
+        return (None, *rets, None, None, None, None, None)
+
+
+class UserEncoderFn(torch.autograd.Function):
+    """NRMS ``UserEncoder.forward`` (reference user/nrms.py:32-41): hist (B, H, D) -> (B, D)."""
+
+    @staticmethod
+    def forward(ctx, hist, w_in, b_in, w_o, b_o, w_a, b_a, q_a, heads, grad_bufs):
+        lib = _lib.load()
+        hist = _chk(hist, torch.float32, "hist_news_vector")
+        params = [_chk(t, torch.float32, "user encoder parameter") for t in (w_in, b_in, w_o, b_o, w_a, b_a, q_a)]
+        if hist.dim() != 3:
+            raise ValueError("newsreclib_amd: hist_news_vector must be (batch, history, dim)")
+        B, H, D = hist.shape
+        bp = _block_params(params, heads)
+        if bp.embed_dim != D:
+            raise ValueError("newsreclib_amd: hist feature dim does not match the encoder")
+        save = any(ctx.needs_input_grad)
+        ws_bytes = lib.nrl_user_encoder_workspace_bytes(B, H, D, heads, bp.query_dim)
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=hist.device)
+        out = torch.empty((B, D), dtype=torch.float32, device=hist.device)
+        _lib.check(lib.nrl_user_encoder_fwd(ctypes.byref(bp), hist.data_ptr(), B, H, int(save),
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "nrl_user_encoder_fwd")
+        if save:
+            ctx.save_for_backward(hist, *params)
+            ctx.ws, ctx.heads, ctx.grad_bufs = ws, heads, grad_bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        hist, *params = ctx.saved_tensors
+        B, H, D = hist.shape
+        d_out = _chk(d_out, torch.float32, "d_out")
+        bp = _block_params(params, ctx.heads)
+        bufs, rets = _grad_targets(params, ctx.grad_bufs)
+        bg = _block_grads(bufs)
+        d_hist = torch.empty_like(hist)
+        ws = ctx.ws
+        _lib.check(lib.nrl_user_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), hist.data_ptr(), B, H,
+                                            d_out.data_ptr(), d_hist.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), _stream()), "nrl_user_encoder_bwd")
+        ctx.ws = None
+        return (d_hist, *rets, None, None)
+
+
+class ToDenseBatchFn(torch.autograd.Function):
+    """``to_dense_batch`` values (torch_geometric; nrms_module.py:233,237): (N, D) -> (B, max_len, D)."""
+
+    @staticmethod
+    def forward(ctx, x, offsets, batch_size, max_len):
+        lib = _lib.load()
+        x = _chk(x, torch.float32, "x")
+        offsets = _chk(offsets, torch.int64, "offsets")
+        N, D = x.shape
+        dense = torch.empty((batch_size, max_len, D), dtype=torch.float32, device=x.device)
+        _lib.check(lib.nrl_to_dense_batch_fwd(x.data_ptr(), offsets.data_ptr(), batch_size, max_len, D,
+                                              dense.data_ptr(), _stream()), "nrl_to_dense_batch_fwd")
+        ctx.save_for_backward(offsets)
+        ctx.shape = (N, D, batch_size, max_len)
+        return dense
+
+    @staticmethod
+    def backward(ctx, d_dense):
+        lib = _lib.load()
+        (offsets,) = ctx.saved_tensors
+        N, D, B, max_len = ctx.shape
+        d_dense = _chk(d_dense, torch.float32, "d_dense")
+        d_x = torch.empty((N, D), dtype=torch.float32, device=d_dense.device)
+        _lib.check(lib.nrl_to_dense_batch_bwd(d_dense.data_ptr(), offsets.data_ptr(), B, max_len, D, N,
+                                              d_x.data_ptr(), _stream()), "nrl_to_dense_batch_bwd")
+        return d_x, None, None, None
+
+
+class DotScoresFn(torch.autograd.Function):
+    """``DotProduct.forward`` (click_predictor.py:9-11): user (B, D) x cand (B, C, D) -> (B, C)."""
+
+    @staticmethod
+    def forward(ctx, user, cand):
+        lib = _lib.load()
+        user = _chk(user, torch.float32, "user_vec")
+        cand = _chk(cand, torch.float32, "cand_news_vector")
+        B, C, D = cand.shape
+        scores = torch.empty((B, C), dtype=torch.float32, device=user.device)
+        _lib.check(lib.nrl_dot_scores_fwd(user.data_ptr(), cand.data_ptr(), B, C, D, scores.data_ptr(),
+                                          _stream()), "nrl_dot_scores_fwd")
+        ctx.save_for_backward(user, cand)
+        return scores
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        lib = _lib.load()
+        user, cand = ctx.saved_tensors
+        B, C, D = cand.shape
+        d_scores = _chk(d_scores, torch.float32, "d_scores")
+        d_user, d_cand = torch.empty_like(user), torch.empty_like(cand)
+        _lib.check(lib.nrl_dot_scores_bwd(d_scores.data_ptr(), user.data_ptr(), cand.data_ptr(), B, C, D,
+                                          d_user.data_ptr(), d_cand.data_ptr(), _stream()),
+                   "nrl_dot_scores_bwd")
+        return d_user, d_cand
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """``CrossEntropyLoss()(scores, y_true)`` with float targets (nrms_module.py:287-288)."""
+
+    @staticmethod
+    def forward(ctx, scores, y_true, grad_scale):
+        lib = _lib.load()
+        scores = _chk(scores, torch.float32, "scores")
+        y_true = _chk(y_true, torch.float32, "y_true")
+        B, C = scores.shape
+        loss = torch.empty((), dtype=torch.float32, device=scores.device)
+        d_scores = torch.empty_like(scores)
+        _lib.check(lib.nrl_ce_loss_fwd_bwd(scores.data_ptr(), y_true.data_ptr(), B, C, float(grad_scale),
+                                           loss.data_ptr(), d_scores.data_ptr(), _stream()),
+                   "nrl_ce_loss_fwd_bwd")
+        ctx.save_for_backward(d_scores)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_scores,) = ctx.saved_tensors
+        return d_scores * g, None, None
+
+
+# ---- plain (non-autograd) entry points ----------------------------------------------------------
+def embedding_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    table, ids = _chk(table, torch.float32, "table"), _chk(ids, torch.int64, "ids")
+    out = torch.empty(tuple(ids.shape) + (table.shape[1],), dtype=torch.float32, device=table.device)
+    _lib.check(lib.nrl_embedding_gather(table.data_ptr(), ids.data_ptr(), ids.numel(), table.shape[1],
+                                        out.data_ptr(), _stream()), "nrl_embedding_gather")
+    return out
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    a, w = _chk(a, torch.float32, "a"), _chk(w, torch.float32, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    b = _chk(bias, torch.float32, "bias").data_ptr() if bias is not None else None
+    _lib.check(lib.nrl_linear_fwd(a.data_ptr(), w.data_ptr(), b, M, N, K, c.data_ptr(), _stream()),
+               "nrl_linear_fwd")
+    return c
+
+
+def dropout_mask(n: int, p: float, seed: int, stream: int, device) -> torch.Tensor:
+    lib = _lib.load()
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    _lib.check(lib.nrl_dropout_mask(keep.data_ptr(), n, float(p), int(seed), int(stream), _stream()),
+               "nrl_dropout_mask")
+    return keep
+
+
+def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+               step: int, lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+               grad_scale: float = 1.0, zero_grad: bool = False) -> None:
+    lib = _lib.load()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise ValueError("newsreclib_amd.adam_step_: contiguous float32 GPU tensors required")
+    _lib.check(lib.nrl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
+                                 exp_avg_sq.data_ptr(), param.numel(), lr, betas[0], betas[1], eps,
+                                 int(step), float(grad_scale), int(zero_grad), _stream()), "nrl_adam_step")
+
+
+def offsets_from_sorted_batch(batch: torch.Tensor, batch_size: int) -> torch.Tensor:
+    """Prefix sums of the sorted assignment vector (``rec_dataset.py:289-293``) -> (B + 1,) int64."""
+    counts = torch.bincount(batch, minlength=batch_size)
+    off = torch.zeros(batch_size + 1, dtype=torch.int64, device=batch.device)
+    torch.cumsum(counts, 0, out=off[1:])
+    return off
