@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- NRMS train-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full train step of the hot path over one synthetic MIND-shaped batch that is
+already resident in HBM: forward (history + candidate news encode, user encode, score), CE loss,
+backward, (N > 1: RCCL all-reduce of the flat gradient), dense Adam -- dropout active, fp32.
+Workload at every N (weak scaling): BASELINE.json configs[1], B = 128 impressions per GPU,
+H = 50 clicks, C = 5 candidates, L = 30 tokens, V = 70,000, D = 300, 15 heads, Q = 200.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, VOCAB, L, H, C, D, HEADS, Q, P_DROP, LR = 128, 70_000, 30, 50, 5, 300, 15, 200, 0.2, 1e-4
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= vector) peak
+N_BATCHES = 4                          # distinct pre-generated batches cycled through
+
+
+def build_module(device):
+    from functools import partial
+
+    from newsreclib_amd.nrms_module import NRMSModule
+    torch.manual_seed(42)              # configs/experiment/nrms_mindsmall_pretrainedemb_*.yaml:18
+    emb = torch.randn(VOCAB, D)        # N(0,1) table mirrors data_utils.py:56
+    mod = NRMSModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=["title"],
+        outputs={"train": [], "val": [], "test": []},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False,
+        temperature=None, use_plm=False, pretrained_embeddings_path=None, plm_model=None, frozen_layers=None,
+        embed_dim=D, num_heads=HEADS, query_dim=Q, dropout_probability=P_DROP, top_k_list=[5, 10],
+        num_categ_classes=18, num_sent_classes=3, save_recs=False, recs_fpath=None,
+        optimizer=partial(torch.optim.Adam, lr=LR), scheduler=None, pretrained_embeddings=emb)
+    return mod.to(device)
+
+
+def cpu_baseline(time_budget_s=20.0):
+    """The reference's CPU path, restated (oracle.TorchGraphNRMS: same nn graph as the reference,
+    proven equal to it in tests/test_oracle_golden.py), timed on this box's host cores on a bounded
+    sample of the SAME workload: B=128 train steps (fwd + bwd + torch.optim.Adam, dropout on)."""
+    from newsreclib_amd.synthetic import make_batch
+    from oracle.nrms_oracle import TorchGraphNRMS          # checker/baseline leg only
+    cores = max(1, min(64, (os.cpu_count() or 2) // 2))    # one socket's physical cores, capped
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    model = TorchGraphNRMS(torch.randn(VOCAB, D), D, HEADS, Q, P_DROP).train()
+    opt = torch.optim.Adam(model.parameters(), lr=LR)
+    batch = make_batch(B_PER_GPU, VOCAB, "fixed", seed=1234)
+
+    def step():
+        opt.zero_grad()
+        loss = model.loss(batch)
+        loss.backward()
+        opt.step()
+
+    step()                                                 # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0 < time_budget_s and n < 50):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B_PER_GPU * n / dt, 2), "unit": "impressions/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of the same B=128 workload ({dt:.1f} s), torch {torch.__version__} "
+                      f"CPU, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+
+    from newsreclib_amd import _lib
+    from newsreclib_amd.nrms_module import prepare_batch
+    from newsreclib_amd.synthetic import make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    lib = _lib.load()
+
+    mod = build_module(device)
+    trainer = NRMSTrainer(mod, lr=LR)
+    # impressions shard on the user axis: rank r owns its own B_PER_GPU impressions (seed by rank)
+    batches = [prepare_batch(make_batch(B_PER_GPU, VOCAB, "fixed", seed=1234 + 1000 * i + rank, device=device))
+               for i in range(N_BATCHES)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(batches[i % N_BATCHES])
+    barrier()
+    lib.nrl_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(batches[i % N_BATCHES])
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    lib.nrl_prof_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(flops))
+    lib.nrl_prof_enable(0)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+
+    if rank == 0:
+        value = world * B_PER_GPU * args.steps / dt
+        achieved = (flops.value / (tot_ms.value * 1e-3)) / 1e12 if tot_ms.value > 0 else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_in_proj_fwd.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "impressions/sec (train step) NRMS MINDsmall-shape", "value": round(value, 1),
+            "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDsmall-shaped train step: "
+                                   "B=128/GPU, H=50, C=5, L=30, V=70000, dropout 0.2, Adam lr 1e-4 "
+                                   "(BASELINE.json configs[1])",
+                       "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<2,2,4,4,KCGather,KCPlain,EpiLinear> "
+                                                    "(in-projection with fused embedding gather + dropout)",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                         "traffic": traffic, "launches": launches.value,
+                         "avg_launch_ms": round(tot_ms.value / max(1, launches.value), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

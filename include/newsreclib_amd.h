@@ -75,6 +75,12 @@ typedef struct NrlBlockGrads {
 int nrl_abi_version(void);
 const char* nrl_last_error(void);
 
+/* ---- measurement hook (bench.py "roofline"): HIP-event timing of the dominant kernel, the
+ * in-projection GEMM with the fused embedding gather, recorded on the launch stream.  The ProfScope
+ * only wraps news-encoder forward launches; total_flops sums 2*M*3D*D per launch. */
+int nrl_prof_enable(int32_t on);
+int nrl_prof_read(double* total_ms, int64_t* launches, double* total_flops);
+
 /* ---- dropout keep-mask specification (normative statement: oracle/nrms_oracle.py) ----------
  * keep(i) = lowbias32(i * 0x9E3779B1 + key) >= floor(p * 2^32), i = row * D + col (32-bit).
  * Replaces nn.Dropout at text.py:220,225,230 (torch's RNG stream is not reproducible on device). */

@@ -35,6 +35,8 @@ class NrlBlockGrads(ctypes.Structure):
 SIGNATURES = {
     "nrl_abi_version": (c_int32, []),
     "nrl_last_error": (c_char_p, []),
+    "nrl_prof_enable": (c_int32, [c_int32]),
+    "nrl_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "nrl_dropout_key": (c_uint32, [c_uint64, c_uint32]),
     "nrl_dropout_mask": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_uint32, c_void_p]),
     "nrl_news_encoder_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),

@@ -7,6 +7,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <utility>
+#include <vector>
+
 #include "nrl_gemm.h"
 #include "nrl_kernels.h"
 
@@ -20,6 +23,41 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- optional HIP-event timing of the dominant kernel (bench.py's roofline line) ----------------
+// Events are recorded on the launch stream right around the in-projection GEMM launch (no sync);
+// nrl_prof_read() synchronises the recorded events and sums their elapsed times.
+struct ProfState {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+  double total_ms = 0.0, total_flops = 0.0;
+  int64_t launches = 0;
+};
+static ProfState g_prof;
+
+struct ProfScope {
+  hipStream_t st;
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  bool active;
+  ProfScope(hipStream_t s, double flops) : st(s), active(g_prof.on && flops > 0.0) {
+    if (!active) return;
+    if (!g_prof.pool.empty()) {
+      ev = g_prof.pool.back();
+      g_prof.pool.pop_back();
+    } else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
+      active = false;
+      return;
+    }
+    g_prof.total_flops += flops;
+    g_prof.launches += 1;
+    (void)hipEventRecord(ev.first, st);
+  }
+  ~ProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(ev.second, st);
+    g_prof.pending.push_back(ev);
+  }
+};
 
 // tile shape used by every projection GEMM: 2x2 waves, 4x4 MFMA blocks each -> 128 x 128
 #define NRL_TILE 2, 2, 4, 4
@@ -98,9 +136,12 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
   const int D = s.D, Q = s.Q;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
   // q|k|v = x W_in^T + b_in           (text.py:229 / user/nrms.py:34; torch in-projection)
-  NRL_TRY((launch_gemm<NRL_TILE>(a_in, KCPlain{P->in_proj_weight, D, 3 * D},
-                                 EpiLinear{w.qkv, 3 * D, P->in_proj_bias, 0, nodrop, 3 * D}, s.M, 3 * D,
-                                 D, 1, st)));
+  {
+    ProfScope prof(st, std::is_same<AOp, KCGather>::value ? 2.0 * (double)s.M * 3.0 * D * D : 0.0);
+    NRL_TRY((launch_gemm<NRL_TILE>(a_in, KCPlain{P->in_proj_weight, D, 3 * D},
+                                   EpiLinear{w.qkv, 3 * D, P->in_proj_bias, 0, nodrop, 3 * D}, s.M, 3 * D,
+                                   D, 1, st)));
+  }
   // per (group, head): softmax(q k^T / sqrt(dh)) v
   NRL_TRY(attn_fwd(w.qkv, w.o, save ? w.lse : nullptr, s.geom, st));
   // y = dropout(o W_o^T + b_o)        (out-projection, text.py:229-230)
@@ -185,6 +226,31 @@ extern "C" {
 
 int nrl_abi_version(void) { return NRL_ABI_VERSION; }
 const char* nrl_last_error(void) { return g_err; }
+
+int nrl_prof_enable(int32_t on) {
+  g_prof.on = on != 0;
+  if (on) {
+    g_prof.total_ms = g_prof.total_flops = 0.0;
+    g_prof.launches = 0;
+  }
+  return NRL_OK;
+}
+
+int nrl_prof_read(double* total_ms, int64_t* launches, double* total_flops) {
+  NRL_REQUIRE(total_ms && launches && total_flops, "prof_read: null output");
+  for (auto& ev : g_prof.pending) {
+    NRL_HIP(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    NRL_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+    g_prof.total_ms += ms;
+    g_prof.pool.push_back(ev);
+  }
+  g_prof.pending.clear();
+  *total_ms = g_prof.total_ms;
+  *launches = g_prof.launches;
+  *total_flops = g_prof.total_flops;
+  return NRL_OK;
+}
 
 uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream) { return dropout_key(seed, stream); }
 
