@@ -59,11 +59,17 @@ struct ProfScope {
   }
 };
 
-// tile shape used by every projection GEMM: 2x2 waves, 4x4 MFMA blocks each -> 128 x 128
-#define NRL_TILE 2, 2, 4, 4
+// Tile shapes (WM, WN, TM, TN), picked per GEMM from tools/gemm_probe.hip measurements at the
+// B=128 shapes (profiles/r01_gemm_probe.txt):
+//   NRL_TILE   8 waves, 128 x 160: N = 300 -> 2 column tiles (320), N = 900 -> 6 (960)
+//   NRL_TILE_Q 8 waves, 128 x 208: the additive-attention projection, N = Q = 200 in one tile
+//   NRL_TILE_W 4 waves,  64 x 160: the small weight-gradient outputs (300 x 301, 200 x 301)
+#define NRL_TILE 4, 2, 2, 5
+#define NRL_TILE_Q 8, 1, 1, 13
+#define NRL_TILE_W 2, 2, 2, 5
 
-static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K) {
-  const int64_t tiles = ceil_div(rows_out, 128) * ceil_div(cols_out, 128);
+static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {
+  const int64_t tiles = ceil_div(rows_out, bm) * ceil_div(cols_out, bn);
   int64_t s = ceil_div(2048, tiles);
   const int64_t max_s = ceil_div(K, 8 * GEMM_BK);
   if (s > max_s) s = max_s;
@@ -148,8 +154,13 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
   NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.o, D, s.M}, KCPlain{P->out_proj_weight, D, D},
                                  EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, 1, st)));
   // t = tanh(y W_a^T + b_a)           (attention.py:34)
-  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.y, D, s.M}, KCPlain{P->att_weight, D, Q},
-                                 EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q}, s.M, Q, D, 1, st)));
+  if (Q <= 208) {
+    NRL_TRY((launch_gemm<NRL_TILE_Q>(KCPlain{w.y, D, s.M}, KCPlain{P->att_weight, D, Q},
+                                     EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q}, s.M, Q, D, 1, st)));
+  } else {
+    NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.y, D, s.M}, KCPlain{P->att_weight, D, Q},
+                                   EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q}, s.M, Q, D, 1, st)));
+  }
   // w = softmax(t . q_a); out = sum w y   (attention.py:37-40)
   NRL_TRY(pool_fwd(w.t, P->att_query, w.y, s.pool_groups, s.pool_len, Q, D, w.w, out, st));
   return NRL_OK;
@@ -166,23 +177,23 @@ static int block_bwd_to_dqkv(const NrlBlockParams* P, const NrlBlockGrads* G, co
   NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.t, Q, s.M}, RCPlain{P->att_weight, D, D, 0},
                                  EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, D, Q, 1, st)));
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
-  NRL_TRY((launch_gemm<NRL_TILE>(RCPlain{w.t, Q, Q, 0}, RCPlain{w.y, D, D, 1},
-                                 EpiAtomicWB{G->att_weight, D, G->att_bias, D}, Q, D + 1, s.M,
-                                 wgrad_splits(Q, D + 1, s.M), st)));
+  NRL_TRY((launch_gemm<NRL_TILE_W>(RCPlain{w.t, Q, Q, 0}, RCPlain{w.y, D, D, 1},
+                                   EpiAtomicWB{G->att_weight, D, G->att_bias, D}, Q, D + 1, s.M,
+                                   wgrad_splits(Q, D + 1, s.M, 64, 160), st)));
   // d_o = dy W_o  (written over y, which is dead from here on)
   float* d_o = w.y;
   NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.dy, D, s.M}, RCPlain{P->out_proj_weight, D, D, 0},
                                  EpiStore{d_o, D}, s.M, D, D, 1, st)));
   // dW_o += dy^T o ; db_o += colsum(dy)
-  NRL_TRY((launch_gemm<NRL_TILE>(RCPlain{w.dy, D, D, 0}, RCPlain{w.o, D, D, 1},
-                                 EpiAtomicWB{G->out_proj_weight, D, G->out_proj_bias, D}, D, D + 1, s.M,
-                                 wgrad_splits(D, D + 1, s.M), st)));
+  NRL_TRY((launch_gemm<NRL_TILE_W>(RCPlain{w.dy, D, D, 0}, RCPlain{w.o, D, D, 1},
+                                   EpiAtomicWB{G->out_proj_weight, D, G->out_proj_bias, D}, D, D + 1, s.M,
+                                   wgrad_splits(D, D + 1, s.M, 64, 160), st)));
   // attention backward -> dqkv
   NRL_TRY(attn_bwd(w.qkv, w.o, d_o, w.lse, w.dqkv, s.geom, st));
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
   NRL_TRY((launch_gemm<NRL_TILE>(RCPlain{w.dqkv, 3 * D, 3 * D, 0}, RCPlain{x_rows, D, D, 1},
                                  EpiAtomicWB{G->in_proj_weight, D, G->in_proj_bias, D}, 3 * D, D + 1, s.M,
-                                 wgrad_splits(3 * D, D + 1, s.M), st)));
+                                 wgrad_splits(3 * D, D + 1, s.M, 128, 160), st)));
   return NRL_OK;
 }
 

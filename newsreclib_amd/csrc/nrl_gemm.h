@@ -35,6 +35,12 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 // ---------------------------------------------------------------------------------------------
 // operand accessors
 // ---------------------------------------------------------------------------------------------
+// Loads are UNCONDITIONAL and branch-free: out-of-range rows / k are clamped to a valid address at
+// load time and zeroed by `finish` when the staged registers are written to LDS (after the MFMA
+// phase).  A predicated load makes hipcc wrap it in an exec-mask branch with an immediate
+// `s_waitcnt vmcnt(0)`, which serialises the whole memory latency into the k-loop (measured:
+// -13 % GEMM throughput).
+//
 // rows x K matrix, K contiguous (row-major activations, nn.Linear weights)
 struct KCPlain {
   static constexpr int kLayout = SRC_KC;
@@ -43,10 +49,17 @@ struct KCPlain {
   int64_t rows;
   struct State {
     const float* ptr;
+    bool ok;
   };
-  __device__ __forceinline__ State init(int64_t r) const { return State{r < rows ? p + r * ld : nullptr}; }
-  __device__ __forceinline__ float4 load(const State& s, int64_t /*r*/, int k, int kend, bool /*primary*/) const {
-    return (s.ptr != nullptr && k < kend) ? *reinterpret_cast<const float4*>(s.ptr + k) : f4zero();
+  __device__ __forceinline__ State init(int64_t r) const {
+    const bool ok = r < rows;
+    return State{p + (ok ? r : 0) * ld, ok};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
+    return *reinterpret_cast<const float4*>(s.ptr + (k < K ? k : K - 4));
+  }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
+    if (!s.ok || k >= kend) v = f4zero();
   }
 };
 
@@ -63,13 +76,21 @@ struct KCGather {
   float* save;  // (rows, dim) or nullptr
   struct State {
     const float* ptr;
+    bool ok;
   };
   __device__ __forceinline__ State init(int64_t r) const {
-    return State{r < rows ? table + ids[r] * (int64_t)dim : nullptr};
+    const bool ok = r < rows;
+    return State{table + ids[ok ? r : 0] * (int64_t)dim, ok};
   }
-  __device__ __forceinline__ float4 load(const State& s, int64_t r, int k, int kend, bool primary) const {
-    if (s.ptr == nullptr || k >= kend) return f4zero();
-    float4 v = *reinterpret_cast<const float4*>(s.ptr + k);
+  __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
+    return *reinterpret_cast<const float4*>(s.ptr + (k < K ? k : K - 4));
+  }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t r, int k, int kend,
+                                         bool primary) const {
+    if (!s.ok || k >= kend) {
+      v = f4zero();
+      return;
+    }
     if (drop.thresh != 0u) {
       const uint32_t idx = (uint32_t)r * (uint32_t)dim + (uint32_t)k;
       v.x *= drop.mult(idx);
@@ -78,7 +99,6 @@ struct KCGather {
       v.w *= drop.mult(idx + 3);
     }
     if (save != nullptr && primary) *reinterpret_cast<float4*>(save + r * (int64_t)dim + k) = v;
-    return v;
   }
 };
 
@@ -91,11 +111,14 @@ struct RCPlain {
   int64_t rows;
   int ones;
   struct State {};  // no per-row state (keeps the kernel's staging arrays uniform)
-  __device__ __forceinline__ float4 load(int64_t k, int64_t r, int64_t kend) const {
-    if (k >= kend) return f4zero();
-    if (r < rows) return *reinterpret_cast<const float4*>(p + k * ld + r);
-    if (ones && r == rows) return make_float4(1.f, 0.f, 0.f, 0.f);
-    return f4zero();
+  __device__ __forceinline__ float4 load(int64_t k, int64_t r, int64_t K) const {
+    return *reinterpret_cast<const float4*>(p + (k < K ? k : K - 1) * ld + (r < rows ? r : rows - 4));
+  }
+  __device__ __forceinline__ void finish(float4& v, int64_t k, int64_t r, int64_t kend) const {
+    if (k >= kend)
+      v = f4zero();
+    else if (r >= rows)
+      v = (ones && r == rows) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
   }
 };
 
@@ -170,7 +193,6 @@ struct EpiScatter {
     atomicAdd(d_table + id * (int64_t)dim + n, v);
   }
 };
-
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
@@ -179,22 +201,29 @@ struct LdsLd {
   static constexpr int value = (ROWS + 31) / 32 * 32 + 16;  // == 16 (mod 32): conflict-free b32 reads
 };
 
-template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
+// ABL: ablation bits for tools/gemm_probe.hip only (1 no barrier, 2 no LDS stores, 4 no global
+// loads, 8 no fragment reads in the loop); product code always uses 0.
+template <int WM, int WN, int TM, int TN, int BK, class AOp, class BOp, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(WM* WN * 64)
     gemm_f32_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N,
                     const int64_t K, const int tiles_n, const int64_t tiles_total,
                     const int64_t k_per_split) {
   constexpr int NT = WM * WN * 64;
-  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = GEMM_BK;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int CPK = BK / 4;  // float4 chunks per row of a k-contiguous tile
   constexpr int LDA = LdsLd<BM>::value, LDB = LdsLd<BN>::value;
-  constexpr int NCH_A = (BM * BK / 4 + NT - 1) / NT;
-  constexpr int NCH_B = (BN * BK / 4 + NT - 1) / NT;
+  constexpr int NCH_A = (BM * CPK + NT - 1) / NT;
+  constexpr int NCH_B = (BN * CPK + NT - 1) / NT;
+  static_assert(BK % 4 == 0 && BM % 4 == 0 && BN % 4 == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
   float* const As = smem;
   float* const Bs = smem + 2 * BK * LDA;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  // readfirstlane makes the wave index (and everything derived from it) provably wave-uniform,
+  // so the block-validity tests below compile to scalar branches instead of exec-mask juggling
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
 
@@ -215,12 +244,13 @@ __global__ void __launch_bounds__(WM* WN * 64)
   if (kbeg >= kend) return;
   const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
 
-  // which of this wave's 16x16 blocks hold any valid output (wave-uniform)
+  // how many of this wave's 16x16 blocks hold any valid output (wave-uniform scalars)
   int nvi = 0, nvj = 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) nvi += (m0 + (wm * TM + i) * 16 < M) ? 1 : 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) nvj += (n0 + (wn * TN + j) * 16 < N) ? 1 : 0;
+  const bool full = (nvi == TM) && (nvj == TN);
 
   // per-thread staging assignment (fixed across k-tiles)
   typename AOp::State sa[NCH_A];
@@ -229,49 +259,52 @@ __global__ void __launch_bounds__(WM* WN * 64)
 #pragma unroll
     for (int c = 0; c < NCH_A; ++c) {
       const int ch = tid + c * NT;
-      sa[c] = A.init(ch < BM * 4 ? m0 + (ch >> 2) : (int64_t)1 << 60);
+      sa[c] = A.init(ch < BM * CPK ? m0 + ch / CPK : (int64_t)1 << 60);
     }
   }
   if constexpr (BOp::kLayout == SRC_KC) {
 #pragma unroll
     for (int c = 0; c < NCH_B; ++c) {
       const int ch = tid + c * NT;
-      sb[c] = B.init(ch < BN * 4 ? (int64_t)n0 + (ch >> 2) : (int64_t)1 << 60);
+      sb[c] = B.init(ch < BN * CPK ? (int64_t)n0 + ch / CPK : (int64_t)1 << 60);
     }
   }
 
   float4 ra[NCH_A], rb[NCH_B];
-  auto load_tiles = [&](int64_t k0) {
+  auto load_tiles = [&](int64_t k0) {  // raw, unconditional global loads: nothing here waits
 #pragma unroll
     for (int c = 0; c < NCH_A; ++c) {
       const int ch = tid + c * NT;
       if constexpr (AOp::kLayout == SRC_KC) {
-        ra[c] = A.load(sa[c], m0 + (ch >> 2), (int)(k0 + 4 * (ch & 3)), (int)kend, primary);
+        ra[c] = A.load(sa[c], (int)(k0 + 4 * (ch % CPK)), (int)K);
       } else {
         constexpr int CPR = BM / 4;
-        ra[c] = (ch < BK * CPR) ? A.load(k0 + ch / CPR, m0 + 4 * (ch % CPR), kend) : f4zero();
+        const int chc = ch < BK * CPR ? ch : BK * CPR - 1;
+        ra[c] = A.load(k0 + chc / CPR, m0 + 4 * (chc % CPR), K);
       }
     }
 #pragma unroll
     for (int c = 0; c < NCH_B; ++c) {
       const int ch = tid + c * NT;
       if constexpr (BOp::kLayout == SRC_KC) {
-        rb[c] = B.load(sb[c], (int64_t)n0 + (ch >> 2), (int)(k0 + 4 * (ch & 3)), (int)kend, false);
+        rb[c] = B.load(sb[c], (int)(k0 + 4 * (ch % CPK)), (int)K);
       } else {
         constexpr int CPR = BN / 4;
-        rb[c] = (ch < BK * CPR) ? B.load(k0 + ch / CPR, (int64_t)n0 + 4 * (ch % CPR), kend) : f4zero();
+        const int chc = ch < BK * CPR ? ch : BK * CPR - 1;
+        rb[c] = B.load(k0 + chc / CPR, (int64_t)n0 + 4 * (chc % CPR), K);
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, int64_t k0) {  // masking / post-load transform + LDS image
     float* as = As + buf * BK * LDA;
     float* bs = Bs + buf * BK * LDB;
 #pragma unroll
     for (int c = 0; c < NCH_A; ++c) {
       const int ch = tid + c * NT;
       if constexpr (AOp::kLayout == SRC_KC) {
-        if (ch < BM * 4) {
-          const int row = ch >> 2, kc = (ch & 3) * 4;
+        if (ch < BM * CPK) {
+          const int row = ch / CPK, kc = (ch % CPK) * 4;
+          A.finish(ra[c], sa[c], m0 + row, (int)(k0 + kc), (int)kend, primary);
           as[(kc + 0) * LDA + row] = ra[c].x;
           as[(kc + 1) * LDA + row] = ra[c].y;
           as[(kc + 2) * LDA + row] = ra[c].z;
@@ -279,15 +312,19 @@ __global__ void __launch_bounds__(WM* WN * 64)
         }
       } else {
         constexpr int CPR = BM / 4;
-        if (ch < BK * CPR) *reinterpret_cast<float4*>(as + (ch / CPR) * LDA + 4 * (ch % CPR)) = ra[c];
+        if (ch < BK * CPR) {
+          A.finish(ra[c], k0 + ch / CPR, m0 + 4 * (ch % CPR), kend);
+          *reinterpret_cast<float4*>(as + (ch / CPR) * LDA + 4 * (ch % CPR)) = ra[c];
+        }
       }
     }
 #pragma unroll
     for (int c = 0; c < NCH_B; ++c) {
       const int ch = tid + c * NT;
       if constexpr (BOp::kLayout == SRC_KC) {
-        if (ch < BN * 4) {
-          const int row = ch >> 2, kc = (ch & 3) * 4;
+        if (ch < BN * CPK) {
+          const int row = ch / CPK, kc = (ch % CPK) * 4;
+          B.finish(rb[c], sb[c], (int64_t)n0 + row, (int)(k0 + kc), (int)kend, false);
           bs[(kc + 0) * LDB + row] = rb[c].x;
           bs[(kc + 1) * LDB + row] = rb[c].y;
           bs[(kc + 2) * LDB + row] = rb[c].z;
@@ -295,7 +332,10 @@ __global__ void __launch_bounds__(WM* WN * 64)
         }
       } else {
         constexpr int CPR = BN / 4;
-        if (ch < BK * CPR) *reinterpret_cast<float4*>(bs + (ch / CPR) * LDB + 4 * (ch % CPR)) = rb[c];
+        if (ch < BK * CPR) {
+          B.finish(rb[c], k0 + ch / CPR, (int64_t)n0 + 4 * (ch % CPR), kend);
+          *reinterpret_cast<float4*>(bs + (ch / CPR) * LDB + 4 * (ch % CPR)) = rb[c];
+        }
       }
     }
   };
@@ -306,39 +346,87 @@ __global__ void __launch_bounds__(WM* WN * 64)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Software pipeline: double-buffered LDS, register-staged global loads issued one k-tile ahead so
+  // the HBM/L2 latency sits under the MFMAs; one barrier per k-tile.
+  // Default order: loads of tile t+1 at the top of iteration t, their LDS write at the bottom of the
+  // SAME iteration (staging registers are not loop-carried, so hipcc inserts no early vmcnt wait).
+  // ABL & 16 selects the prefetch-distance-2 order (write at the top of the next iteration), which
+  // measured ~10 % slower because hipcc copies the loop-carried staging registers right after the
+  // loads and waits for them there.
+  constexpr bool kDist2 = (ABL & 16) != 0;
   load_tiles(kbeg);
-  store_tiles(0);
+  store_tiles(0, kbeg);
+  if (kDist2 && ntiles > 1) load_tiles(kbeg + BK);
   __syncthreads();
 
-  for (int tt = 0; tt < ntiles; ++tt) {
-    const int buf = tt & 1;
-    const int64_t k0 = kbeg + (int64_t)tt * BK;
-    if (tt + 1 < ntiles) load_tiles(k0 + BK);  // global loads in flight under the MFMAs below
+  // Two copies of the k-loop, selected once per wave: interior waves (every block valid) run a
+  // branch-free MFMA stream; edge waves test the (scalar) block counts.
+  auto k_loop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    for (int tt = 0; tt < ntiles; ++tt) {
+      const int buf = tt & 1;
+      const int64_t k0 = kbeg + (int64_t)tt * BK;
+      if constexpr (kDist2) {
+        if constexpr (ABL & 2) {
+#pragma unroll
+          for (int c = 0; c < NCH_A; ++c) asm volatile("" ::"v"(ra[c].x), "v"(ra[c].y), "v"(ra[c].z), "v"(ra[c].w));
+#pragma unroll
+          for (int c = 0; c < NCH_B; ++c) asm volatile("" ::"v"(rb[c].x), "v"(rb[c].y), "v"(rb[c].z), "v"(rb[c].w));
+        } else {
+          if (tt + 1 < ntiles) store_tiles(buf ^ 1, k0 + BK);
+        }
+        if constexpr (!(ABL & 4)) {
+          if (tt + 2 < ntiles) load_tiles(k0 + 2 * BK);
+        }
+      } else {
+        if (tt + 1 < ntiles) load_tiles(k0 + BK);
+      }
 
-    const float* as = As + buf * BK * LDA + (wm * TM * 16 + l15);
-    const float* bs = Bs + buf * BK * LDB + (wn * TN * 16 + l15);
+      const float* as = As + buf * BK * LDA + (wm * TM * 16 + l15);
+      const float* bs = Bs + buf * BK * LDB + (wn * TN * 16 + l15);
+      // fragments are double-buffered in registers: the ds_reads of k-step s+1 are issued before
+      // the MFMAs of k-step s.  A partial last k-tile is zero-filled by the loaders, so every tile
+      // runs all BK/4 k-steps branch-free (K = 300 costs 76 instead of 75 steps).
+      float a[2][TM], b[2][TN];
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      if (k0 + 4 * ks < kend) {
-        float a[TM], b[TN];
+      for (int i = 0; i < TM; ++i) a[0][i] = as[g * LDA + i * 16];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = as[(4 * ks + g) * LDA + i * 16];
+      for (int j = 0; j < TN; ++j) b[0][j] = bs[g * LDB + j * 16];
+      if constexpr (ABL & 8) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = bs[(4 * ks + g) * LDB + j * 16];
+        for (int i = 0; i < TM; ++i) a[1][i] = a[0][i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[1][j] = b[0][j];
+      }
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        if (ks + 1 < BK / 4 && !(ABL & 8)) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = as[(4 * (ks + 1) + g) * LDA + i * 16];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = bs[(4 * (ks + 1) + g) * LDB + j * 16];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          if (i < nvi) {
+          if (FULL || i < nvi) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              if (j < nvj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+              if (FULL || j < nvj)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
             }
           }
         }
       }
+      if constexpr (!kDist2) {
+        if (tt + 1 < ntiles) store_tiles(buf ^ 1, k0 + BK);
+      }
+      if constexpr (!(ABL & 1)) __syncthreads();
     }
-    if (tt + 1 < ntiles) store_tiles(buf ^ 1);
-    __syncthreads();
-  }
+  };
+  if (full)
+    k_loop(std::true_type{});
+  else
+    k_loop(std::false_type{});
 
   // epilogue: lane holds C[row = 4g + r][col = l15] of each block
 #pragma unroll
@@ -356,7 +444,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
 }
 
 // host launcher.  `splits` > 1 partitions K over blockIdx.y (epilogue must accumulate atomically).
-template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
+template <int WM, int WN, int TM, int TN, int BK = GEMM_BK, int ABL = 0, class AOp, class BOp, class Epi>
 int launch_gemm(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, int64_t K, int splits,
                 hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -365,11 +453,11 @@ int launch_gemm(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, in
   const int tiles_n = (int)ceil_div(N, BN);
   const int64_t tiles_total = tiles_m * tiles_n;
   if (splits < 1) splits = 1;
-  int64_t kps = ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK;
+  int64_t kps = ceil_div(ceil_div(K, splits), BK) * BK;
   splits = (int)ceil_div(K, kps);
   NRL_REQUIRE(tiles_total < (1LL << 31) && splits < 65536, "gemm grid too large");
   dim3 grid((unsigned)tiles_total, (unsigned)splits, 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AOp, BOp, Epi>), grid, dim3(WM * WN * 64), 0,
+  hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, BK, AOp, BOp, Epi, ABL>), grid, dim3(WM * WN * 64), 0,
                      stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps);
   NRL_LAUNCH_CHECK();
   return NRL_OK;

@@ -145,15 +145,16 @@ __global__ void __launch_bounds__(GPW * 32)
     attn_bwd_small(const float* __restrict__ qkv, const float* __restrict__ o,
                    const float* __restrict__ d_o, const float* __restrict__ lse,
                    float* __restrict__ dqkv, const AttnGeom G) {
-  __shared__ float4 smem4[GPW * (4 * 32 * DH + 64) / 4];
+  // LDS per group: two row buffers (K,V in phase 1; scaled Q, dO in phase 2) + row statistics.
+  // Re-using the buffers across the phases halves the footprint -> twice the resident waves.
+  constexpr int PER = 2 * 32 * DH + 64;
+  __shared__ float4 smem4[GPW * PER / 4];
   const int tid = threadIdx.x, li = tid & 31, grp = tid >> 5;
   const int64_t g = (int64_t)blockIdx.x * GPW + grp;
   const bool gvalid = g < G.groups;
-  float* Ks = reinterpret_cast<float*>(smem4) + grp * (4 * 32 * DH + 64);
-  float* Vs = Ks + 32 * DH;
-  float* Qs = Vs + 32 * DH;   // scaled q rows
-  float* Ds = Qs + 32 * DH;   // dO rows
-  float* lse_s = Ds + 32 * DH;
+  float* Ra = reinterpret_cast<float*>(smem4) + grp * PER;
+  float* Rb = Ra + 32 * DH;
+  float* lse_s = Rb + 32 * DH;
   float* dl_s = lse_s + 32;
   const int64_t outer = gvalid ? g / G.heads : 0;
   const int head = gvalid ? (int)(g % G.heads) : 0;
@@ -161,19 +162,18 @@ __global__ void __launch_bounds__(GPW * 32)
   const float* ob = o + outer * G.o_outer + head * DH;
   const float* dob = d_o + outer * G.o_outer + head * DH;
   float* dqb = dqkv + outer * G.q_outer + head * DH;
+  const bool active = gvalid && li < G.S;
   if (gvalid) {
-    stage_rows<DH>(qb, G.q_seq, G.S, Qs, li, 32, G.scale);
-    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ks, li, 32);
-    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Vs, li, 32);
-    stage_rows<DH>(dob, G.o_seq, G.S, Ds, li, 32);
+    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ra, li, 32);      // K
+    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Rb, li, 32);  // V
   }
   __syncthreads();
-  const bool active = gvalid && li < G.S;
   // phase 1: lane = query row -> dq, and the row statistics phase 2 needs
+  float k[DH], v[DH];
   if (active) {
     float q[DH], dout[DH], dq[DH];
-    load_row<DH>(Qs + li * DH, q, 1.0f);
-    load_row<DH>(Ds + li * DH, dout, 1.0f);
+    load_row<DH>(qb + li * G.q_seq, q, G.scale);
+    load_row<DH>(dob + li * G.o_seq, dout, 1.0f);
     const float dl = dot_row<DH>(dout, ob + li * G.o_seq);  // rowsum(dO * O) = rowsum(P * dP)
     const float ls = lse[g * G.S + li];
     lse_s[li] = ls;
@@ -181,25 +181,30 @@ __global__ void __launch_bounds__(GPW * 32)
 #pragma unroll
     for (int d = 0; d < DH; ++d) dq[d] = 0.f;
     for (int c = 0; c < G.S; ++c) {
-      const float p = expf(dot_row<DH>(q, Ks + c * DH) - ls);
-      const float dp = dot_row<DH>(dout, Vs + c * DH);
-      axpy_row<DH>(p * (dp - dl), Ks + c * DH, dq);
+      const float p = expf(dot_row<DH>(q, Ra + c * DH) - ls);
+      const float dp = dot_row<DH>(dout, Rb + c * DH);
+      axpy_row<DH>(p * (dp - dl), Ra + c * DH, dq);
     }
     store_row<DH>(dqb + li * G.q_seq, dq, G.scale);
+    load_row<DH>(Ra + li * DH, k, 1.0f);  // this lane's key/value rows for phase 2
+    load_row<DH>(Rb + li * DH, v, 1.0f);
+  }
+  __syncthreads();
+  if (gvalid) {
+    stage_rows<DH>(qb, G.q_seq, G.S, Ra, li, 32, G.scale);  // scaled Q
+    stage_rows<DH>(dob, G.o_seq, G.S, Rb, li, 32);          // dO
   }
   __syncthreads();
   // phase 2: lane = key row -> dk, dv
   if (active) {
-    float k[DH], v[DH], dk[DH], dv[DH];
-    load_row<DH>(Ks + li * DH, k, 1.0f);
-    load_row<DH>(Vs + li * DH, v, 1.0f);
+    float dk[DH], dv[DH];
 #pragma unroll
     for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
     for (int r = 0; r < G.S; ++r) {
-      const float p = expf(dot_row<DH>(k, Qs + r * DH) - lse_s[r]);
-      const float dp = dot_row<DH>(v, Ds + r * DH);
-      axpy_row<DH>(p * (dp - dl_s[r]), Qs + r * DH, dk);
-      axpy_row<DH>(p, Ds + r * DH, dv);
+      const float p = expf(dot_row<DH>(k, Ra + r * DH) - lse_s[r]);
+      const float dp = dot_row<DH>(v, Rb + r * DH);
+      axpy_row<DH>(p * (dp - dl_s[r]), Ra + r * DH, dk);
+      axpy_row<DH>(p, Rb + r * DH, dv);
     }
     store_row<DH>(dqb + li * G.q_seq + G.D, dk, 1.0f);
     store_row<DH>(dqb + li * G.q_seq + 2 * G.D, dv, 1.0f);
@@ -377,7 +382,7 @@ int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* ls
   if (G.groups == 0) return NRL_OK;
   NRL_DISPATCH_DH(G.dh, {
     if (G.S <= 32) {
-      constexpr int GPW = DH <= 32 ? 4 : 2;
+      constexpr int GPW = DH <= 32 ? 8 : 4;
       hipLaunchKernelGGL((attn_bwd_small<DH, GPW>), dim3((unsigned)ceil_div(G.groups, GPW)),
                          dim3(GPW * 32), 0, stream, qkv, o, d_o, lse, dqkv, G);
     } else {

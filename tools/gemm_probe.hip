@@ -1,0 +1,177 @@
+// Tuning probe (not product code): times the fp32-MFMA GEMM template at the NRMS shapes for
+// several tile configurations inside one process (interleaved rounds), prints TFLOP/s.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics tools/gemm_probe.hip -o gpurun_out/gemm_probe
+#include <stdarg.h>
+
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../newsreclib_amd/csrc/nrl_gemm.h"
+
+namespace nrl {
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "\n");
+}
+}  // namespace nrl
+using namespace nrl;
+
+#define CK(x)                                                      \
+  do {                                                             \
+    hipError_t e = (x);                                            \
+    if (e != hipSuccess) {                                         \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));       \
+      exit(1);                                                     \
+    }                                                              \
+  } while (0)
+
+struct Bufs {
+  float *a, *w, *c, *bias, *tbl;
+  int64_t* ids;
+};
+
+template <int WM, int WN, int TM, int TN, int BK>
+int run_nt(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {
+  return launch_gemm<WM, WN, TM, TN, BK>(KCPlain{b.a, K, M}, KCPlain{b.w, K, N},
+                                         EpiLinear{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N}, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN, int BK>
+int run_gather(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {
+  return launch_gemm<WM, WN, TM, TN, BK>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a},
+                                         KCPlain{b.w, K, N},
+                                         EpiLinear{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N}, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN, int BK>
+int run_nn(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {  // dgrad: A (M,K), W as (K,N)
+  return launch_gemm<WM, WN, TM, TN, BK>(KCPlain{b.a, K, M}, RCPlain{b.w, N, N, 0}, EpiStore{b.c, N}, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN, int BK>
+int run_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {  // wgrad: dW(I,J) = dY(Mr,I)^T X(Mr,J)
+  const int64_t tiles = ceil_div(I, WM * TM * 16) * ceil_div(J + 1, WN * TN * 16);
+  int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(2048, tiles), ceil_div(Mr, 8 * BK)));
+  return launch_gemm<WM, WN, TM, TN, BK>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
+                                         EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
+}
+
+struct EpiNull {  // keeps the accumulators alive, writes nothing
+  __device__ __forceinline__ void operator()(int64_t, int, float v) const { asm volatile("" ::"v"(v)); }
+};
+template <int ABL, bool NOEPI>
+int run_nn_abl(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {
+  if (NOEPI)
+    return launch_gemm<4, 2, 2, 5, 16, ABL>(KCPlain{b.a, K, M}, RCPlain{b.w, N, N, 0}, EpiNull{}, M, N, K, 1, st);
+  return launch_gemm<4, 2, 2, 5, 16, ABL>(KCPlain{b.a, K, M}, RCPlain{b.w, N, N, 0}, EpiStore{b.c, N}, M, N, K, 1, st);
+}
+
+struct Case {
+  std::string name;
+  double flops;
+  std::function<int(hipStream_t)> fn;
+};
+
+int main(int argc, char** argv) {
+  const int64_t M = 211200;  // B=128: 7040 news x 30 tokens
+  const int V = 70000, D = 300;
+  Bufs b;
+  CK(hipMalloc(&b.a, (size_t)M * 912 * 4));
+  CK(hipMalloc(&b.w, (size_t)M * 304 * 4));
+  CK(hipMalloc(&b.c, (size_t)M * 912 * 4));
+  CK(hipMalloc(&b.bias, 4096 * 4));
+  CK(hipMalloc(&b.tbl, (size_t)V * D * 4));
+  CK(hipMalloc(&b.ids, (size_t)M * 8));
+  {
+    std::vector<float> h((size_t)M * 912);
+    uint32_t s = 12345;
+    for (auto& x : h) { s = s * 1664525u + 1013904223u; x = ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    CK(hipMemcpy(b.a, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b.w, h.data(), (size_t)M * 304 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b.tbl, h.data(), (size_t)V * D * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b.bias, h.data(), 4096 * 4, hipMemcpyHostToDevice));
+    std::vector<int64_t> ids(M);
+    for (auto& x : ids) { s = s * 1664525u + 1013904223u; x = (s >> 4) % V; }
+    CK(hipMemcpy(b.ids, ids.data(), ids.size() * 8, hipMemcpyHostToDevice));
+  }
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  std::vector<Case> cases;
+#define ADD_CFG(tag, WM, WN, TM, TN, BK)                                                                    \
+  cases.push_back({std::string("gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                       \
+                   [=](hipStream_t s) { return run_gather<WM, WN, TM, TN, BK>(b, M, 900, 300, s); }});       \
+  cases.push_back({std::string("nt_outproj  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                       \
+                   [=](hipStream_t s) { return run_nt<WM, WN, TM, TN, BK>(b, M, 300, 300, s); }});           \
+  cases.push_back({std::string("nt_addatt   N=200 K=300 ") + tag, 2.0 * M * 200 * 300,                       \
+                   [=](hipStream_t s) { return run_nt<WM, WN, TM, TN, BK>(b, M, 200, 300, s); }});           \
+  cases.push_back({std::string("nn_dgrad_in N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                       \
+                   [=](hipStream_t s) { return run_nn<WM, WN, TM, TN, BK>(b, M, 300, 900, s); }});           \
+  cases.push_back({std::string("nn_dgrad_o  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                       \
+                   [=](hipStream_t s) { return run_nn<WM, WN, TM, TN, BK>(b, M, 300, 300, s); }});           \
+  cases.push_back({std::string("tn_wgrad_in 900x300     ") + tag, 2.0 * M * 900 * 300,                       \
+                   [=](hipStream_t s) { return run_tn<WM, WN, TM, TN, BK>(b, M, 900, 300, s); }});           \
+  cases.push_back({std::string("tn_wgrad_o  300x300     ") + tag, 2.0 * M * 300 * 300,                       \
+                   [=](hipStream_t s) { return run_tn<WM, WN, TM, TN, BK>(b, M, 300, 300, s); }});           \
+  cases.push_back({std::string("tn_wgrad_a  200x300     ") + tag, 2.0 * M * 200 * 300,                       \
+                   [=](hipStream_t s) { return run_tn<WM, WN, TM, TN, BK>(b, M, 200, 300, s); }});           \
+  cases.push_back({std::string("nn_dgrad_a  N=300 K=200 ") + tag, 2.0 * M * 300 * 200,                       \
+                   [=](hipStream_t s) { return run_nn<WM, WN, TM, TN, BK>(b, M, 300, 200, s); }});
+
+  ADD_CFG("4x2w 2x5b bk16 (128x160 8w)", 4, 2, 2, 5, 16)
+  ADD_CFG("4x2w 2x5b bk32 (128x160 8w)", 4, 2, 2, 5, 32)
+  ADD_CFG("8x1w 1x13b bk16 (128x208 8w)", 8, 1, 1, 13, 16)
+  ADD_CFG("4x2w 2x7b bk16 (128x224 8w)", 4, 2, 2, 7, 16)
+  ADD_CFG("2x4w 4x3b bk16 (128x192 8w)", 2, 4, 4, 3, 16)
+  ADD_CFG("2x4w 3x5b bk16 (96x320 8w)", 2, 4, 3, 5, 16)
+  ADD_CFG("4x4w 2x5b bk16 (128x320 16w)", 4, 4, 2, 5, 16)
+  ADD_CFG("2x2w 2x5b bk16 (64x160 4w)", 2, 2, 2, 5, 16)
+  ADD_CFG("4x2w 1x5b bk16 (64x160 8w)", 4, 2, 1, 5, 16)
+
+#define ADD_ABL(tag, ABL, NOEPI)                                                                          \
+  cases.push_back({std::string("abl nn N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                           \
+                   [=](hipStream_t s) { return run_nn_abl<ABL, NOEPI>(b, M, 300, 300, s); }});              \
+  cases.push_back({std::string("abl nn N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                           \
+                   [=](hipStream_t s) { return run_nn_abl<ABL, NOEPI>(b, M, 300, 900, s); }});
+  ADD_ABL("baseline", 0, false)
+  ADD_ABL("prefetch-dist-2", 16, false)
+  ADD_ABL("no-epilogue", 0, true)
+  ADD_ABL("no-barrier", 1, false)
+  ADD_ABL("no-lds-store", 2, false)
+  ADD_ABL("no-global-load", 4, false)
+  ADD_ABL("no-frag-read", 8, false)
+  ADD_ABL("no-store,load", 6, false)
+  ADD_ABL("no-barrier,store,load", 7, false)
+  ADD_ABL("mfma-only(+epi)", 15, false)
+  ADD_ABL("mfma-only no-epi", 15, true)
+  if (argc > 1) {  // keep only cases whose name contains argv[1]
+    std::vector<Case> keep;
+    for (auto& c : cases) if (c.name.find(argv[1]) != std::string::npos) keep.push_back(c);
+    cases.swap(keep);
+  }
+  const int rounds = argc > 2 ? atoi(argv[2]) : 5;
+  std::vector<std::vector<float>> ms(cases.size());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int r = 0; r < rounds + 1; ++r) {
+    for (size_t i = 0; i < cases.size(); ++i) {
+      if (cases[i].name.find("tn_") == 0) CK(hipMemsetAsync(b.c, 0, 912 * 304 * 4, st));
+      CK(hipEventRecord(e0, st));
+      if (cases[i].fn(st) != 0) { fprintf(stderr, "launch failed: %s\n", cases[i].name.c_str()); return 1; }
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float t;
+      CK(hipEventElapsedTime(&t, e0, e1));
+      if (r > 0) ms[i].push_back(t);
+    }
+  }
+  for (size_t i = 0; i < cases.size(); ++i) {
+    std::sort(ms[i].begin(), ms[i].end());
+    const float med = ms[i][ms[i].size() / 2], mn = ms[i][0];
+    printf("%-52s median %7.3f ms  %6.1f TF   (min %7.3f ms %6.1f TF)\n", cases[i].name.c_str(), med,
+           cases[i].flops / med / 1e9, mn, cases[i].flops / mn / 1e9);
+  }
+  return 0;
+}
