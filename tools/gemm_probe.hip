@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../newsreclib_amd/csrc/nrl_gemm.h"
+#include "experimental/nrl_gemm_dma.h"
 
 namespace nrl {
 void set_error(const char* fmt, ...) {
@@ -58,6 +58,29 @@ int run_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {  // wgrad:
                                          EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
 }
 
+template <int WM, int WN, int TM, int TN>
+int dma_nt(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {
+  return launch_gemm_dma<WM, WN, TM, TN>(KCPlain{b.a, K, M}, KCPlain{b.w, K, N},
+                                         EpiLinear{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N}, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN>
+int dma_gather(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {
+  return launch_gemm_dma<WM, WN, TM, TN>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a},
+                                         KCPlain{b.w, K, N},
+                                         EpiLinear{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N}, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN>
+int dma_nn(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {
+  return launch_gemm_dma<WM, WN, TM, TN>(KCPlain{b.a, K, M}, RCPlain{b.w, N, N, 0}, EpiStore{b.c, N}, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN>
+int dma_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
+  const int64_t tiles = ceil_div(I, WM * TM * 16) * ceil_div(J + 1, WN * TN * 16);
+  int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(2048, tiles), ceil_div(Mr, 8 * 16)));
+  return launch_gemm_dma<WM, WN, TM, TN>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
+                                         EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
+}
+
 struct EpiNull {  // keeps the accumulators alive, writes nothing
   __device__ __forceinline__ void operator()(int64_t, int, float v) const { asm volatile("" ::"v"(v)); }
 };
@@ -98,6 +121,48 @@ int main(int argc, char** argv) {
   }
   hipStream_t st;
   CK(hipStreamCreate(&st));
+  {  // ---- correctness: LDS-DMA kernel vs the register-staged kernel on ragged shapes ----------
+    const int64_t Mv = 1000 + 37;
+    auto fetch = [&](float* dev, size_t n) {
+      std::vector<float> h(n);
+      CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(h.data(), dev, n * 4, hipMemcpyDeviceToHost));
+      return h;
+    };
+    auto maxdiff = [](const std::vector<float>& x, const std::vector<float>& y) {
+      double d = 0;
+      for (size_t i = 0; i < x.size(); ++i) d = std::max(d, (double)fabsf(x[i] - y[i]));
+      return d;
+    };
+    struct V { const char* name; std::function<int()> ref, dma; size_t n; bool zero; };
+    float* xsave = b.a + (size_t)M * 600;  // scratch region inside b.a for the gather's x output
+    Bufs bx = b; bx.a = xsave;
+    std::vector<V> vs = {
+      {"nt 300x300", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 300, 300, st); }, [&] { return dma_nt<4, 2, 2, 5>(b, Mv, 300, 300, st); }, (size_t)Mv * 300, false},
+      {"nt 200x300 (8x1w)", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 200, 300, st); }, [&] { return dma_nt<8, 1, 1, 13>(b, Mv, 200, 300, st); }, (size_t)Mv * 200, false},
+      {"gather 900x300 (+dropout)", [&] { return run_gather<4, 2, 2, 5, 16>(bx, Mv, 900, 300, st); }, [&] { return dma_gather<4, 2, 2, 5>(bx, Mv, 900, 300, st); }, (size_t)Mv * 900, false},
+      {"nn 300x900", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 900, st); }, [&] { return dma_nn<4, 2, 2, 5>(b, Mv, 300, 900, st); }, (size_t)Mv * 300, false},
+      {"nn 300x200", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 200, st); }, [&] { return dma_nn<4, 2, 2, 5>(b, Mv, 300, 200, st); }, (size_t)Mv * 300, false},
+      {"tn 900x300", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 900, 300, st); }, [&] { return dma_tn<4, 2, 2, 5>(b, Mv, 900, 300, st); }, (size_t)900 * 300, true},
+      {"tn 200x300 (4w)", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 200, 300, st); }, [&] { return dma_tn<2, 2, 2, 5>(b, Mv, 200, 300, st); }, (size_t)200 * 300, true},
+    };
+    for (auto& v : vs) {
+      std::vector<float> r[2], xs[2], bias[2];
+      for (int w = 0; w < 2; ++w) {
+        CK(hipMemsetAsync(b.c, v.zero ? 0 : 0xFF, v.n * 4, st));
+        CK(hipMemsetAsync(xsave, 0, (size_t)Mv * 300 * 4, st));
+        if (v.zero) CK(hipMemsetAsync(b.bias, 0, 4096 * 4, st));
+        if ((w == 0 ? v.ref() : v.dma()) != 0) { fprintf(stderr, "verify launch failed\n"); return 1; }
+        r[w] = fetch(b.c, v.n);
+        xs[w] = fetch(xsave, (size_t)Mv * 300);
+        bias[w] = fetch(b.bias, 1024);
+      }
+      printf("verify %-28s max|dma-ref| = %.3e   x-save diff %.3e   bias diff %.3e\n", v.name, maxdiff(r[0], r[1]),
+             maxdiff(xs[0], xs[1]), maxdiff(bias[0], bias[1]));
+    }
+    // restore the bias buffer content used by the timing cases
+    CK(hipMemsetAsync(b.bias, 0, 4096 * 4, st));
+  }
   std::vector<Case> cases;
 #define ADD_CFG(tag, WM, WN, TM, TN, BK)                                                                    \
   cases.push_back({std::string("gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                       \
@@ -129,6 +194,27 @@ int main(int argc, char** argv) {
   ADD_CFG("2x2w 2x5b bk16 (64x160 4w)", 2, 2, 2, 5, 16)
   ADD_CFG("4x2w 1x5b bk16 (64x160 8w)", 4, 2, 1, 5, 16)
 
+#define ADD_DMA(tag, WM, WN, TM, TN)                                                                       \
+  cases.push_back({std::string("dma gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                   \
+                   [=](hipStream_t s) { return dma_gather<WM, WN, TM, TN>(b, M, 900, 300, s); }});           \
+  cases.push_back({std::string("dma nt_outproj  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                   \
+                   [=](hipStream_t s) { return dma_nt<WM, WN, TM, TN>(b, M, 300, 300, s); }});               \
+  cases.push_back({std::string("dma nt_addatt   N=200 K=300 ") + tag, 2.0 * M * 200 * 300,                   \
+                   [=](hipStream_t s) { return dma_nt<WM, WN, TM, TN>(b, M, 200, 300, s); }});               \
+  cases.push_back({std::string("dma nn_dgrad_in N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                   \
+                   [=](hipStream_t s) { return dma_nn<WM, WN, TM, TN>(b, M, 300, 900, s); }});               \
+  cases.push_back({std::string("dma nn_dgrad_o  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                   \
+                   [=](hipStream_t s) { return dma_nn<WM, WN, TM, TN>(b, M, 300, 300, s); }});               \
+  cases.push_back({std::string("dma tn_wgrad_in 900x300     ") + tag, 2.0 * M * 900 * 300,                   \
+                   [=](hipStream_t s) { return dma_tn<WM, WN, TM, TN>(b, M, 900, 300, s); }});               \
+  cases.push_back({std::string("dma tn_wgrad_o  300x300     ") + tag, 2.0 * M * 300 * 300,                   \
+                   [=](hipStream_t s) { return dma_tn<WM, WN, TM, TN>(b, M, 300, 300, s); }});               \
+  cases.push_back({std::string("dma tn_wgrad_a  200x300     ") + tag, 2.0 * M * 200 * 300,                   \
+                   [=](hipStream_t s) { return dma_tn<WM, WN, TM, TN>(b, M, 200, 300, s); }});
+  ADD_DMA("4x2w 2x5b (128x160 8w)", 4, 2, 2, 5)
+  ADD_DMA("2x2w 2x5b (64x160 4w)", 2, 2, 2, 5)
+  ADD_DMA("8x1w 1x13b (128x208 8w)", 8, 1, 1, 13)
+  ADD_DMA("2x2w 4x5b (128x160 4w)", 2, 2, 4, 5)
 #define ADD_ABL(tag, ABL, NOEPI)                                                                          \
   cases.push_back({std::string("abl nn N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                           \
                    [=](hipStream_t s) { return run_nn_abl<ABL, NOEPI>(b, M, 300, 300, s); }});              \
