@@ -25,6 +25,12 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, VOCAB, L, H, C, D, HEADS, Q, P_DROP, LR = 128, 70_000, 30, 50, 5, 300, 15, 200, 0.2, 1e-4
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= vector) peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (no sparsity)
+HBM_PEAK_GBPS = 8000.0                 # HBM3E spec (6.3 TB/s achievable)
+# algorithmic HBM bytes of ONE in-projection forward launch: ids + gathered
+# embedding rows + qkv written + post-dropout x written for the weight gradient
+M_ROWS = B_PER_GPU * (H + C) * L
+IN_PROJ_ALGO_BYTES = M_ROWS * 8 + M_ROWS * D * 4 + M_ROWS * 3 * D * 4 + M_ROWS * D * 4
 N_BATCHES = 4                          # distinct pre-generated batches cycled through
 
 
@@ -81,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="projection-GEMM engine: exact fp32 MFMA, or fp32 via 3 bf16 MFMAs per product")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -101,6 +109,7 @@ def main():
     from newsreclib_amd.synthetic import make_batch
     from newsreclib_amd.trainer import NRMSTrainer
     lib = _lib.load()
+    _lib.set_gemm_engine(args.engine)
 
     mod = build_module(device)
     trainer = NRMSTrainer(mod, lr=LR)
@@ -133,26 +142,40 @@ def main():
 
     if rank == 0:
         value = world * B_PER_GPU * args.steps / dt
-        achieved = (flops.value / (tot_ms.value * 1e-3)) / 1e12 if tot_ms.value > 0 else None
+        avg_s = tot_ms.value * 1e-3 / max(1, launches.value)
+        tflops = (flops.value / max(1, launches.value)) / avg_s / 1e12 if avg_s > 0 else None
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_in_proj_fwd.json")
+        pmc = os.path.join(ROOT, "profiles", f"pmc_in_proj_fwd_{args.engine}.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        if args.engine == "f32":
+            # exact fp32 MFMA: intensity 90 FLOP/B >> ridge 25 -> MFMA-bound
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<4,2,2,5,16,KCGather,KCPlain,EpiLinear> (in-projection "
+                                              "forward with fused embedding gather + dropout)",
+                    "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
+        else:
+            # bf16x3: 3 bf16 MFMA products per fp32 product -> 342 GFLOP issued on a 2.5 PF pipe (0.14 ms)
+            # vs 1.27 GB over 8 TB/s (0.16 ms): the HBM roofline is the binding one for this kernel
+            gbps = IN_PROJ_ALGO_BYTES / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": "gemm_bf16x3_kernel<4,2,4,5,KCGather,KCSplit,EpiLinear> (in-projection "
+                                             "forward with fused embedding gather + dropout)",
+                    "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(gbps / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": IN_PROJ_ALGO_BYTES,
+                    "mfma_view": {"algorithmic_fp32_TFLOPs": round(tflops, 1),
+                                  "issued_bf16_TFLOPs": round(3 * tflops, 1), "bf16_peak": BF16_MFMA_PEAK_TFLOPS}}
+        roof.update({"traffic": traffic, "launches": launches.value, "avg_launch_ms": round(avg_s * 1e3, 4)})
         out = {
             "metric": "impressions/sec (train step) NRMS MINDsmall-shape", "value": round(value, 1),
             "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.engine == "f32" else "f32 (projections: 3xbf16 split MFMA)",
+            "data": "synthetic",
             "config": {"workload": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDsmall-shaped train step: "
                                    "B=128/GPU, H=50, C=5, L=30, V=70000, dropout 0.2, Adam lr 1e-4 "
                                    "(BASELINE.json configs[1])",
-                       "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<2,2,4,4,KCGather,KCPlain,EpiLinear> "
-                                                    "(in-projection with fused embedding gather + dropout)",
-                         "achieved": round(achieved, 2) if achieved else None, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
-                         "traffic": traffic, "launches": launches.value,
-                         "avg_launch_ms": round(tot_ms.value / max(1, launches.value), 4)},
+                       "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "gemm_engine": args.engine},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

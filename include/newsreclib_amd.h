@@ -75,6 +75,15 @@ typedef struct NrlBlockGrads {
 int nrl_abi_version(void);
 const char* nrl_last_error(void);
 
+/* ---- projection GEMM engine (process-wide; the same entry points serve both) ------------------
+ *   0 = exact fp32: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain (the reference's arithmetic type)
+ *   1 = "bf16x3" (default): fp32 operands split a = hi + lo (two bf16), three bf16 MFMAs per product
+ *       (hi*hi + hi*lo + lo*hi) with fp32 accumulation; ~2^-16 relative per product, scores within
+ *       1e-4 of the fp32 path (contract 1e-3), ~1.3-2x faster GEMMs.  Attention, softmax, pooling,
+ *       loss and Adam are fp32 in both engines. */
+int nrl_set_gemm_engine(int32_t engine);
+int nrl_get_gemm_engine(void);
+
 /* ---- measurement hook (bench.py "roofline"): HIP-event timing of the dominant kernel, the
  * in-projection GEMM with the fused embedding gather, recorded on the launch stream.  The ProfScope
  * only wraps news-encoder forward launches; total_flops sums 2*M*3D*D per launch. */

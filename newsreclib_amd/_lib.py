@@ -35,6 +35,8 @@ class NrlBlockGrads(ctypes.Structure):
 SIGNATURES = {
     "nrl_abi_version": (c_int32, []),
     "nrl_last_error": (c_char_p, []),
+    "nrl_set_gemm_engine": (c_int32, [c_int32]),
+    "nrl_get_gemm_engine": (c_int32, []),
     "nrl_prof_enable": (c_int32, [c_int32]),
     "nrl_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "nrl_dropout_key": (c_uint32, [c_uint64, c_uint32]),
@@ -85,7 +87,25 @@ def load() -> ctypes.CDLL:
     if got != ABI_VERSION:
         raise RuntimeError(f"ABI version mismatch: library {got}, binding {ABI_VERSION} (rebuild)")
     _lib = lib
+    eng = os.environ.get("NRL_GEMM_ENGINE")
+    if eng:
+        set_gemm_engine(eng)
     return lib
+
+
+ENGINES = {"f32": 0, "bf16x3": 1}
+
+
+def set_gemm_engine(name: str) -> None:
+    """"f32" = exact fp32 MFMA; "bf16x3" = fp32 via three bf16 MFMAs per product (default)."""
+    if name not in ENGINES:
+        raise ValueError(f"unknown GEMM engine {name!r}; choose from {sorted(ENGINES)}")
+    check(load().nrl_set_gemm_engine(ENGINES[name]), "nrl_set_gemm_engine")
+
+
+def get_gemm_engine() -> str:
+    code = load().nrl_get_gemm_engine()
+    return {v: k for k, v in ENGINES.items()}[code]
 
 
 def check(rc: int, what: str) -> None:

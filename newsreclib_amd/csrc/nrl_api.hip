@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "nrl_gemm.h"
+#include "nrl_gemm_bf16x3.h"
 #include "nrl_kernels.h"
 
 namespace nrl {
@@ -68,6 +69,16 @@ struct ProfScope {
 #define NRL_TILE_Q 8, 1, 1, 13
 #define NRL_TILE_W 2, 2, 2, 5
 
+// bf16x3 engine (nrl_gemm_bf16x3.h): with the MFMA time cut ~5x the GEMMs are staging/epilogue
+// bound, so the big forward/dgrad GEMMs take 256-row tiles (profiles/r01_gemm_bf16x3_probe.txt)
+#define X3_TILE_BIG 4, 2, 4, 5   // 256 x 160
+#define X3_TILE 4, 2, 2, 5       // 128 x 160 (small M)
+#define X3_TILE_Q 4, 2, 2, 7     // 128 x 224 (Q = 200 in one tile)
+#define X3_TILE_W 2, 2, 2, 5     //  64 x 160 weight gradients
+
+enum { ENGINE_F32 = 0, ENGINE_BF16X3 = 1 };
+static int g_engine = ENGINE_BF16X3;
+
 static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {
   const int64_t tiles = ceil_div(rows_out, bm) * ceil_div(cols_out, bn);
   int64_t s = ceil_div(2048, tiles);
@@ -86,7 +97,12 @@ struct BlockShape {
 
 struct BlockWs {
   float *x, *qkv, *o, *y, *t, *w, *lse, *dy, *dqkv;
+  uint16_t* planes;  // bf16 hi/lo planes of the three weights (bf16x3 engine)
 };
+
+static size_t plane_elems(int D, int Q) {
+  return split_weight_elems(3 * D, D) + split_weight_elems(D, D) + split_weight_elems(Q, D);
+}
 
 static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
   auto al = [](size_t n) { return align_up(n, 64); };
@@ -97,6 +113,7 @@ static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
   n += al((size_t)M * Q);          // t / d_pre
   n += al((size_t)M);              // w
   n += al((size_t)M * heads);      // lse
+  n += al((plane_elems(D, Q) + 1) / 2);  // bf16 weight planes
   return n;
 }
 
@@ -118,6 +135,7 @@ static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x,
   out->t = take((size_t)s.M * s.Q);
   out->w = take((size_t)s.M);
   out->lse = take((size_t)s.M * s.heads);
+  out->planes = reinterpret_cast<uint16_t*>(take((plane_elems(s.D, s.Q) + 1) / 2));
   return NRL_OK;
 }
 
@@ -135,32 +153,95 @@ static int check_params(const NrlBlockParams* p) {
   return NRL_OK;
 }
 
+struct BlockPlanes {
+  SplitWeight in, out, att;
+};
+
+// carve (and, in the forward, fill) the bf16 planes of the block's three weights
+static int block_planes(const NrlBlockParams* P, const BlockShape& s, const BlockWs& w, bool fill,
+                        BlockPlanes* bp, hipStream_t st) {
+  const int D = s.D, Q = s.Q;
+  uint16_t* p = w.planes;
+  const float* ws[3] = {P->in_proj_weight, P->out_proj_weight, P->att_weight};
+  const int ns[3] = {3 * D, D, Q};
+  SplitWeight* outs[3] = {&bp->in, &bp->out, &bp->att};
+  for (int i = 0; i < 3; ++i) {
+    if (fill) {
+      NRL_TRY(split_weight(ws[i], ns[i], D, p, outs[i], st));
+    } else {
+      SplitWeight& o = *outs[i];
+      o.N = ns[i]; o.K = D; o.Kp = (D + 31) / 32 * 32; o.Np = (ns[i] + 31) / 32 * 32;
+      o.hi = p; o.lo = o.hi + (size_t)o.N * o.Kp; o.hi_t = o.lo + (size_t)o.N * o.Kp;
+      o.lo_t = o.hi_t + (size_t)o.K * o.Np;
+    }
+    p += split_weight_elems(ns[i], D);
+  }
+  return NRL_OK;
+}
+
+static bool big_tiles(int64_t M, int N) { return ceil_div(M, 256) * ceil_div(N, 160) >= 512; }
+
+// C = epi(A W^T): nn.Linear forward.  W (N, K) fp32 in place / its bf16 planes.
+template <class AOp, class Epi>
+static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int N, int K,
+                    bool q_tile, hipStream_t st) {
+  if (g_engine == ENGINE_BF16X3) {
+    const KCSplit b{sw.hi, sw.lo, sw.Kp, N};
+    if (q_tile && N <= 224) return launch_gemm_bf16x3<X3_TILE_Q>(a, b, epi, M, N, K, 1, st);
+    if (big_tiles(M, N)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, N, K, 1, st);
+    return launch_gemm_bf16x3<X3_TILE>(a, b, epi, M, N, K, 1, st);
+  }
+  const KCPlain b{W, K, N};
+  if (q_tile && N <= 208) return launch_gemm<NRL_TILE_Q>(a, b, epi, M, N, K, 1, st);
+  return launch_gemm<NRL_TILE>(a, b, epi, M, N, K, 1, st);
+}
+
+// dX = epi(dY W): dY (M, Nw), W (Nw, Kw) -> (M, Kw)
+template <class Epi>
+static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int Nw,
+                      int Kw, hipStream_t st) {
+  const KCPlain a{dy, Nw, M};
+  if (g_engine == ENGINE_BF16X3) {
+    const KCSplit b{sw.hi_t, sw.lo_t, sw.Np, Kw};
+    if (big_tiles(M, Kw)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, Kw, Nw, 1, st);
+    return launch_gemm_bf16x3<X3_TILE>(a, b, epi, M, Kw, Nw, 1, st);
+  }
+  return launch_gemm<NRL_TILE>(a, RCPlain{W, Kw, Kw, 0}, epi, M, Kw, Nw, 1, st);
+}
+
+// dW (I, J) += dY^T X, db (I) += colsum(dY): dY (M, I), X (M, J); split-K over M
+static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, float* db, int64_t M,
+                      hipStream_t st) {
+  const RCPlain a{dy, I, I, 0}, b{x, J, J, 1};
+  const EpiAtomicWB epi{dW, J, db, J};
+  if (g_engine == ENGINE_BF16X3)
+    return launch_gemm_bf16x3<X3_TILE_W>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 64, 160), st);
+  if (I > 512) return launch_gemm<NRL_TILE>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 128, 160), st);
+  return launch_gemm<NRL_TILE_W>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 64, 160), st);
+}
+
 // forward of the shared block given an A-operand accessor for the in-projection
 template <class AOp>
 static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape& s, const BlockWs& w,
                      Dropout drop2, bool save, float* out, hipStream_t st) {
   const int D = s.D, Q = s.Q;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
+  BlockPlanes bp;
+  NRL_TRY(block_planes(P, s, w, g_engine == ENGINE_BF16X3, &bp, st));
   // q|k|v = x W_in^T + b_in           (text.py:229 / user/nrms.py:34; torch in-projection)
   {
     ProfScope prof(st, std::is_same<AOp, KCGather>::value ? 2.0 * (double)s.M * 3.0 * D * D : 0.0);
-    NRL_TRY((launch_gemm<NRL_TILE>(a_in, KCPlain{P->in_proj_weight, D, 3 * D},
-                                   EpiLinear{w.qkv, 3 * D, P->in_proj_bias, 0, nodrop, 3 * D}, s.M, 3 * D,
-                                   D, 1, st)));
+    NRL_TRY(gemm_fwd(a_in, P->in_proj_weight, bp.in, EpiLinear{w.qkv, 3 * D, P->in_proj_bias, 0, nodrop, 3 * D},
+                     s.M, 3 * D, D, false, st));
   }
   // per (group, head): softmax(q k^T / sqrt(dh)) v
   NRL_TRY(attn_fwd(w.qkv, w.o, save ? w.lse : nullptr, s.geom, st));
   // y = dropout(o W_o^T + b_o)        (out-projection, text.py:229-230)
-  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.o, D, s.M}, KCPlain{P->out_proj_weight, D, D},
-                                 EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, 1, st)));
+  NRL_TRY(gemm_fwd(KCPlain{w.o, D, s.M}, P->out_proj_weight, bp.out,
+                   EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, false, st));
   // t = tanh(y W_a^T + b_a)           (attention.py:34)
-  if (Q <= 208) {
-    NRL_TRY((launch_gemm<NRL_TILE_Q>(KCPlain{w.y, D, s.M}, KCPlain{P->att_weight, D, Q},
-                                     EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q}, s.M, Q, D, 1, st)));
-  } else {
-    NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.y, D, s.M}, KCPlain{P->att_weight, D, Q},
-                                   EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q}, s.M, Q, D, 1, st)));
-  }
+  NRL_TRY(gemm_fwd(KCPlain{w.y, D, s.M}, P->att_weight, bp.att, EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q},
+                   s.M, Q, D, true, st));
   // w = softmax(t . q_a); out = sum w y   (attention.py:37-40)
   NRL_TRY(pool_fwd(w.t, P->att_query, w.y, s.pool_groups, s.pool_len, Q, D, w.w, out, st));
   return NRL_OK;
@@ -168,32 +249,24 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
 
 // backward of the shared block up to d(qkv); the caller finishes with the in-projection dgrad
 static int block_bwd_to_dqkv(const NrlBlockParams* P, const NrlBlockGrads* G, const float* x_rows,
-                             const BlockShape& s, const BlockWs& w, Dropout drop2, const float* d_out,
-                             hipStream_t st) {
+                             const BlockShape& s, const BlockWs& w, const BlockPlanes& bp, Dropout drop2,
+                             const float* d_out, hipStream_t st) {
   const int D = s.D, Q = s.Q;
   // additive attention backward: t -> d_pre in place, dq_a
   NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st));
   // dy = (d_pre W_a + w * d_out) * dropout2
-  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.t, Q, s.M}, RCPlain{P->att_weight, D, D, 0},
-                                 EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, D, Q, 1, st)));
+  NRL_TRY(gemm_dgrad(w.t, P->att_weight, bp.att, EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, Q, D, st));
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
-  NRL_TRY((launch_gemm<NRL_TILE_W>(RCPlain{w.t, Q, Q, 0}, RCPlain{w.y, D, D, 1},
-                                   EpiAtomicWB{G->att_weight, D, G->att_bias, D}, Q, D + 1, s.M,
-                                   wgrad_splits(Q, D + 1, s.M, 64, 160), st)));
+  NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
   // d_o = dy W_o  (written over y, which is dead from here on)
   float* d_o = w.y;
-  NRL_TRY((launch_gemm<NRL_TILE>(KCPlain{w.dy, D, s.M}, RCPlain{P->out_proj_weight, D, D, 0},
-                                 EpiStore{d_o, D}, s.M, D, D, 1, st)));
+  NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{d_o, D}, s.M, D, D, st));
   // dW_o += dy^T o ; db_o += colsum(dy)
-  NRL_TRY((launch_gemm<NRL_TILE_W>(RCPlain{w.dy, D, D, 0}, RCPlain{w.o, D, D, 1},
-                                   EpiAtomicWB{G->out_proj_weight, D, G->out_proj_bias, D}, D, D + 1, s.M,
-                                   wgrad_splits(D, D + 1, s.M, 64, 160), st)));
+  NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
   // attention backward -> dqkv
   NRL_TRY(attn_bwd(w.qkv, w.o, d_o, w.lse, w.dqkv, s.geom, st));
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
-  NRL_TRY((launch_gemm<NRL_TILE>(RCPlain{w.dqkv, 3 * D, 3 * D, 0}, RCPlain{x_rows, D, D, 1},
-                                 EpiAtomicWB{G->in_proj_weight, D, G->in_proj_bias, D}, 3 * D, D + 1, s.M,
-                                 wgrad_splits(3 * D, D + 1, s.M, 128, 160), st)));
+  NRL_TRY(gemm_wgrad(w.dqkv, 3 * D, x_rows, D, G->in_proj_weight, G->in_proj_bias, s.M, st));
   return NRL_OK;
 }
 
@@ -263,6 +336,13 @@ int nrl_prof_read(double* total_ms, int64_t* launches, double* total_flops) {
   return NRL_OK;
 }
 
+int nrl_set_gemm_engine(int32_t engine) {
+  NRL_REQUIRE(engine == ENGINE_F32 || engine == ENGINE_BF16X3, "unknown GEMM engine %d", engine);
+  g_engine = engine;
+  return NRL_OK;
+}
+int nrl_get_gemm_engine(void) { return g_engine; }
+
 uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream) { return dropout_key(seed, stream); }
 
 int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, uint32_t stream,
@@ -307,10 +387,11 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
   BlockWs w;
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
-  NRL_TRY(block_bwd_to_dqkv(p, g, w.x, s, w, d2, d_out, st));
+  BlockPlanes bp;
+  NRL_TRY(block_planes(p, s, w, false, &bp, st));  // filled by the forward; weights unchanged since
+  NRL_TRY(block_bwd_to_dqkv(p, g, w.x, s, w, bp, d2, d_out, st));
   // dx = dqkv W_in, times dropout1, scatter-added into the table rows (embedding_dense_backward)
-  return launch_gemm<NRL_TILE>(KCPlain{w.dqkv, 3 * s.D, s.M}, RCPlain{p->in_proj_weight, s.D, s.D, 0},
-                               EpiScatter{d_emb_table, ids, s.D, d1}, s.M, s.D, 3 * s.D, 1, st);
+  return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiScatter{d_emb_table, ids, s.D, d1}, s.M, 3 * s.D, s.D, st);
 }
 
 size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t embed_dim,
@@ -341,9 +422,10 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   const BlockShape s = user_shape(p, batch, hist_len);
   BlockWs w;
   NRL_TRY(carve_ws(ws, ws_bytes, s, false, &w));
-  NRL_TRY(block_bwd_to_dqkv(p, g, hist, s, w, make_dropout(0.0, 0, 0), d_out, st));
-  return launch_gemm<NRL_TILE>(KCPlain{w.dqkv, 3 * s.D, s.M}, RCPlain{p->in_proj_weight, s.D, s.D, 0},
-                               EpiStore{d_hist, s.D}, s.M, s.D, 3 * s.D, 1, st);
+  BlockPlanes bp;
+  NRL_TRY(block_planes(p, s, w, false, &bp, st));
+  NRL_TRY(block_bwd_to_dqkv(p, g, hist, s, w, bp, make_dropout(0.0, 0, 0), d_out, st));
+  return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiStore{d_hist, s.D}, s.M, 3 * s.D, s.D, st);
 }
 
 int nrl_to_dense_batch_fwd(const float* x, const int64_t* offsets, int64_t batch, int64_t max_len,

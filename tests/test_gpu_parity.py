@@ -18,6 +18,19 @@ DEV = "cuda"
 TOL = 1e-3   # contract tolerance on scores (north_star); observed errors are printed
 
 
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def engine(request):
+    """Every parity test runs under both projection-GEMM engines (include/newsreclib_amd.h)."""
+    from newsreclib_amd import _lib
+    _lib.set_gemm_engine(request.param)
+    yield request.param
+    _lib.set_gemm_engine("bf16x3")
+
+
+def _eng_tol(engine, f32_tol, x3_tol):
+    return f32_tol if engine == "f32" else x3_tol
+
+
 def _maxerr(a, b):
     return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
 

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "experimental/nrl_gemm_dma.h"
+#include "../newsreclib_amd/csrc/nrl_gemm_bf16x3.h"
 
 namespace nrl {
 void set_error(const char* fmt, ...) {
@@ -81,6 +82,33 @@ int dma_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
                                          EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
 }
 
+// ---- bf16x3 engine ---------------------------------------------------------------------------
+static uint16_t* g_planes = nullptr;
+template <int WM, int WN, int TM, int TN>
+int x3_nt(const Bufs& b, int64_t M, int N, int K, hipStream_t st, bool gather = false) {
+  SplitWeight sw;
+  if (split_weight(b.w, N, K, g_planes, &sw, st) != 0) return -1;
+  KCSplit B{sw.hi, sw.lo, sw.Kp, N};
+  EpiLinear e{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N};
+  if (gather)
+    return launch_gemm_bf16x3<WM, WN, TM, TN>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a}, B, e, M, N, K, 1, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN>(KCPlain{b.a, K, M}, B, e, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN>
+int x3_nn(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {  // b.w is W (K rows = out, N cols = in)
+  SplitWeight sw;
+  if (split_weight(b.w, K, N, g_planes, &sw, st) != 0) return -1;  // W is (out=K, in=N): transposed planes [N][Kp']
+  KCSplit B{sw.hi_t, sw.lo_t, sw.Np, N};
+  return launch_gemm_bf16x3<WM, WN, TM, TN>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
+}
+template <int WM, int WN, int TM, int TN>
+int x3_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
+  const int64_t tiles = ceil_div(I, WM * TM * 16) * ceil_div(J + 1, WN * TN * 16);
+  int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(2048, tiles), ceil_div(Mr, 8 * 32)));
+  return launch_gemm_bf16x3<WM, WN, TM, TN>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
+                                            EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
+}
+
 struct EpiNull {  // keeps the accumulators alive, writes nothing
   __device__ __forceinline__ void operator()(int64_t, int, float v) const { asm volatile("" ::"v"(v)); }
 };
@@ -137,7 +165,15 @@ int main(int argc, char** argv) {
     struct V { const char* name; std::function<int()> ref, dma; size_t n; bool zero; };
     float* xsave = b.a + (size_t)M * 600;  // scratch region inside b.a for the gather's x output
     Bufs bx = b; bx.a = xsave;
+    CK(hipMalloc(&g_planes, (size_t)8 << 20));
     std::vector<V> vs = {
+      {"x3 nt 300x300", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 300, 300, st); }, [&] { return x3_nt<4, 2, 2, 5>(b, Mv, 300, 300, st); }, (size_t)Mv * 300, false},
+      {"x3 nt 200x300", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 200, 300, st); }, [&] { return x3_nt<4, 2, 2, 5>(b, Mv, 200, 300, st); }, (size_t)Mv * 200, false},
+      {"x3 gather 900x300 (+dropout)", [&] { return run_gather<4, 2, 2, 5, 16>(bx, Mv, 900, 300, st); }, [&] { return x3_nt<4, 2, 2, 5>(bx, Mv, 900, 300, st, true); }, (size_t)Mv * 900, false},
+      {"x3 nn 300x900", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 900, st); }, [&] { return x3_nn<4, 2, 2, 5>(b, Mv, 300, 900, st); }, (size_t)Mv * 300, false},
+      {"x3 nn 300x200", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 200, st); }, [&] { return x3_nn<4, 2, 2, 5>(b, Mv, 300, 200, st); }, (size_t)Mv * 300, false},
+      {"x3 tn 900x300", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 900, 300, st); }, [&] { return x3_tn<4, 2, 2, 5>(b, Mv, 900, 300, st); }, (size_t)900 * 300, true},
+      {"x3 tn 200x300 (4w)", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 200, 300, st); }, [&] { return x3_tn<2, 2, 2, 5>(b, Mv, 200, 300, st); }, (size_t)200 * 300, true},
       {"nt 300x300", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 300, 300, st); }, [&] { return dma_nt<4, 2, 2, 5>(b, Mv, 300, 300, st); }, (size_t)Mv * 300, false},
       {"nt 200x300 (8x1w)", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 200, 300, st); }, [&] { return dma_nt<8, 1, 1, 13>(b, Mv, 200, 300, st); }, (size_t)Mv * 200, false},
       {"gather 900x300 (+dropout)", [&] { return run_gather<4, 2, 2, 5, 16>(bx, Mv, 900, 300, st); }, [&] { return dma_gather<4, 2, 2, 5>(bx, Mv, 900, 300, st); }, (size_t)Mv * 900, false},
@@ -215,6 +251,27 @@ int main(int argc, char** argv) {
   ADD_DMA("2x2w 2x5b (64x160 4w)", 2, 2, 2, 5)
   ADD_DMA("8x1w 1x13b (128x208 8w)", 8, 1, 1, 13)
   ADD_DMA("2x2w 4x5b (128x160 4w)", 2, 2, 4, 5)
+#define ADD_X3(tag, WM, WN, TM, TN)                                                                        \
+  cases.push_back({std::string("x3 gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                    \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN>(b, M, 900, 300, s, true); }});          \
+  cases.push_back({std::string("x3 nt_outproj  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                    \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN>(b, M, 300, 300, s); }});                \
+  cases.push_back({std::string("x3 nt_addatt   N=200 K=300 ") + tag, 2.0 * M * 200 * 300,                    \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN>(b, M, 200, 300, s); }});                \
+  cases.push_back({std::string("x3 nn_dgrad_in N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                    \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN>(b, M, 300, 900, s); }});                \
+  cases.push_back({std::string("x3 nn_dgrad_o  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                    \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN>(b, M, 300, 300, s); }});                \
+  cases.push_back({std::string("x3 tn_wgrad_in 900x300     ") + tag, 2.0 * M * 900 * 300,                    \
+                   [=](hipStream_t s) { return x3_tn<WM, WN, TM, TN>(b, M, 900, 300, s); }});                \
+  cases.push_back({std::string("x3 tn_wgrad_o  300x300     ") + tag, 2.0 * M * 300 * 300,                    \
+                   [=](hipStream_t s) { return x3_tn<WM, WN, TM, TN>(b, M, 300, 300, s); }});                \
+  cases.push_back({std::string("x3 tn_wgrad_a  200x300     ") + tag, 2.0 * M * 200 * 300,                    \
+                   [=](hipStream_t s) { return x3_tn<WM, WN, TM, TN>(b, M, 200, 300, s); }});
+  ADD_X3("4x2w 2x5b (128x160 8w)", 4, 2, 2, 5)
+  ADD_X3("2x2w 2x5b (64x160 4w)", 2, 2, 2, 5)
+  ADD_X3("4x2w 2x7b (128x224 8w)", 4, 2, 2, 7)
+  ADD_X3("4x2w 4x5b (256x160 8w)", 4, 2, 4, 5)
 #define ADD_ABL(tag, ABL, NOEPI)                                                                          \
   cases.push_back({std::string("abl nn N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                           \
                    [=](hipStream_t s) { return run_nn_abl<ABL, NOEPI>(b, M, 300, 300, s); }});              \

@@ -10,6 +10,7 @@ import os
 import sys
 
 out_dir, tag = sys.argv[1], sys.argv[2]
+engine = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
 
 
 def find(sub, pattern):
@@ -69,6 +70,6 @@ for k, e in summary.items():
                    "raw_FETCH_SIZE_KiB": e.get("FETCH_SIZE"), "raw_WRITE_SIZE_KiB": e.get("WRITE_SIZE"),
                    "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 half-count), write = WRITE_SIZE x 1024",
                    "source": f"{tag}_pmc_summary.json"},
-                  open(os.path.join(out_dir, "pmc_in_proj_fwd.json"), "w"), indent=1)
+                  open(os.path.join(out_dir, f"pmc_in_proj_fwd_{engine}.json"), "w"), indent=1)
 print(json.dumps({k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in e.items()}
                   for k, e in summary.items() if "gemm" in k}, indent=1)[:3000])
