@@ -214,8 +214,19 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
                       hipStream_t st) {
   const RCPlain a{dy, I, I, 0}, b{x, J, J, 1};
   const EpiAtomicWB epi{dW, J, db, J};
-  if (g_engine == ENGINE_BF16X3)
-    return launch_gemm_bf16x3<X3_TILE_W>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 64, 160), st);
+  if (g_engine == ENGINE_BF16X3) {
+    // ~1.6k rows per k-split (profiles/r01_gemm_bf16x3_probe.txt): the split's operand slices are
+    // re-read by all of its tiles from ONE XCD's L2 (split -> XCD mapping in the kernel)
+    auto splits = [&](int bm) {
+      const int64_t tiles = ceil_div(I, bm) * ceil_div(J + 1, 160);
+      int64_t sp = ceil_div(M, 1664);
+      if (sp * tiles < 512) sp = ceil_div(512, tiles);
+      const int64_t max_s = ceil_div(M, 256);
+      return (int)(sp > max_s ? max_s : (sp < 1 ? 1 : sp));
+    };
+    if (I > 512) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, I, J + 1, M, splits(256), st);
+    return launch_gemm_bf16x3<X3_TILE_W>(a, b, epi, I, J + 1, M, splits(64), st);
+  }
   if (I > 512) return launch_gemm<NRL_TILE>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 128, 160), st);
   return launch_gemm<NRL_TILE_W>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 64, 160), st);
 }
@@ -375,9 +386,9 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
 }
 
 int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
-                         int64_t vocab, const int64_t* ids, int64_t n_news, int32_t seq_len,
-                         double p_drop, uint64_t seed, uint32_t stream0, const float* d_out, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
+                         int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed, uint32_t stream0,
+                         const float* d_out, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(d_emb_table && ids && d_out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_bwd: bad arguments");
@@ -390,7 +401,14 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
   BlockPlanes bp;
   NRL_TRY(block_planes(p, s, w, false, &bp, st));  // filled by the forward; weights unchanged since
   NRL_TRY(block_bwd_to_dqkv(p, g, w.x, s, w, bp, d2, d_out, st));
-  // dx = dqkv W_in, times dropout1, scatter-added into the table rows (embedding_dense_backward)
+  // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
+  if (sorted_positions != nullptr) {
+    // dx is materialised (in the dead `dy` buffer) and reduced in id-sorted order: no hot-row contention
+    float* dx = w.dy;
+    NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{dx, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
+                       s.D, st));
+    return embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st);
+  }
   return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiScatter{d_emb_table, ids, s.D, d1}, s.M, 3 * s.D, s.D, st);
 }
 

@@ -50,7 +50,7 @@ template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
 __global__ void __launch_bounds__(WM* WN * 64)
     gemm_bf16x3_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N,
                        const int64_t K, const int tiles_n, const int64_t tiles_total,
-                       const int64_t k_per_split) {
+                       const int64_t k_per_split, const int nsplit) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;       // bytes per plane
@@ -65,17 +65,28 @@ __global__ void __launch_bounds__(WM* WN * 64)
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
 
-  int64_t t;
+  // Tile / k-split of this workgroup.  Workgroup b runs on XCD b % 8 (private 4 MiB L2 each):
+  //  * no split-K: XCD-aware bijective tile order, n-tiles sharing an A row-panel share an L2;
+  //  * split-K (weight gradients): ALL tiles of one k-split are given to ONE XCD, so the split's
+  //    slices of both operands are fetched from HBM once and re-read from that L2 by every tile.
+  int64_t t, split;
   {
     const int64_t bid = blockIdx.x;
-    const int64_t q = tiles_total / 8, rem = tiles_total % 8;
     const int64_t xcd = bid % 8, local = bid / 8;
-    t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+    if (nsplit > 1) {
+      t = local % tiles_total;
+      split = (local / tiles_total) * 8 + xcd;
+      if (split >= nsplit) return;
+    } else {
+      const int64_t q = tiles_total / 8, rem = tiles_total % 8;
+      t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+      split = 0;
+    }
   }
   const int64_t m0 = (t / tiles_n) * BM;
   const int n0 = (int)(t % tiles_n) * BN;
   const bool primary = (n0 == 0);
-  const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+  const int64_t kbeg = split * k_per_split;
   const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
   if (kbeg >= kend) return;
   const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
@@ -308,10 +319,10 @@ int launch_gemm_bf16x3(const AOp& A, const BOp& B, const Epi& epi, int64_t M, in
   if (splits < 1) splits = 1;
   int64_t kps = ceil_div(ceil_div(K, splits), 32) * 32;
   splits = (int)ceil_div(K, kps);
-  NRL_REQUIRE(tiles_total < (1LL << 31) && splits < 65536, "gemm grid too large");
-  dim3 grid((unsigned)tiles_total, (unsigned)splits, 1);
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, AOp, BOp, Epi>), grid, dim3(WM * WN * 64), 0, stream,
-                     A, B, epi, M, N, K, tiles_n, tiles_total, kps);
+  const int64_t nblocks = splits > 1 ? ceil_div(splits, 8) * 8 * tiles_total : tiles_total;
+  NRL_REQUIRE(nblocks < (1LL << 31), "gemm grid too large");
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, AOp, BOp, Epi>), dim3((unsigned)nblocks),
+                     dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -44,14 +44,15 @@ class MHSAAddAtt(nn.Module):
         return (self.embedding_layer.weight, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                 mha.out_proj.bias, att.linear.weight, att.linear.bias, att.query)
 
-    def forward(self, text: torch.Tensor, seed: Optional[int] = None) -> torch.Tensor:
+    def forward(self, text: torch.Tensor, seed: Optional[int] = None,
+                order: Optional[torch.Tensor] = None) -> torch.Tensor:
         p = float(self.dropout.p) if self.training else 0.0
         if p > 0.0 and seed is None:
             # host-side draw from torch's CPU generator (no device sync); reproducible under
             # torch.manual_seed
             seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62))
         params = self._params()
-        return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, 0, _grad_bufs(params))
+        return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, 0, _grad_bufs(params), order)
 
 
 class NewsEncoder(nn.Module):
@@ -86,4 +87,9 @@ class NewsEncoder(nn.Module):
 
     def forward(self, news: Dict[str, torch.Tensor], seed: Optional[int] = None) -> torch.Tensor:
         (name, encoder), = self.text_encoders.items()
-        return encoder(news[name], seed=seed) if seed is not None else encoder(news[name])
+        kw = {}
+        if seed is not None:
+            kw["seed"] = seed
+        if news.get(name + "_order") is not None:      # optional argsort of the flat ids (prepare_batch)
+            kw["order"] = news[name + "_order"]
+        return encoder(news[name], **kw)

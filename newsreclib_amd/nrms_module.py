@@ -44,6 +44,13 @@ def prepare_batch(batch: Dict) -> Dict:
         out[key + "_offsets"] = off
         out["max_" + key] = int((off[1:] - off[:-1]).max())
     out["cand_flat_idx"] = dense_slot_index(batch["batch_cand"], out["cand_offsets"], out["max_cand"])
+    # history + candidate token ids as the single encoder call sees them, and their id-sorted
+    # visiting order for the embedding gradient (pure index bookkeeping, like the offsets above)
+    for attr in ("title", "abstract"):
+        if attr in batch["x_hist"] and attr in batch["x_cand"]:
+            ids = torch.cat([batch["x_hist"][attr], batch["x_cand"][attr]], dim=0)
+            out.setdefault("x_all", {})[attr] = ids
+            out["x_all"][attr + "_order"] = torch.argsort(ids.reshape(-1))
     return out
 
 
@@ -123,11 +130,9 @@ class NRMSModule(LightningModuleBase):
     def forward(self, batch: Dict) -> torch.Tensor:
         batch = prepare_batch(batch)
         B = batch["batch_size"]
-        ids_hist = batch["x_hist"][self._text_attr]
-        ids_cand = batch["x_cand"][self._text_attr]
-        n_hist = ids_hist.shape[0]
+        n_hist = batch["x_hist"][self._text_attr].shape[0]
         # one encoder call for history + candidate news (the reference makes two, :232,236)
-        news_vector = self.news_encoder({self._text_attr: torch.cat([ids_hist, ids_cand], dim=0)})
+        news_vector = self.news_encoder(batch["x_all"])
         hist_news_vector_agg, _ = to_dense_batch(news_vector[:n_hist], batch["batch_hist"], B,
                                                  batch["max_hist"], batch["hist_offsets"])
         cand_news_vector_agg, _ = to_dense_batch(news_vector[n_hist:], batch["batch_cand"], B,

@@ -68,7 +68,7 @@ class NewsEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, emb, w_in, b_in, w_o, b_o, w_a, b_a, q_a, heads, p_drop, seed, stream0,
-                grad_bufs):
+                grad_bufs, order=None):
         lib = _lib.load()
         ids = _chk(ids, torch.int64, "ids")
         params = [_chk(t, torch.float32, n) for t, n in zip(
@@ -90,14 +90,19 @@ class NewsEncoderFn(torch.autograd.Function):
                                             out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
                    "nrl_news_encoder_fwd")
         if save:
-            ctx.save_for_backward(ids, *params)
+            if order is None:
+                # id-sorted visiting order for the table gradient (index bookkeeping on the int64 ids;
+                # `prepare_batch` precomputes it once per batch so the step does not pay the sort)
+                order = torch.argsort(ids.reshape(-1))
+            order = _chk(order, torch.int64, "order")
+            ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
-        ids, *params = ctx.saved_tensors
+        ids, order, *params = ctx.saved_tensors
         emb = params[0]
         heads, p_drop, seed, stream0 = ctx.cfg
         N, L = ids.shape
@@ -108,11 +113,11 @@ class NewsEncoderFn(torch.autograd.Function):
         bg = _block_grads(bufs[1:])
         ws = ctx.ws
         _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), bufs[0].data_ptr(), V,
-                                            ids.data_ptr(), N, L, p_drop, seed, stream0,
+                                            ids.data_ptr(), order.data_ptr(), N, L, p_drop, seed, stream0,
                                             d_out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
                    "nrl_news_encoder_bwd")
         ctx.ws = None
-        return (None, *rets, None, None, None, None, None)
+        return (None, *rets, None, None, None, None, None, None)
 
 
 class UserEncoderFn(torch.autograd.Function):

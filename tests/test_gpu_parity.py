@@ -184,7 +184,7 @@ def test_module_matches_reference_golden(name):
     te = mod.news_encoder.text_encoders["title"]
     # pin the dropout seed to the one the golden masks were drawn with
     orig = te.forward
-    te.forward = lambda text, seed=None: orig(text, seed=int(g["cfg_seed"]))
+    te.forward = lambda text, seed=None, **kw: orig(text, seed=int(g["cfg_seed"]), **kw)
     loss, preds, targets, cand_size, *_ = mod.model_step(batch)
     scores = mod.forward(batch)
     err_s = float(np.abs(scores.detach().cpu().numpy() - g["out_scores"]).max())

@@ -101,10 +101,12 @@ int x3_nn(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {  // b.w is W
   KCSplit B{sw.hi_t, sw.lo_t, sw.Np, N};
   return launch_gemm_bf16x3<WM, WN, TM, TN>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
 }
+static int g_x3_splits = 0;  // 0 = heuristic
 template <int WM, int WN, int TM, int TN>
 int x3_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
   const int64_t tiles = ceil_div(I, WM * TM * 16) * ceil_div(J + 1, WN * TN * 16);
   int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(2048, tiles), ceil_div(Mr, 8 * 32)));
+  if (g_x3_splits > 0) splits = g_x3_splits;
   return launch_gemm_bf16x3<WM, WN, TM, TN>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
                                             EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
 }
@@ -268,6 +270,25 @@ int main(int argc, char** argv) {
                    [=](hipStream_t s) { return x3_tn<WM, WN, TM, TN>(b, M, 300, 300, s); }});                \
   cases.push_back({std::string("x3 tn_wgrad_a  200x300     ") + tag, 2.0 * M * 200 * 300,                    \
                    [=](hipStream_t s) { return x3_tn<WM, WN, TM, TN>(b, M, 200, 300, s); }});
+#define ADD_X3S(S, tag, WM, WN, TM, TN)                                                                    \
+  cases.push_back({std::string("x3split tn_wgrad_in 900x300 S=" #S " ") + tag, 2.0 * M * 900 * 300,         \
+                   [=](hipStream_t s) { g_x3_splits = S; int r = x3_tn<WM, WN, TM, TN>(b, M, 900, 300, s); g_x3_splits = 0; return r; }}); \
+  cases.push_back({std::string("x3split tn_wgrad_o  300x300 S=" #S " ") + tag, 2.0 * M * 300 * 300,         \
+                   [=](hipStream_t s) { g_x3_splits = S; int r = x3_tn<WM, WN, TM, TN>(b, M, 300, 300, s); g_x3_splits = 0; return r; }}); \
+  cases.push_back({std::string("x3split tn_wgrad_a  200x300 S=" #S " ") + tag, 2.0 * M * 200 * 300,         \
+                   [=](hipStream_t s) { g_x3_splits = S; int r = x3_tn<WM, WN, TM, TN>(b, M, 200, 300, s); g_x3_splits = 0; return r; }});
+  ADD_X3S(32, "64x160", 2, 2, 2, 5)
+  ADD_X3S(64, "64x160", 2, 2, 2, 5)
+  ADD_X3S(128, "64x160", 2, 2, 2, 5)
+  ADD_X3S(256, "64x160", 2, 2, 2, 5)
+  ADD_X3S(512, "64x160", 2, 2, 2, 5)
+  ADD_X3S(64, "128x160", 4, 2, 2, 5)
+  ADD_X3S(128, "128x160", 4, 2, 2, 5)
+  ADD_X3S(256, "128x160", 4, 2, 2, 5)
+  ADD_X3S(512, "128x160", 4, 2, 2, 5)
+  ADD_X3S(128, "256x160", 4, 2, 4, 5)
+  ADD_X3S(256, "256x160", 4, 2, 4, 5)
+  ADD_X3S(512, "256x160", 4, 2, 4, 5)
   ADD_X3("4x2w 2x5b (128x160 8w)", 4, 2, 2, 5)
   ADD_X3("2x2w 2x5b (64x160 4w)", 2, 2, 2, 5)
   ADD_X3("4x2w 2x7b (128x224 8w)", 4, 2, 2, 7)
