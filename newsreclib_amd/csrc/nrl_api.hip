@@ -71,10 +71,11 @@ struct ProfScope {
 
 // bf16x3 engine (nrl_gemm_bf16x3.h): with the MFMA time cut ~5x the GEMMs are staging/epilogue
 // bound, so the big forward/dgrad GEMMs take 256-row tiles (profiles/r01_gemm_bf16x3_probe.txt)
-#define X3_TILE_BIG 4, 2, 4, 5   // 256 x 160
-#define X3_TILE 4, 2, 2, 5       // 128 x 160 (small M)
-#define X3_TILE_Q 4, 2, 2, 7     // 128 x 224 (Q = 200 in one tile)
-#define X3_TILE_W 2, 2, 2, 5     //  64 x 160 weight gradients
+// (last number: prefetch depth flag DEEP -- two staging register sets only where they fit without spills)
+#define X3_TILE_BIG 4, 2, 4, 5, 0   // 256 x 160
+#define X3_TILE 4, 2, 2, 5, 1       // 128 x 160 (small M)
+#define X3_TILE_Q 4, 2, 2, 7, 1     // 128 x 224 (Q = 200 in one tile)
+#define X3_TILE_W 2, 2, 2, 5, 0     //  64 x 160 weight gradients
 
 enum { ENGINE_F32 = 0, ENGINE_BF16X3 = 1 };
 static int g_engine = ENGINE_BF16X3;

@@ -46,7 +46,10 @@ struct KCSplit {
 
 __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((4 - ((row >> 2) & 3)) & 3); }
 
-template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
+// DEEP = 1: two named staging-register sets, global loads issued TWO k-tiles ahead (the k-loop is
+// unrolled by two so neither set is a loop-carried array the compiler has to copy); DEEP = 0: one set,
+// loads one tile ahead.
+template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi, int DEEP = 0>
 __global__ void __launch_bounds__(WM* WN * 64)
     gemm_bf16x3_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N,
                        const int64_t K, const int tiles_n, const int64_t tiles_total,
@@ -117,11 +120,16 @@ __global__ void __launch_bounds__(WM* WN * 64)
     }
   }
 
-  float4 ra[AOp::kLayout == SRC_KC ? NCH_A : 2 * NPC_A];
+  constexpr int NRA = AOp::kLayout == SRC_KC ? NCH_A : 2 * NPC_A;
   constexpr int NRB = BOp::kLayout == SRC_SPLIT ? 2 * NCH_B : 2 * NPC_B;
-  uint4 rb[NRB];  // SPLIT: hi/lo 16-B chunks; RC: the two float4 of a patch, bit-cast
+  struct Stage {
+    float4 ra[NRA];
+    uint4 rb[NRB];  // SPLIT: hi/lo 16-B chunks; RC: the two float4 of a patch, bit-cast
+  };
 
-  auto load_tiles = [&](int64_t k0) {
+  auto load_tiles = [&](int64_t k0, Stage& S) {
+    float4* ra = S.ra;
+    uint4* rb = S.rb;
     if constexpr (AOp::kLayout == SRC_KC) {
 #pragma unroll
       for (int c = 0; c < NCH_A; ++c) {
@@ -176,7 +184,9 @@ __global__ void __launch_bounds__(WM* WN * 64)
     }
   };
 
-  auto store_tiles = [&](int buf, int64_t k0) {
+  auto store_tiles = [&](int buf, int64_t k0, Stage& S) {
+    float4* ra = S.ra;
+    uint4* rb = S.rb;
     unsigned char* base = smem + buf * BUF;
     unsigned char* a_hi = base;
     unsigned char* a_lo = base + PLANE_A;
@@ -242,51 +252,72 @@ __global__ void __launch_bounds__(WM* WN * 64)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(kbeg);
-  store_tiles(0, kbeg);
-  __syncthreads();
-
-  auto k_loop = [&](auto full_tag) {
+  auto compute = [&](int buf, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
-    for (int tt = 0; tt < ntiles; ++tt) {
-      const int buf = tt & 1;
-      const int64_t k0 = kbeg + (int64_t)tt * BK;
-      if (tt + 1 < ntiles) load_tiles(k0 + BK);
-
-      const unsigned char* base = smem + buf * BUF;
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    const unsigned char* base = smem + buf * BUF;
+    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = (wm * TM + i) * 16 + l15;
+      const int off = row * 64 + swz(g, row) * 16;
+      ah[i] = *reinterpret_cast<const bf16x8*>(base + off);
+      al[i] = *reinterpret_cast<const bf16x8*>(base + PLANE_A + off);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = (wn * TN + j) * 16 + l15;
+      const int off = row * 64 + swz(g, row) * 16;
+      bh[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + off);
+      bl[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + PLANE_B + off);
+    }
+    // small cross terms first, the dominant hi*hi term last; each pass touches all blocks, so
+    // consecutive MFMAs never depend on each other
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 16 + l15;
-        const int off = row * 64 + swz(g, row) * 16;
-        ah[i] = *reinterpret_cast<const bf16x8*>(base + off);
-        al[i] = *reinterpret_cast<const bf16x8*>(base + PLANE_A + off);
-      }
+        if (FULL || i < nvi) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = (wn * TN + j) * 16 + l15;
-        const int off = row * 64 + swz(g, row) * 16;
-        bh[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + off);
-        bl[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + PLANE_B + off);
-      }
-      // small cross terms first, the dominant hi*hi term last; each pass touches all blocks, so
-      // consecutive MFMAs never depend on each other
-#pragma unroll
-      for (int pass = 0; pass < 3; ++pass) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          if (FULL || i < nvi) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              if (FULL || j < nvj)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
-                                                                   pass == 0 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
-            }
+          for (int j = 0; j < TN; ++j) {
+            if (FULL || j < nvj)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
+                                                                 pass == 0 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
           }
         }
       }
-      if (tt + 1 < ntiles) store_tiles(buf ^ 1, k0 + BK);
-      __syncthreads();
+    }
+  };
+
+  Stage S0, S1;
+  auto kk = [&](int tt) { return kbeg + (int64_t)tt * BK; };
+  load_tiles(kbeg, S0);
+  store_tiles(0, kbeg, S0);
+  if (DEEP && ntiles > 1) load_tiles(kk(1), S1);
+  __syncthreads();
+
+  auto k_loop = [&](auto full_tag) {
+    if constexpr (DEEP) {
+      // tile tt sits in LDS buffer 0, S1 holds tile tt+1 (in flight since the previous half-step)
+      for (int tt = 0; tt < ntiles; tt += 2) {
+        if (tt + 2 < ntiles) load_tiles(kk(tt + 2), S0);
+        compute(0, full_tag);
+        if (tt + 1 < ntiles) store_tiles(1, kk(tt + 1), S1);
+        __syncthreads();
+        if (tt + 1 < ntiles) {
+          if (tt + 3 < ntiles) load_tiles(kk(tt + 3), S1);
+          compute(1, full_tag);
+          if (tt + 2 < ntiles) store_tiles(0, kk(tt + 2), S0);
+          __syncthreads();
+        }
+      }
+    } else {
+      for (int tt = 0; tt < ntiles; ++tt) {
+        const int buf = tt & 1;
+        if (tt + 1 < ntiles) load_tiles(kk(tt + 1), S0);
+        compute(buf, full_tag);
+        if (tt + 1 < ntiles) store_tiles(buf ^ 1, kk(tt + 1), S0);
+        __syncthreads();
+      }
     }
   };
   if (full)
@@ -308,7 +339,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
   }
 }
 
-template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
+template <int WM, int WN, int TM, int TN, int DEEP = 0, class AOp, class BOp, class Epi>
 int launch_gemm_bf16x3(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, int64_t K, int splits,
                        hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -321,7 +352,7 @@ int launch_gemm_bf16x3(const AOp& A, const BOp& B, const Epi& epi, int64_t M, in
   splits = (int)ceil_div(K, kps);
   const int64_t nblocks = splits > 1 ? ceil_div(splits, 8) * 8 * tiles_total : tiles_total;
   NRL_REQUIRE(nblocks < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, AOp, BOp, Epi>), dim3((unsigned)nblocks),
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, AOp, BOp, Epi, DEEP>), dim3((unsigned)nblocks),
                      dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits);
   NRL_LAUNCH_CHECK();
   return NRL_OK;

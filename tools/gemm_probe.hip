@@ -84,31 +84,31 @@ int dma_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
 
 // ---- bf16x3 engine ---------------------------------------------------------------------------
 static uint16_t* g_planes = nullptr;
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int DEEP = 1>
 int x3_nt(const Bufs& b, int64_t M, int N, int K, hipStream_t st, bool gather = false) {
   SplitWeight sw;
   if (split_weight(b.w, N, K, g_planes, &sw, st) != 0) return -1;
   KCSplit B{sw.hi, sw.lo, sw.Kp, N};
   EpiLinear e{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N};
   if (gather)
-    return launch_gemm_bf16x3<WM, WN, TM, TN>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a}, B, e, M, N, K, 1, st);
-  return launch_gemm_bf16x3<WM, WN, TM, TN>(KCPlain{b.a, K, M}, B, e, M, N, K, 1, st);
+    return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a}, B, e, M, N, K, 1, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{b.a, K, M}, B, e, M, N, K, 1, st);
 }
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int DEEP = 1>
 int x3_nn(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {  // b.w is W (K rows = out, N cols = in)
   SplitWeight sw;
   if (split_weight(b.w, K, N, g_planes, &sw, st) != 0) return -1;  // W is (out=K, in=N): transposed planes [N][Kp']
   KCSplit B{sw.hi_t, sw.lo_t, sw.Np, N};
-  return launch_gemm_bf16x3<WM, WN, TM, TN>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
 }
 static int g_x3_splits = 0;  // 0 = heuristic
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int DEEP = 1>
 int x3_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
   const int64_t tiles = ceil_div(I, WM * TM * 16) * ceil_div(J + 1, WN * TN * 16);
   int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(2048, tiles), ceil_div(Mr, 8 * 32)));
   if (g_x3_splits > 0) splits = g_x3_splits;
-  return launch_gemm_bf16x3<WM, WN, TM, TN>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
-                                            EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
+                                                  EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
 }
 
 struct EpiNull {  // keeps the accumulators alive, writes nothing
@@ -270,6 +270,32 @@ int main(int argc, char** argv) {
                    [=](hipStream_t s) { return x3_tn<WM, WN, TM, TN>(b, M, 300, 300, s); }});                \
   cases.push_back({std::string("x3 tn_wgrad_a  200x300     ") + tag, 2.0 * M * 200 * 300,                    \
                    [=](hipStream_t s) { return x3_tn<WM, WN, TM, TN>(b, M, 200, 300, s); }});
+#define ADD_X3D(tag, WM, WN, TM, TN, DEEP)                                                                 \
+  cases.push_back({std::string("x3deep gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, DEEP>(b, M, 900, 300, s, true); }});    \
+  cases.push_back({std::string("x3deep nt_outproj  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, DEEP>(b, M, 300, 300, s); }});          \
+  cases.push_back({std::string("x3deep nt_addatt   N=200 K=300 ") + tag, 2.0 * M * 200 * 300,                \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, DEEP>(b, M, 200, 300, s); }});          \
+  cases.push_back({std::string("x3deep nn_dgrad_in N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, DEEP>(b, M, 300, 900, s); }});          \
+  cases.push_back({std::string("x3deep nn_dgrad_o  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, DEEP>(b, M, 300, 300, s); }});          \
+  cases.push_back({std::string("x3deep tn_wgrad_in 900x300 S128 ") + tag, 2.0 * M * 900 * 300,               \
+                   [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, DEEP>(b, M, 900, 300, s); g_x3_splits = 0; return r; }}); \
+  cases.push_back({std::string("x3deep tn_wgrad_o  300x300 S128 ") + tag, 2.0 * M * 300 * 300,               \
+                   [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, DEEP>(b, M, 300, 300, s); g_x3_splits = 0; return r; }});
+  ADD_X3D("128x160 4w shallow", 2, 2, 4, 5, 0)
+  ADD_X3D("128x160 4w deep", 2, 2, 4, 5, 1)
+  ADD_X3D("64x320 4w shallow", 1, 4, 4, 5, 0)
+  ADD_X3D("128x160 deep", 4, 2, 2, 5, 1)
+  ADD_X3D("128x160 shallow", 4, 2, 2, 5, 0)
+  ADD_X3D("256x160 deep(spill)", 4, 2, 4, 5, 1)
+  ADD_X3D("256x160 shallow", 4, 2, 4, 5, 0)
+  ADD_X3D("64x160 deep", 2, 2, 2, 5, 1)
+  ADD_X3D("64x160 shallow", 2, 2, 2, 5, 0)
+  ADD_X3D("128x224 deep", 4, 2, 2, 7, 1)
+  ADD_X3D("128x224 shallow", 4, 2, 2, 7, 0)
 #define ADD_X3S(S, tag, WM, WN, TM, TN)                                                                    \
   cases.push_back({std::string("x3split tn_wgrad_in 900x300 S=" #S " ") + tag, 2.0 * M * 900 * 300,         \
                    [=](hipStream_t s) { g_x3_splits = S; int r = x3_tn<WM, WN, TM, TN>(b, M, 900, 300, s); g_x3_splits = 0; return r; }}); \
