@@ -49,8 +49,8 @@ __device__ __forceinline__ int swz(int chunk, int row) { return chunk ^ ((4 - ((
 // DEEP = 1: two named staging-register sets, global loads issued TWO k-tiles ahead (the k-loop is
 // unrolled by two so neither set is a loop-carried array the compiler has to copy); DEEP = 0: one set,
 // loads one tile ahead.
-template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi, int DEEP = 0>
-__global__ void __launch_bounds__(WM* WN * 64)
+template <int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi, int DEEP = 0, int OCC = 1>
+__global__ void __launch_bounds__(WM* WN * 64, OCC)
     gemm_bf16x3_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N,
                        const int64_t K, const int tiles_n, const int64_t tiles_total,
                        const int64_t k_per_split, const int nsplit) {
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
   }
 }
 
-template <int WM, int WN, int TM, int TN, int DEEP = 0, class AOp, class BOp, class Epi>
+template <int WM, int WN, int TM, int TN, int DEEP = 0, int OCC = 1, class AOp, class BOp, class Epi>
 int launch_gemm_bf16x3(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, int64_t K, int splits,
                        hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -352,7 +352,7 @@ int launch_gemm_bf16x3(const AOp& A, const BOp& B, const Epi& epi, int64_t M, in
   splits = (int)ceil_div(K, kps);
   const int64_t nblocks = splits > 1 ? ceil_div(splits, 8) * 8 * tiles_total : tiles_total;
   NRL_REQUIRE(nblocks < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, AOp, BOp, Epi, DEEP>), dim3((unsigned)nblocks),
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, AOp, BOp, Epi, DEEP, OCC>), dim3((unsigned)nblocks),
                      dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits);
   NRL_LAUNCH_CHECK();
   return NRL_OK;

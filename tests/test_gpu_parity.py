@@ -279,6 +279,57 @@ def test_full_size_properties_b128():
     assert pad.any() and (sr[pad] == 0).all()
 
 
+def test_embedding_gradient_hot_token_and_both_scatter_paths():
+    """A token filling most of the batch (the Zipf head) must not change the table gradient: the
+    id-sorted segment reduction and the atomic-epilogue fallback agree with the oracle."""
+    from newsreclib_amd import ops
+    from newsreclib_amd.news_encoder import MHSAAddAtt
+    params = _news_params(vocab=50, seed=4)
+    gen = torch.Generator().manual_seed(12)
+    ids = torch.randint(1, 50, (70, 30), generator=gen)
+    ids[:, 5:21] = 7                     # one hot token: 16 of 30 positions in every title
+    ids[:, 24:] = 0                      # padding tail
+    enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
+    enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+    enc = enc.to(DEV).eval()
+    d_out = torch.randn(70, 300, generator=gen)
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith(O.NEWS_PREFIX)}
+    O.news_encoder_fwd(ids, op, 15).backward(d_out)
+    ref = op[O.EMB_KEY].grad.clone()
+    ref[0].zero_()
+    enc(ids.to(DEV)).backward(d_out.to(DEV))            # sorted-segment path (order computed in ops)
+    g_sorted = enc.embedding_layer.weight.grad.clone()
+    scale = float(ref.abs().max())
+    assert _maxerr(g_sorted, ref) <= 2e-4 * scale
+    assert float(g_sorted[0].abs().max()) == 0.0
+    # atomic-epilogue fallback: call the C ABI with sorted_positions = NULL
+    import ctypes
+    from newsreclib_amd import _lib
+    lib = _lib.load()
+    prm = [p.detach() for p in enc._params()]
+    bp = ops._block_params(prm[1:], 15)
+    idg = ids.to(DEV)
+    nbytes = lib.nrl_news_encoder_workspace_bytes(70, 30, 300, 15, 200)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    out = torch.empty(70, 300, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.nrl_news_encoder_fwd(ctypes.byref(bp), prm[0].data_ptr(), 50, idg.data_ptr(), 70, 30, 0.0, 0, 0, 1,
+                                        out.data_ptr(), ws.data_ptr(), nbytes, st), "fwd")
+    bufs = [torch.zeros_like(p) for p in prm]
+    bg = ops._block_grads(bufs[1:])
+    dg = d_out.to(DEV)
+    _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), bufs[0].data_ptr(), 50, idg.data_ptr(),
+                                        None, 70, 30, 0.0, 0, 0, dg.data_ptr(), ws.data_ptr(), nbytes, st), "bwd")
+    assert _maxerr(bufs[0], ref) <= 2e-4 * scale
+
+
+def test_gemm_engine_switch_is_visible_and_exact_mode_is_tighter(engine):
+    from newsreclib_amd import _lib, ops
+    assert _lib.get_gemm_engine() == engine
+    with pytest.raises(ValueError):
+        _lib.set_gemm_engine("fp8")
+
+
 def test_c_abi_reports_errors():
     from newsreclib_amd import ops
     with pytest.raises(RuntimeError, match="GPU"):

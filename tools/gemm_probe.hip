@@ -84,22 +84,22 @@ int dma_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
 
 // ---- bf16x3 engine ---------------------------------------------------------------------------
 static uint16_t* g_planes = nullptr;
-template <int WM, int WN, int TM, int TN, int DEEP = 1>
+template <int WM, int WN, int TM, int TN, int DEEP = 1, int OCC = 1>
 int x3_nt(const Bufs& b, int64_t M, int N, int K, hipStream_t st, bool gather = false) {
   SplitWeight sw;
   if (split_weight(b.w, N, K, g_planes, &sw, st) != 0) return -1;
   KCSplit B{sw.hi, sw.lo, sw.Kp, N};
   EpiLinear e{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N};
   if (gather)
-    return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a}, B, e, M, N, K, 1, st);
-  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{b.a, K, M}, B, e, M, N, K, 1, st);
+    return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a}, B, e, M, N, K, 1, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC>(KCPlain{b.a, K, M}, B, e, M, N, K, 1, st);
 }
-template <int WM, int WN, int TM, int TN, int DEEP = 1>
+template <int WM, int WN, int TM, int TN, int DEEP = 1, int OCC = 1>
 int x3_nn(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {  // b.w is W (K rows = out, N cols = in)
   SplitWeight sw;
   if (split_weight(b.w, K, N, g_planes, &sw, st) != 0) return -1;  // W is (out=K, in=N): transposed planes [N][Kp']
   KCSplit B{sw.hi_t, sw.lo_t, sw.Np, N};
-  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
 }
 static int g_x3_splits = 0;  // 0 = heuristic
 template <int WM, int WN, int TM, int TN, int DEEP = 1>
@@ -285,6 +285,21 @@ int main(int argc, char** argv) {
                    [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, DEEP>(b, M, 900, 300, s); g_x3_splits = 0; return r; }}); \
   cases.push_back({std::string("x3deep tn_wgrad_o  300x300 S128 ") + tag, 2.0 * M * 300 * 300,               \
                    [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, DEEP>(b, M, 300, 300, s); g_x3_splits = 0; return r; }});
+#define ADD_X3O(tag, WM, WN, TM, TN, OCC)                                                                  \
+  cases.push_back({std::string("x3occ gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                 \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, OCC>(b, M, 900, 300, s, true); }});  \
+  cases.push_back({std::string("x3occ nt_outproj  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                 \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, OCC>(b, M, 300, 300, s); }});        \
+  cases.push_back({std::string("x3occ nn_dgrad_in N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                 \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, 0, OCC>(b, M, 300, 900, s); }});        \
+  cases.push_back({std::string("x3occ nn_dgrad_o  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                 \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, 0, OCC>(b, M, 300, 300, s); }});
+  ADD_X3O("128x160 8w occ4", 4, 2, 2, 5, 4)
+  ADD_X3O("128x160 8w occ3", 4, 2, 2, 5, 3)
+  ADD_X3O("128x160 8w occ2", 4, 2, 2, 5, 2)
+  ADD_X3O("64x160 4w occ4", 2, 2, 2, 5, 4)
+  ADD_X3O("64x160 4w occ3", 2, 2, 2, 5, 3)
+  ADD_X3O("128x160 4w occ2", 2, 2, 4, 5, 2)
   ADD_X3D("128x160 4w shallow", 2, 2, 4, 5, 0)
   ADD_X3D("128x160 4w deep", 2, 2, 4, 5, 1)
   ADD_X3D("64x320 4w shallow", 1, 4, 4, 5, 0)
