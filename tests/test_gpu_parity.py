@@ -333,6 +333,31 @@ def test_gemm_engine_switch_is_visible_and_exact_mode_is_tighter(engine):
         _lib.set_gemm_engine("fp8")
 
 
+def test_mindlarge_shaped_rank_batch_train_step(engine):
+    """BASELINE config 3 per-rank shape (V=150k, 64 impressions/GPU): one full train step through the
+    trainer; checks that need no oracle run -- finite loss, every parameter moves by <= lr under Adam,
+    the flat gradient is zeroed again, and a second step with the same batch lowers the loss."""
+    from newsreclib_amd.nrms_module import prepare_batch
+    from newsreclib_amd.synthetic import make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    params = O.make_params(150_000, seed=11)
+    mod = build_module(params, p_drop=0.2)
+    before = {k: p.detach().clone() for k, p in mod.named_parameters()}
+    tr = NRMSTrainer(mod, lr=1e-4)
+    batch = prepare_batch(make_batch(64, 150_000, "ragged", seed=5, device=DEV))
+    l1 = float(tr.step(batch))
+    assert math.isfinite(l1)
+    assert float(tr.flat.grad.abs().max()) == 0.0            # Adam kernel zeroed the gradient buffer
+    moved = 0
+    for k, p in mod.named_parameters():
+        d = (p.detach() - before[k]).abs()
+        assert float(d.max()) <= 1.01e-4, k                   # |step| <= lr (+ fp32 ulp of the weight)
+        moved += int((d > 0).sum())
+    assert moved > 0.3 * sum(p.numel() for p in mod.parameters()) * 0.001
+    losses = [float(tr.step(batch)) for _ in range(3)]
+    assert losses[-1] < l1
+
+
 def test_c_abi_reports_errors():
     from newsreclib_amd import ops
     with pytest.raises(RuntimeError, match="GPU"):
