@@ -123,15 +123,20 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
 
 /* ---- user encoder: nrms UserEncoder.forward, user/nrms.py:32-41 --------------------------------
  * hist (B, H, D) -> out (B, D).  Reproduces the reference's seq-first nn.MultiheadAttention call:
- * attention runs across the B users for each history slot (SURVEY.md headline fact 3). */
+ * attention runs across the B rows of dim 0 for each slot of dim 1 (SURVEY.md headline fact 3), then
+ * additive attention pools over dim 1.  With p_drop > 0 a dropout (stream0) is applied to the input
+ * and another (stream0 + 1) between attention and pooling: that is exactly the tail of the PLM text
+ * encoder, PLM.forward text.py:92-99, called with hist = last_hidden_state (N_news, L, D). */
 size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t embed_dim,
                                         int32_t num_heads, int32_t query_dim);
 int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t batch,
-                         int64_t hist_len, int32_t save_for_backward, float* out, void* ws,
-                         size_t ws_bytes, void* stream);
+                         int64_t hist_len, double p_drop, uint64_t seed, uint32_t stream0,
+                         int32_t save_for_backward, float* out, void* ws, size_t ws_bytes,
+                         void* stream);
 int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
-                         int64_t batch, int64_t hist_len, const float* d_out, float* d_hist,
-                         void* ws, size_t ws_bytes, void* stream);
+                         int64_t batch, int64_t hist_len, double p_drop, uint64_t seed,
+                         uint32_t stream0, const float* d_out, float* d_hist, void* ws,
+                         size_t ws_bytes, void* stream);
 
 /* ---- to_dense_batch (torch_geometric 2.3.0; call sites nrms_module.py:233,237,277-284) ---------
  * x (N, D) + offsets (B+1) int64 (prefix sums of the sorted assignment vector) ->

@@ -49,10 +49,11 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_int64, c_int32, c_double, c_uint64, c_uint32,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_user_encoder_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32, c_int32]),
-    "nrl_user_encoder_fwd": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_int64, c_int32, c_void_p,
-                                       c_void_p, c_size_t, c_void_p]),
+    "nrl_user_encoder_fwd": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_int64, c_double, c_uint64,
+                                       c_uint32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_user_encoder_bwd": (c_int32, [POINTER(NrlBlockParams), POINTER(NrlBlockGrads), c_void_p, c_int64,
-                                       c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                       c_int64, c_double, c_uint64, c_uint32, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "nrl_to_dense_batch_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nrl_to_dense_batch_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_void_p,
                                          c_void_p]),

@@ -235,14 +235,14 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
 // forward of the shared block given an A-operand accessor for the in-projection
 template <class AOp>
 static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape& s, const BlockWs& w,
-                     Dropout drop2, bool save, float* out, hipStream_t st) {
+                     Dropout drop2, bool save, bool prof_in_proj, float* out, hipStream_t st) {
   const int D = s.D, Q = s.Q;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
   BlockPlanes bp;
   NRL_TRY(block_planes(P, s, w, g_engine == ENGINE_BF16X3, &bp, st));
   // q|k|v = x W_in^T + b_in           (text.py:229 / user/nrms.py:34; torch in-projection)
   {
-    ProfScope prof(st, std::is_same<AOp, KCGather>::value ? 2.0 * (double)s.M * 3.0 * D * D : 0.0);
+    ProfScope prof(st, prof_in_proj ? 2.0 * (double)s.M * 3.0 * D * D : 0.0);
     NRL_TRY(gemm_fwd(a_in, P->in_proj_weight, bp.in, EpiLinear{w.qkv, 3 * D, P->in_proj_bias, 0, nodrop, 3 * D},
                      s.M, 3 * D, D, false, st));
   }
@@ -383,7 +383,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   KCGather a_in{emb_table, ids, s.M, s.D, d1, save_for_backward ? w.x : nullptr};
-  return block_fwd(p, a_in, s, w, d2, save_for_backward != 0, out, (hipStream_t)stream);
+  return block_fwd(p, a_in, s, w, d2, save_for_backward != 0, true, out, (hipStream_t)stream);
 }
 
 int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
@@ -415,36 +415,46 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
 
 size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t embed_dim,
                                         int32_t num_heads, int32_t query_dim) {
-  return block_ws_floats(batch * hist_len, embed_dim, query_dim, num_heads, false) * sizeof(float);
+  return block_ws_floats(batch * hist_len, embed_dim, query_dim, num_heads, true) * sizeof(float);
 }
 
 int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t batch, int64_t hist_len,
-                         int32_t save_for_backward, float* out, void* ws, size_t ws_bytes,
-                         void* stream) {
+                         double p_drop, uint64_t seed, uint32_t stream0, int32_t save_for_backward,
+                         float* out, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   NRL_REQUIRE(hist && out && batch > 0 && hist_len > 0, "user_encoder_fwd: bad arguments");
   NRL_REQUIRE(((uintptr_t)hist & 15) == 0, "hist must be 16-byte aligned");
+  NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
   const BlockShape s = user_shape(p, batch, hist_len);
+  NRL_REQUIRE(p_drop == 0.0 || s.M * s.D < (1LL << 32), "activation too large for the 32-bit dropout index space");
   BlockWs w;
-  NRL_TRY(carve_ws(ws, ws_bytes, s, false, &w));
-  return block_fwd(p, KCPlain{hist, s.D, s.M}, s, w, make_dropout(0.0, 0, 0), save_for_backward != 0, out,
+  NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
+  if (p_drop > 0.0) {
+    // seq-first block with dropouts around the attention = the PLM text encoder's tail (text.py:92-96)
+    const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
+    return block_fwd(p, KCGather{hist, nullptr, s.M, s.D, d1, save_for_backward ? w.x : nullptr}, s, w, d2,
+                     save_for_backward != 0, false, out, (hipStream_t)stream);
+  }
+  return block_fwd(p, KCPlain{hist, s.D, s.M}, s, w, make_dropout(0.0, 0, 0), save_for_backward != 0, false, out,
                    (hipStream_t)stream);
 }
 
 int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
-                         int64_t batch, int64_t hist_len, const float* d_out, float* d_hist, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         int64_t batch, int64_t hist_len, double p_drop, uint64_t seed, uint32_t stream0,
+                         const float* d_out, float* d_hist, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(hist && d_out && d_hist && batch > 0 && hist_len > 0, "user_encoder_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const BlockShape s = user_shape(p, batch, hist_len);
   BlockWs w;
-  NRL_TRY(carve_ws(ws, ws_bytes, s, false, &w));
+  NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
+  const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
   NRL_TRY(block_planes(p, s, w, false, &bp, st));
-  NRL_TRY(block_bwd_to_dqkv(p, g, hist, s, w, bp, make_dropout(0.0, 0, 0), d_out, st));
-  return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiStore{d_hist, s.D}, s.M, 3 * s.D, s.D, st);
+  NRL_TRY(block_bwd_to_dqkv(p, g, p_drop > 0.0 ? w.x : hist, s, w, bp, d2, d_out, st));
+  return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{d_hist, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
+                    s.D, st);
 }
 
 int nrl_to_dense_batch_fwd(const float* x, const int64_t* offsets, int64_t batch, int64_t max_len,

@@ -65,7 +65,8 @@ struct KCPlain {
 
 // rows gathered from an embedding table through int64 ids (nn.Embedding, text.py:224), times the
 // dropout multiplier of text.py:225; the tile column 0 workgroup also saves the post-dropout row
-// (needed by the in-projection weight gradient).
+// (needed by the in-projection weight gradient).  ids == nullptr means identity rows: a dense
+// activation with an input dropout (the PLM text encoder's first dropout, text.py:92-93).
 struct KCGather {
   static constexpr int kLayout = SRC_KC;
   const float* table;
@@ -80,7 +81,8 @@ struct KCGather {
   };
   __device__ __forceinline__ State init(int64_t r) const {
     const bool ok = r < rows;
-    return State{table + ids[ok ? r : 0] * (int64_t)dim, ok};
+    const int64_t rr = ok ? r : 0;
+    return State{table + (ids != nullptr ? ids[rr] : rr) * (int64_t)dim, ok};
   }
   __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
     return *reinterpret_cast<const float4*>(s.ptr + (k < K ? k : K - 4));

@@ -55,6 +55,53 @@ class MHSAAddAtt(nn.Module):
         return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, 0, _grad_bufs(params), order)
 
 
+class PLM(nn.Module):
+    """Text encoder over a pretrained language model, mirroring the reference ``PLM`` (text.py:15-109)
+    for the NRMS configuration ``use_mhsa=True, apply_reduce_dim=False``: transformer body -> dropout
+    -> multi-head self-attention -> dropout -> additive attention.
+
+    The transformer body is HF ``AutoModel`` running on PyTorch-ROCm (hipBLASLt / SDPA; SURVEY.md build
+    plan step 8); everything after ``last_hidden_state`` is ONE call into the HIP library
+    (``nrl_user_encoder_fwd`` with dropouts).  The reference feeds the (N, L, D) hidden states to a
+    seq-first ``nn.MultiheadAttention``, so attention runs ACROSS THE NEWS ITEMS of the call for each
+    token position (SURVEY.md headline fact 3) -- reproduced, and no attention mask is applied after
+    the body, exactly as in the reference."""
+
+    def __init__(self, plm_model, frozen_layers: Optional[List[int]], embed_dim: int, use_mhsa: bool,
+                 apply_reduce_dim: bool, reduced_embed_dim: Optional[int], num_heads: Optional[int],
+                 query_dim: Optional[int], dropout_probability: float) -> None:
+        super().__init__()
+        if not isinstance(plm_model, str):
+            raise ValueError(f"Expected keyword argument `plm_model` to be a `str` but got {plm_model}")
+        if not isinstance(dropout_probability, float):
+            raise ValueError(
+                f"Expected keyword argument `dropout_probability` to be a `float` but got {dropout_probability}")
+        if not use_mhsa or apply_reduce_dim:
+            raise NotImplementedError("newsreclib_amd.PLM covers use_mhsa=True, apply_reduce_dim=False (NRMS)")
+        from transformers import AutoModel
+        self.use_mhsa, self.apply_reduce_dim = use_mhsa, apply_reduce_dim
+        self.plm_model = AutoModel.from_pretrained(plm_model)
+        for name, param in self.plm_model.base_model.named_parameters():   # text.py:69-73
+            for layer in (frozen_layers or []):
+                if "layer." + str(layer) + "." in name:
+                    param.requires_grad = False
+        assert isinstance(num_heads, int) and num_heads > 0
+        self.multihead_attention = nn.MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads)
+        self.additive_attention = AdditiveAttention(input_dim=embed_dim, query_dim=query_dim)
+        self.dropout = nn.Dropout(p=dropout_probability)
+        self.num_heads = num_heads
+
+    def forward(self, text: Dict[str, torch.Tensor], seed: Optional[int] = None) -> torch.Tensor:
+        hidden = self.plm_model(**text)[0]                      # (N, L, D)
+        p = float(self.dropout.p) if self.training else 0.0
+        if p > 0.0 and seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62))
+        mha, att = self.multihead_attention, self.additive_attention
+        params = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
+                  att.linear.weight, att.linear.bias, att.query)
+        return ops.UserEncoderFn.apply(hidden, *params, self.num_heads, _grad_bufs(params), p, seed or 0)
+
+
 class NewsEncoder(nn.Module):
     """Dispatches news attributes to their encoders (news.py:134-183).  NRMS uses exactly one text
     encoder (``attributes2encode=["title"]``), for which the reference returns that encoder's output

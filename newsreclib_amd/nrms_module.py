@@ -24,7 +24,7 @@ from ._lightning import LightningModuleBase
 from .click_predictor import CrossEntropyLoss, DotProduct
 from .dense_batch import dense_slot_index, to_dense_batch
 from .metrics import ranking_metrics
-from .news_encoder import MHSAAddAtt, NewsEncoder
+from .news_encoder import PLM, MHSAAddAtt, NewsEncoder
 from .user_encoder import UserEncoder
 
 
@@ -48,9 +48,13 @@ def prepare_batch(batch: Dict) -> Dict:
     # visiting order for the embedding gradient (pure index bookkeeping, like the offsets above)
     for attr in ("title", "abstract"):
         if attr in batch["x_hist"] and attr in batch["x_cand"]:
-            ids = torch.cat([batch["x_hist"][attr], batch["x_cand"][attr]], dim=0)
-            out.setdefault("x_all", {})[attr] = ids
-            out["x_all"][attr + "_order"] = torch.argsort(ids.reshape(-1))
+            h, c = batch["x_hist"][attr], batch["x_cand"][attr]
+            if torch.is_tensor(h):
+                ids = torch.cat([h, c], dim=0)
+                out.setdefault("x_all", {})[attr] = ids
+                out["x_all"][attr + "_order"] = torch.argsort(ids.reshape(-1))
+            else:   # PLM tokenizer output: dict of (N, L) tensors (rec_dataset.py:180-190)
+                out.setdefault("x_all", {})[attr] = {k: torch.cat([h[k], c[k]], dim=0) for k in h.keys()}
     return out
 
 
@@ -92,19 +96,24 @@ class NRMSModule(LightningModuleBase):
         if dual_loss_training or loss != "cross_entropy_loss":
             raise NotImplementedError("newsreclib_amd.NRMSModule implements loss='cross_entropy_loss' "
                                       "(configs/model/nrms.yaml:6); sup_con / dual loss are out of scope")
-        if use_plm:
-            raise NotImplementedError("use_plm=True (PLM news encoder) is not built yet")
         if late_fusion:
             raise NotImplementedError("late_fusion=True is not built yet")
         self.criterion = CrossEntropyLoss()
 
-        # pretrained embeddings + contextualisation (nrms_module.py:122-135)
-        if pretrained_embeddings is None:
-            assert isinstance(pretrained_embeddings_path, str)
-            pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
-        text_encoder = MHSAAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=embed_dim,
-                                  num_heads=num_heads, query_dim=query_dim,
-                                  dropout_probability=dropout_probability)
+        if not use_plm:
+            # pretrained embeddings + contextualisation (nrms_module.py:122-135)
+            if pretrained_embeddings is None:
+                assert isinstance(pretrained_embeddings_path, str)
+                pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
+            text_encoder = MHSAAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=embed_dim,
+                                      num_heads=num_heads, query_dim=query_dim,
+                                      dropout_probability=dropout_probability)
+        else:
+            # PLM news encoder (nrms_module.py:136-149)
+            assert isinstance(plm_model, str)
+            text_encoder = PLM(plm_model=plm_model, frozen_layers=frozen_layers, embed_dim=embed_dim,
+                               use_mhsa=True, apply_reduce_dim=False, reduced_embed_dim=None,
+                               num_heads=num_heads, query_dim=query_dim, dropout_probability=dropout_probability)
         self.news_encoder = NewsEncoder(
             dataset_attributes=dataset_attributes, attributes2encode=attributes2encode,
             concatenate_inputs=False, text_encoder=text_encoder, category_encoder=None,
@@ -130,7 +139,8 @@ class NRMSModule(LightningModuleBase):
     def forward(self, batch: Dict) -> torch.Tensor:
         batch = prepare_batch(batch)
         B = batch["batch_size"]
-        n_hist = batch["x_hist"][self._text_attr].shape[0]
+        hist_text = batch["x_hist"][self._text_attr]
+        n_hist = (hist_text if torch.is_tensor(hist_text) else next(iter(hist_text.values()))).shape[0]
         # one encoder call for history + candidate news (the reference makes two, :232,236)
         news_vector = self.news_encoder(batch["x_all"])
         hist_news_vector_agg, _ = to_dense_batch(news_vector[:n_hist], batch["batch_hist"], B,

@@ -230,6 +230,25 @@ def user_encoder_fwd(hist: torch.Tensor, params: Dict[str, torch.Tensor], num_he
                               params[P + "additive_attention.query"])
 
 
+def plm_tail_fwd(hidden: torch.Tensor, params: Dict[str, torch.Tensor], num_heads: int,
+                 mult1: Optional[torch.Tensor] = None, mult2: Optional[torch.Tensor] = None,
+                 prefix: str = "") -> torch.Tensor:
+    """Tail of ``PLM.forward`` with ``use_mhsa=True`` (``text.py:92-99``): last_hidden_state (N, L, D)
+    -> dropout -> seq-first MHA (attention ACROSS THE N NEWS for each token position, the same
+    batch_first quirk as the user encoder) -> dropout -> additive attention over L -> (N, D).
+    The transformer body itself is third-party (HF ``AutoModel``) and is not restated."""
+    x = hidden if mult1 is None else hidden * mult1
+    y = _mhsa_seq_first(x, params[prefix + "multihead_attention.in_proj_weight"],
+                        params[prefix + "multihead_attention.in_proj_bias"],
+                        params[prefix + "multihead_attention.out_proj.weight"],
+                        params[prefix + "multihead_attention.out_proj.bias"], num_heads)
+    if mult2 is not None:
+        y = y * mult2
+    return additive_attention(y, params[prefix + "additive_attention.linear.weight"],
+                              params[prefix + "additive_attention.linear.bias"],
+                              params[prefix + "additive_attention.query"])
+
+
 def click_scores(user: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
     """``DotProduct.forward`` as called at ``nrms_module.py:251-253``: (B, D), (B, C, D) -> (B, C)."""
     return torch.bmm(user.unsqueeze(1), cand.permute(0, 2, 1)).squeeze(1)

@@ -30,7 +30,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, "/root/reference")
 
 from newsreclib.models.components.encoders.news.news import NewsEncoder  # noqa: E402
-from newsreclib.models.components.encoders.news.text import MHSAAddAtt  # noqa: E402
+from newsreclib.models.components.encoders.news.text import PLM, MHSAAddAtt  # noqa: E402
 from newsreclib.models.components.encoders.user.nrms import UserEncoder  # noqa: E402
 from newsreclib.models.components.layers.click_predictor import DotProduct  # noqa: E402
 
@@ -237,6 +237,60 @@ def case_adam(n_steps=3, lr=1e-4):
     print("adam3: losses", losses)
 
 
+def case_plm():
+    """Config-4 path: the reference ``PLM`` text encoder (text.py:15-109) over a tiny random-init
+    roberta-shaped body (no network for roberta-base).  Eval forward + a train forward with injected
+    dropout masks, and gradients of the encoder tail."""
+    import tempfile
+
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nrl_test_helpers", os.path.join(REPO, "tests", "helpers.py"))
+    th = importlib.util.module_from_spec(spec)      # (the reference ships its own tests/helpers package)
+    spec.loader.exec_module(th)
+    PLM_HEADS, PLM_Q, make_plm_tail_params, make_tiny_roberta = (th.PLM_HEADS, th.PLM_Q, th.make_plm_tail_params,
+                                                                  th.make_tiny_roberta)
+    tmp = tempfile.mkdtemp()
+    make_tiny_roberta(tmp)
+    enc = PLM(plm_model=tmp, frozen_layers=[0], embed_dim=96, use_mhsa=True, apply_reduce_dim=False,
+              reduced_embed_dim=None, num_heads=PLM_HEADS, query_dim=PLM_Q, dropout_probability=0.2)
+    tail = make_plm_tail_params()
+    missing = enc.load_state_dict(tail, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("plm_model.") for k in missing.missing_keys)
+    inj = InjectedDropout()
+    enc.dropout = inj
+    rng = np.random.default_rng(31)
+    N, L = 7, 12
+    ids = rng.integers(3, 200, (N, L))
+    lens = rng.integers(4, L + 1, N)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    ids = np.where(mask == 1, ids, 1)
+    text = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    arrays = {"in_input_ids": ids, "in_attention_mask": mask}
+    d_out = torch.from_numpy(rng.standard_normal((N, 96)).astype(np.float32))
+    arrays["in_d_out"] = d_out.numpy()
+    for tag, p_drop, seed in (("eval", 0.0, 0), ("train", 0.2, 5)):
+        enc.zero_grad()
+        if p_drop > 0:
+            inj.arm([dropout_multiplier(seed, 0, p_drop, (N, L, 96)), dropout_multiplier(seed, 1, p_drop, (N, L, 96))])
+        else:
+            inj.arm([])
+        out = enc(text)
+        (out * d_out).sum().backward()
+        arrays[f"out_{tag}"] = out.detach().numpy()
+        for k in tail:
+            obj = enc
+            for part in k.split("."):
+                obj = getattr(obj, part)
+            arrays[f"grad_{tag}/{k}"] = obj.grad.detach().numpy().copy()
+        emb_g = enc.plm_model.embeddings.word_embeddings.weight.grad
+        arrays[f"grad_{tag}/plm_word_embeddings_norm"] = np.float64(emb_g.double().norm())
+        arrays[f"cfg_{tag}_p_drop"], arrays[f"cfg_{tag}_seed"] = np.float64(p_drop), np.int64(seed)
+    with torch.no_grad():
+        arrays["out_hidden"] = enc.plm_model(**text)[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "plm_tiny.npz"), **arrays)
+    print("plm_tiny: out", arrays["out_eval"].shape, "|out|max", float(np.abs(arrays["out_eval"]).max()))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -247,6 +301,7 @@ def main():
     run_case("mind32_train", b32, vocab=2000, param_seed=2, p_drop=0.2, seed=99)
     case_quirks()
     case_adam()
+    case_plm()
 
 
 if __name__ == "__main__":

@@ -82,12 +82,50 @@ def module_grads(mod):
 
 
 def batch_to(batch, device):
-    out = {}
-    for k, v in batch.items():
+    def mv(v):
         if isinstance(v, dict):
-            out[k] = {kk: vv.to(device) for kk, vv in v.items()}
-        elif torch.is_tensor(v):
-            out[k] = v.to(device)
+            return {kk: mv(vv) for kk, vv in v.items()}
+        return v.to(device) if torch.is_tensor(v) else v
+
+    return {k: mv(v) for k, v in batch.items()}
+
+
+PLM_CFG = dict(vocab_size=200, hidden_size=96, num_hidden_layers=2, num_attention_heads=6, intermediate_size=192,
+               max_position_embeddings=40, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2,
+               hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+PLM_HEADS, PLM_Q = 6, 32
+
+
+def make_tiny_roberta(save_dir, seed=17):
+    """Random-init roberta-shaped body with portable (numpy default_rng) weights, saved where
+    ``AutoModel.from_pretrained`` can load it -- there is no network / HF cache for roberta-base."""
+    from transformers import RobertaConfig, RobertaModel
+    model = RobertaModel(RobertaConfig(**PLM_CFG), add_pooling_layer=False)
+    rng = np.random.default_rng(seed)
+    sd = model.state_dict()
+    new = {}
+    for k in sorted(sd.keys()):
+        v = sd[k]
+        if not torch.is_floating_point(v):
+            new[k] = v
+        elif k.endswith("LayerNorm.weight"):
+            new[k] = torch.from_numpy((1.0 + 0.05 * rng.standard_normal(tuple(v.shape))).astype(np.float32))
         else:
-            out[k] = v
+            new[k] = torch.from_numpy((0.08 * rng.standard_normal(tuple(v.shape))).astype(np.float32))
+    model.load_state_dict(new)
+    model.save_pretrained(save_dir)
+    return save_dir
+
+
+def make_plm_tail_params(dim=96, query_dim=PLM_Q, seed=23):
+    """MHA + additive-attention parameters of the PLM encoder tail (reference state_dict key names)."""
+    rng = np.random.default_rng(seed)
+    shapes = {"multihead_attention.in_proj_weight": (3 * dim, dim), "multihead_attention.in_proj_bias": (3 * dim,),
+              "multihead_attention.out_proj.weight": (dim, dim), "multihead_attention.out_proj.bias": (dim,),
+              "additive_attention.linear.weight": (query_dim, dim), "additive_attention.linear.bias": (query_dim,),
+              "additive_attention.query": (query_dim,)}
+    out = {}
+    for k in sorted(shapes):
+        scale = 0.1 if k.endswith("query") else (0.05 if k.endswith("bias") else 1.0 / np.sqrt(dim))
+        out[k] = torch.from_numpy((scale * rng.standard_normal(shapes[k])).astype(np.float32))
     return out

@@ -358,6 +358,127 @@ def test_mindlarge_shaped_rank_batch_train_step(engine):
     assert losses[-1] < l1
 
 
+def test_plm_news_encoder_matches_reference_plm(tmp_path, engine):
+    """BASELINE config 4 path on a tiny roberta-shaped body: product ``PLM`` (HF body on PyTorch-ROCm +
+    ONE HIP call for dropout/MHA/dropout/additive attention) vs the reference's PLM module."""
+    from newsreclib_amd.news_encoder import PLM
+    from tests.helpers import PLM_HEADS, PLM_Q, make_plm_tail_params, make_tiny_roberta
+    g = load_golden("plm_tiny")
+    enc = PLM(plm_model=make_tiny_roberta(str(tmp_path)), frozen_layers=[0], embed_dim=96, use_mhsa=True,
+              apply_reduce_dim=False, reduced_embed_dim=None, num_heads=PLM_HEADS, query_dim=PLM_Q,
+              dropout_probability=0.2)
+    missing = enc.load_state_dict(make_plm_tail_params(), strict=False)
+    assert not missing.unexpected_keys
+    enc = enc.to(DEV)
+    text = {"input_ids": torch.from_numpy(g["in_input_ids"]).to(DEV),
+            "attention_mask": torch.from_numpy(g["in_attention_mask"]).to(DEV)}
+    d_out = torch.from_numpy(g["in_d_out"]).to(DEV)
+    for tag in ("eval", "train"):
+        enc.train(tag == "train")
+        enc.plm_model.eval()                       # HF-internal dropouts are 0 in this config anyway
+        enc.zero_grad()
+        out = enc(text, seed=int(g[f"cfg_{tag}_seed"]))
+        err = float(np.abs(out.detach().cpu().numpy() - g[f"out_{tag}"]).max())
+        print(f"plm {tag}: max abs err {err:.3e}")
+        assert err <= 2e-4
+        (out * d_out).sum().backward()
+        for k in make_plm_tail_params():
+            obj = enc
+            for part in k.split("."):
+                obj = getattr(obj, part)
+            ref = g[f"grad_{tag}/{k}"]
+            e = float(np.abs(obj.grad.cpu().numpy() - ref).max())
+            assert e <= 5e-4 * max(1.0, float(np.abs(ref).max())), (tag, k, e)
+        # the gradient flows on into the (unfrozen) transformer body, text.py:70-73
+        gn = float(enc.plm_model.embeddings.word_embeddings.weight.grad.double().norm())
+        ref_n = float(g[f"grad_{tag}/plm_word_embeddings_norm"])
+        assert abs(gn - ref_n) <= 2e-3 * ref_n, (gn, ref_n)
+
+
+def test_nrms_module_with_plm_news_encoder_end_to_end(tmp_path, engine):
+    """use_plm=True through the drop-in module (nrms_module.py:136-149): scores vs the oracle built
+    from the same HF body (CPU) + restated tail + user encoder + scorer."""
+    from functools import partial
+
+    from transformers import AutoModel
+
+    from newsreclib_amd.nrms_module import NRMSModule
+    from tests.helpers import PLM_HEADS, PLM_Q, make_plm_tail_params, make_tiny_roberta
+    path = make_tiny_roberta(str(tmp_path))
+    mod = NRMSModule(
+        dataset_attributes=["title", "abstract"], attributes2encode=["title"],
+        outputs={"train": ["preds", "targets", "cand_news_size"], "val": [], "test": []},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False,
+        temperature=None, use_plm=True, pretrained_embeddings_path=None, plm_model=path, frozen_layers=[0],
+        embed_dim=96, num_heads=PLM_HEADS, query_dim=PLM_Q, dropout_probability=0.2, top_k_list=[5, 10],
+        num_categ_classes=18, num_sent_classes=3, save_recs=False, recs_fpath=None,
+        optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None)
+    tail = make_plm_tail_params()
+    utail = make_plm_tail_params(seed=29)
+    sd = {"news_encoder.text_encoders.title." + k: v for k, v in tail.items()}
+    sd.update({"user_encoder." + k: v for k, v in utail.items()})
+    assert not mod.load_state_dict(sd, strict=False).unexpected_keys
+    mod = mod.to(DEV).eval()
+    rng = np.random.default_rng(3)
+    hist_sizes, cand_sizes, L = [2, 3, 1], [5, 5, 5], 10
+
+    def toks(n):
+        ids = rng.integers(3, 200, (n, L))
+        lens = rng.integers(3, L + 1, n)
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+        return {"input_ids": torch.from_numpy(np.where(m == 1, ids, 1)), "attention_mask": torch.from_numpy(m)}
+
+    batch = {"x_hist": {"title": toks(sum(hist_sizes))}, "x_cand": {"title": toks(sum(cand_sizes))},
+             "batch_hist": torch.repeat_interleave(torch.arange(3), torch.tensor(hist_sizes)),
+             "batch_cand": torch.repeat_interleave(torch.arange(3), torch.tensor(cand_sizes)),
+             "labels": torch.tensor([1., 0, 0, 0, 0] * 3), "user_ids": torch.arange(3) + 1,
+             "user_idx": torch.arange(3)}
+    scores = mod(batch_to(batch, DEV)).detach().cpu()
+    # oracle: one body call over [hist; cand] (attention across ALL news of the call, as the product does)
+    body = AutoModel.from_pretrained(path).eval()
+    allt = {k: torch.cat([batch["x_hist"]["title"][k], batch["x_cand"]["title"][k]]) for k in ("input_ids", "attention_mask")}
+    with torch.no_grad():
+        hidden = body(**allt)[0]
+        news = O.plm_tail_fwd(hidden, tail, PLM_HEADS)
+        nh = sum(hist_sizes)
+        hd, _ = O.to_dense_batch(news[:nh], batch["batch_hist"], 3)
+        cd, _ = O.to_dense_batch(news[nh:], batch["batch_cand"], 3)
+        user = O.plm_tail_fwd(hd, utail, PLM_HEADS)         # same seq-first block = NRMS user encoder
+        ref = O.click_scores(user, cd)
+    err = float((scores - ref).abs().max())
+    print(f"plm module scores max abs err {err:.3e}")
+    assert err <= 2e-4
+
+
+def test_plm_tail_at_roberta_base_dims(engine):
+    """D=768, 16 heads (d_h = 48), L=96, Q=200: the config-4 tail at full width vs the oracle."""
+    from newsreclib_amd import ops
+    gen = torch.Generator().manual_seed(77)
+    N, L, D, Hh, Q = 6, 96, 768, 16, 200
+    hidden = torch.randn(N, L, D, generator=gen) * 0.5
+    prm = make_tail(D, Q, gen)
+    hg = hidden.to(DEV).requires_grad_(True)
+    out = ops.UserEncoderFn.apply(hg, *[p.to(DEV) for p in prm.values()], Hh, None, 0.1, 99)
+    hc = hidden.clone().requires_grad_(True)
+    m1 = O.dropout_multiplier(99, 0, 0.1, (N, L, D))
+    m2 = O.dropout_multiplier(99, 1, 0.1, (N, L, D))
+    ref = O.plm_tail_fwd(hc, prm, Hh, m1, m2)
+    assert _maxerr(out, ref) <= 2e-4
+    d_out = torch.randn(N, D, generator=gen)
+    out.backward(d_out.to(DEV))
+    ref.backward(d_out)
+    assert _maxerr(hg.grad, hc.grad) <= 2e-4 * max(1.0, float(hc.grad.abs().max()))
+
+
+def make_tail(D, Q, gen):
+    sh = {"multihead_attention.in_proj_weight": (3 * D, D), "multihead_attention.in_proj_bias": (3 * D,),
+          "multihead_attention.out_proj.weight": (D, D), "multihead_attention.out_proj.bias": (D,),
+          "additive_attention.linear.weight": (Q, D), "additive_attention.linear.bias": (Q,),
+          "additive_attention.query": (Q,)}
+    return {k: torch.randn(*v, generator=gen) * (0.1 if "bias" in k or "query" in k else 1.0 / math.sqrt(D))
+            for k, v in sh.items()}
+
+
 def test_c_abi_reports_errors():
     from newsreclib_amd import ops
     with pytest.raises(RuntimeError, match="GPU"):

@@ -128,3 +128,31 @@ def test_torch_graph_matches_oracle():
     m.load_oracle_params(params)
     scores = m(golden_batch(g))
     assert np.abs(scores.detach().numpy() - g["out_scores"]).max() <= 2e-5
+
+
+def test_plm_tail_matches_reference_plm(tmp_path):
+    """Config-4 path: oracle tail (dropout -> seq-first MHA -> dropout -> additive attention) on top of
+    the SAME third-party HF body reproduces the reference ``PLM`` module (text.py:15-109), eval and
+    train mode, forward and the tail's parameter gradients."""
+    from transformers import AutoModel
+
+    from tests.helpers import PLM_HEADS, make_plm_tail_params, make_tiny_roberta
+    g = load_golden("plm_tiny")
+    body = AutoModel.from_pretrained(make_tiny_roberta(str(tmp_path))).eval()
+    text = {"input_ids": torch.from_numpy(g["in_input_ids"]), "attention_mask": torch.from_numpy(g["in_attention_mask"])}
+    with torch.no_grad():
+        hidden = body(**text)[0]
+    assert np.abs(hidden.numpy() - g["out_hidden"]).max() <= 2e-5
+    N, L, D = hidden.shape
+    d_out = torch.from_numpy(g["in_d_out"])
+    for tag in ("eval", "train"):
+        p, seed = float(g[f"cfg_{tag}_p_drop"]), int(g[f"cfg_{tag}_seed"])
+        params = {k: v.clone().requires_grad_(True) for k, v in make_plm_tail_params().items()}
+        m1 = O.dropout_multiplier(seed, 0, p, (N, L, D)) if p > 0 else None
+        m2 = O.dropout_multiplier(seed, 1, p, (N, L, D)) if p > 0 else None
+        out = O.plm_tail_fwd(hidden, params, PLM_HEADS, m1, m2)
+        assert np.abs(out.detach().numpy() - g[f"out_{tag}"]).max() <= 2e-5, tag
+        (out * d_out).sum().backward()
+        for k, v in params.items():
+            ref = g[f"grad_{tag}/{k}"]
+            assert np.abs(v.grad.numpy() - ref).max() <= 2e-4 * max(1.0, float(np.abs(ref).max())), (tag, k)
