@@ -125,8 +125,11 @@ struct RCPlain {
 };
 
 // ---------------------------------------------------------------------------------------------
-// epilogues
+// epilogues: `row(m)` is evaluated once per output row a lane owns (per-row loads / index math),
+// `operator()(row_state, m, n, v)` once per valid element.
 // ---------------------------------------------------------------------------------------------
+struct NoRow {};
+
 // C = act(v + bias[n]) * dropout(m, n)      (nn.Linear + optional tanh + optional nn.Dropout)
 struct EpiLinear {
   float* c;
@@ -135,11 +138,16 @@ struct EpiLinear {
   int act_tanh;
   Dropout drop;
   int n_cols;  // logical row width for the dropout flat index
-  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
+  struct Row {
+    float* out;
+    uint32_t idx0;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc, (uint32_t)m * (uint32_t)n_cols}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
     if (bias != nullptr) v += bias[n];
     if (act_tanh) v = tanhf(v);
-    if (drop.thresh != 0u) v *= drop.mult((uint32_t)m * (uint32_t)n_cols + (uint32_t)n);
-    c[m * ldc + n] = v;
+    if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n);
+    r.out[n] = v;
   }
 };
 
@@ -147,7 +155,11 @@ struct EpiLinear {
 struct EpiStore {
   float* c;
   int64_t ldc;
-  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const { c[m * ldc + n] = v; }
+  struct Row {
+    float* out;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const { r.out[n] = v; }
 };
 
 // additive-attention backward, fused: dy = (v + w[m] * d_out[group(m)][n]) * dropout(m, n)
@@ -160,10 +172,19 @@ struct EpiPoolBwd {
   const float* d_out;  // (groups, N)
   int group_len;       // rows per group
   Dropout drop;
-  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
-    v += w[m] * d_out[(m / group_len) * ldc + n];
-    if (drop.thresh != 0u) v *= drop.mult((uint32_t)m * (uint32_t)ldc + (uint32_t)n);
-    c[m * ldc + n] = v;
+  struct Row {
+    float* out;
+    const float* g;
+    float wm;
+    uint32_t idx0;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const {
+    return Row{c + m * ldc, d_out + (m / group_len) * ldc, w[m], (uint32_t)m * (uint32_t)ldc};
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    v += r.wm * r.g[n];
+    if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n);
+    r.out[n] = v;
   }
 };
 
@@ -173,9 +194,13 @@ struct EpiAtomicWB {
   int64_t ldc;
   float* db;  // may be null
   int n_w;
-  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
+  struct Row {
+    float* out;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{dw + m * ldc}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t m, int n, float v) const {
     if (n < n_w)
-      atomicAdd(dw + m * ldc + n, v);
+      atomicAdd(r.out + n, v);
     else if (n == n_w && db != nullptr)
       atomicAdd(db + m, v);
   }
@@ -188,13 +213,21 @@ struct EpiScatter {
   const int64_t* ids;
   int dim;
   Dropout drop;
-  __device__ __forceinline__ void operator()(int64_t m, int n, float v) const {
+  struct Row {
+    float* out;  // null for the pad token
+    uint32_t idx0;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const {
     const int64_t id = ids[m];
-    if (id == 0) return;
-    if (drop.thresh != 0u) v *= drop.mult((uint32_t)m * (uint32_t)dim + (uint32_t)n);
-    atomicAdd(d_table + id * (int64_t)dim + n, v);
+    return Row{id == 0 ? nullptr : d_table + id * (int64_t)dim, (uint32_t)m * (uint32_t)dim};
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    if (r.out == nullptr) return;
+    if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n);
+    atomicAdd(r.out + n, v);
   }
 };
+
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
@@ -434,12 +467,15 @@ __global__ void __launch_bounds__(WM* WN * 64)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 16 + l15;
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + r;
+      if (m < M) {
+        const typename Epi::Row rs = epi.row(m);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + r;
-        if (m < M && n < N) epi(m, n, acc[i][j][r]);
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wn * TN + j) * 16 + l15;
+          if (n < N) epi(rs, m, n, acc[i][j][r]);
+        }
       }
     }
   }

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   auto compute = [&](int buf, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     const unsigned char* base = smem + buf * BUF;
-    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    bf16x8 ah[TM], al[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = (wm * TM + i) * 16 + l15;
@@ -263,25 +263,59 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
       ah[i] = *reinterpret_cast<const bf16x8*>(base + off);
       al[i] = *reinterpret_cast<const bf16x8*>(base + PLANE_A + off);
     }
+    if constexpr (OCC >= 4) {
+      // register-lean order (lets two 8-wave workgroups share a CU): B fragments are fetched two
+      // column blocks at a time; the 3 split products of a block are issued small-terms-first and
+      // interleaved over TM x 2 independent accumulators
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = (wn * TN + j) * 16 + l15;
-      const int off = row * 64 + swz(g, row) * 16;
-      bh[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + off);
-      bl[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + PLANE_B + off);
-    }
-    // small cross terms first, the dominant hi*hi term last; each pass touches all blocks, so
-    // consecutive MFMAs never depend on each other
+      for (int j0 = 0; j0 < TN; j0 += 2) {
+        bf16x8 bh[2], bl[2];
 #pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
+        for (int jj = 0; jj < 2; ++jj) {
+          if (j0 + jj < TN) {
+            const int row = (wn * TN + j0 + jj) * 16 + l15;
+            const int off = row * 64 + swz(g, row) * 16;
+            bh[jj] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + off);
+            bl[jj] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + PLANE_B + off);
+          }
+        }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (FULL || i < nvi) {
+        for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if (FULL || j < nvj)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
-                                                                 pass == 0 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i) {
+            if (FULL || i < nvi) {
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                if (j0 + jj < TN && (FULL || j0 + jj < nvj))
+                  acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      pass == 1 ? al[i] : ah[i], pass == 0 ? bl[jj] : bh[jj], acc[i][j0 + jj], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      bf16x8 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 16 + l15;
+        const int off = row * 64 + swz(g, row) * 16;
+        bh[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + off);
+        bl[j] = *reinterpret_cast<const bf16x8*>(base + 2 * PLANE_A + PLANE_B + off);
+      }
+      // small cross terms first, the dominant hi*hi term last; each pass touches all blocks, so
+      // consecutive MFMAs never depend on each other
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (FULL || i < nvi) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (FULL || j < nvj)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
+                                                                   pass == 0 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+            }
           }
         }
       }
@@ -328,12 +362,15 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 16 + l15;
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + r;
+      if (m < M) {
+        const typename Epi::Row rs = epi.row(m);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + r;
-        if (m < M && n < N) epi(m, n, acc[i][j][r]);
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wn * TN + j) * 16 + l15;
+          if (n < N) epi(rs, m, n, acc[i][j][r]);
+        }
       }
     }
   }

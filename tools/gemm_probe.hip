@@ -112,7 +112,9 @@ int x3_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
 }
 
 struct EpiNull {  // keeps the accumulators alive, writes nothing
-  __device__ __forceinline__ void operator()(int64_t, int, float v) const { asm volatile("" ::"v"(v)); }
+  struct Row {};
+  __device__ __forceinline__ Row row(int64_t) const { return Row{}; }
+  __device__ __forceinline__ void operator()(const Row&, int64_t, int, float v) const { asm volatile("" ::"v"(v)); }
 };
 template <int ABL, bool NOEPI>
 int run_nn_abl(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {
