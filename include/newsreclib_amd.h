@@ -114,12 +114,15 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
  * d_emb_table (vocab, D).  `ws` must be the workspace the forward filled.
  * sorted_positions: optional (may be NULL) argsort of the flat (N*L) id vector; when given, the
  * table gradient is reduced in id-sorted order (one atomic per (id, 64-row segment)) instead of one
- * atomic per element -- frequent tokens otherwise serialise on their row. */
+ * atomic per element -- frequent tokens otherwise serialise on their row.
+ * phase: 0 = whole backward; 1 = activation-gradient chain + table gradient only; 2 = the three
+ * weight/bias-gradient GEMMs only (call 1 then 2: a data-parallel caller starts the all-reduce of the
+ * table gradient, >96 % of the bytes, between them so it overlaps the weight-gradient GEMMs). */
 int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
                          int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
                          int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed,
-                         uint32_t stream0, const float* d_out, void* ws, size_t ws_bytes,
-                         void* stream);
+                         uint32_t stream0, const float* d_out, int32_t phase, void* ws,
+                         size_t ws_bytes, void* stream);
 
 /* ---- user encoder: nrms UserEncoder.forward, user/nrms.py:32-41 --------------------------------
  * hist (B, H, D) -> out (B, D).  Reproduces the reference's seq-first nn.MultiheadAttention call:

@@ -47,7 +47,7 @@ SIGNATURES = {
                                        c_void_p]),
     "nrl_news_encoder_bwd": (c_int32, [POINTER(NrlBlockParams), POINTER(NrlBlockGrads), c_void_p, c_int64,
                                        c_void_p, c_void_p, c_int64, c_int32, c_double, c_uint64, c_uint32,
-                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+                                       c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "nrl_user_encoder_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32, c_int32]),
     "nrl_user_encoder_fwd": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_int64, c_double, c_uint64,
                                        c_uint32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),

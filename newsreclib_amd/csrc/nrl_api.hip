@@ -97,7 +97,7 @@ struct BlockShape {
 };
 
 struct BlockWs {
-  float *x, *qkv, *o, *y, *t, *w, *lse, *dy, *dqkv;
+  float *x, *qkv, *o, *y, *t, *w, *lse, *dy, *dqkv, *d_o;
   uint16_t* planes;  // bf16 hi/lo planes of the three weights (bf16x3 engine)
 };
 
@@ -110,7 +110,7 @@ static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
   size_t n = 0;
   if (with_x) n += al((size_t)M * D);
   n += al((size_t)M * 3 * D) * 2;  // qkv, dqkv
-  n += al((size_t)M * D) * 3;      // o, y, dy
+  n += al((size_t)M * D) * 4;      // o, y, dy, d_o (later dx)
   n += al((size_t)M * Q);          // t / d_pre
   n += al((size_t)M);              // w
   n += al((size_t)M * heads);      // lse
@@ -133,6 +133,7 @@ static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x,
   out->o = take((size_t)s.M * s.D);
   out->y = take((size_t)s.M * s.D);
   out->dy = take((size_t)s.M * s.D);
+  out->d_o = take((size_t)s.M * s.D);
   out->t = take((size_t)s.M * s.Q);
   out->w = take((size_t)s.M);
   out->lse = take((size_t)s.M * s.heads);
@@ -259,24 +260,32 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
   return NRL_OK;
 }
 
-// backward of the shared block up to d(qkv); the caller finishes with the in-projection dgrad
-static int block_bwd_to_dqkv(const NrlBlockParams* P, const NrlBlockGrads* G, const float* x_rows,
-                             const BlockShape& s, const BlockWs& w, const BlockPlanes& bp, Dropout drop2,
-                             const float* d_out, hipStream_t st) {
+// Backward of the shared block, in two phases so that a data-parallel caller can start the
+// all-reduce of the (large) input-side gradient while the weight gradients are still being computed:
+//   phase 1: everything on the activation-gradient chain down to d(qkv)  (the caller then runs the
+//            in-projection dgrad -> table gradient / d_hist)
+//   phase 2: the three weight(+bias)-gradient GEMMs, which only READ saved activations/gradients.
+static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, const BlockShape& s, const BlockWs& w,
+                            const BlockPlanes& bp, Dropout drop2, const float* d_out, hipStream_t st) {
   const int D = s.D, Q = s.Q;
   // additive attention backward: t -> d_pre in place, dq_a
   NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st));
   // dy = (d_pre W_a + w * d_out) * dropout2
   NRL_TRY(gemm_dgrad(w.t, P->att_weight, bp.att, EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, Q, D, st));
+  // d_o = dy W_o
+  NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{w.d_o, D}, s.M, D, D, st));
+  // attention backward -> dqkv
+  NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+  return NRL_OK;
+}
+
+static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const BlockShape& s, const BlockWs& w,
+                            hipStream_t st) {
+  const int D = s.D, Q = s.Q;
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
   NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
-  // d_o = dy W_o  (written over y, which is dead from here on)
-  float* d_o = w.y;
-  NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{d_o, D}, s.M, D, D, st));
   // dW_o += dy^T o ; db_o += colsum(dy)
   NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
-  // attention backward -> dqkv
-  NRL_TRY(attn_bwd(w.qkv, w.o, d_o, w.lse, w.dqkv, s.geom, st));
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
   NRL_TRY(gemm_wgrad(w.dqkv, 3 * D, x_rows, D, G->in_proj_weight, G->in_proj_bias, s.M, st));
   return NRL_OK;
@@ -389,10 +398,11 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
 int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
                          int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
                          int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed, uint32_t stream0,
-                         const float* d_out, void* ws, size_t ws_bytes, void* stream) {
+                         const float* d_out, int32_t phase, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(d_emb_table && ids && d_out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_bwd: bad arguments");
+  NRL_REQUIRE(phase >= 0 && phase <= 2, "news_encoder_bwd: phase must be 0 (all), 1 or 2");
   if (n_news == 0) return NRL_OK;
   hipStream_t st = (hipStream_t)stream;
   const BlockShape s = news_shape(p, n_news, seq_len);
@@ -401,16 +411,22 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
   NRL_TRY(block_planes(p, s, w, false, &bp, st));  // filled by the forward; weights unchanged since
-  NRL_TRY(block_bwd_to_dqkv(p, g, w.x, s, w, bp, d2, d_out, st));
-  // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
-  if (sorted_positions != nullptr) {
-    // dx is materialised (in the dead `dy` buffer) and reduced in id-sorted order: no hot-row contention
-    float* dx = w.dy;
-    NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{dx, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
-                       s.D, st));
-    return embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st);
+  if (phase != 2) {
+    NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st));
+    // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
+    if (sorted_positions != nullptr) {
+      // dx is materialised (in the now dead d_o buffer) and reduced in id-sorted order: no hot-row contention
+      float* dx = w.d_o;
+      NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{dx, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
+                         s.D, st));
+      NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));
+    } else {
+      NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiScatter{d_emb_table, ids, s.D, d1}, s.M, 3 * s.D,
+                         s.D, st));
+    }
   }
-  return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiScatter{d_emb_table, ids, s.D, d1}, s.M, 3 * s.D, s.D, st);
+  if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, s, w, st));
+  return NRL_OK;
 }
 
 size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t embed_dim,
@@ -452,9 +468,10 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
   NRL_TRY(block_planes(p, s, w, false, &bp, st));
-  NRL_TRY(block_bwd_to_dqkv(p, g, p_drop > 0.0 ? w.x : hist, s, w, bp, d2, d_out, st));
-  return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{d_hist, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
-                    s.D, st);
+  NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st));
+  NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{d_hist, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
+                     s.D, st));
+  return block_bwd_phase2(g, p_drop > 0.0 ? w.x : hist, s, w, st);
 }
 
 int nrl_to_dense_batch_fwd(const float* x, const int64_t* offsets, int64_t batch, int64_t max_len,

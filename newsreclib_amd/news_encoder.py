@@ -37,7 +37,7 @@ class MHSAAddAtt(nn.Module):
         self.additive_attention = AdditiveAttention(input_dim=embed_dim, query_dim=query_dim)
         self.dropout = nn.Dropout(dropout_probability)  # holds p; the kernels draw the mask
         self.num_heads = num_heads
-        self._calls = 0
+        self.table_grad_hook = None   # optional callable(grad_tensor), see trainer.NRMSTrainer
 
     def _params(self):
         mha, att = self.multihead_attention, self.additive_attention
@@ -52,7 +52,8 @@ class MHSAAddAtt(nn.Module):
             # torch.manual_seed
             seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62))
         params = self._params()
-        return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, 0, _grad_bufs(params), order)
+        return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, 0, _grad_bufs(params), order,
+                                       self.table_grad_hook)
 
 
 class PLM(nn.Module):

@@ -68,7 +68,7 @@ class NewsEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, emb, w_in, b_in, w_o, b_o, w_a, b_a, q_a, heads, p_drop, seed, stream0,
-                grad_bufs, order=None):
+                grad_bufs, order=None, table_grad_hook=None):
         lib = _lib.load()
         ids = _chk(ids, torch.int64, "ids")
         params = [_chk(t, torch.float32, n) for t, n in zip(
@@ -97,6 +97,7 @@ class NewsEncoderFn(torch.autograd.Function):
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
+            ctx.table_grad_hook = table_grad_hook
         return out
 
     @staticmethod
@@ -112,12 +113,23 @@ class NewsEncoderFn(torch.autograd.Function):
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         bg = _block_grads(bufs[1:])
         ws = ctx.ws
-        _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), bufs[0].data_ptr(), V,
-                                            ids.data_ptr(), order.data_ptr(), N, L, p_drop, seed, stream0,
-                                            d_out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-                   "nrl_news_encoder_bwd")
+        def run(phase):
+            _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), bufs[0].data_ptr(), V,
+                                                ids.data_ptr(), order.data_ptr(), N, L, p_drop, seed, stream0,
+                                                d_out.data_ptr(), phase, ws.data_ptr(), ws.numel(), _stream()),
+                       "nrl_news_encoder_bwd")
+
+        hook = ctx.table_grad_hook
+        if hook is None:
+            run(0)
+        else:
+            # the embedding-table gradient (>96 % of all gradient bytes) is complete after phase 1: let the
+            # data-parallel trainer start its all-reduce now, under the weight-gradient GEMMs of phase 2
+            run(1)
+            hook(bufs[0])
+            run(2)
         ctx.ws = None
-        return (None, *rets, None, None, None, None, None, None)
+        return (None, *rets, None, None, None, None, None, None, None)
 
 
 class UserEncoderFn(torch.autograd.Function):

@@ -79,19 +79,65 @@ def allreduce_gradients(grad: torch.Tensor, group=None) -> float:
     return 1.0 / world
 
 
+class OverlappedGradReduce:
+    """Two-piece gradient all-reduce over the flat buffer.
+
+    The first parameter of the module (the (V, D) embedding table, >96 % of the gradient bytes) is
+    complete as soon as the news encoder's activation-gradient chain has run; `start_head` is called
+    at that point (from inside the backward, see ``ops.NewsEncoderFn``) and launches an ASYNC all-reduce
+    of that leading segment, which RCCL carries over xGMI while the weight-gradient GEMMs still run.
+    `finish` reduces the small tail and waits for the head.  With no process group (or world 1) both
+    are no-ops and the scale is 1."""
+
+    def __init__(self, flat: "FlatParams", head_numel: int, group=None):
+        self.flat, self.head, self.group = flat, int(head_numel), group
+        self._work = None
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def start_head(self, _grad=None) -> None:
+        if self._active() and self.head > 0:
+            self._work = dist.all_reduce(self.flat.grad[: self.head], op=dist.ReduceOp.SUM, group=self.group,
+                                         async_op=True)
+
+    def finish(self) -> float:
+        if not self._active():
+            return 1.0
+        if self._work is None:                      # the hook did not fire: reduce everything now
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            if self.head < self.flat.numel:
+                dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
+            self._work.wait()
+            self._work = None
+        return 1.0 / dist.get_world_size(self.group)
+
+
 class NRMSTrainer:
-    """forward -> CE loss -> backward -> (all-reduce) -> fused Adam; one call = one train step."""
+    """forward -> CE loss -> backward (table-gradient all-reduce overlapped) -> fused Adam."""
 
     def __init__(self, module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, group=None):
         self.module = module
         self.flat = FlatParams(module.parameters())
         self.opt = FusedAdam(self.flat, lr, betas, eps)
         self.group = group
+        # leading segment = first parameter = the embedding table when the news encoder is MHSAAddAtt
+        head = 0
+        te = None
+        enc = getattr(module, "news_encoder", None)
+        if enc is not None and hasattr(enc, "text_encoders"):
+            te = next(iter(enc.text_encoders.values()))
+        if te is not None and hasattr(te, "embedding_layer") and self.flat.params[0] is te.embedding_layer.weight:
+            head = self.flat.offsets[1] if len(self.flat.offsets) > 1 else self.flat.numel
+        self.reduce = OverlappedGradReduce(self.flat, head, group)
+        if head > 0:
+            te.table_grad_hook = self.reduce.start_head
 
     def step(self, batch: Dict) -> torch.Tensor:
         self.module.train()
         loss = self.module.training_step(batch, 0)
         loss.backward()
-        scale = allreduce_gradients(self.flat.grad, self.group)
+        scale = self.reduce.finish()
         self.opt.step(grad_scale=scale, zero_grad=True)
         return loss.detach()

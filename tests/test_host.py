@@ -119,6 +119,49 @@ def test_ranking_metrics_known_answers():
     assert abs(m["auc"] - 6.0 / 8.0) < 1e-6
 
 
+_OVERLAP_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from newsreclib_amd.trainer import FlatParams, OverlappedGradReduce
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+torch.manual_seed(0)
+emb = torch.nn.Embedding(50, 8)
+lin = torch.nn.Linear(8, 4)
+params = list(emb.parameters()) + list(lin.parameters())
+flat = FlatParams(params)
+red = OverlappedGradReduce(flat, flat.offsets[1])
+
+
+class TwoPhase(torch.autograd.Function):          # mimics ops.NewsEncoderFn: table grad, hook, then weights
+    @staticmethod
+    def forward(ctx, w, lw, lb):
+        return (w.sum() + lw.sum() + lb.sum()).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        params[0].main_grad.add_(float(rank + 1))          # "phase 1": table gradient complete
+        red.start_head(params[0].main_grad)
+        params[1].main_grad.add_(10.0 * (rank + 1))        # "phase 2": weight gradients
+        params[2].main_grad.add_(100.0 * (rank + 1))
+        return None, None, None
+
+
+TwoPhase.apply(*params).backward()
+scale = red.finish()
+assert scale == 0.5
+assert torch.allclose(params[0].main_grad * scale, torch.full_like(params[0], 1.5))
+assert torch.allclose(params[1].main_grad * scale, torch.full_like(params[1], 15.0))
+assert torch.allclose(params[2].main_grad * scale, torch.full_like(params[2], 150.0))
+# hook never fired -> finish() must still reduce everything
+flat.grad.zero_()
+flat.grad.add_(float(rank + 1))
+assert red.finish() == 0.5 and torch.allclose(flat.grad, torch.full_like(flat.grad, 3.0))
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
 _DP_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["REPO"])
@@ -149,6 +192,26 @@ for i, p in enumerate(lin.parameters()):
 dist.destroy_process_group()
 print("OK", rank)
 """
+
+
+def _run_two_ranks(tmp_path, script_text, name):
+    script = tmp_path / name
+    script.write_text(script_text)
+    port = str(29500 + (os.getpid() * 7 + len(name)) % 2000)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0 and b"OK" in out, out.decode()
+
+
+def test_overlapped_gradient_reduce_two_processes_gloo(tmp_path):
+    """The two-piece all-reduce (async head launched from inside backward, tail afterwards) equals one
+    sum all-reduce of the whole flat gradient; also when the hook never fires."""
+    _run_two_ranks(tmp_path, _OVERLAP_SCRIPT, "overlap.py")
 
 
 def test_data_parallel_allreduce_two_processes_gloo(tmp_path):
