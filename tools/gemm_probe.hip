@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "experimental/nrl_gemm_dma.h"
-#include "../newsreclib_amd/csrc/nrl_gemm_bf16x3.h"
+#include "experimental/nrl_gemm_bf16x3_ws.h"
 
 namespace nrl {
 void set_error(const char* fmt, ...) {
@@ -84,31 +84,31 @@ int dma_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
 
 // ---- bf16x3 engine ---------------------------------------------------------------------------
 static uint16_t* g_planes = nullptr;
-template <int WM, int WN, int TM, int TN, int DEEP = 1, int OCC = 1>
+template <int WM, int WN, int TM, int TN, int DEEP = 1, int OCC = 1, int WS = 0>
 int x3_nt(const Bufs& b, int64_t M, int N, int K, hipStream_t st, bool gather = false) {
   SplitWeight sw;
   if (split_weight(b.w, N, K, g_planes, &sw, st) != 0) return -1;
   KCSplit B{sw.hi, sw.lo, sw.Kp, N};
   EpiLinear e{b.c, N, b.bias, 0, make_dropout(0.0, 0, 0), N};
   if (gather)
-    return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a}, B, e, M, N, K, 1, st);
-  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC>(KCPlain{b.a, K, M}, B, e, M, N, K, 1, st);
+    return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC, WS>(KCGather{b.tbl, b.ids, M, K, make_dropout(0.2, 1, 0), b.a}, B, e, M, N, K, 1, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC, WS>(KCPlain{b.a, K, M}, B, e, M, N, K, 1, st);
 }
-template <int WM, int WN, int TM, int TN, int DEEP = 1, int OCC = 1>
+template <int WM, int WN, int TM, int TN, int DEEP = 1, int OCC = 1, int WS = 0>
 int x3_nn(const Bufs& b, int64_t M, int N, int K, hipStream_t st) {  // b.w is W (K rows = out, N cols = in)
   SplitWeight sw;
   if (split_weight(b.w, K, N, g_planes, &sw, st) != 0) return -1;  // W is (out=K, in=N): transposed planes [N][Kp']
   KCSplit B{sw.hi_t, sw.lo_t, sw.Np, N};
-  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, OCC, WS>(KCPlain{b.a, K, M}, B, EpiStore{b.c, N}, M, N, K, 1, st);
 }
 static int g_x3_splits = 0;  // 0 = heuristic
-template <int WM, int WN, int TM, int TN, int DEEP = 1>
+template <int WM, int WN, int TM, int TN, int DEEP = 1, int WS = 0>
 int x3_tn(const Bufs& b, int64_t Mr, int I, int J, hipStream_t st) {
   const int64_t tiles = ceil_div(I, WM * TM * 16) * ceil_div(J + 1, WN * TN * 16);
   int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(2048, tiles), ceil_div(Mr, 8 * 32)));
   if (g_x3_splits > 0) splits = g_x3_splits;
-  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
-                                                  EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
+  return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP, 1, WS>(RCPlain{b.a, I, I, 0}, RCPlain{b.w, J, J, 1},
+                                                         EpiAtomicWB{b.c, J, b.bias, J}, I, J + 1, Mr, splits, st);
 }
 
 struct EpiNull {  // keeps the accumulators alive, writes nothing
@@ -177,6 +177,14 @@ int main(int argc, char** argv) {
       {"x3 nn 300x900", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 900, st); }, [&] { return x3_nn<4, 2, 2, 5>(b, Mv, 300, 900, st); }, (size_t)Mv * 300, false},
       {"x3 nn 300x200", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 200, st); }, [&] { return x3_nn<4, 2, 2, 5>(b, Mv, 300, 200, st); }, (size_t)Mv * 300, false},
       {"x3 tn 900x300", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 900, 300, st); }, [&] { return x3_tn<4, 2, 2, 5>(b, Mv, 900, 300, st); }, (size_t)900 * 300, true},
+      {"x3rot nt 300x300", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 300, 300, st); }, [&] { return x3_nt<2, 2, 4, 5, 0, 1, 2>(b, Mv, 300, 300, st); }, (size_t)Mv * 300, false},
+      {"x3rot gather 900x300 (+dropout)", [&] { return run_gather<4, 2, 2, 5, 16>(bx, Mv, 900, 300, st); }, [&] { return x3_nt<2, 2, 4, 5, 0, 1, 2>(bx, Mv, 900, 300, st, true); }, (size_t)Mv * 900, false},
+      {"x3rot nn 300x200", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 200, st); }, [&] { return x3_nn<2, 2, 4, 5, 0, 1, 2>(b, Mv, 300, 200, st); }, (size_t)Mv * 300, false},
+      {"x3rot tn 900x300", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 900, 300, st); }, [&] { return x3_tn<2, 2, 4, 5, 0, 2>(b, Mv, 900, 300, st); }, (size_t)900 * 300, true},
+      {"x3ws nt 300x300", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 300, 300, st); }, [&] { return x3_nt<2, 2, 4, 5, 0, 1, 1>(b, Mv, 300, 300, st); }, (size_t)Mv * 300, false},
+      {"x3ws gather 900x300 (+dropout)", [&] { return run_gather<4, 2, 2, 5, 16>(bx, Mv, 900, 300, st); }, [&] { return x3_nt<2, 2, 4, 5, 0, 1, 1>(bx, Mv, 900, 300, st, true); }, (size_t)Mv * 900, false},
+      {"x3ws nn 300x900", [&] { return run_nn<4, 2, 2, 5, 16>(b, Mv, 300, 900, st); }, [&] { return x3_nn<2, 2, 4, 5, 0, 1, 1>(b, Mv, 300, 900, st); }, (size_t)Mv * 300, false},
+      {"x3ws tn 900x300", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 900, 300, st); }, [&] { return x3_tn<2, 2, 4, 5, 0, 1>(b, Mv, 900, 300, st); }, (size_t)900 * 300, true},
       {"x3 tn 200x300 (4w)", [&] { return run_tn<4, 2, 2, 5, 16>(b, Mv, 200, 300, st); }, [&] { return x3_tn<2, 2, 2, 5>(b, Mv, 200, 300, st); }, (size_t)200 * 300, true},
       {"nt 300x300", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 300, 300, st); }, [&] { return dma_nt<4, 2, 2, 5>(b, Mv, 300, 300, st); }, (size_t)Mv * 300, false},
       {"nt 200x300 (8x1w)", [&] { return run_nt<4, 2, 2, 5, 16>(b, Mv, 200, 300, st); }, [&] { return dma_nt<8, 1, 1, 13>(b, Mv, 200, 300, st); }, (size_t)Mv * 200, false},
@@ -287,6 +295,41 @@ int main(int argc, char** argv) {
                    [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, DEEP>(b, M, 900, 300, s); g_x3_splits = 0; return r; }}); \
   cases.push_back({std::string("x3deep tn_wgrad_o  300x300 S128 ") + tag, 2.0 * M * 300 * 300,               \
                    [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, DEEP>(b, M, 300, 300, s); g_x3_splits = 0; return r; }});
+#define ADD_X3W(tag, WM, WN, TM, TN)                                                                       \
+  cases.push_back({std::string("x3ws gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                  \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, 1, 1>(b, M, 900, 300, s, true); }}); \
+  cases.push_back({std::string("x3ws nt_outproj  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                  \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, 1, 1>(b, M, 300, 300, s); }});       \
+  cases.push_back({std::string("x3ws nt_addatt   N=200 K=300 ") + tag, 2.0 * M * 200 * 300,                  \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, 1, 1>(b, M, 200, 300, s); }});       \
+  cases.push_back({std::string("x3ws nn_dgrad_in N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                  \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, 0, 1, 1>(b, M, 300, 900, s); }});       \
+  cases.push_back({std::string("x3ws nn_dgrad_o  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                  \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, 0, 1, 1>(b, M, 300, 300, s); }});       \
+  cases.push_back({std::string("x3ws tn_wgrad_in 900x300 S128 ") + tag, 2.0 * M * 900 * 300,                 \
+                   [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, 0, 1>(b, M, 900, 300, s); g_x3_splits = 0; return r; }}); \
+  cases.push_back({std::string("x3ws tn_wgrad_o  300x300 S128 ") + tag, 2.0 * M * 300 * 300,                 \
+                   [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, 0, 1>(b, M, 300, 300, s); g_x3_splits = 0; return r; }});
+#define ADD_X3R(tag, WM, WN, TM, TN)                                                                       \
+  cases.push_back({std::string("x3rot gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                 \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, 1, 2>(b, M, 900, 300, s, true); }}); \
+  cases.push_back({std::string("x3rot nt_outproj  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                 \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, 1, 2>(b, M, 300, 300, s); }});       \
+  cases.push_back({std::string("x3rot nt_addatt   N=200 K=300 ") + tag, 2.0 * M * 200 * 300,                 \
+                   [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, 1, 2>(b, M, 200, 300, s); }});       \
+  cases.push_back({std::string("x3rot nn_dgrad_in N=300 K=900 ") + tag, 2.0 * M * 300 * 900,                 \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, 0, 1, 2>(b, M, 300, 900, s); }});       \
+  cases.push_back({std::string("x3rot nn_dgrad_o  N=300 K=300 ") + tag, 2.0 * M * 300 * 300,                 \
+                   [=](hipStream_t s) { return x3_nn<WM, WN, TM, TN, 0, 1, 2>(b, M, 300, 300, s); }});       \
+  cases.push_back({std::string("x3rot tn_wgrad_in 900x300 S128 ") + tag, 2.0 * M * 900 * 300,                \
+                   [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, 0, 2>(b, M, 900, 300, s); g_x3_splits = 0; return r; }}); \
+  cases.push_back({std::string("x3rot tn_wgrad_o  300x300 S128 ") + tag, 2.0 * M * 300 * 300,                \
+                   [=](hipStream_t s) { g_x3_splits = 128; int r = x3_tn<WM, WN, TM, TN, 0, 2>(b, M, 300, 300, s); g_x3_splits = 0; return r; }});
+  ADD_X3R("128x160", 2, 2, 4, 5)
+  ADD_X3R("64x160", 2, 2, 2, 5)
+  ADD_X3W("128x160", 2, 2, 4, 5)
+  ADD_X3W("64x160", 2, 2, 2, 5)
+  ADD_X3W("128x224", 2, 2, 4, 7)
 #define ADD_X3O(tag, WM, WN, TM, TN, OCC)                                                                  \
   cases.push_back({std::string("x3occ gather_qkv  N=900 K=300 ") + tag, 2.0 * M * 900 * 300,                 \
                    [=](hipStream_t s) { return x3_nt<WM, WN, TM, TN, 0, OCC>(b, M, 900, 300, s, true); }});  \
