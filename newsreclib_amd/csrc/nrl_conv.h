@@ -1,0 +1,96 @@
+// Operand accessors that turn the LSTUR/NAML text CNN (reference CNNAddAtt, text.py:112-176:
+// nn.Conv2d(1, F, kernel (W, D), padding ((W-1)/2, 0)) over the token axis + ReLU) into the same
+// tiled GEMMs as the NRMS projections -- no im2col buffer is ever materialised.  With rows
+// m = news * L + token of a dense (M, inner) activation, the window of row m is the CONTIGUOUS
+// range starting `pad` rows earlier, so a windowed operand is an overlapping-row matrix (ld = inner,
+// K = W * inner) plus a mask for taps that cross a news boundary:
+//
+//   forward   c[m, f]       = b_f + sum_{t, d} x[m + t - pad, d] * Wc[f, t*D + d]        K = W*D
+//   dgrad     dx[m, d]      = sum_{t', f} dc[m + t' - pad', f] * Wc[f, (W-1-t')*D + d]    K = W*F
+//             (taps reversed, t' = W-1-t, pad' = W-1-pad, so the dc rows are contiguous too)
+//   wgrad     dWc[f, t*D+d] = sum_m dc[m, f] * x[m + t - pad, d]                          K = M
+//
+// The dense buffers carry W*inner floats of slack on both sides (carved by the workspace), so the
+// unconditional tile loads of the first / last rows stay inside the allocation.
+#pragma once
+#include "nrl_gemm.h"
+
+namespace nrl {
+
+// k-contiguous windowed rows: element (m, k = t*inner + j) = p[(m + t - pad) * inner + j], or 0 if
+// token(m) + t - pad falls outside [0, L)
+struct KCWindow {
+  static constexpr int kLayout = SRC_KC;
+  const float* p;  // dense (rows, inner), with slack
+  int64_t rows;
+  int inner, L, W, pad;
+  struct State {
+    const float* ptr;
+    int lo, hi;  // valid k range [lo, hi) of this row (whole taps)
+  };
+  __device__ __forceinline__ State init(int64_t m) const {
+    const bool ok = m < rows;
+    const int64_t mm = ok ? m : 0;
+    const int l = (int)(mm % L);
+    // tap t valid iff 0 <= l + t - pad < L
+    int t0 = pad - l;
+    t0 = t0 < 0 ? 0 : t0;
+    int t1 = L + pad - l;  // exclusive
+    t1 = t1 > W ? W : t1;
+    return State{p + (mm - pad) * (int64_t)inner, ok ? t0 * inner : 0, ok ? t1 * inner : 0};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
+    return *reinterpret_cast<const float4*>(s.ptr + (k < K ? k : K - 4));
+  }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
+    if (k >= kend || k < s.lo || k >= s.hi) v = f4zero();
+  }
+};
+
+// k-major windowed source for the conv weight gradient: element (k = m, r = t*inner + j) is
+// x[m + t - pad][j] (0 outside the news); `ones` appends the bias column as in RCPlain.
+struct RCWindow {
+  static constexpr int kLayout = SRC_RC;
+  const float* x;  // (M, inner) with slack
+  int inner, L, pad, ones;
+  int64_t rows;    // = W * inner
+  struct State {};
+  __device__ __forceinline__ float4 load(int64_t k, int64_t r, int64_t K) const {
+    const int64_t kk = k < K ? k : K - 1;
+    const int64_t rr = r < rows ? r : rows - 4;
+    return *reinterpret_cast<const float4*>(x + (kk - pad) * inner + rr);
+  }
+  __device__ __forceinline__ void finish(float4& v, int64_t k, int64_t r, int64_t kend) const {
+    if (k >= kend) {
+      v = f4zero();
+      return;
+    }
+    if (r >= rows) {
+      v = (ones && r == rows) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
+      return;
+    }
+    const int l = (int)(k % L) + (int)(r / inner) - pad;
+    if (l < 0 || l >= L) v = f4zero();
+  }
+};
+
+// conv weight Wc (F, W*D) as the (K = W*F, N = D) operand of the dgrad with reversed taps:
+// element (k = t'*F + f, r = d) = Wc[f][(W-1-t')*D + d]
+struct RCConvT {
+  static constexpr int kLayout = SRC_RC;
+  const float* w;
+  int F, D, W;
+  int64_t rows;  // = D
+  struct State {};
+  __device__ __forceinline__ float4 load(int64_t k, int64_t r, int64_t K) const {
+    const int64_t kk = k < K ? k : K - 1;
+    const int tr = (int)(kk / F), f = (int)(kk - (int64_t)tr * F);
+    const int64_t rr = r < rows ? r : rows - 4;
+    return *reinterpret_cast<const float4*>(w + ((int64_t)f * W + (W - 1 - tr)) * D + rr);
+  }
+  __device__ __forceinline__ void finish(float4& v, int64_t k, int64_t r, int64_t kend) const {
+    if (k >= kend || r >= rows) v = f4zero();
+  }
+};
+
+}  // namespace nrl

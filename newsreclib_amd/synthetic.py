@@ -97,3 +97,24 @@ def batch_from_sizes(hist_sizes, cand_sizes, labels, vocab: int, seed: int, L: i
         "user_idx": np.arange(B, dtype=np.int64),
     }
     return batch_to_torch(batch, B)
+
+
+def add_lstur_fields(batch: Dict, vocab: int, n_categ: int = 19, n_users: int = 1000, L_abstract: int = 50,
+                     seed: int = 4321) -> Dict:
+    """Adds what ``LSTURModule.forward`` reads on top of the NRMS batch (``lstur_module.py:278-303``):
+    abstract token ids and category ids per news row (``rec_dataset.py:148-168``), and ``user_idx``
+    drawn from [0, n_users) -- 0 is the reference's "unknown user" / padding row."""
+    rng = np.random.default_rng(seed)
+    dev = batch["labels"].device
+    for part in ("x_hist", "x_cand"):
+        n = batch[part]["title"].shape[0]
+        lens = np.clip(np.rint(rng.normal(32.0, 12.0, n)), 5, L_abstract).astype(np.int64)
+        ids = _zipf_ids(rng, n * L_abstract, vocab).reshape(n, L_abstract)
+        ids[np.arange(L_abstract)[None, :] >= lens[:, None]] = 0
+        batch[part]["abstract"] = torch.as_tensor(ids).to(dev)
+        batch[part]["category"] = torch.as_tensor(rng.integers(1, n_categ, n)).to(dev)
+    B = batch["batch_size"]
+    uidx = rng.integers(1, n_users, B)
+    uidx[rng.random(B) < 0.15] = 0
+    batch["user_idx"] = torch.as_tensor(uidx).to(dev)
+    return batch

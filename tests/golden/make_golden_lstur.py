@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/lstur_*.npz by running the REFERENCE's own LSTUR components.
+
+Same rules as make_golden.py: runs only where /root/reference exists; the fixtures hold inputs,
+seeds and the reference's outputs, never reference source text.
+
+Imported from the reference: ``CNNAddAtt`` (text.py:112-176), ``LinearEncoder`` (category.py:9-80),
+``NewsEncoder`` (news.py:9-183), LSTUR ``UserEncoder`` (user/lstur.py:6-87), ``DotProduct``
+(click_predictor.py:5-11).  ``LSTURModule`` itself needs lightning / torch_geometric / torchmetrics
+(not installed), so its constructor wiring (lstur_module.py:139-218) and forward glue (:278-303) +
+loss (:326-360) are restated here around the imported components.
+
+``nn.Dropout`` / ``nn.Dropout2d`` are replaced by multiplication with the product's counter-based
+masks (oracle.lstur_oracle header), i.e. the reference forward under a known Bernoulli draw.
+
+Usage:  python tests/golden/make_golden_lstur.py   (from the repo root)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from newsreclib.models.components.encoders.news.category import LinearEncoder  # noqa: E402
+from newsreclib.models.components.encoders.news.news import NewsEncoder  # noqa: E402
+from newsreclib.models.components.encoders.news.text import CNNAddAtt  # noqa: E402
+from newsreclib.models.components.encoders.user.lstur import UserEncoder  # noqa: E402
+from newsreclib.models.components.layers.click_predictor import DotProduct  # noqa: E402
+
+from newsreclib_amd.synthetic import add_lstur_fields, batch_from_sizes, make_batch  # noqa: E402
+from oracle.lstur_oracle import (TEXT_PREFIX, TEXT_STREAMS, USER_MASK_STREAM, make_lstur_params,  # noqa: E402
+                                 unique_params)
+from oracle.nrms_oracle import dropout_multiplier  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SAMPLE_STRIDE = 97
+
+
+class Injected(torch.nn.Module):
+    """Stands in for nn.Dropout / nn.Dropout2d: call k multiplies by mults[k] (identity when empty)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mults, self.k = [], 0
+
+    def arm(self, mults):
+        self.mults, self.k = list(mults), 0
+
+    def forward(self, x):
+        if not self.mults:
+            return x
+        m = self.mults[self.k]
+        self.k += 1
+        if m.shape != x.shape:          # second text dropout sees (N, F, L) (text.py:169-171)
+            m = m.permute(0, 2, 1)
+        assert m.shape == x.shape
+        return x * m
+
+
+class RefLSTUR(torch.nn.Module):
+    """Reference components wired as lstur_module.py:139-218 does (=> reference state_dict keys)."""
+
+    def __init__(self, params, cfg, text_attrs, method):
+        super().__init__()
+        pre = TEXT_PREFIX.format(text_attrs[0])
+        text_encoder = CNNAddAtt(pretrained_embeddings=params[pre + "embedding_layer.weight"].numpy(),
+                                 embed_dim=cfg["D"], num_filters=cfg["F"], window_size=cfg["W"],
+                                 query_dim=cfg["Q"], dropout_probability=0.2)
+        category_encoder = LinearEncoder(pretrained_embeddings=None, from_pretrained=False,
+                                         freeze_pretrained_emb=False, num_categories=cfg["n_categ"],
+                                         embed_dim=cfg["categ_dim"], use_dropout=False, dropout_probability=None,
+                                         linear_transform=False, output_dim=None)
+        self.news_encoder = NewsEncoder(
+            dataset_attributes=["title", "abstract", "category"], attributes2encode=list(text_attrs) + ["category"],
+            concatenate_inputs=False, text_encoder=text_encoder, category_encoder=category_encoder,
+            entity_encoder=None, combine_vectors=True, combine_type="concat", input_dim=None,
+            query_dim=None, output_dim=None)
+        din = cfg["F"] * len(text_attrs) + cfg["categ_dim"]
+        self.user_encoder = UserEncoder(num_users=cfg["n_users"], input_dim=din, user_masking_probability=0.5,
+                                        long_short_term_method=method)
+        self.click_predictor = DotProduct()
+        res = self.load_state_dict(params, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        self.inj_text, self.inj_user = Injected(), Injected()
+        text_encoder.dropout = self.inj_text
+        self.user_encoder.dropout = self.inj_user
+        self.criterion = torch.nn.CrossEntropyLoss()
+        # the order the reference iterates its text encoders in (a ModuleDict filled from a Python set)
+        self.text_order = list(self.news_encoder.text_encoders.keys())
+
+
+def dense_batch_loops(x, batch, B):
+    counts = [int((batch == b).sum()) for b in range(B)]
+    mx = max(counts)
+    rows, mask, start = [], torch.zeros(B, mx, dtype=torch.bool), 0
+    for b in range(B):
+        r = x.new_zeros((mx,) + tuple(x.shape[1:]))
+        if counts[b]:
+            r[: counts[b]] = x[start:start + counts[b]]
+            mask[b, : counts[b]] = True
+        rows.append(r)
+        start += counts[b]
+    return torch.stack(rows), mask
+
+
+def ref_forward(model, batch, cfg, p_drop, p_mask, seed):
+    """lstur_module.py:278-303 + the loss lines, around the imported components."""
+    B = batch["batch_size"]
+    order = model.text_order
+    nh, nc = batch["x_hist"][order[0]].shape[0], batch["x_cand"][order[0]].shape[0]
+    if p_drop > 0:
+        mults = []
+        for lo, hi in ((0, nh), (nh, nh + nc)):           # history call, then candidate call
+            for a in order:
+                L = batch["x_hist"][a].shape[1]
+                s1, s2 = TEXT_STREAMS[a]
+                mults.append(dropout_multiplier(seed, s1, p_drop, (nh + nc, L, cfg["D"]))[lo:hi])
+                mults.append(dropout_multiplier(seed, s2, p_drop, (nh + nc, L, cfg["F"]))[lo:hi])
+        model.inj_text.arm(mults)
+    else:
+        model.inj_text.arm([])
+    if p_mask > 0:
+        model.inj_user.arm([dropout_multiplier(seed, USER_MASK_STREAM, p_mask, (B,)).reshape(1, B, 1).expand(
+            1, B, model.user_encoder.long_term_user_embedding.weight.shape[1])])
+    else:
+        model.inj_user.arm([])
+    hist_vec = model.news_encoder(batch["x_hist"])
+    hist_dense, mask_hist = dense_batch_loops(hist_vec, batch["batch_hist"], B)
+    cand_vec = model.news_encoder(batch["x_cand"])
+    cand_dense, _ = dense_batch_loops(cand_vec, batch["batch_cand"], B)
+    hist_size = torch.tensor([torch.where(mask_hist[i])[0].shape[0] for i in range(mask_hist.shape[0])])
+    user = model.user_encoder(batch["user_idx"], hist_dense, hist_size)
+    scores = model.click_predictor(user.unsqueeze(dim=1), cand_dense.permute(0, 2, 1))
+    y_true, _ = dense_batch_loops(batch["labels"], batch["batch_cand"], B)
+    loss = model.criterion(scores, y_true)
+    return dict(hist_vec=hist_vec, cand_vec=cand_vec, user_vec=user, scores=scores, y_true=y_true, loss=loss)
+
+
+def batch_arrays(batch):
+    a = {"in_batch_hist": batch["batch_hist"].numpy(), "in_batch_cand": batch["batch_cand"].numpy(),
+         "in_labels": batch["labels"].numpy(), "in_batch_size": np.int64(batch["batch_size"]),
+         "in_user_idx": batch["user_idx"].numpy()}
+    for part in ("hist", "cand"):
+        for k, v in batch["x_" + part].items():
+            a[f"in_{k}_{part}"] = v.numpy()
+    return a
+
+
+def run_case(name, batch, cfg, text_attrs=("title", "abstract"), method="ini", param_seed=1, p_drop=0.0,
+             p_mask=0.0, seed=0, full_grads=False, row_stride=1):
+    params = make_lstur_params(cfg["vocab"], cfg["n_categ"], cfg["n_users"], cfg["D"], cfg["F"], cfg["W"],
+                               cfg["Q"], cfg["categ_dim"], text_attrs, method, seed=param_seed)
+    model = RefLSTUR(params, cfg, text_attrs, method)
+    model.train()
+    out = ref_forward(model, batch, cfg, p_drop, p_mask, seed)
+    out["loss"].backward()
+    arrays = batch_arrays(batch)
+    arrays.update({"cfg_" + k: np.int64(v) for k, v in cfg.items()})
+    arrays.update(cfg_param_seed=np.int64(param_seed), cfg_p_drop=np.float64(p_drop), cfg_p_mask=np.float64(p_mask),
+                  cfg_seed=np.int64(seed), cfg_sample_stride=np.int64(SAMPLE_STRIDE),
+                  cfg_row_stride=np.int64(row_stride), cfg_method=np.array(method),
+                  cfg_text_attrs=np.array(list(text_attrs)), cfg_text_order=np.array(model.text_order))
+    for k in ("user_vec", "scores", "y_true", "loss"):
+        arrays["out_" + k] = out[k].detach().numpy()
+    for k in ("hist_vec", "cand_vec"):
+        arrays["out_" + k] = out[k].detach().numpy()[::row_stride].copy()
+    sd = model.state_dict(keep_vars=True)
+    for k in unique_params(params):
+        g = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        flat = g.detach().reshape(-1).double()
+        arrays["gnorm/" + k] = np.float64(flat.norm())
+        arrays["gsum/" + k] = np.float64(flat.sum())
+        if full_grads:
+            arrays["gfull/" + k] = g.detach().numpy()
+        elif g.dim() == 2 and k.endswith("embedding.weight") or k.endswith("embedding_layer.weight"):
+            rows = torch.nonzero(g.abs().sum(1) > 0).reshape(-1)[:8]
+            arrays["grows_idx/" + k] = rows.numpy()
+            arrays["grows/" + k] = g[rows].detach().numpy()
+        else:
+            arrays["gsample/" + k] = g.detach().reshape(-1)[::SAMPLE_STRIDE].numpy().copy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: order={model.text_order} loss={float(out['loss'].detach()):.6f} "
+          f"scores{tuple(out['scores'].shape)} -> {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+SMALL = dict(vocab=64, n_categ=7, n_users=9, D=64, F=48, W=3, Q=32, categ_dim=16)
+FULL = dict(vocab=2000, n_categ=19, n_users=200, D=300, F=300, W=3, Q=200, categ_dim=100)
+
+
+def tiny_batch(cfg, L_title=12, L_abstract=20):
+    labels = [0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1]
+    b = batch_from_sizes([1, 4, 2], [5, 10, 5], labels, vocab=cfg["vocab"], seed=11, L=L_title)
+    b = add_lstur_fields(b, cfg["vocab"], cfg["n_categ"], cfg["n_users"], L_abstract, seed=12)
+    b["user_idx"] = torch.tensor([3, 0, 5])             # user 1 is the padding / unknown user
+    return b
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    # torch's native conv path: with oneDNN (v3.7.1 in this image) the fp32 Conv2d backward-weights of
+    # the (F=300, W=3, D=300) shape returns ONE filter row (136, taps 1-2) off by 3.6e-4 against a float64
+    # evaluation (and against torch's own non-oneDNN path, which agrees with float64 to 1e-7), so the
+    # fixtures are generated with it disabled.
+    with torch.backends.mkldnn.flags(enabled=False):
+        _cases()
+
+
+def _cases():
+    run_case("lstur_tiny_eval", tiny_batch(SMALL), SMALL, param_seed=1, full_grads=True)
+    run_case("lstur_tiny_train", tiny_batch(SMALL), SMALL, param_seed=1, p_drop=0.2, p_mask=0.5, seed=7,
+             full_grads=True)
+    run_case("lstur_tiny_con", tiny_batch(SMALL), SMALL, method="con", param_seed=2, p_drop=0.2, p_mask=0.5,
+             seed=3, full_grads=True)
+    run_case("lstur_tiny_title_only", tiny_batch(SMALL), SMALL, text_attrs=("title",), param_seed=4,
+             full_grads=True)
+    b16 = add_lstur_fields(make_batch(16, vocab=FULL["vocab"], mode="ragged", seed=23), FULL["vocab"],
+                           FULL["n_categ"], FULL["n_users"], 50, seed=24)
+    run_case("lstur16_train", b16, FULL, param_seed=6, p_drop=0.2, p_mask=0.5, seed=41, row_stride=9)
+
+
+if __name__ == "__main__":
+    main()

@@ -129,3 +129,53 @@ def make_plm_tail_params(dim=96, query_dim=PLM_Q, seed=23):
         scale = 0.1 if k.endswith("query") else (0.05 if k.endswith("bias") else 1.0 / np.sqrt(dim))
         out[k] = torch.from_numpy((scale * rng.standard_normal(shapes[k])).astype(np.float32))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# LSTUR (BASELINE config 5) fixtures
+# ---------------------------------------------------------------------------------------------
+LSTUR_CASES = ["lstur_tiny_eval", "lstur_tiny_train", "lstur_tiny_con", "lstur_tiny_title_only", "lstur16_train"]
+
+
+def lstur_golden_batch(g, device="cpu"):
+    t = lambda a: torch.as_tensor(a).to(device)  # noqa: E731
+    attrs = [str(a) for a in g["cfg_text_attrs"]] + ["category"]
+    return {
+        "x_hist": {a: t(g[f"in_{a}_hist"]) for a in attrs}, "x_cand": {a: t(g[f"in_{a}_cand"]) for a in attrs},
+        "batch_hist": t(g["in_batch_hist"]), "batch_cand": t(g["in_batch_cand"]),
+        "labels": t(g["in_labels"]), "batch_size": int(g["in_batch_size"]),
+        "user_ids": torch.arange(int(g["in_batch_size"])) + 1, "user_idx": t(g["in_user_idx"]),
+    }
+
+
+def lstur_golden_cfg(g):
+    cfg = {k: int(g["cfg_" + k]) for k in ("vocab", "n_categ", "n_users", "D", "F", "W", "Q", "categ_dim")}
+    cfg.update(text_attrs=tuple(str(a) for a in g["cfg_text_attrs"]), text_order=tuple(str(a) for a in g["cfg_text_order"]),
+               method=str(g["cfg_method"]), p_drop=float(g["cfg_p_drop"]), p_mask=float(g["cfg_p_mask"]),
+               seed=int(g["cfg_seed"]), param_seed=int(g["cfg_param_seed"]))
+    return cfg
+
+
+def lstur_golden_params(cfg):
+    from oracle.lstur_oracle import make_lstur_params
+    return make_lstur_params(cfg["vocab"], cfg["n_categ"], cfg["n_users"], cfg["D"], cfg["F"], cfg["W"], cfg["Q"],
+                             cfg["categ_dim"], cfg["text_attrs"], cfg["method"], seed=cfg["param_seed"])
+
+
+def check_lstur_grads(g, grads, tol=2e-4, rtol=2e-4, atol=2e-5):
+    """grads: reference-state_dict-key -> tensor, one entry per unique parameter."""
+    stride = int(g["cfg_sample_stride"])
+    for key in [k[len("gnorm/"):] for k in g if k.startswith("gnorm/")]:
+        gr = grads[key].detach().cpu().double()
+        ref_norm = float(g["gnorm/" + key])
+        assert abs(float(gr.norm()) - ref_norm) <= rtol * ref_norm + atol, (key, float(gr.norm()), ref_norm)
+        for kind in ("gfull/", "gsample/", "grows/"):
+            if kind + key not in g:
+                continue
+            ref = torch.from_numpy(g[kind + key]).double()
+            got = gr if kind == "gfull/" else (gr.reshape(-1)[::stride] if kind == "gsample/" else
+                                                gr[torch.from_numpy(g["grows_idx/" + key])])
+            scale = max(1.0, float(ref.abs().max()))
+            assert float((got - ref).abs().max()) <= tol * scale, (key, kind, float((got - ref).abs().max()))
+        if key.endswith("embedding_layer.weight") or key.endswith("long_term_user_embedding.weight"):
+            assert float(gr[0].abs().max()) == 0.0, key      # padding_idx = 0
