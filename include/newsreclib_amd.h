@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 1
+#define NRL_ABI_VERSION 2
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -168,6 +168,105 @@ int nrl_ce_loss_fwd_bwd(const float* scores, const float* y_true, int64_t batch,
 int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int64_t step, float grad_scale,
                   int32_t zero_grad, void* stream);
+
+/* =================================================================================================
+ * LSTUR path (BASELINE config 5): CNN text encoder, row-masked embedding
+ * lookups (category / long-term user vector) and the GRU user encoder.
+ * ================================================================================================= */
+
+/* CNN + additive-attention text encoder.  Field <-> reference state_dict key (prefix
+ * `news_encoder.text_encoders.<attr>.`, ONE module shared by title and abstract, news.py:69-79):
+ *   conv_weight  cnn.weight                        (F, 1, W, D) contiguous = (F, W*D), k = t*D + d
+ *   conv_bias    cnn.bias                          (F)
+ *   att_weight   additive_attention.linear.weight  (Q, F)
+ *   att_bias     additive_attention.linear.bias    (Q)
+ *   att_query    additive_attention.query          (Q)
+ * Replaces nn.Conv2d + F.relu + AdditiveAttention as wired in text.py:146-176 (CNNAddAtt). */
+typedef struct NrlCnnParams {
+  const float* conv_weight;
+  const float* conv_bias;
+  const float* att_weight;
+  const float* att_bias;
+  const float* att_query;
+  int32_t embed_dim;   /* D, multiple of 4 */
+  int32_t num_filters; /* F, multiple of 4 */
+  int32_t window;      /* W, odd, <= 7 (padding (W-1)/2 as text.py:152) */
+  int32_t query_dim;   /* Q, multiple of 4 */
+} NrlCnnParams;
+
+typedef struct NrlCnnGrads { /* accumulators, kernels ADD */
+  float* conv_weight;
+  float* conv_bias;
+  float* att_weight;
+  float* att_bias;
+  float* att_query;
+} NrlCnnGrads;
+
+/* CNNAddAtt.forward, text.py:163-176: ids (N, L) int64 -> out (N, F).
+ * x = dropout(emb[ids]) (stream0, flat index over (N, L, D)); c = dropout(relu(conv(x))) (stream0 + 1,
+ * flat index over (N, L, F)); out = additive attention over the L tokens.  The convolution runs as
+ * ONE GEMM with K = W*D over overlapping rows of x (no im2col buffer). */
+size_t nrl_cnn_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t embed_dim,
+                                       int32_t num_filters, int32_t window, int32_t query_dim);
+int nrl_cnn_encoder_fwd(const NrlCnnParams* p, const float* emb_table, int64_t vocab,
+                        const int64_t* ids, int64_t n_news, int32_t seq_len, double p_drop,
+                        uint64_t seed, uint32_t stream0, int32_t save_for_backward, float* out,
+                        void* ws, size_t ws_bytes, void* stream);
+/* Backward (autograd of text.py:163-176 incl. embedding_dense_backward, padding_idx = 0).  d_out (N, F).
+ * Adds into `g` and d_emb_table.  sorted_positions as in nrl_news_encoder_bwd (may be NULL). */
+int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_emb_table,
+                        int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
+                        int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed,
+                        uint32_t stream0, const float* d_out, void* ws, size_t ws_bytes,
+                        void* stream);
+
+/* nn.Embedding(padding_idx=0) lookup followed by a ROW mask: out[i] = table[ids[i]] * m(i),
+ * m(i) in {0, 1/(1-p)} from dropout stream `stream_id` with flat index i (whole rows dropped).
+ * p_row = 0: plain lookup = LinearEncoder.forward, category.py:72-73.  p_row > 0: the long-term user
+ * vector of LSTUR, user/lstur.py:70-71 (nn.Dropout2d on a (1, B, D) tensor drops whole users).
+ * _bwd adds d_out[i] * m(i) into d_table[ids[i]], skipping id 0 (padding_idx). */
+int nrl_embedding_rows_fwd(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,
+                           double p_row, uint64_t seed, uint32_t stream_id, float* out,
+                           void* stream);
+int nrl_embedding_rows_bwd(const float* d_out, const int64_t* ids, int64_t n_ids, int32_t dim,
+                           double p_row, uint64_t seed, uint32_t stream_id, float* d_table,
+                           void* stream);
+
+/* Single-layer nn.GRU.  Field <-> reference state_dict key (prefix `user_encoder.gru.`):
+ *   weight_ih  weight_ih_l0 (3*Hd, Din) rows [W_ir; W_iz; W_in]      bias_ih  bias_ih_l0 (3*Hd)
+ *   weight_hh  weight_hh_l0 (3*Hd, Hd)  rows [W_hr; W_hz; W_hn]      bias_hh  bias_hh_l0 (3*Hd) */
+typedef struct NrlGruParams {
+  const float* weight_ih;
+  const float* weight_hh;
+  const float* bias_ih;
+  const float* bias_hh;
+  int32_t input_dim;  /* Din, multiple of 4 */
+  int32_t hidden_dim; /* Hd, multiple of 4 */
+} NrlGruParams;
+
+typedef struct NrlGruGrads { /* accumulators, kernels ADD */
+  float* weight_ih;
+  float* weight_hh;
+  float* bias_ih;
+  float* bias_hh;
+} NrlGruGrads;
+
+/* gru(pack_padded_sequence(hist, lengths, batch_first=True, enforce_sorted=False), h0)[1], i.e. the
+ * hidden state of every sequence after its own last valid step: user/lstur.py:74-83.
+ * hist (B, T, Din), lengths (B) int64 in [1, T] (validated by the caller, as pack_padded_sequence
+ * does on the host), h0 (B, Hd) or NULL for zeros ("con" variant, lstur.py:85) -> out (B, Hd).
+ * The input projection of all steps is one GEMM; the recurrence runs one small GEMM + one gate kernel
+ * per step, t = 0 .. T-1, rows with t >= lengths[b] frozen. */
+size_t nrl_gru_workspace_bytes(int64_t batch, int64_t max_len, int32_t input_dim, int32_t hidden_dim);
+int nrl_gru_fwd(const NrlGruParams* p, const float* hist, const int64_t* lengths, const float* h0,
+                int64_t batch, int64_t max_len, int32_t save_for_backward, float* out, void* ws,
+                size_t ws_bytes, void* stream);
+/* Backward through time.  d_out (B, Hd) -> d_hist (B, T, Din) overwritten, d_h0 (B, Hd) overwritten
+ * (may be NULL); adds into `g`. */
+int nrl_gru_bwd(const NrlGruParams* p, const NrlGruGrads* g, const float* hist,
+                const int64_t* lengths, const float* h0, int64_t batch, int64_t max_len,
+                const float* d_out, float* d_hist, float* d_h0, void* ws, size_t ws_bytes,
+                void* stream);
 
 /* ---- building blocks exported for unit parity tests and reuse ------------------------------- */
 /* nn.Embedding lookup alone (bit-exact), text.py:224. */

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -29,6 +29,28 @@ class NrlBlockGrads(ctypes.Structure):
         ("out_proj_weight", c_void_p), ("out_proj_bias", c_void_p),
         ("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p),
     ]
+
+
+class NrlCnnParams(ctypes.Structure):
+    _fields_ = [
+        ("conv_weight", c_void_p), ("conv_bias", c_void_p), ("att_weight", c_void_p), ("att_bias", c_void_p),
+        ("att_query", c_void_p),
+        ("embed_dim", c_int32), ("num_filters", c_int32), ("window", c_int32), ("query_dim", c_int32),
+    ]
+
+
+class NrlCnnGrads(ctypes.Structure):
+    _fields_ = [("conv_weight", c_void_p), ("conv_bias", c_void_p), ("att_weight", c_void_p),
+                ("att_bias", c_void_p), ("att_query", c_void_p)]
+
+
+class NrlGruParams(ctypes.Structure):
+    _fields_ = [("weight_ih", c_void_p), ("weight_hh", c_void_p), ("bias_ih", c_void_p), ("bias_hh", c_void_p),
+                ("input_dim", c_int32), ("hidden_dim", c_int32)]
+
+
+class NrlGruGrads(ctypes.Structure):
+    _fields_ = [("weight_ih", c_void_p), ("weight_hh", c_void_p), ("bias_ih", c_void_p), ("bias_hh", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/newsreclib_amd.h one to one
@@ -64,6 +86,22 @@ SIGNATURES = {
                                       c_void_p]),
     "nrl_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
                                 c_double, c_int64, c_float, c_int32, c_void_p]),
+    "nrl_cnn_encoder_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "nrl_cnn_encoder_fwd": (c_int32, [POINTER(NrlCnnParams), c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                      c_double, c_uint64, c_uint32, c_int32, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
+    "nrl_cnn_encoder_bwd": (c_int32, [POINTER(NrlCnnParams), POINTER(NrlCnnGrads), c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_int64, c_int32, c_double, c_uint64, c_uint32, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "nrl_embedding_rows_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_double, c_uint64, c_uint32,
+                                         c_void_p, c_void_p]),
+    "nrl_embedding_rows_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_double, c_uint64, c_uint32,
+                                         c_void_p, c_void_p]),
+    "nrl_gru_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    "nrl_gru_fwd": (c_int32, [POINTER(NrlGruParams), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
+                              c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nrl_gru_bwd": (c_int32, [POINTER(NrlGruParams), POINTER(NrlGruGrads), c_void_p, c_void_p, c_void_p, c_int64,
+                              c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_embedding_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "nrl_linear_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
 }

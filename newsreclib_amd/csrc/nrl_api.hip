@@ -13,6 +13,7 @@
 #include "nrl_gemm.h"
 #include "nrl_gemm_bf16x3.h"
 #include "nrl_kernels.h"
+#include "nrl_conv.h"
 
 namespace nrl {
 
@@ -528,3 +529,5 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
 }
 
 }  // extern "C"
+
+#include "nrl_api_lstur.inc"

@@ -130,12 +130,12 @@ struct RCPlain {
 // ---------------------------------------------------------------------------------------------
 struct NoRow {};
 
-// C = act(v + bias[n]) * dropout(m, n)      (nn.Linear + optional tanh + optional nn.Dropout)
+// C = act(v + bias[n]) * dropout(m, n)      (nn.Linear / conv + optional tanh / relu + optional nn.Dropout)
 struct EpiLinear {
   float* c;
   int64_t ldc;
   const float* bias;  // may be null
-  int act_tanh;
+  int act;            // 0 none, 1 tanh, 2 relu
   Dropout drop;
   int n_cols;  // logical row width for the dropout flat index
   struct Row {
@@ -145,7 +145,8 @@ struct EpiLinear {
   __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc, (uint32_t)m * (uint32_t)n_cols}; }
   __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
     if (bias != nullptr) v += bias[n];
-    if (act_tanh) v = tanhf(v);
+    if (act == 1) v = tanhf(v);
+    if (act == 2) v = fmaxf(v, 0.0f);
     if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n);
     r.out[n] = v;
   }
@@ -172,20 +173,35 @@ struct EpiPoolBwd {
   const float* d_out;  // (groups, N)
   int group_len;       // rows per group
   Dropout drop;
+  const float* relu_src = nullptr;  // (M, N) post-ReLU(-dropout) activation: gradient gated by src > 0
   struct Row {
     float* out;
     const float* g;
+    const float* src;
     float wm;
     uint32_t idx0;
   };
   __device__ __forceinline__ Row row(int64_t m) const {
-    return Row{c + m * ldc, d_out + (m / group_len) * ldc, w[m], (uint32_t)m * (uint32_t)ldc};
+    return Row{c + m * ldc, d_out + (m / group_len) * ldc, relu_src != nullptr ? relu_src + m * ldc : nullptr, w[m],
+               (uint32_t)m * (uint32_t)ldc};
   }
   __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
     v += r.wm * r.g[n];
     if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n);
+    if (r.src != nullptr && !(r.src[n] > 0.0f)) v = 0.0f;
     r.out[n] = v;
   }
+};
+
+// out += v, single writer per element (the recurrent term of the GRU's dL/dh_{t-1})
+struct EpiAddStore {
+  float* c;
+  int64_t ldc;
+  struct Row {
+    float* out;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const { r.out[n] += v; }
 };
 
 // split-K weight gradient: dW[m][n] += v for n < n_w, bias gradient db[m] += v for n == n_w

@@ -56,4 +56,25 @@ int embedding_grad_sorted(const float* dx, const int64_t* ids, const int64_t* or
                           float* d_table, hipStream_t stream);
 int dropout_mask(uint8_t* keep, int64_t n, Dropout d, hipStream_t stream);
 
+// ---- LSTUR path ------------------------------------------------------------------------------
+// out[i] = table[ids[i]] * m; row_mode 0: elementwise dropout with flat index i*D + col (the CNN text
+// encoder's post-embedding dropout, text.py:165-166); row_mode 1: one multiplier per row i
+// (nn.Dropout2d on (1, B, D), user/lstur.py:71); drop.thresh == 0: bit-exact lookup
+int embedding_rows_fwd(const float* table, const int64_t* ids, int64_t n_ids, int D, Dropout drop, int row_mode,
+                       float* out, hipStream_t stream);
+// d_table[ids[i]] += d_out[i] * m(i) (row multiplier), id 0 skipped
+int embedding_rows_bwd(const float* d_out, const int64_t* ids, int64_t n_ids, int D, Dropout drop, float* d_table,
+                       hipStream_t stream);
+// dst (Bd, A, D) = src (A, Bd, D) with the two leading axes swapped
+int transpose01(const float* src, int64_t A, int64_t Bd, int D, float* dst, hipStream_t stream);
+// one GRU step (torch nn.GRU cell, gates r|z|n): gi / gh (B, 3Hd) pre-activations incl. biases, h_prev
+// (B, Hd) -> h_new; rows with t >= len[b] keep h_prev.  gates (B, 3Hd) <- (r, z, n) (may alias gi) and
+// ghn (B, Hd) <- gh_n when non-null (saved for backward).
+int gru_gate_fwd(const float* gi, const float* gh, const float* h_prev, const int64_t* len, int t, int64_t B,
+                 int Hd, float* gates, float* ghn, float* h_new, hipStream_t stream);
+// adjoint of one step: dh (B, Hd) holds dL/dh_t on entry and the DIRECT part z * dh of dL/dh_{t-1} on
+// exit (the recurrent part dgh W_hh is added by the caller's GEMM); dgi (may alias gates) / dgh (B, 3Hd)
+int gru_gate_bwd(const float* gates, const float* ghn, const float* h_prev, const int64_t* len, int t, int64_t B,
+                 int Hd, float* dh, float* dgi, float* dgh, hipStream_t stream);
+
 }  // namespace nrl

@@ -790,4 +790,157 @@ int dropout_mask(uint8_t* keep, int64_t n, Dropout d, hipStream_t stream) {
   return NRL_OK;
 }
 
+// =============================================================================================
+// LSTUR path: row-masked embedding lookups, axis swap, GRU cell
+// =============================================================================================
+__global__ void embedding_rows_fwd_kernel(const float4* __restrict__ table, const int64_t* __restrict__ ids,
+                                          int64_t total4, int D4, Dropout drop, int row_mode,
+                                          float4* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D4;
+    const int c4 = (int)(i % D4);
+    float4 v = table[ids[row] * D4 + c4];
+    if (drop.thresh != 0u) {
+      if (row_mode) {
+        const float m = drop.mult((uint32_t)row);
+        v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+      } else {
+        const uint32_t idx = (uint32_t)row * (uint32_t)(4 * D4) + 4u * (uint32_t)c4;
+        v.x *= drop.mult(idx); v.y *= drop.mult(idx + 1); v.z *= drop.mult(idx + 2); v.w *= drop.mult(idx + 3);
+      }
+    }
+    out[i] = v;
+  }
+}
+
+int embedding_rows_fwd(const float* table, const int64_t* ids, int64_t n_ids, int D, Dropout drop, int row_mode,
+                       float* out, hipStream_t stream) {
+  NRL_REQUIRE(D % 4 == 0, "embedding dim must be a multiple of 4");
+  NRL_REQUIRE(n_ids * D < (1LL << 32), "dropout index space is 32-bit");
+  const int64_t total4 = n_ids * (D / 4);
+  if (total4 == 0) return NRL_OK;
+  hipLaunchKernelGGL(embedding_rows_fwd_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, stream,
+                     (const float4*)table, ids, total4, D / 4, drop, row_mode, (float4*)out);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+__global__ void embedding_rows_bwd_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
+                                          int64_t total, int D, Dropout drop, float* __restrict__ d_table) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D;
+    const int64_t id = ids[row];
+    if (id == 0) continue;  // padding_idx
+    const float m = drop.thresh != 0u ? drop.mult((uint32_t)row) : 1.0f;
+    if (m != 0.0f) atomicAdd(d_table + id * D + (i % D), d_out[i] * m);
+  }
+}
+
+int embedding_rows_bwd(const float* d_out, const int64_t* ids, int64_t n_ids, int D, Dropout drop, float* d_table,
+                       hipStream_t stream) {
+  const int64_t total = n_ids * D;
+  if (total == 0) return NRL_OK;
+  hipLaunchKernelGGL(embedding_rows_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, d_out, ids,
+                     total, D, drop, d_table);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+__global__ void transpose01_kernel(const float4* __restrict__ src, int64_t A, int64_t Bd, int D4,
+                                   float4* __restrict__ dst) {
+  const int64_t total = A * Bd * D4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D4;  // destination row = b * A + a
+    const int64_t b = row / A, a = row % A;
+    dst[i] = src[(a * Bd + b) * D4 + (i % D4)];
+  }
+}
+
+int transpose01(const float* src, int64_t A, int64_t Bd, int D, float* dst, hipStream_t stream) {
+  NRL_REQUIRE(D % 4 == 0, "transpose01: dim must be a multiple of 4");
+  const int64_t total = A * Bd * (D / 4);
+  if (total == 0) return NRL_OK;
+  hipLaunchKernelGGL(transpose01_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const float4*)src, A,
+                     Bd, D / 4, (float4*)dst);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void gru_gate_fwd_kernel(const float* gi, const float* __restrict__ gh,
+                                    const float* __restrict__ h_prev, const int64_t* __restrict__ len, int t,
+                                    int64_t total, int Hd, float* gates, float* __restrict__ ghn,
+                                    float* __restrict__ h_new) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / Hd;
+    const int j = (int)(i % Hd);
+    const int64_t o = b * 3 * Hd + j;
+    const float hn = gh[o + 2 * Hd];
+    const float r = sigmoidf_(gi[o] + gh[o]);
+    const float z = sigmoidf_(gi[o + Hd] + gh[o + Hd]);
+    const float n = tanhf(gi[o + 2 * Hd] + r * hn);
+    const float hp = h_prev[i];
+    h_new[i] = (int64_t)t < len[b] ? (1.0f - z) * n + z * hp : hp;
+    if (ghn != nullptr) {
+      gates[o] = r;
+      gates[o + Hd] = z;
+      gates[o + 2 * Hd] = n;
+      ghn[i] = hn;
+    }
+  }
+}
+
+int gru_gate_fwd(const float* gi, const float* gh, const float* h_prev, const int64_t* len, int t, int64_t B,
+                 int Hd, float* gates, float* ghn, float* h_new, hipStream_t stream) {
+  const int64_t total = B * Hd;
+  if (total == 0) return NRL_OK;
+  hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, gi, gh, h_prev, len, t,
+                     total, Hd, gates, ghn, h_new);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+__global__ void gru_gate_bwd_kernel(const float* gates, const float* __restrict__ ghn,
+                                    const float* __restrict__ h_prev, const int64_t* __restrict__ len, int t,
+                                    int64_t total, int Hd, float* __restrict__ dh, float* dgi,
+                                    float* __restrict__ dgh) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / Hd;
+    const int j = (int)(i % Hd);
+    const int64_t o = b * 3 * Hd + j;
+    float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dn_r = 0.f;
+    if ((int64_t)t < len[b]) {
+      const float r = gates[o], z = gates[o + Hd], n = gates[o + 2 * Hd];
+      const float d = dh[i];
+      dn_pre = d * (1.0f - z) * (1.0f - n * n);
+      dz_pre = d * (h_prev[i] - n) * z * (1.0f - z);
+      dr_pre = dn_pre * ghn[i] * r * (1.0f - r);
+      dn_r = dn_pre * r;
+      dh[i] = d * z;
+    }
+    dgi[o] = dr_pre;
+    dgi[o + Hd] = dz_pre;
+    dgi[o + 2 * Hd] = dn_pre;
+    dgh[o] = dr_pre;
+    dgh[o + Hd] = dz_pre;
+    dgh[o + 2 * Hd] = dn_r;
+  }
+}
+
+int gru_gate_bwd(const float* gates, const float* ghn, const float* h_prev, const int64_t* len, int t, int64_t B,
+                 int Hd, float* dh, float* dgi, float* dgh, hipStream_t stream) {
+  const int64_t total = B * Hd;
+  if (total == 0) return NRL_OK;
+  hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, gates, ghn, h_prev, len,
+                     t, total, Hd, dh, dgi, dgh);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
 }  // namespace nrl

@@ -1,17 +1,28 @@
 """News-encoder modules with the reference's interfaces, running on the HIP kernels.
 
-``MHSAAddAtt`` mirrors ``newsreclib.models.components.encoders.news.text.MHSAAddAtt``
-(text.py:179-236) and ``NewsEncoder`` mirrors ``...encoders.news.news.NewsEncoder``
-(news.py:9-183) for the NRMS configuration (one text attribute, no category/entity encoders).
-Constructor signatures, attribute names and ``state_dict`` keys are the reference's.
+``MHSAAddAtt`` / ``CNNAddAtt`` / ``PLM`` mirror ``newsreclib.models.components.encoders.news.text``
+(text.py:179-236, 112-176, 15-109), ``LinearEncoder`` mirrors ``...news.category.LinearEncoder``
+(category.py:9-80) and ``NewsEncoder`` mirrors ``...encoders.news.news.NewsEncoder`` (news.py:9-183)
+for the NRMS configuration (one text attribute) and the LSTUR one (shared text encoder over title +
+abstract, category embedding, ``combine_type="concat"``).  Constructor signatures, attribute names
+and ``state_dict`` keys are the reference's.
 """
 from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops_lstur
 from .attention import AdditiveAttention
+
+# dropout stream pair of each text attribute (fixed by NAME: the reference iterates its text encoders
+# in Python-set order, which must not change which random numbers an attribute sees)
+TEXT_STREAMS = {"title": 0, "abstract": 2, "text": 0}
+
+
+def _draw_seed() -> int:
+    # host-side draw from torch's CPU generator (no device sync); reproducible under torch.manual_seed
+    return int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62))
 
 
 def _grad_bufs(params):
@@ -45,15 +56,72 @@ class MHSAAddAtt(nn.Module):
                 mha.out_proj.bias, att.linear.weight, att.linear.bias, att.query)
 
     def forward(self, text: torch.Tensor, seed: Optional[int] = None,
-                order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                order: Optional[torch.Tensor] = None, stream0: int = 0) -> torch.Tensor:
         p = float(self.dropout.p) if self.training else 0.0
         if p > 0.0 and seed is None:
-            # host-side draw from torch's CPU generator (no device sync); reproducible under
-            # torch.manual_seed
-            seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62))
+            seed = _draw_seed()
         params = self._params()
-        return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, 0, _grad_bufs(params), order,
-                                       self.table_grad_hook)
+        return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, stream0, _grad_bufs(params),
+                                       order, self.table_grad_hook)
+
+
+class CNNAddAtt(nn.Module):
+    """Embedding lookup -> dropout -> Conv2d over (window, embed_dim) -> ReLU -> dropout -> additive
+    attention (reference text.py:112-176) as one HIP pipeline (``nrl_cnn_encoder_fwd``/``_bwd``): the
+    convolution is a single GEMM with K = window * embed_dim over overlapping token rows."""
+
+    def __init__(self, pretrained_embeddings: torch.Tensor, embed_dim: int, num_filters: int, window_size: int,
+                 query_dim: int, dropout_probability: float) -> None:
+        super().__init__()
+        if not isinstance(dropout_probability, float):
+            raise ValueError(
+                f"Expected keyword argument `dropout_probability` to be a `float` but got {dropout_probability}")
+        self.embedding_layer = nn.Embedding.from_pretrained(
+            torch.as_tensor(pretrained_embeddings, dtype=torch.float32), freeze=False, padding_idx=0)
+        # nn.Conv2d is the parameter container only (names, shapes, default init of text.py:148-153)
+        self.cnn = nn.Conv2d(in_channels=1, out_channels=num_filters, kernel_size=(window_size, embed_dim),
+                             padding=(int((window_size - 1) / 2), 0))
+        self.additive_attention = AdditiveAttention(input_dim=num_filters, query_dim=query_dim)
+        self.dropout = nn.Dropout(dropout_probability)
+
+    def _params(self):
+        att = self.additive_attention
+        return (self.embedding_layer.weight, self.cnn.weight, self.cnn.bias, att.linear.weight, att.linear.bias,
+                att.query)
+
+    def forward(self, text: torch.Tensor, seed: Optional[int] = None, order: Optional[torch.Tensor] = None,
+                stream0: int = 0) -> torch.Tensor:
+        p = float(self.dropout.p) if self.training else 0.0
+        if p > 0.0 and seed is None:
+            seed = _draw_seed()
+        params = self._params()
+        return ops_lstur.CnnEncoderFn.apply(text, *params, p, seed or 0, stream0, _grad_bufs(params), order)
+
+
+class LinearEncoder(nn.Module):
+    """Category encoder (reference category.py:9-80) for the configuration the recommenders in scope use
+    (LSTUR, lstur_module.py:173-183): a trainable ``nn.Embedding(padding_idx=0)`` lookup, no dropout, no
+    linear transform."""
+
+    def __init__(self, pretrained_embeddings: Optional[torch.Tensor], from_pretrained: bool,
+                 freeze_pretrained_emb: bool, num_categories: int, embed_dim: Optional[int], use_dropout: bool,
+                 dropout_probability: Optional[float], linear_transform: bool, output_dim: Optional[int]) -> None:
+        super().__init__()
+        if use_dropout or linear_transform:
+            raise NotImplementedError("newsreclib_amd.LinearEncoder covers use_dropout=False, "
+                                      "linear_transform=False (the LSTUR category encoder)")
+        if from_pretrained:
+            assert isinstance(pretrained_embeddings, torch.Tensor)
+            self.embedding_layer = nn.Embedding.from_pretrained(
+                embeddings=pretrained_embeddings, freeze=freeze_pretrained_emb, padding_idx=0)
+        else:
+            assert isinstance(embed_dim, int) and embed_dim > 0
+            self.embedding_layer = nn.Embedding(num_embeddings=num_categories, embedding_dim=embed_dim, padding_idx=0)
+        self.use_dropout, self.linear_transform = use_dropout, linear_transform
+
+    def forward(self, category: torch.Tensor) -> torch.Tensor:
+        w = self.embedding_layer.weight
+        return ops_lstur.EmbeddingRowsFn.apply(category, w, 0.0, 0, 0, _grad_bufs((w,)))
 
 
 class PLM(nn.Module):
@@ -96,7 +164,7 @@ class PLM(nn.Module):
         hidden = self.plm_model(**text)[0]                      # (N, L, D)
         p = float(self.dropout.p) if self.training else 0.0
         if p > 0.0 and seed is None:
-            seed = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 62))
+            seed = _draw_seed()
         mha, att = self.multihead_attention, self.additive_attention
         params = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
                   att.linear.weight, att.linear.bias, att.query)
@@ -104,10 +172,17 @@ class PLM(nn.Module):
 
 
 class NewsEncoder(nn.Module):
-    """Dispatches news attributes to their encoders (news.py:134-183).  NRMS uses exactly one text
-    encoder (``attributes2encode=["title"]``), for which the reference returns that encoder's output
-    unchanged (news.py:159-160); the multi-attribute combinations belong to other recommenders and
-    are out of this build's scope (they raise)."""
+    """Dispatches news attributes to their encoders and combines the vectors (news.py:134-183).
+
+    Built configurations: NRMS (one text attribute -> that encoder's output unchanged, news.py:159-160)
+    and LSTUR (ONE text encoder registered under every text attribute, a category encoder,
+    ``combine_type="concat"``, news.py:69-79,128,181).  Entity encoders and the ``add_att`` / ``linear``
+    combine layers belong to recommenders that are out of this build's scope (they raise).
+
+    Text-vector order: the reference fills its ``ModuleDict`` from a Python ``set`` (news.py:72-77), so the
+    title/abstract order of the concatenation depends on the process's string-hash seed.  Here it is
+    deterministic -- the order of ``attributes2encode`` -- and ``set_text_order`` pins any other order
+    (e.g. the one a reference checkpoint was trained with)."""
 
     def __init__(self, dataset_attributes: List[str], attributes2encode: List[str],
                  concatenate_inputs: bool, text_encoder: Optional[nn.Module],
@@ -117,27 +192,53 @@ class NewsEncoder(nn.Module):
         super().__init__()
         assert len(dataset_attributes) > 0
         self.concatenate_inputs = concatenate_inputs
-        if category_encoder is not None or entity_encoder is not None or combine_vectors:
-            raise NotImplementedError("newsreclib_amd.NewsEncoder covers the NRMS configuration only "
-                                      "(text attributes, no category/entity encoders, no combine layer)")
-        assert isinstance(text_encoder, nn.Module)
-        if not concatenate_inputs:
-            names = sorted(set(dataset_attributes) & set(attributes2encode) & {"title", "abstract"})
-            if len(names) != 1:
-                raise NotImplementedError("newsreclib_amd.NewsEncoder needs exactly one text attribute "
-                                          f"to encode, got {names}")
-            self.text_encoders = nn.ModuleDict({name: text_encoder for name in names})
-        else:
-            self.text_encoders = nn.ModuleDict({"text": text_encoder})
-        self.encode_text = True
-        self.encode_category = False
-        self.encode_entity = False
+        if entity_encoder is not None:
+            raise NotImplementedError("newsreclib_amd.NewsEncoder: entity encoders are not built")
+        if combine_vectors and combine_type != "concat":
+            raise NotImplementedError("newsreclib_amd.NewsEncoder: combine_type must be 'concat' "
+                                      f"(got {combine_type!r})")
+        self.encode_text = self.encode_category = self.encode_entity = False
+        if ("title" in attributes2encode) or ("abstract" in attributes2encode):
+            assert isinstance(text_encoder, nn.Module)
+            if not concatenate_inputs:
+                names = [a for a in attributes2encode if a in dataset_attributes and a in ("title", "abstract")]
+                self.text_encoders = nn.ModuleDict({name: text_encoder for name in names})
+            else:
+                self.text_encoders = nn.ModuleDict({"text": text_encoder})
+            self.encode_text = True
+        if ("category" in attributes2encode) or ("subcategory" in attributes2encode):
+            assert isinstance(category_encoder, nn.Module)
+            names = [a for a in attributes2encode if a in dataset_attributes and a in ("category", "subcategory")]
+            self.category_encoders = nn.ModuleDict({name: category_encoder for name in names})
+            self.encode_category = True
+        n_vec = (len(self.text_encoders) if self.encode_text else 0) + \
+            (len(self.category_encoders) if self.encode_category else 0)
+        if n_vec == 0:
+            raise ValueError("no news attribute to encode")
+        if n_vec > 1 and not combine_vectors:
+            raise ValueError("several news attributes need combine_vectors=True")
+        if combine_vectors:
+            self.combine_type = combine_type
+
+    def set_text_order(self, order) -> None:
+        """Re-register the text encoders in the given attribute order (state_dict keys are unchanged)."""
+        assert sorted(order) == sorted(self.text_encoders.keys())
+        self.text_encoders = nn.ModuleDict({name: self.text_encoders[name] for name in order})
 
     def forward(self, news: Dict[str, torch.Tensor], seed: Optional[int] = None) -> torch.Tensor:
-        (name, encoder), = self.text_encoders.items()
-        kw = {}
-        if seed is not None:
-            kw["seed"] = seed
-        if news.get(name + "_order") is not None:      # optional argsort of the flat ids (prepare_batch)
-            kw["order"] = news[name + "_order"]
-        return encoder(news[name], **kw)
+        vectors = []
+        if self.encode_text:
+            for name, encoder in self.text_encoders.items():
+                kw = {}
+                if seed is not None:
+                    kw["seed"] = seed
+                if news.get(name + "_order") is not None:   # optional argsort of the flat ids (prepare_batch)
+                    kw["order"] = news[name + "_order"]
+                if len(self.text_encoders) > 1:
+                    kw["stream0"] = TEXT_STREAMS[name]
+                vectors.append(encoder(news[name], **kw))
+        if self.encode_category:
+            vectors += [encoder(news[name]) for name, encoder in self.category_encoders.items()]
+        if len(vectors) == 1:
+            return vectors[0]
+        return torch.cat(vectors, dim=1)                     # news.py:128

