@@ -193,15 +193,16 @@ struct EpiPoolBwd {
   }
 };
 
-// out += v, single writer per element (the recurrent term of the GRU's dL/dh_{t-1})
-struct EpiAddStore {
+// out += v with atomics: split-K partial sums of the small per-step GRU GEMMs (the k-loop of a 128-row
+// GEMM is latency bound, so K is cut into ~200-wide slices that run on different CUs)
+struct EpiAtomicAdd {
   float* c;
   int64_t ldc;
   struct Row {
     float* out;
   };
   __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc}; }
-  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const { r.out[n] += v; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const { atomicAdd(r.out + n, v); }
 };
 
 // split-K weight gradient: dW[m][n] += v for n < n_w, bias gradient db[m] += v for n == n_w

@@ -67,11 +67,12 @@ int embedding_rows_bwd(const float* d_out, const int64_t* ids, int64_t n_ids, in
                        hipStream_t stream);
 // dst (Bd, A, D) = src (A, Bd, D) with the two leading axes swapped
 int transpose01(const float* src, int64_t A, int64_t Bd, int D, float* dst, hipStream_t stream);
-// one GRU step (torch nn.GRU cell, gates r|z|n): gi / gh (B, 3Hd) pre-activations incl. biases, h_prev
-// (B, Hd) -> h_new; rows with t >= len[b] keep h_prev.  gates (B, 3Hd) <- (r, z, n) (may alias gi) and
-// ghn (B, Hd) <- gh_n when non-null (saved for backward).
-int gru_gate_fwd(const float* gi, const float* gh, const float* h_prev, const int64_t* len, int t, int64_t B,
-                 int Hd, float* gates, float* ghn, float* h_new, hipStream_t stream);
+// one GRU step (torch nn.GRU cell, gates r|z|n): gi (B, 3Hd) = x W_ih^T + b_ih, gh (B, 3Hd) = h W_hh^T
+// WITHOUT its bias (b_hh (3Hd) is added here), h_prev (B, Hd) -> h_new; rows with t >= len[b] keep h_prev.
+// gates (B, 3Hd) <- (r, z, n) (may alias gi) and ghn (B, Hd) <- gh_n + b_hn when non-null (saved for
+// backward).  gh is cleared after use (it is the atomic accumulator of the next step's split-K GEMM).
+int gru_gate_fwd(const float* gi, float* gh, const float* b_hh, const float* h_prev, const int64_t* len, int t,
+                 int64_t B, int Hd, float* gates, float* ghn, float* h_new, hipStream_t stream);
 // adjoint of one step: dh (B, Hd) holds dL/dh_t on entry and the DIRECT part z * dh of dL/dh_{t-1} on
 // exit (the recurrent part dgh W_hh is added by the caller's GEMM); dgi (may alias gates) / dgh (B, 3Hd)
 int gru_gate_bwd(const float* gates, const float* ghn, const float* h_prev, const int64_t* len, int t, int64_t B,

@@ -871,7 +871,7 @@ int transpose01(const float* src, int64_t A, int64_t Bd, int D, float* dst, hipS
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ void gru_gate_fwd_kernel(const float* gi, const float* __restrict__ gh,
+__global__ void gru_gate_fwd_kernel(const float* gi, float* __restrict__ gh, const float* __restrict__ b_hh,
                                     const float* __restrict__ h_prev, const int64_t* __restrict__ len, int t,
                                     int64_t total, int Hd, float* gates, float* __restrict__ ghn,
                                     float* __restrict__ h_new) {
@@ -880,10 +880,13 @@ __global__ void gru_gate_fwd_kernel(const float* gi, const float* __restrict__ g
     const int64_t b = i / Hd;
     const int j = (int)(i % Hd);
     const int64_t o = b * 3 * Hd + j;
-    const float hn = gh[o + 2 * Hd];
-    const float r = sigmoidf_(gi[o] + gh[o]);
-    const float z = sigmoidf_(gi[o + Hd] + gh[o + Hd]);
+    const float hn = gh[o + 2 * Hd] + b_hh[j + 2 * Hd];
+    const float r = sigmoidf_(gi[o] + gh[o] + b_hh[j]);
+    const float z = sigmoidf_(gi[o + Hd] + gh[o + Hd] + b_hh[j + Hd]);
     const float n = tanhf(gi[o + 2 * Hd] + r * hn);
+    gh[o] = 0.f;
+    gh[o + Hd] = 0.f;
+    gh[o + 2 * Hd] = 0.f;
     const float hp = h_prev[i];
     h_new[i] = (int64_t)t < len[b] ? (1.0f - z) * n + z * hp : hp;
     if (ghn != nullptr) {
@@ -895,12 +898,12 @@ __global__ void gru_gate_fwd_kernel(const float* gi, const float* __restrict__ g
   }
 }
 
-int gru_gate_fwd(const float* gi, const float* gh, const float* h_prev, const int64_t* len, int t, int64_t B,
-                 int Hd, float* gates, float* ghn, float* h_new, hipStream_t stream) {
+int gru_gate_fwd(const float* gi, float* gh, const float* b_hh, const float* h_prev, const int64_t* len, int t,
+                 int64_t B, int Hd, float* gates, float* ghn, float* h_new, hipStream_t stream) {
   const int64_t total = B * Hd;
   if (total == 0) return NRL_OK;
-  hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, gi, gh, h_prev, len, t,
-                     total, Hd, gates, ghn, h_new);
+  hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, gi, gh, b_hh, h_prev, len,
+                     t, total, Hd, gates, ghn, h_new);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

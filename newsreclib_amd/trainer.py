@@ -128,7 +128,10 @@ class NRMSTrainer:
         enc = getattr(module, "news_encoder", None)
         if enc is not None and hasattr(enc, "text_encoders"):
             te = next(iter(enc.text_encoders.values()))
-        if te is not None and hasattr(te, "embedding_layer") and self.flat.params[0] is te.embedding_layer.weight:
+        # (only the fused MHSA encoder exposes the two-phase backward; a text encoder shared by several
+        # attributes -- LSTUR -- finishes its table gradient only after the LAST of its backward calls)
+        if te is not None and hasattr(te, "table_grad_hook") and len(enc.text_encoders) == 1 \
+                and self.flat.params[0] is te.embedding_layer.weight:
             head = self.flat.offsets[1] if len(self.flat.offsets) > 1 else self.flat.numel
         self.reduce = OverlappedGradReduce(self.flat, head, group)
         if head > 0:
