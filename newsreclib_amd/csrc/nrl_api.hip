@@ -5,6 +5,7 @@
 // with dropout vs. a dense history tensor), in which axis the tiny attentions run over, and in
 // where the input gradient goes (scatter-add into the table vs. a dense d_hist).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <utility>
@@ -12,6 +13,7 @@
 
 #include "nrl_gemm.h"
 #include "nrl_gemm_bf16x3.h"
+#include "nrl_gemm_bf16x3_dma.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
 
@@ -77,9 +79,19 @@ struct ProfScope {
 #define X3_TILE 4, 2, 2, 5, 1       // 128 x 160 (small M)
 #define X3_TILE_Q 4, 2, 2, 7, 1     // 128 x 224 (Q = 200 in one tile)
 #define X3_TILE_W 2, 2, 2, 5, 0     //  64 x 160 weight gradients
+// LDS-DMA staged variant (nrl_gemm_bf16x3_dma.h; WM, WN, TM, TN, ring depth) for plain / windowed fp32 A:
+// 4-wave 128 x 160 workgroups with a 2-deep ring = 72 KB LDS, so TWO workgroups share a CU and their
+// split / MFMA phases interleave (profiles/r01_gemm_x3_dma_probe.txt: dgrad N=300 K=900 0.60 -> 0.45 ms)
+#define X3_DMA_TILE 2, 2, 4, 5, 2
+#define X3_DMA_TILE_Q 4, 2, 2, 7, 2  // 128 x 224, 8 waves: Q = 200 in one column tile (0.32 -> 0.24 ms)
 
 enum { ENGINE_F32 = 0, ENGINE_BF16X3 = 1 };
 static int g_engine = ENGINE_BF16X3;
+// A/B switch for measurements: NRL_X3_DMA=0 keeps every bf16x3 GEMM on the register-staged kernel
+static const bool g_x3_dma = [] {
+  const char* e = getenv("NRL_X3_DMA");
+  return !(e != nullptr && e[0] == '0');
+}();
 
 static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {
   const int64_t tiles = ceil_div(rows_out, bm) * ceil_div(cols_out, bn);
@@ -190,6 +202,12 @@ static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const E
                     bool q_tile, hipStream_t st) {
   if (g_engine == ENGINE_BF16X3) {
     const KCSplit b{sw.hi, sw.lo, sw.Kp, N};
+    if constexpr (!std::is_same<AOp, KCGather>::value) if (g_x3_dma) {
+      // (the gathered operand keeps the register-staged kernel: its dropout hash would be re-evaluated by
+      // every wave column at fragment-read time)
+      if (q_tile && N <= 224) return launch_gemm_bf16x3_dma<X3_DMA_TILE_Q>(a, b, epi, M, N, K, st);
+      return launch_gemm_bf16x3_dma<X3_DMA_TILE>(a, b, epi, M, N, K, st);
+    }
     if (q_tile && N <= 224) return launch_gemm_bf16x3<X3_TILE_Q>(a, b, epi, M, N, K, 1, st);
     if (big_tiles(M, N)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, N, K, 1, st);
     return launch_gemm_bf16x3<X3_TILE>(a, b, epi, M, N, K, 1, st);
@@ -206,6 +224,7 @@ static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, co
   const KCPlain a{dy, Nw, M};
   if (g_engine == ENGINE_BF16X3) {
     const KCSplit b{sw.hi_t, sw.lo_t, sw.Np, Kw};
+    if (g_x3_dma) return launch_gemm_bf16x3_dma<X3_DMA_TILE>(a, b, epi, M, Kw, Nw, st);
     if (big_tiles(M, Kw)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, Kw, Nw, 1, st);
     return launch_gemm_bf16x3<X3_TILE>(a, b, epi, M, Kw, Nw, 1, st);
   }

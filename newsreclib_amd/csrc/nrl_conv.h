@@ -42,6 +42,7 @@ struct KCWindow {
   __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
     return *reinterpret_cast<const float4*>(s.ptr + (k < K ? k : K - 4));
   }
+  __device__ __forceinline__ const float* src(const State& s, int k, int K) const { return s.ptr + (k < K ? k : K - 4); }
   __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
     if (k >= kend || k < s.lo || k >= s.hi) v = f4zero();
   }

@@ -58,6 +58,8 @@ struct KCPlain {
   __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
     return *reinterpret_cast<const float4*>(s.ptr + (k < K ? k : K - 4));
   }
+  // address form of `load` (LDS-DMA staging fetches it without touching VGPRs)
+  __device__ __forceinline__ const float* src(const State& s, int k, int K) const { return s.ptr + (k < K ? k : K - 4); }
   __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
     if (!s.ok || k >= kend) v = f4zero();
   }
@@ -87,6 +89,7 @@ struct KCGather {
   __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
     return *reinterpret_cast<const float4*>(s.ptr + (k < K ? k : K - 4));
   }
+  __device__ __forceinline__ const float* src(const State& s, int k, int K) const { return s.ptr + (k < K ? k : K - 4); }
   __device__ __forceinline__ void finish(float4& v, const State& s, int64_t r, int k, int kend,
                                          bool primary) const {
     if (!s.ok || k >= kend) {

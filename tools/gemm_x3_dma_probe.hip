@@ -1,0 +1,191 @@
+// Probe (not product code): DMA-staged bf16x3 GEMM vs the register-staged one -- equality and speed at
+// the NRMS forward/dgrad shapes (M = 211200).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Inewsreclib_amd/csrc tools/gemm_x3_dma_probe.hip -o tools/bin/gemm_x3_dma_probe
+#include <stdarg.h>
+
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "nrl_gemm_bf16x3_dma.h"
+
+namespace nrl {
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "\n");
+}
+}  // namespace nrl
+using namespace nrl;
+
+#define CK(x)                                                \
+  do {                                                       \
+    hipError_t e = (x);                                      \
+    if (e != hipSuccess) {                                   \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); \
+      exit(1);                                               \
+    }                                                        \
+  } while (0)
+
+static float *g_a, *g_w, *g_c, *g_c2, *g_bias, *g_tbl, *g_x, *g_x2;
+static int64_t* g_ids;
+static uint16_t* g_planes;
+static const int64_t M = 211200;
+
+// kind 0: dgrad (A (M,K) plain, W (K out, N in) -> transposed planes), EpiStore
+// kind 1: fwd linear with bias + dropout epilogue (A plain, W (N,K))
+// kind 2: fwd with gathered A + input dropout + x save
+template <class F>
+int with_b(int kind, int N, int K, hipStream_t st, F f) {
+  SplitWeight sw;
+  if (kind == 0) {
+    if (split_weight(g_w, K, N, g_planes, &sw, st) != 0) return -1;
+    return f(KCSplit{sw.hi_t, sw.lo_t, sw.Np, N});
+  }
+  if (split_weight(g_w, N, K, g_planes, &sw, st) != 0) return -1;
+  return f(KCSplit{sw.hi, sw.lo, sw.Kp, N});
+}
+
+template <int WM, int WN, int TM, int TN, int S, int ABL = 0>
+int run_dma(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
+  return with_b(kind, N, K, st, [&](KCSplit B) {
+    if (kind == 0) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL>(KCPlain{g_a, K, M}, B, EpiStore{c, N}, M, N, K, st);
+    EpiLinear e{c, N, g_bias, 0, make_dropout(0.2, 3, 1), N};
+    if (kind == 1) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL>(KCPlain{g_a, K, M}, B, e, M, N, K, st);
+    return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, st);
+  });
+}
+template <int WM, int WN, int TM, int TN, int DEEP>
+int run_reg(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
+  return with_b(kind, N, K, st, [&](KCSplit B) {
+    if (kind == 0) return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{g_a, K, M}, B, EpiStore{c, N}, M, N, K, 1, st);
+    EpiLinear e{c, N, g_bias, 0, make_dropout(0.2, 3, 1), N};
+    if (kind == 1) return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{g_a, K, M}, B, e, M, N, K, 1, st);
+    return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, 1, st);
+  });
+}
+
+struct Case {
+  std::string name;
+  double flops;
+  std::function<int(float*, float*, hipStream_t)> fn;
+  int kind, N, K;
+};
+
+static double max_diff(const float* d0, const float* d1, size_t n) {
+  std::vector<float> a(n), b(n);
+  CK(hipMemcpy(a.data(), d0, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), d1, n * 4, hipMemcpyDeviceToHost));
+  double m = 0;
+  for (size_t i = 0; i < n; ++i) m = std::max(m, (double)fabsf(a[i] - b[i]));
+  return m;
+}
+
+int main(int argc, char** argv) {
+  const int V = 70000;
+  CK(hipMalloc(&g_a, M * 900 * 4));
+  CK(hipMalloc(&g_w, 900 * 900 * 4));
+  CK(hipMalloc(&g_c, M * 900 * 4));
+  CK(hipMalloc(&g_c2, M * 900 * 4));
+  CK(hipMalloc(&g_x, M * 300 * 4));
+  CK(hipMalloc(&g_x2, M * 300 * 4));
+  CK(hipMalloc(&g_bias, 1024 * 4));
+  CK(hipMalloc(&g_tbl, (size_t)V * 300 * 4));
+  CK(hipMalloc(&g_ids, M * 8));
+  CK(hipMalloc(&g_planes, split_weight_elems(900, 900) * 2 + 1024));
+  {
+    std::vector<float> h((size_t)M * 900);
+    uint32_t s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : h) v = rnd();
+    CK(hipMemcpy(g_a, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(g_w, h.data() + 777, 900 * 900 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(g_bias, h.data() + 5, 1024 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(g_tbl, h.data() + 99, (size_t)V * 300 * 4, hipMemcpyHostToDevice));
+    std::vector<int64_t> ids(M);
+    for (auto& v : ids) { s = s * 1664525u + 1013904223u; v = (s >> 4) % V; }
+    CK(hipMemcpy(g_ids, ids.data(), M * 8, hipMemcpyHostToDevice));
+  }
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  std::vector<Case> cases;
+  struct Shape { const char* n; int kind, N, K; };
+  const Shape shapes[] = {{"dgrad_o  N=300 K=300", 0, 300, 300}, {"dgrad_in N=300 K=900", 0, 300, 900},
+                          {"fwd_out  N=300 K=300", 1, 300, 300}, {"fwd_att  N=200 K=300", 1, 200, 300},
+                          {"gather   N=900 K=300", 2, 900, 300}, {"plain    N=900 K=300", 1, 900, 300}};
+  for (const Shape& sh : shapes) {
+    const double fl = 2.0 * M * sh.N * sh.K;
+    const int kind = sh.kind, N = sh.N, K = sh.K;
+#define REG(tag, ...) cases.push_back({std::string(sh.n) + " reg " tag, fl, [=](float* c, float* x, hipStream_t s) { return run_reg<__VA_ARGS__>(kind, N, K, c, x, s); }, kind, N, K});
+#define DMA(tag, ...) cases.push_back({std::string(sh.n) + " dma " tag, fl, [=](float* c, float* x, hipStream_t s) { return run_dma<__VA_ARGS__>(kind, N, K, c, x, s); }, kind, N, K});
+    REG("256x160 8w      ", 4, 2, 4, 5, 0)
+    DMA("256x160 8w S=3  ", 4, 2, 4, 5, 3)
+    DMA("256x160 8w S=2  ", 4, 2, 4, 5, 2)
+    DMA("128x160 8w S=4  ", 4, 2, 2, 5, 4)
+    DMA("128x160 8w S=3  ", 4, 2, 2, 5, 3)
+    DMA("128x160 4w S=4  ", 2, 2, 4, 5, 4)
+    DMA("128x224 8w S=3  ", 4, 2, 2, 7, 3)
+    DMA("128x160 4w S=2  ", 2, 2, 4, 5, 2)
+    DMA("128x160 4w S=3  ", 2, 2, 4, 5, 3)
+    DMA("128x80 4w S=3   ", 4, 1, 2, 5, 3)
+    DMA("64x160 4w S=2   ", 2, 2, 2, 5, 2)
+    DMA("64x224 4w S=2   ", 2, 2, 2, 7, 2)
+    DMA("128x112 4w S=2  ", 2, 2, 4, 7 / 2, 2)
+    DMA("128x224 8w S=2  ", 4, 2, 2, 7, 2)
+    DMA("abl no-dma      ", 4, 2, 4, 5, 2, 1)
+    DMA("abl no-split    ", 4, 2, 4, 5, 2, 2)
+    DMA("abl no-mfma     ", 4, 2, 4, 5, 2, 4)
+    DMA("abl no-barrier  ", 4, 2, 4, 5, 2, 8)
+    DMA("abl no-dma,split", 4, 2, 4, 5, 2, 3)
+    DMA("abl no-dma,mfma ", 4, 2, 4, 5, 2, 5)
+    DMA("abl dma only    ", 4, 2, 4, 5, 2, 6)
+  }
+  if (argc > 1) {
+    std::vector<Case> keep;
+    for (auto& c : cases)
+      if (c.name.find(argv[1]) != std::string::npos) keep.push_back(c);
+    cases.swap(keep);
+  }
+  // equality against the first (register-staged) case of each shape
+  size_t ref = 0;
+  for (size_t i = 0; i < cases.size(); ++i) {
+    if (cases[i].name.find(" reg ") != std::string::npos) {
+      ref = i;
+      continue;
+    }
+    if (cases[i].name.find(" abl ") != std::string::npos) continue;
+    CK(hipMemset(g_c, 0, M * 900 * 4));
+    CK(hipMemset(g_c2, 0, M * 900 * 4));
+    CK(hipMemset(g_x, 0, M * 300 * 4));
+    CK(hipMemset(g_x2, 0, M * 300 * 4));
+    if (cases[ref].fn(g_c, g_x, st) != 0 || cases[i].fn(g_c2, g_x2, st) != 0) return 1;
+    CK(hipStreamSynchronize(st));
+    const double d = max_diff(g_c, g_c2, (size_t)M * cases[i].N);
+    const double dx = cases[i].kind == 2 ? max_diff(g_x, g_x2, (size_t)M * 300) : 0.0;
+    printf("verify %-44s max|dma-reg| = %.3e  x-save diff %.3e\n", cases[i].name.c_str(), d, dx);
+  }
+  const int rounds = 5;
+  std::vector<std::vector<float>> ms(cases.size());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int r = 0; r < rounds + 1; ++r)
+    for (size_t i = 0; i < cases.size(); ++i) {
+      CK(hipEventRecord(e0, st));
+      if (cases[i].fn(g_c, g_x, st) != 0) return 1;
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float t;
+      CK(hipEventElapsedTime(&t, e0, e1));
+      if (r > 0) ms[i].push_back(t);
+    }
+  for (size_t i = 0; i < cases.size(); ++i) {
+    std::sort(ms[i].begin(), ms[i].end());
+    const float med = ms[i][ms[i].size() / 2];
+    printf("%-48s median %7.3f ms  %6.1f TF\n", cases[i].name.c_str(), med, cases[i].flops / med / 1e9);
+  }
+  return 0;
+}
