@@ -184,10 +184,7 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
     if (fill) {
       NRL_TRY(split_weight(ws[i], ns[i], D, p, outs[i], st));
     } else {
-      SplitWeight& o = *outs[i];
-      o.N = ns[i]; o.K = D; o.Kp = (D + 31) / 32 * 32; o.Np = (ns[i] + 31) / 32 * 32;
-      o.hi = p; o.lo = o.hi + (size_t)o.N * o.Kp; o.hi_t = o.lo + (size_t)o.N * o.Kp;
-      o.lo_t = o.hi_t + (size_t)o.K * o.Np;
+      *outs[i] = split_weight_view(p, ns[i], D);
     }
     p += split_weight_elems(ns[i], D);
   }
@@ -201,7 +198,7 @@ template <class AOp, class Epi>
 static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int N, int K,
                     bool q_tile, hipStream_t st) {
   if (g_engine == ENGINE_BF16X3) {
-    const KCSplit b{sw.hi, sw.lo, sw.Kp, N};
+    const KCSplit b{sw.hi, sw.lo, sw.ld, N};
     if constexpr (!std::is_same<AOp, KCGather>::value) if (g_x3_dma) {
       // (the gathered operand keeps the register-staged kernel: its dropout hash would be re-evaluated by
       // every wave column at fragment-read time)
@@ -223,7 +220,7 @@ static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, co
                       int Kw, hipStream_t st) {
   const KCPlain a{dy, Nw, M};
   if (g_engine == ENGINE_BF16X3) {
-    const KCSplit b{sw.hi_t, sw.lo_t, sw.Np, Kw};
+    const KCSplit b{sw.hi_t, sw.lo_t, sw.ld_t, Kw};
     if (g_x3_dma) return launch_gemm_bf16x3_dma<X3_DMA_TILE>(a, b, epi, M, Kw, Nw, st);
     if (big_tiles(M, Kw)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, Kw, Nw, 1, st);
     return launch_gemm_bf16x3<X3_TILE>(a, b, epi, M, Kw, Nw, 1, st);

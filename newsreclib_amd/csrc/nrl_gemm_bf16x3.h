@@ -34,7 +34,11 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint3
   lo = pack_bf16((__bf16)(a - (float)ha), (__bf16)(b - (float)hb));
 }
 
-// pre-split weight: rows x ld bf16 planes, ld a multiple of 32, zero padded past K
+// pre-split weight, zero padded past K to a multiple of 32.  The hi and lo halves of one k-tile are
+// ADJACENT: row r holds [k-tile 0: 32 hi | 32 lo][k-tile 1: 32 hi | 32 lo]..., i.e. element (r, k) of the
+// hi plane sits at hi[r * ld + 2 * (k - k % 32) + k % 32], ld = 2 * Kp, and lo == hi + 32.  One k-tile of a
+// row is then exactly one aligned 128-B line (two half-line fetches from separate planes cost twice the
+// L2 -> L1 traffic; the staging of these GEMMs is bound by exactly that, profiles/r01_bw_probe.txt).
 struct KCSplit {
   static constexpr int kLayout = SRC_SPLIT;
   const uint16_t* hi;
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
         ch = ch < BN * 4 ? ch : BN * 4 - 1;
         int64_t row = (int64_t)n0 + (ch >> 2);
         row = row < B.rows ? row : B.rows - 1;
-        const int64_t off = row * B.ld + k0 + 8 * (ch & 3);
+        const int64_t off = row * B.ld + 2 * k0 + 8 * (ch & 3);
         rb[2 * c] = *reinterpret_cast<const uint4*>(B.hi + off);
         rb[2 * c + 1] = *reinterpret_cast<const uint4*>(B.lo + off);
       }
@@ -395,10 +399,12 @@ int launch_gemm_bf16x3(const AOp& A, const BOp& B, const Epi& epi, int64_t M, in
   return NRL_OK;
 }
 
-// ---- weight preparation: W (N, K) fp32 -> planes [N][Kp] (for x W^T) and [K][Np] (for dy W) ------
+// ---- weight preparation: W (N, K) fp32 -> interleaved planes [N][2*Kp] (for x W^T) and [K][2*Np] (for dy W)
+__device__ __forceinline__ int64_t split_pos(int64_t row, int k, int ld) {  // hi position; lo is + 32
+  return row * ld + 2 * (k & ~31) + (k & 31);
+}
 __global__ void split_weight_kernel(const float* __restrict__ w, int N, int K, int Kp, int Np,
-                                    uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                    uint16_t* __restrict__ hi_t, uint16_t* __restrict__ lo_t) {
+                                    uint16_t* __restrict__ hi, uint16_t* __restrict__ hi_t) {
   const int64_t total = (int64_t)N * Kp, total_t = (int64_t)K * Np;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + total_t;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -406,37 +412,43 @@ __global__ void split_weight_kernel(const float* __restrict__ w, int N, int K, i
       const int n = (int)(i / Kp), k = (int)(i % Kp);
       const float v = k < K ? w[(int64_t)n * K + k] : 0.f;
       const __bf16 h = (__bf16)v;
-      hi[i] = __builtin_bit_cast(unsigned short, h);
-      lo[i] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+      const int64_t pos = split_pos(n, k, 2 * Kp);
+      hi[pos] = __builtin_bit_cast(unsigned short, h);
+      hi[pos + 32] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
     } else {
       const int64_t q = i - total;
       const int k = (int)(q / Np), n = (int)(q % Np);
       const float v = n < N ? w[(int64_t)n * K + k] : 0.f;
       const __bf16 h = (__bf16)v;
-      hi_t[q] = __builtin_bit_cast(unsigned short, h);
-      lo_t[q] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+      const int64_t pos = split_pos(k, n, 2 * Np);
+      hi_t[pos] = __builtin_bit_cast(unsigned short, h);
+      hi_t[pos + 32] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
     }
   }
 }
 
 struct SplitWeight {  // device pointers into the workspace
-  uint16_t *hi, *lo, *hi_t, *lo_t;
+  uint16_t *hi, *lo, *hi_t, *lo_t;  // lo == hi + 32, lo_t == hi_t + 32 (interleaved layout, see KCSplit)
   int N, K, Kp, Np;
+  int64_t ld, ld_t;                 // 2 * Kp, 2 * Np
 };
 static inline size_t split_weight_elems(int N, int K) {
   const int64_t Kp = (K + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
   return (size_t)(2 * ((int64_t)N * Kp + (int64_t)K * Np));
 }
+static inline SplitWeight split_weight_view(uint16_t* buf, int N, int K) {
+  SplitWeight o;
+  o.N = N; o.K = K; o.Kp = (K + 31) / 32 * 32; o.Np = (N + 31) / 32 * 32;
+  o.ld = 2 * (int64_t)o.Kp; o.ld_t = 2 * (int64_t)o.Np;
+  o.hi = buf; o.lo = buf + 32;
+  o.hi_t = buf + (size_t)N * o.ld; o.lo_t = o.hi_t + 32;
+  return o;
+}
 static inline int split_weight(const float* w, int N, int K, uint16_t* buf, SplitWeight* out, hipStream_t st) {
-  const int Kp = (K + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
-  out->N = N; out->K = K; out->Kp = Kp; out->Np = Np;
-  out->hi = buf;
-  out->lo = out->hi + (size_t)N * Kp;
-  out->hi_t = out->lo + (size_t)N * Kp;
-  out->lo_t = out->hi_t + (size_t)K * Np;
-  const int64_t total = (int64_t)N * Kp + (int64_t)K * Np;
-  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, N, K, Kp, Np,
-                     out->hi, out->lo, out->hi_t, out->lo_t);
+  *out = split_weight_view(buf, N, K);
+  const int64_t total = (int64_t)N * out->Kp + (int64_t)K * out->Np;
+  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, N, K, out->Kp,
+                     out->Np, out->hi, out->hi_t);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -9,13 +9,20 @@
 // (no VGPRs), so S - 1 k-tiles are in flight per workgroup, and the fp32 -> (hi, lo) split moves to the
 // fragment read (a few VALU ops per MFMA operand, hidden under the MFMAs of the other wave).
 //
+// Measured (tools/gemm_x3_dma_probe.hip, profiles/r01_gemm_x3_dma_probe.txt, bit-identical outputs): dgrad
+// N=300 K=900 0.60 -> 0.45 ms with 4-wave 128x160 workgroups and a 2-deep ring (two workgroups per CU, so one
+// wave's split phase overlaps its SIMD partner's MFMA phase); deeper rings and splitting one tile ahead in the
+// MFMA shadow (PIPE) do not help further: with the DMA removed the loop runs in 0.40 ms, the DMA alone in
+// 0.45 ms -- the kernel now sits on the L2 -> LDS delivery rate of this access pattern (~8 TB/s aggregate;
+// 128-B aligned A rows would give another 4-10 %).
+//
 // The DMA is issued through inline asm: with the builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of the
 // next ds_read (it cannot tell the DMA's LDS destination from the fragment reads), which serialises the ring.
 // The waits are explicit instead: before tile t is consumed, `s_waitcnt vmcnt((S-2) * G)` (G = DMA
 // instructions per wave per tile, identical for every wave) + one barrier per k-tile.
 //
 // LDS image of one stage: A fp32 [BM rows][32 k] (128 B per row, the eight 16-B chunks XOR-swizzled by
-// (row >> 1) & 7 so the two ds_read_b128 of a fragment are conflict-free), then the hi and lo planes of B
+// (row >> 1) & 5 so the two ds_read_b128 of a fragment are conflict-free), then the hi and lo planes of B
 // [BN rows][32 bf16] with the 4-chunk swizzle of nrl_gemm_bf16x3.h.  LDS-DMA writes lane-linear, so the
 // swizzle is applied to the SOURCE address each lane fetches.
 #pragma once
@@ -38,7 +45,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int S, class AOp, class Epi, int ABL = 0>
+template <int WM, int WN, int TM, int TN, int S, class AOp, class Epi, int ABL = 0, int PIPE = 0>
 __global__ void __launch_bounds__(WM* WN * 64)
     gemm_bf16x3_dma_kernel(const AOp A, const KCSplit B, const Epi epi, const int64_t M, const int N,
                            const int64_t K, const int tiles_n, const int64_t tiles_total) {
@@ -95,7 +102,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
     const int ch = piece * 64 + lane;
     const int row = ch >> 3, pc = ch & 7;
     sa[c] = A.init(m0 + row);
-    ka[c] = 4 * (pc ^ ((row >> 1) & 7));
+    ka[c] = 4 * (pc ^ ((row >> 1) & 5));
     da[c] = (uint32_t)piece * 1024u;
   }
   const uint16_t* pb[GB];  // source of this lane's chunk at k0 = 0
@@ -120,7 +127,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
 #pragma unroll
     for (int c = 0; c < GA; ++c) glds16_asm(A.src(sa[c], k0 + ka[c], (int)K), base + da[c]);
 #pragma unroll
-    for (int c = 0; c < GB; ++c) glds16_asm(pb[c] + k0, base + db[c]);
+    for (int c = 0; c < GB; ++c) glds16_asm(pb[c] + 2 * k0, base + db[c]);  // interleaved planes: k-tile stride 64
   };
 
   // fragment-row states (for `finish`: row validity, dropout, window mask, x save)
@@ -134,18 +141,17 @@ __global__ void __launch_bounds__(WM* WN * 64)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int buf, int k0, auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
+  // raw fp32 A fragments of one stage -> finish (row / k masks, dropout, x save) -> (hi, lo) bf16 fragments
+  auto convert_a = [&](int buf, int k0, bool prim, bf16x8 (&ah)[TM], bf16x8 (&al)[TM]) {
     const unsigned char* base = smem + buf * STAGE;
-    bf16x8 ah[TM], al[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = (wm * TM + i) * 16 + l15;
-      const int s = (row >> 1) & 7;
+      const int s = (row >> 1) & 5;
       float4 v0 = *reinterpret_cast<const float4*>(base + row * 128 + ((2 * g) ^ s) * 16);
       float4 v1 = *reinterpret_cast<const float4*>(base + row * 128 + ((2 * g + 1) ^ s) * 16);
-      A.finish(v0, fa[i], m0 + row, k0 + 8 * g, (int)K, primary);
-      A.finish(v1, fa[i], m0 + row, k0 + 8 * g + 4, (int)K, primary);
+      A.finish(v0, fa[i], m0 + row, k0 + 8 * g, (int)K, prim);
+      A.finish(v1, fa[i], m0 + row, k0 + 8 * g + 4, (int)K, prim);
       uint32_t h[4], l[4];
       if constexpr (ABL & 2) {  // probe only: no split
         h[0] = __float_as_uint(v0.x); h[1] = __float_as_uint(v0.y); h[2] = __float_as_uint(v0.z); h[3] = __float_as_uint(v0.w);
@@ -159,6 +165,10 @@ __global__ void __launch_bounds__(WM* WN * 64)
       ah[i] = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
       al[i] = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
     }
+  };
+  auto mfma_tile = [&](int buf, const bf16x8 (&ah)[TM], const bf16x8 (&al)[TM], auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const unsigned char* base = smem + buf * STAGE;
     bf16x8 bh[TN], bl[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -189,6 +199,11 @@ __global__ void __launch_bounds__(WM* WN * 64)
       }
     }
   };
+  auto compute = [&](int buf, int k0, auto full_tag) {
+    bf16x8 ah[TM], al[TM];
+    convert_a(buf, k0, primary, ah, al);
+    mfma_tile(buf, ah, al, full_tag);
+  };
 
   // prologue: tiles 0 .. S-2 in flight
 #pragma unroll
@@ -213,10 +228,65 @@ __global__ void __launch_bounds__(WM* WN * 64)
       nbuf = nbuf + 1 == S ? 0 : nbuf + 1;
     }
   };
-  if (full)
-    k_loop(std::true_type{});
-  else
-    k_loop(std::false_type{});
+  // PIPE: the A fragments of tile tt + 1 are read and split WHILE the MFMAs of tile tt run (the split is
+  // ~150 VALU ops per k-tile and wave; done up front it idles the matrix pipe for a third of the iteration).
+  // Two named fragment sets alternate (loop unrolled by two, no register copies); the MFMA / VALU
+  // interleave is requested from the scheduler with sched_group_barrier.
+  auto k_loop_pipe = [&](auto full_tag) {
+    static_assert(!PIPE || S >= 3, "pipelined mode reads two stages per iteration");
+    bf16x8 ah0[TM], al0[TM], ah1[TM], al1[TM];
+    if (ntiles - 1 >= S - 2) {
+      wait_vmcnt<(S - 2) * G>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __syncthreads();
+    convert_a(0, 0, primary, ah0, al0);
+    int buf = 0;
+    auto step = [&](int tt, const bf16x8 (&ahc)[TM], const bf16x8 (&alc)[TM], bf16x8 (&ahn)[TM], bf16x8 (&aln)[TM]) {
+      const bool more = tt + 1 < ntiles;
+      if (more) {  // tile tt + 1 must have landed; tiles tt + 2 .. may still be in flight
+        if (S > 3 && ntiles - tt - 2 >= S - 3) {
+          wait_vmcnt<(S > 3 ? (S - 3) * G : 0)>();
+        } else {
+          wait_vmcnt<0>();
+        }
+      }
+      __syncthreads();
+      const int b1 = buf + 1 == S ? 0 : buf + 1;
+      const int bp = buf == 0 ? S - 1 : buf - 1;  // stage of tile tt - 1 == stage of tile tt + S - 1
+      if (tt + S - 1 < ntiles) issue(tt + S - 1, bp);
+      mfma_tile(buf, ahc, alc, full_tag);
+      convert_a(b1, (tt + 1) * BK, primary && more, ahn, aln);  // (a stale stage on the last tile: unused)
+      // pin the split to THIS block (otherwise it is sunk into the next iteration, in front of the barrier)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(ahn[i]), "+v"(aln[i]));
+      constexpr int NMF = 3 * TM * TN;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * TN + 2 * TM, 0);  // all fragment reads first
+#pragma unroll
+      for (int q = 0; q < NMF; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU ops in its shadow
+      }
+      buf = b1;
+    };
+    for (int tt = 0; tt < ntiles; tt += 2) {
+      step(tt, ah0, al0, ah1, al1);
+      if (tt + 1 >= ntiles) break;
+      step(tt + 1, ah1, al1, ah0, al0);
+    }
+  };
+  if constexpr (PIPE) {
+    if (full)
+      k_loop_pipe(std::true_type{});
+    else
+      k_loop_pipe(std::false_type{});
+  } else {
+    if (full)
+      k_loop(std::true_type{});
+    else
+      k_loop(std::false_type{});
+  }
 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -235,7 +305,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
   }
 }
 
-template <int WM, int WN, int TM, int TN, int S, int ABL = 0, class AOp, class Epi>
+template <int WM, int WN, int TM, int TN, int S, int ABL = 0, int PIPE = 0, class AOp, class Epi>
 int launch_gemm_bf16x3_dma(const AOp& A, const KCSplit& B, const Epi& epi, int64_t M, int N, int64_t K,
                            hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -244,7 +314,7 @@ int launch_gemm_bf16x3_dma(const AOp& A, const KCSplit& B, const Epi& epi, int64
   const int tiles_n = (int)ceil_div(N, BN);
   const int64_t tiles_total = tiles_m * tiles_n;
   NRL_REQUIRE(tiles_total < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<WM, WN, TM, TN, S, AOp, Epi, ABL>), dim3((unsigned)tiles_total),
+  hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<WM, WN, TM, TN, S, AOp, Epi, ABL, PIPE>), dim3((unsigned)tiles_total),
                      dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total);
   NRL_LAUNCH_CHECK();
   return NRL_OK;

@@ -34,6 +34,7 @@ static float *g_a, *g_w, *g_c, *g_c2, *g_bias, *g_tbl, *g_x, *g_x2;
 static int64_t* g_ids;
 static uint16_t* g_planes;
 static const int64_t M = 211200;
+static int g_lda_pad = 0;  // extra floats per A row (alignment experiment)
 
 // kind 0: dgrad (A (M,K) plain, W (K out, N in) -> transposed planes), EpiStore
 // kind 1: fwd linear with bias + dropout epilogue (A plain, W (N,K))
@@ -43,27 +44,27 @@ int with_b(int kind, int N, int K, hipStream_t st, F f) {
   SplitWeight sw;
   if (kind == 0) {
     if (split_weight(g_w, K, N, g_planes, &sw, st) != 0) return -1;
-    return f(KCSplit{sw.hi_t, sw.lo_t, sw.Np, N});
+    return f(KCSplit{sw.hi_t, sw.lo_t, sw.ld_t, N});
   }
   if (split_weight(g_w, N, K, g_planes, &sw, st) != 0) return -1;
-  return f(KCSplit{sw.hi, sw.lo, sw.Kp, N});
+  return f(KCSplit{sw.hi, sw.lo, sw.ld, N});
 }
 
-template <int WM, int WN, int TM, int TN, int S, int ABL = 0>
+template <int WM, int WN, int TM, int TN, int S, int ABL = 0, int PIPE = 0>
 int run_dma(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
   return with_b(kind, N, K, st, [&](KCSplit B) {
-    if (kind == 0) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL>(KCPlain{g_a, K, M}, B, EpiStore{c, N}, M, N, K, st);
+    if (kind == 0) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE>(KCPlain{g_a, K + g_lda_pad, M}, B, EpiStore{c, N}, M, N, K, st);
     EpiLinear e{c, N, g_bias, 0, make_dropout(0.2, 3, 1), N};
-    if (kind == 1) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL>(KCPlain{g_a, K, M}, B, e, M, N, K, st);
-    return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, st);
+    if (kind == 1) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE>(KCPlain{g_a, K + g_lda_pad, M}, B, e, M, N, K, st);
+    return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, st);
   });
 }
 template <int WM, int WN, int TM, int TN, int DEEP>
 int run_reg(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
   return with_b(kind, N, K, st, [&](KCSplit B) {
-    if (kind == 0) return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{g_a, K, M}, B, EpiStore{c, N}, M, N, K, 1, st);
+    if (kind == 0) return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{g_a, K + g_lda_pad, M}, B, EpiStore{c, N}, M, N, K, 1, st);
     EpiLinear e{c, N, g_bias, 0, make_dropout(0.2, 3, 1), N};
-    if (kind == 1) return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{g_a, K, M}, B, e, M, N, K, 1, st);
+    if (kind == 1) return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCPlain{g_a, K + g_lda_pad, M}, B, e, M, N, K, 1, st);
     return launch_gemm_bf16x3<WM, WN, TM, TN, DEEP>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, 1, st);
   });
 }
@@ -86,7 +87,8 @@ static double max_diff(const float* d0, const float* d1, size_t n) {
 
 int main(int argc, char** argv) {
   const int V = 70000;
-  CK(hipMalloc(&g_a, M * 900 * 4));
+  CK(hipMalloc(&g_a, M * 960 * 4));
+  if (getenv("LDA_PAD")) g_lda_pad = atoi(getenv("LDA_PAD"));
   CK(hipMalloc(&g_w, 900 * 900 * 4));
   CK(hipMalloc(&g_c, M * 900 * 4));
   CK(hipMalloc(&g_c2, M * 900 * 4));
@@ -97,7 +99,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&g_ids, M * 8));
   CK(hipMalloc(&g_planes, split_weight_elems(900, 900) * 2 + 1024));
   {
-    std::vector<float> h((size_t)M * 900);
+    std::vector<float> h((size_t)M * 960);
     uint32_t s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
     for (auto& v : h) v = rnd();
@@ -135,6 +137,12 @@ int main(int argc, char** argv) {
     DMA("64x224 4w S=2   ", 2, 2, 2, 7, 2)
     DMA("128x112 4w S=2  ", 2, 2, 4, 7 / 2, 2)
     DMA("128x224 8w S=2  ", 4, 2, 2, 7, 2)
+    DMA("pipe 256x160 8w S=3", 4, 2, 4, 5, 3, 0, 1)
+    DMA("pipe 128x160 4w S=3", 2, 2, 4, 5, 3, 0, 1)
+    DMA("pipe 128x160 4w S=4", 2, 2, 4, 5, 4, 0, 1)
+    DMA("pipe 128x160 8w S=3", 4, 2, 2, 5, 3, 0, 1)
+    DMA("pipe 128x160 8w S=4", 4, 2, 2, 5, 4, 0, 1)
+    DMA("pipe 64x160 4w S=3 ", 2, 2, 2, 5, 3, 0, 1)
     DMA("abl no-dma      ", 4, 2, 4, 5, 2, 1)
     DMA("abl no-split    ", 4, 2, 4, 5, 2, 2)
     DMA("abl no-mfma     ", 4, 2, 4, 5, 2, 4)
