@@ -45,7 +45,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int S, class AOp, class Epi, int ABL = 0, int PIPE = 0>
+template <int WM, int WN, int TM, int TN, int S, class AOp, class Epi, int ABL = 0, int PIPE = 0, int JC = TN>
 __global__ void __launch_bounds__(WM* WN * 64)
     gemm_bf16x3_dma_kernel(const AOp A, const KCSplit B, const Epi epi, const int64_t M, const int N,
                            const int64_t K, const int tiles_n, const int64_t tiles_total) {
@@ -169,31 +169,38 @@ __global__ void __launch_bounds__(WM* WN * 64)
   auto mfma_tile = [&](int buf, const bf16x8 (&ah)[TM], const bf16x8 (&al)[TM], auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     const unsigned char* base = smem + buf * STAGE;
-    bf16x8 bh[TN], bl[TN];
+    // B fragments are fetched JC column blocks at a time (wide tiles: all TN at once would not fit next to
+    // the accumulators); per accumulator the three split products keep the order lo-terms first, hi*hi last
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = (wn * TN + j) * 16 + l15;
-      const int off = row * 64 + swz(g, row) * 16;
-      bh[j] = *reinterpret_cast<const bf16x8*>(base + A_BYTES + off);
-      bl[j] = *reinterpret_cast<const bf16x8*>(base + A_BYTES + PLANE_B + off);
-    }
-    if constexpr (ABL & 4) {  // probe only: no MFMA, keep the fragments alive
+    for (int j0 = 0; j0 < TN; j0 += JC) {
+      bf16x8 bh[JC], bl[JC];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+      for (int jj = 0; jj < JC; ++jj) {
+        if (j0 + jj < TN) {
+          const int row = (wn * TN + j0 + jj) * 16 + l15;
+          const int off = row * 64 + swz(g, row) * 16;
+          bh[jj] = *reinterpret_cast<const bf16x8*>(base + A_BYTES + off);
+          bl[jj] = *reinterpret_cast<const bf16x8*>(base + A_BYTES + PLANE_B + off);
+        }
+      }
+      if constexpr (ABL & 4) {  // probe only: no MFMA, keep the fragments alive
 #pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
-      return;
-    }
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
 #pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
+        for (int jj = 0; jj < JC; ++jj) asm volatile("" ::"v"(bh[jj]), "v"(bl[jj]));
+        continue;
+      }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (FULL || i < nvi) {
+      for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if (FULL || j < nvj)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
-                                                                 pass == 0 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) {
+          if (FULL || i < nvi) {
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj) {
+              if (j0 + jj < TN && (FULL || j0 + jj < nvj))
+                acc[i][j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    pass == 1 ? al[i] : ah[i], pass == 0 ? bl[jj] : bh[jj], acc[i][j0 + jj], 0, 0, 0);
+            }
           }
         }
       }
@@ -305,7 +312,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
   }
 }
 
-template <int WM, int WN, int TM, int TN, int S, int ABL = 0, int PIPE = 0, class AOp, class Epi>
+template <int WM, int WN, int TM, int TN, int S, int ABL = 0, int PIPE = 0, int JC = TN, class AOp, class Epi>
 int launch_gemm_bf16x3_dma(const AOp& A, const KCSplit& B, const Epi& epi, int64_t M, int N, int64_t K,
                            hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -314,7 +321,7 @@ int launch_gemm_bf16x3_dma(const AOp& A, const KCSplit& B, const Epi& epi, int64
   const int tiles_n = (int)ceil_div(N, BN);
   const int64_t tiles_total = tiles_m * tiles_n;
   NRL_REQUIRE(tiles_total < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<WM, WN, TM, TN, S, AOp, Epi, ABL, PIPE>), dim3((unsigned)tiles_total),
+  hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<WM, WN, TM, TN, S, AOp, Epi, ABL, PIPE, JC>), dim3((unsigned)tiles_total),
                      dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total);
   NRL_LAUNCH_CHECK();
   return NRL_OK;

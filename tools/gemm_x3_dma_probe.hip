@@ -50,13 +50,13 @@ int with_b(int kind, int N, int K, hipStream_t st, F f) {
   return f(KCSplit{sw.hi, sw.lo, sw.ld, N});
 }
 
-template <int WM, int WN, int TM, int TN, int S, int ABL = 0, int PIPE = 0>
+template <int WM, int WN, int TM, int TN, int S, int ABL = 0, int PIPE = 0, int JC = TN>
 int run_dma(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
   return with_b(kind, N, K, st, [&](KCSplit B) {
-    if (kind == 0) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE>(KCPlain{g_a, K + g_lda_pad, M}, B, EpiStore{c, N}, M, N, K, st);
+    if (kind == 0) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE, JC>(KCPlain{g_a, K + g_lda_pad, M}, B, EpiStore{c, N}, M, N, K, st);
     EpiLinear e{c, N, g_bias, 0, make_dropout(0.2, 3, 1), N};
-    if (kind == 1) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE>(KCPlain{g_a, K + g_lda_pad, M}, B, e, M, N, K, st);
-    return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, st);
+    if (kind == 1) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE, JC>(KCPlain{g_a, K + g_lda_pad, M}, B, e, M, N, K, st);
+    return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE, JC>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, st);
   });
 }
 template <int WM, int WN, int TM, int TN, int DEEP>
@@ -137,6 +137,10 @@ int main(int argc, char** argv) {
     DMA("64x224 4w S=2   ", 2, 2, 2, 7, 2)
     DMA("128x112 4w S=2  ", 2, 2, 4, 7 / 2, 2)
     DMA("128x224 8w S=2  ", 4, 2, 2, 7, 2)
+    DMA("256x320 8w S=2 jc2", 4, 2, 4, 10, 2, 0, 0, 2)
+    DMA("256x320 8w S=2 jc5", 4, 2, 4, 10, 2, 0, 0, 5)
+    DMA("128x320 8w S=2 jc5", 2, 4, 4, 5, 2, 0, 0, 5)
+    DMA("128x320 4w S=2 jc5", 2, 2, 4, 10, 2, 0, 0, 5)
     DMA("pipe 256x160 8w S=3", 4, 2, 4, 5, 3, 0, 1)
     DMA("pipe 128x160 4w S=3", 2, 2, 4, 5, 3, 0, 1)
     DMA("pipe 128x160 4w S=4", 2, 2, 4, 5, 4, 0, 1)
