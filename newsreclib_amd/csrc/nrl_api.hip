@@ -244,6 +244,9 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
       return (int)(sp > max_s ? max_s : (sp < 1 ? 1 : sp));
     };
     if (I > 512) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, I, J + 1, M, splits(256), st);
+    // small outputs: LDS-DMA staged, transposition at the fragment read (0.35 -> 0.30 ms at 300 x 300;
+    // the 900-row gradient is faster register-staged, profiles/r01_gemm_x3_dma_probe.txt)
+    if (g_x3_dma) return launch_gemm_bf16x3_dma_tn<2, 2, 2, 5, 2>(a, b, epi, I, J + 1, M, splits(64), st);
     return launch_gemm_bf16x3<X3_TILE_W>(a, b, epi, I, J + 1, M, splits(64), st);
   }
   if (I > 512) return launch_gemm<NRL_TILE>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 128, 160), st);

@@ -73,6 +73,12 @@ struct RCWindow {
     const int l = (int)(k % L) + (int)(r / inner) - pad;
     if (l < 0 || l >= L) v = f4zero();
   }
+  __device__ __forceinline__ const float* src(int64_t k, int64_t r, int64_t kend) const {
+    if (k >= kend) return nrl_dma_zero16;
+    if (r >= rows) return (ones && r == rows) ? nrl_dma_ones16 : nrl_dma_zero16;
+    const int l = (int)((uint32_t)k % (uint32_t)L) + (int)((uint32_t)r / (uint32_t)inner) - pad;
+    return (l < 0 || l >= L) ? nrl_dma_zero16 : x + (k - pad) * inner + r;
+  }
 };
 
 // conv weight Wc (F, W*D) as the (K = W*F, N = D) operand of the dgrad with reversed taps:

@@ -32,6 +32,11 @@ enum { SRC_KC = 0, SRC_RC = 1 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// 16-byte constants an LDS-DMA lane is pointed at instead of predicating the load (out-of-range rows /
+// k, and the virtual ones-column of a weight-gradient operand)
+__device__ const float nrl_dma_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ const float nrl_dma_ones16[4] = {1.f, 0.f, 0.f, 0.f};
+
 // ---------------------------------------------------------------------------------------------
 // operand accessors
 // ---------------------------------------------------------------------------------------------
@@ -124,6 +129,12 @@ struct RCPlain {
       v = f4zero();
     else if (r >= rows)
       v = (ones && r == rows) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
+  }
+  // address form of load + finish (LDS-DMA staging): where to fetch the 16 bytes of (k, r .. r + 3) from
+  __device__ __forceinline__ const float* src(int64_t k, int64_t r, int64_t kend) const {
+    if (k >= kend) return nrl_dma_zero16;
+    if (r < rows) return p + k * ld + r;
+    return (ones && r == rows) ? nrl_dma_ones16 : nrl_dma_zero16;
   }
 };
 

@@ -327,4 +327,204 @@ int launch_gemm_bf16x3_dma(const AOp& A, const KCSplit& B, const Epi& epi, int64
   return NRL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight-gradient form: C (I x J) += A^T B with BOTH operands k-major fp32 (element (k, r) at p[k*ld + r]),
+// split-K over k with all tiles of one k-split on one XCD (as in nrl_gemm_bf16x3.h).  The k-tile of an
+// operand is 32 k-rows x ROWS floats; LDS-DMA copies it row-major ([k][ROWS], 16-B chunks XOR-swizzled by
+// 4 * ((k >> 3) & 1) so the two k-groups of a 32-lane ds_read_b32 group use disjoint bank halves), and the
+// TRANSPOSITION happens at the fragment read: a lane fetches its 8 consecutive k of one column with eight
+// ds_read_b32 (immediate offsets s * ROWS * 4) and splits them to (hi, lo) bf16.  No VGPR staging, no
+// ds_write pass.  Out-of-range rows / k tails / the virtual ones-column are served by pointing the lane at
+// 16-byte constants (accessor `src`).
+// ---------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int S, class AOp, class BOp, class Epi>
+__global__ void __launch_bounds__(WM* WN * 64)
+    gemm_bf16x3_dma_tn_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N,
+                              const int64_t K, const int tiles_n, const int64_t tiles_total,
+                              const int64_t k_per_split, const int nsplit) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
+  constexpr int A_BYTES = BK * BM * 4, B_BYTES = BK * BN * 4;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int CA = BM / 4, CB = BN / 4;        // 16-B chunks per k-row
+  constexpr int PA_TOT = BK * CA / 64, PB_TOT = BK * CB / 64;
+  constexpr int GA = (PA_TOT + NW - 1) / NW, GB = (PB_TOT + NW - 1) / NW;
+  constexpr int G = GA + GB;
+  static_assert(AOp::kLayout == SRC_RC && BOp::kLayout == SRC_RC, "both operands k-major fp32");
+  static_assert(CA % 8 == 0 && CB % 8 == 0, "tile rows must be multiples of 32 (chunk swizzle)");
+  static_assert(S >= 2 && (S - 2) * G <= 63, "ring depth vs vmcnt range");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[S * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  int64_t t, split;
+  {
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid % 8, local = bid / 8;
+    if (nsplit > 1) {
+      t = local % tiles_total;
+      split = (local / tiles_total) * 8 + xcd;
+      if (split >= nsplit) return;
+    } else {
+      const int64_t q = tiles_total / 8, rem = tiles_total % 8;
+      t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + local;
+      split = 0;
+    }
+  }
+  const int64_t m0 = (t / tiles_n) * BM;
+  const int n0 = (int)(t % tiles_n) * BN;
+  const int64_t kbeg = split * k_per_split;
+  const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  if (kbeg >= kend) return;
+  const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
+
+  int nvi = 0, nvj = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) nvi += (m0 + (wm * TM + i) * 16 < M) ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) nvj += (n0 + (wn * TN + j) * 16 < N) ? 1 : 0;
+  const bool full = (nvi == TM) && (nvj == TN);
+
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // DMA assignment (pieces clamped so every wave issues exactly G instructions per k-tile)
+  int kra[GA], ca[GA], krb[GB], cb[GB];
+  uint32_t da[GA], db[GB];
+#pragma unroll
+  for (int c = 0; c < GA; ++c) {
+    int piece = wave + c * NW;
+    piece = piece < PA_TOT ? piece : PA_TOT - 1;
+    const int ch = piece * 64 + lane;
+    kra[c] = ch / CA;
+    ca[c] = 4 * ((ch % CA) ^ (((kra[c] >> 3) & 1) << 2));
+    da[c] = (uint32_t)piece * 1024u;
+  }
+#pragma unroll
+  for (int c = 0; c < GB; ++c) {
+    int piece = wave + c * NW;
+    piece = piece < PB_TOT ? piece : PB_TOT - 1;
+    const int ch = piece * 64 + lane;
+    krb[c] = ch / CB;
+    cb[c] = 4 * ((ch % CB) ^ (((krb[c] >> 3) & 1) << 2));
+    db[c] = (uint32_t)A_BYTES + (uint32_t)piece * 1024u;
+  }
+  auto issue = [&](int tile, int buf) {
+    const int64_t k0 = kbeg + (int64_t)tile * BK;
+    const uint32_t base = smem_base + (uint32_t)buf * (uint32_t)STAGE;
+#pragma unroll
+    for (int c = 0; c < GA; ++c) glds16_asm(A.src(k0 + kra[c], m0 + ca[c], kend), base + da[c]);
+#pragma unroll
+    for (int c = 0; c < GB; ++c) glds16_asm(B.src(k0 + krb[c], (int64_t)n0 + cb[c], kend), base + db[c]);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // float offset of this lane's column inside a k-row image (chunk swizzle of its k-group applied)
+  const int fsw = (g & 1) << 2;
+  auto frag = [&](const float* img, int rows_per_k, int col, bf16x8& hi, bf16x8& lo) {
+    const float* p = img + (8 * g) * rows_per_k + ((((col >> 2) ^ fsw) << 2) | (col & 3));
+    float v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = p[s * rows_per_k];
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], h[q], l[q]);
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+  };
+
+  auto compute = [&](int buf, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const float* as = reinterpret_cast<const float*>(smem + buf * STAGE);
+    const float* bs = reinterpret_cast<const float*>(smem + buf * STAGE + A_BYTES);
+    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) frag(as, BM, (wm * TM + i) * 16 + l15, ah[i], al[i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) frag(bs, BN, (wn * TN + j) * 16 + l15, bh[j], bl[j]);
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (FULL || i < nvi) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (FULL || j < nvj)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
+                                                                 pass == 0 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+#pragma unroll
+  for (int p = 0; p < S - 1; ++p)
+    if (p < ntiles) issue(p, p);
+
+  auto k_loop = [&](auto full_tag) {
+    int buf = 0, nbuf = S - 1;
+    for (int tt = 0; tt < ntiles; ++tt) {
+      const int ahead = ntiles - 1 - tt;
+      if (ahead >= S - 2) {
+        wait_vmcnt<(S - 2) * G>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __syncthreads();
+      if (tt + S - 1 < ntiles) issue(tt + S - 1, nbuf);
+      compute(buf, full_tag);
+      buf = buf + 1 == S ? 0 : buf + 1;
+      nbuf = nbuf + 1 == S ? 0 : nbuf + 1;
+    }
+  };
+  if (full)
+    k_loop(std::true_type{});
+  else
+    k_loop(std::false_type{});
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + r;
+      if (m < M) {
+        const typename Epi::Row rs = epi.row(m);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wn * TN + j) * 16 + l15;
+          if (n < N) epi(rs, m, n, acc[i][j][r]);
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN, int S, class AOp, class BOp, class Epi>
+int launch_gemm_bf16x3_dma_tn(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, int64_t K, int splits,
+                              hipStream_t stream) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
+  const int64_t tiles_m = ceil_div(M, BM);
+  const int tiles_n = (int)ceil_div(N, BN);
+  const int64_t tiles_total = tiles_m * tiles_n;
+  if (splits < 1) splits = 1;
+  int64_t kps = ceil_div(ceil_div(K, splits), 32) * 32;
+  splits = (int)ceil_div(K, kps);
+  const int64_t nblocks = splits > 1 ? ceil_div(splits, 8) * 8 * tiles_total : tiles_total;
+  NRL_REQUIRE(nblocks < (1LL << 31), "gemm grid too large");
+  hipLaunchKernelGGL((gemm_bf16x3_dma_tn_kernel<WM, WN, TM, TN, S, AOp, BOp, Epi>), dim3((unsigned)nblocks),
+                     dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
 }  // namespace nrl

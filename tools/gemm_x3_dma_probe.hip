@@ -30,7 +30,7 @@ using namespace nrl;
     }                                                        \
   } while (0)
 
-static float *g_a, *g_w, *g_c, *g_c2, *g_bias, *g_tbl, *g_x, *g_x2;
+static float *g_a, *g_w, *g_c, *g_c2, *g_bias, *g_bias2, *g_tbl, *g_x, *g_x2;
 static int64_t* g_ids;
 static uint16_t* g_planes;
 static const int64_t M = 211200;
@@ -69,6 +69,26 @@ int run_reg(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
   });
 }
 
+// kind 3: weight gradient dW (I, J) += dY (M, I)^T X (M, J), db via the ones-column; c must be zeroed first
+static int tn_splits(int I, int J, int bm) {
+  const int64_t tiles = ceil_div(I, bm) * ceil_div(J + 1, 160);
+  int64_t sp = ceil_div(M, 1664);
+  if (sp * tiles < 512) sp = ceil_div(512, tiles);
+  const int64_t max_s = ceil_div(M, 256);
+  return (int)(sp > max_s ? max_s : (sp < 1 ? 1 : sp));
+}
+template <int WM, int WN, int TM, int TN>
+int run_reg_tn(int I, int J, float* c, hipStream_t st) {
+  return launch_gemm_bf16x3<WM, WN, TM, TN, 0>(RCPlain{g_a, I, I, 0}, RCPlain{g_x, J, J, 1}, EpiAtomicWB{c, J, g_bias2, J}, I,
+                                               J + 1, M, tn_splits(I, J, WM * TM * 16), st);
+}
+template <int WM, int WN, int TM, int TN, int S>
+int run_dma_tn(int I, int J, float* c, hipStream_t st) {
+  return launch_gemm_bf16x3_dma_tn<WM, WN, TM, TN, S>(RCPlain{g_a, I, I, 0}, RCPlain{g_x, J, J, 1},
+                                                      EpiAtomicWB{c, J, g_bias2, J}, I, J + 1, M,
+                                                      tn_splits(I, J, WM * TM * 16), st);
+}
+
 struct Case {
   std::string name;
   double flops;
@@ -95,6 +115,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&g_x, M * 300 * 4));
   CK(hipMalloc(&g_x2, M * 300 * 4));
   CK(hipMalloc(&g_bias, 1024 * 4));
+  CK(hipMalloc(&g_bias2, 1024 * 4));
   CK(hipMalloc(&g_tbl, (size_t)V * 300 * 4));
   CK(hipMalloc(&g_ids, M * 8));
   CK(hipMalloc(&g_planes, split_weight_elems(900, 900) * 2 + 1024));
@@ -155,6 +176,23 @@ int main(int argc, char** argv) {
     DMA("abl no-dma,mfma ", 4, 2, 4, 5, 2, 5)
     DMA("abl dma only    ", 4, 2, 4, 5, 2, 6)
   }
+  {
+    struct TShape { const char* n; int I, J; };
+    const TShape ts[] = {{"wgrad_in 900x300", 900, 300}, {"wgrad_o  300x300", 300, 300}, {"wgrad_a  200x300", 200, 300}};
+    for (const TShape& sh : ts) {
+      const double fl = 2.0 * M * sh.I * sh.J;
+      const int I = sh.I, J = sh.J;
+#define TREG(tag, ...) cases.push_back({std::string(sh.n) + " reg " tag, fl, [=](float* c, float*, hipStream_t s) { return run_reg_tn<__VA_ARGS__>(I, J, c, s); }, 3, J, I});
+#define TDMA(tag, ...) cases.push_back({std::string(sh.n) + " dma " tag, fl, [=](float* c, float*, hipStream_t s) { return run_dma_tn<__VA_ARGS__>(I, J, c, s); }, 3, J, I});
+      if (I > 512) { TREG("256x160 8w      ", 4, 2, 4, 5) } else { TREG("64x160 4w       ", 2, 2, 2, 5) }
+      TDMA("128x160 4w S=2  ", 2, 2, 4, 5, 2)
+      TDMA("256x160 8w S=2  ", 4, 2, 4, 5, 2)
+      TDMA("256x160 8w S=3  ", 4, 2, 4, 5, 3)
+      TDMA("128x160 8w S=2  ", 4, 2, 2, 5, 2)
+      TDMA("64x160 4w S=2   ", 2, 2, 2, 5, 2)
+      TDMA("128x160 4w S=3  ", 2, 2, 4, 5, 3)
+    }
+  }
   if (argc > 1) {
     std::vector<Case> keep;
     for (auto& c : cases)
@@ -169,6 +207,19 @@ int main(int argc, char** argv) {
       continue;
     }
     if (cases[i].name.find(" abl ") != std::string::npos) continue;
+    if (cases[i].kind == 3) {
+      CK(hipMemset(g_c, 0, 1024 * 1024 * 4));
+      CK(hipMemset(g_c2, 0, 1024 * 1024 * 4));
+      CK(hipMemset(g_bias2, 0, 1024 * 4));
+      CK(hipMemcpy(g_x, g_a + 12345, M * 300 * 4, hipMemcpyDeviceToDevice));
+      if (cases[ref].fn(g_c, g_x, st) != 0 || cases[i].fn(g_c2, g_x2, st) != 0) return 1;
+      CK(hipStreamSynchronize(st));
+      const double d = max_diff(g_c, g_c2, (size_t)cases[i].K * cases[i].N);
+      std::vector<float> h(16);
+      CK(hipMemcpy(h.data(), g_c, 64, hipMemcpyDeviceToHost));
+      printf("verify %-44s max|dma-reg| = %.3e (ref[0..2] = %.4f %.4f %.4f)\n", cases[i].name.c_str(), d, h[0], h[1], h[2]);
+      continue;
+    }
     CK(hipMemset(g_c, 0, M * 900 * 4));
     CK(hipMemset(g_c2, 0, M * 900 * 4));
     CK(hipMemset(g_x, 0, M * 300 * 4));
