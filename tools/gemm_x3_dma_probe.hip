@@ -1,6 +1,6 @@
 // Probe (not product code): DMA-staged bf16x3 GEMM vs the register-staged one -- equality and speed at
 // the NRMS forward/dgrad shapes (M = 211200).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Inewsreclib_amd/csrc tools/gemm_x3_dma_probe.hip -o tools/bin/gemm_x3_dma_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Inewsreclib_amd/csrc -Itools tools/gemm_x3_dma_probe.hip -o tools/bin/gemm_x3_dma_probe
 #include <stdarg.h>
 
 #include <algorithm>
@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "nrl_gemm_bf16x3_dma.h"
+#include "experimental/nrl_gemm_bf16x3_astat.h"
 
 namespace nrl {
 void set_error(const char* fmt, ...) {
@@ -57,6 +57,15 @@ int run_dma(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
     EpiLinear e{c, N, g_bias, 0, make_dropout(0.2, 3, 1), N};
     if (kind == 1) return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE, JC>(KCPlain{g_a, K + g_lda_pad, M}, B, e, M, N, K, st);
     return launch_gemm_bf16x3_dma<WM, WN, TM, TN, S, ABL, PIPE, JC>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, st);
+  });
+}
+template <int WM, int WN, int TM, int TN, int KT>
+int run_astat(int kind, int N, int K, float* c, float* xsave, hipStream_t st) {
+  return with_b(kind, N, K, st, [&](KCSplit B) {
+    if (kind == 0) return launch_gemm_bf16x3_astat<WM, WN, TM, TN, KT>(KCPlain{g_a, K + g_lda_pad, M}, B, EpiStore{c, N}, M, N, K, st);
+    EpiLinear e{c, N, g_bias, 0, make_dropout(0.2, 3, 1), N};
+    if (kind == 1) return launch_gemm_bf16x3_astat<WM, WN, TM, TN, KT>(KCPlain{g_a, K + g_lda_pad, M}, B, e, M, N, K, st);
+    return launch_gemm_bf16x3_astat<WM, WN, TM, TN, KT>(KCGather{g_tbl, g_ids, M, K, make_dropout(0.2, 1, 0), xsave}, B, e, M, N, K, st);
   });
 }
 template <int WM, int WN, int TM, int TN, int DEEP>
@@ -158,6 +167,12 @@ int main(int argc, char** argv) {
     DMA("64x224 4w S=2   ", 2, 2, 2, 7, 2)
     DMA("128x112 4w S=2  ", 2, 2, 4, 7 / 2, 2)
     DMA("128x224 8w S=2  ", 4, 2, 2, 7, 2)
+    if (K <= 320) {
+#define AST(tag, ...) cases.push_back({std::string(sh.n) + " astat " tag, fl, [=](float* c, float* x, hipStream_t s) { return run_astat<__VA_ARGS__>(kind, N, K, c, x, s); }, kind, N, K});
+      AST("96x160 6w       ", 3, 2, 2, 5, 10)
+      AST("64x160 4w       ", 2, 2, 2, 5, 10)
+      AST("96x160 6w (6x1) ", 6, 1, 1, 10, 10)
+    }
     DMA("256x320 8w S=2 jc2", 4, 2, 4, 10, 2, 0, 0, 2)
     DMA("256x320 8w S=2 jc5", 4, 2, 4, 10, 2, 0, 0, 5)
     DMA("128x320 8w S=2 jc5", 2, 4, 4, 5, 2, 0, 0, 5)
