@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 2
+#define NRL_ABI_VERSION 3
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -272,9 +272,13 @@ int nrl_gru_bwd(const NrlGruParams* p, const NrlGruGrads* g, const float* hist,
 /* nn.Embedding lookup alone (bit-exact), text.py:224. */
 int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,
                          float* out, void* stream);
-/* C(M,N) = A(M,K) * W(N,K)^T + bias  (nn.Linear), exact-fp32 MFMA. */
+/* C(M,N) = A(M,K) * W(N,K)^T + bias  (nn.Linear) through the selected GEMM engine -- the same code path
+ * (tile choice, LDS-DMA staging) the encoders' forward projections take.  The bf16x3 engine needs
+ * nrl_linear_workspace_bytes(n, k) of workspace for the split weight planes; ws == NULL forces the exact
+ * fp32 engine. */
+size_t nrl_linear_workspace_bytes(int32_t n, int32_t k);
 int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n,
-                   int32_t k, float* c, void* stream);
+                   int32_t k, float* c, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

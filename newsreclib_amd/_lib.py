@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -103,7 +103,9 @@ SIGNATURES = {
     "nrl_gru_bwd": (c_int32, [POINTER(NrlGruParams), POINTER(NrlGruGrads), c_void_p, c_void_p, c_void_p, c_int64,
                               c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_embedding_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
-    "nrl_linear_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "nrl_linear_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "nrl_linear_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                 c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -538,13 +538,26 @@ int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, 
   return embedding_gather(table, ids, n_ids, dim, out, (hipStream_t)stream);
 }
 
+size_t nrl_linear_workspace_bytes(int32_t n, int32_t k) {
+  return align_up(split_weight_elems(n, k) * sizeof(uint16_t), 256);
+}
+
 int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k,
-                   float* c, void* stream) {
+                   float* c, void* ws, size_t ws_bytes, void* stream) {
   NRL_REQUIRE(a && w && c && m >= 0 && n > 0 && k > 0 && k % 4 == 0, "linear_fwd: bad arguments (k % 4 == 0)");
   NRL_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0, "linear_fwd: operands must be 16-byte aligned");
-  return launch_gemm<NRL_TILE>(KCPlain{a, k, m}, KCPlain{w, k, n},
-                               EpiLinear{c, n, bias, 0, make_dropout(0.0, 0, 0), n}, m, n, k, 1,
-                               (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  const EpiLinear epi{c, n, bias, 0, make_dropout(0.0, 0, 0), n};
+  if (ws == nullptr || g_engine != ENGINE_BF16X3)
+    return launch_gemm<NRL_TILE>(KCPlain{a, k, m}, KCPlain{w, k, n}, epi, m, n, k, 1, st);
+  NRL_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+  if (ws_bytes < nrl_linear_workspace_bytes(n, k)) {
+    set_error("workspace too small: %zu < %zu bytes", ws_bytes, nrl_linear_workspace_bytes(n, k));
+    return NRL_E_WORKSPACE;
+  }
+  SplitWeight sw;
+  NRL_TRY(split_weight(w, n, k, (uint16_t*)ws, &sw, st));
+  return gemm_fwd(KCPlain{a, k, m}, w, sw, epi, m, n, k, n <= 224, st);
 }
 
 }  // extern "C"

@@ -272,8 +272,9 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     N = w.shape[0]
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     b = _chk(bias, torch.float32, "bias").data_ptr() if bias is not None else None
-    _lib.check(lib.nrl_linear_fwd(a.data_ptr(), w.data_ptr(), b, M, N, K, c.data_ptr(), _stream()),
-               "nrl_linear_fwd")
+    ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=a.device)
+    _lib.check(lib.nrl_linear_fwd(a.data_ptr(), w.data_ptr(), b, M, N, K, c.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  _stream()), "nrl_linear_fwd")
     return c
 
 

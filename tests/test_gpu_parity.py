@@ -55,8 +55,9 @@ def test_embedding_gather_bit_exact():
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (1, 16, 4), (257, 900, 300), (1000, 300, 300),
-                                   (333, 200, 300), (64, 300, 900), (5000, 912, 304)])
-def test_linear_fwd_matches_fp32_reference(M, N, K):
+                                   (333, 200, 300), (64, 300, 900), (5000, 912, 304), (129, 161, 36),
+                                   (2049, 224, 200), (127, 8, 700), (40000, 300, 2100)])
+def test_linear_fwd_matches_fp32_reference(M, N, K, engine):
     from newsreclib_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)
     a = torch.randn(M, K, generator=g)
@@ -67,8 +68,9 @@ def test_linear_fwd_matches_fp32_reference(M, N, K):
     got = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV)).cpu()
     err = float((got.double() - ref).abs().max())
     scale = float(ref.abs().max())
-    print(f"linear {M}x{N}x{K}: max abs err {err:.3e} (|ref| max {scale:.1f})")
-    assert err <= 2e-5 * max(1.0, scale)
+    print(f"linear {M}x{N}x{K} [{engine}]: max abs err {err:.3e} (|ref| max {scale:.1f})")
+    # bf16x3: every product carries ~2^-16 relative error (the dropped lo*lo term and the lo roundings)
+    assert err <= (2e-5 if engine == "f32" else 1e-4) * max(1.0, scale)
 
 
 def _news_params(vocab=64, seed=1):

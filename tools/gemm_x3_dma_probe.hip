@@ -173,6 +173,10 @@ int main(int argc, char** argv) {
       AST("64x160 4w       ", 2, 2, 2, 5, 10)
       AST("96x160 6w (6x1) ", 6, 1, 1, 10, 10)
     }
+    DMA("192x160 12w S=2 ", 6, 2, 2, 5, 2)
+    DMA("256x160 16w S=2 ", 8, 2, 2, 5, 2)
+    DMA("128x320 16w S=2 ", 4, 4, 2, 5, 2)
+    DMA("192x160 12w S=3 ", 6, 2, 2, 5, 3)
     DMA("256x320 8w S=2 jc2", 4, 2, 4, 10, 2, 0, 0, 2)
     DMA("256x320 8w S=2 jc5", 4, 2, 4, 10, 2, 0, 0, 5)
     DMA("128x320 8w S=2 jc5", 2, 4, 4, 5, 2, 0, 0, 5)
