@@ -70,7 +70,7 @@ struct RCWindow {
       v = (ones && r == rows) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
       return;
     }
-    const int l = (int)(k % L) + (int)(r / inner) - pad;
+    const int l = (int)((uint32_t)k % (uint32_t)L) + (int)((uint32_t)r / (uint32_t)inner) - pad;  // k, r < 2^32
     if (l < 0 || l >= L) v = f4zero();
   }
   __device__ __forceinline__ const float* src(int64_t k, int64_t r, int64_t kend) const {
