@@ -397,21 +397,34 @@ int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* ls
 // =============================================================================================
 // additive-attention pooling
 // =============================================================================================
+// One workgroup (4 waves) per group of S rows.  All global traffic is float4: a row of t (Q floats) or y
+// (D floats) is one coalesced wave access, and the column passes split the 256 threads into
+// RG = 256 / (D/4) row-groups x (D/4) float4 columns (D = 300: 3 x 75) whose partial sums meet in LDS.
+__device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
+  acc = fmaf(a.x, b.x, acc);
+  acc = fmaf(a.y, b.y, acc);
+  acc = fmaf(a.z, b.z, acc);
+  return fmaf(a.w, b.w, acc);
+}
+
 __global__ void __launch_bounds__(256)
     pool_fwd_kernel(const float* __restrict__ t, const float* __restrict__ q_a,
                     const float* __restrict__ y, int S, int Q, int D, float* __restrict__ w,
                     float* __restrict__ out) {
-  extern __shared__ float sm[];  // a[S] then w[S]
+  extern __shared__ float sm[];  // a[S] -> w[S]
+  __shared__ float4 part[256];
   float* a_s = sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g = blockIdx.x;
   const int64_t row0 = g * S;
+  const int Q4 = Q >> 2, D4 = D >> 2;
+  const float4* q4 = reinterpret_cast<const float4*>(q_a);
   for (int l = wave; l < S; l += 4) {
-    const float* tr = t + (row0 + l) * Q;
-    float part = 0.f;
-    for (int n = lane; n < Q; n += 64) part = fmaf(tr[n], q_a[n], part);
-    part = wave_sum(part);
-    if (lane == 0) a_s[l] = part;
+    const float4* tr = reinterpret_cast<const float4*>(t + (row0 + l) * Q);
+    float acc = 0.f;
+    for (int n = lane; n < Q4; n += 64) acc = dot4(tr[n], q4[n], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) a_s[l] = acc;
   }
   __syncthreads();
   if (wave == 0) {
@@ -429,49 +442,119 @@ __global__ void __launch_bounds__(256)
     }
   }
   __syncthreads();
-  for (int d = tid; d < D; d += 256) {
-    float acc = 0.f;
-    for (int l = 0; l < S; ++l) acc = fmaf(a_s[l], y[(row0 + l) * D + d], acc);
-    out[g * D + d] = acc;
+  // out[d] = sum_l w_l y[l][d]
+  const int cpp = D4 < 256 ? D4 : 256;           // float4 columns per pass
+  const int RG = 256 / cpp, rg = tid / cpp, cc = tid - rg * cpp;
+  const float4* y4 = reinterpret_cast<const float4*>(y + row0 * D);
+  float4* o4 = reinterpret_cast<float4*>(out + g * D);
+  for (int c4 = cc; c4 < D4; c4 += cpp) {        // one iteration unless D > 1024
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rg < RG) {
+      for (int l = rg; l < S; l += RG) {
+        const float wl = a_s[l];
+        const float4 v = y4[(int64_t)l * D4 + c4];
+        acc.x = fmaf(wl, v.x, acc.x); acc.y = fmaf(wl, v.y, acc.y);
+        acc.z = fmaf(wl, v.z, acc.z); acc.w = fmaf(wl, v.w, acc.w);
+      }
+    }
+    if (RG == 1) {
+      o4[c4] = acc;
+    } else {
+      part[tid] = acc;
+      __syncthreads();
+      if (rg == 0) {
+        for (int r = 1; r < RG; ++r) {
+          const float4 p = part[r * cpp + cc];
+          acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        o4[c4] = acc;
+      }
+      __syncthreads();
+    }
   }
 }
 
 __global__ void __launch_bounds__(256)
     pool_bwd_pre_kernel(const float* __restrict__ d_out, const float* __restrict__ y,
                         const float* __restrict__ w, float* __restrict__ t_dpre,
-                        const float* __restrict__ q_a, float* __restrict__ dq_a, int S, int Q, int D) {
+                        const float* __restrict__ q_a, float* __restrict__ dq_a, int64_t groups, int S, int Q,
+                        int D) {
   extern __shared__ float sm[];  // c[S] -> da[S]
+  __shared__ float4 part[256];
   float* c_s = sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t g = blockIdx.x;
-  const int64_t row0 = g * S;
-  const float* dr = d_out + g * D;
-  for (int l = wave; l < S; l += 4) {
-    const float* yr = y + (row0 + l) * D;
-    float part = 0.f;
-    for (int d = lane; d < D; d += 64) part = fmaf(dr[d], yr[d], part);
-    part = wave_sum(part);
-    if (lane == 0) c_s[l] = part;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float dbar = 0.f;
-    for (int l = lane; l < S; l += 64) dbar = fmaf(w[row0 + l], c_s[l], dbar);
-    dbar = wave_sum(dbar);
-    for (int l = lane; l < S; l += 64) c_s[l] = w[row0 + l] * (c_s[l] - dbar);  // da_l
-  }
-  __syncthreads();
-  for (int n = tid; n < Q; n += 256) {
-    const float qn = q_a[n];
-    float accq = 0.f;
-    for (int l = 0; l < S; ++l) {
-      const int64_t idx = (row0 + l) * Q + n;
-      const float tv = t_dpre[idx];
-      const float da = c_s[l];
-      accq = fmaf(da, tv, accq);
-      t_dpre[idx] = da * qn * (1.0f - tv * tv);
+  const int Q4 = Q >> 2, D4 = D >> 2;
+  const int cpp = Q4 < 256 ? Q4 : 256;
+  const int RG = 256 / cpp, rg = tid / cpp, cc = tid - rg * cpp;
+  const float4* q4 = reinterpret_cast<const float4*>(q_a);
+  // dq_a partial sums live in registers across ALL groups of this workgroup (persistent over groups) and
+  // are flushed with one coalesced atomic per element at the end: the query gradient is a reduction over
+  // every row of the batch onto Q addresses, and atomics are served per (instruction, cache line)
+  float4 accq[4];                                 // Q4 <= 4 * 256
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int64_t row0 = g * S;
+    const float4* dr = reinterpret_cast<const float4*>(d_out + g * D);
+    for (int l = wave; l < S; l += 4) {
+      const float4* yr = reinterpret_cast<const float4*>(y + (row0 + l) * D);
+      float acc = 0.f;
+      for (int d = lane; d < D4; d += 64) acc = dot4(dr[d], yr[d], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) c_s[l] = acc;
     }
-    atomicAdd(dq_a + n, accq);
+    __syncthreads();
+    if (wave == 0) {
+      float dbar = 0.f;
+      for (int l = lane; l < S; l += 64) dbar = fmaf(w[row0 + l], c_s[l], dbar);
+      dbar = wave_sum(dbar);
+      for (int l = lane; l < S; l += 64) c_s[l] = w[row0 + l] * (c_s[l] - dbar);  // da_l
+    }
+    __syncthreads();
+    // t -> d_pre = da * q * (1 - t^2) in place; dq_a[n] += sum_l da_l t[l][n]
+    float4* t4 = reinterpret_cast<float4*>(t_dpre + row0 * Q);
+    if (rg < RG) {
+      int it = 0;
+      for (int c4 = cc; c4 < Q4; c4 += cpp, ++it) {
+        const float4 qn = q4[c4];
+        float4 acc = accq[it & 3];
+        for (int l = rg; l < S; l += RG) {
+          const float da = c_s[l];
+          const float4 tv = t4[(int64_t)l * Q4 + c4];
+          acc.x = fmaf(da, tv.x, acc.x); acc.y = fmaf(da, tv.y, acc.y);
+          acc.z = fmaf(da, tv.z, acc.z); acc.w = fmaf(da, tv.w, acc.w);
+          t4[(int64_t)l * Q4 + c4] = make_float4(da * qn.x * (1.0f - tv.x * tv.x), da * qn.y * (1.0f - tv.y * tv.y),
+                                                 da * qn.z * (1.0f - tv.z * tv.z), da * qn.w * (1.0f - tv.w * tv.w));
+        }
+        accq[it & 3] = acc;
+      }
+    }
+    __syncthreads();                              // c_s is rewritten by the next group
+  }
+  // flush: row-groups meet in LDS, then Q contiguous atomics
+  int it = 0;
+  for (int c4 = cc; c4 < Q4; c4 += cpp, ++it) {
+    float4 acc = accq[it & 3];
+    if (RG > 1) {
+      part[tid] = rg < RG ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+      if (rg == 0)
+        for (int r = 1; r < RG; ++r) {
+          const float4 p = part[r * cpp + cc];
+          acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+      __syncthreads();
+      if (rg == 0) part[cc] = acc;
+      __syncthreads();
+      const float* pf = reinterpret_cast<const float*>(part);
+      if (tid < 4 * cpp) atomicAdd(dq_a + 4 * (c4 - cc) + tid, pf[tid]);
+      __syncthreads();
+    } else {
+      atomicAdd(dq_a + 4 * c4 + 0, acc.x);
+      atomicAdd(dq_a + 4 * c4 + 1, acc.y);
+      atomicAdd(dq_a + 4 * c4 + 2, acc.z);
+      atomicAdd(dq_a + 4 * c4 + 3, acc.w);
+    }
   }
 }
 
@@ -479,6 +562,7 @@ int pool_fwd(const float* t, const float* q_a, const float* y, int64_t groups, i
              float* w, float* out, hipStream_t stream) {
   if (groups == 0) return NRL_OK;
   NRL_REQUIRE(S > 0 && S <= 8192 && groups < (1LL << 31), "pool_fwd: bad shape");
+  NRL_REQUIRE(Q % 4 == 0 && D % 4 == 0, "pool_fwd: Q and D must be multiples of 4");
   hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)groups), dim3(256), S * sizeof(float), stream, t,
                      q_a, y, S, Q, D, w, out);
   NRL_LAUNCH_CHECK();
@@ -489,8 +573,11 @@ int pool_bwd_pre(const float* d_out, const float* y, const float* w, float* t_dp
                  float* dq_a, int64_t groups, int S, int Q, int D, hipStream_t stream) {
   if (groups == 0) return NRL_OK;
   NRL_REQUIRE(S > 0 && S <= 8192 && groups < (1LL << 31), "pool_bwd_pre: bad shape");
-  hipLaunchKernelGGL(pool_bwd_pre_kernel, dim3((unsigned)groups), dim3(256), S * sizeof(float), stream,
-                     d_out, y, w, t_dpre, q_a, dq_a, S, Q, D);
+  NRL_REQUIRE(Q % 4 == 0 && D % 4 == 0, "pool_bwd_pre: Q and D must be multiples of 4");
+  NRL_REQUIRE(Q <= 4096, "pool_bwd_pre: query_dim > 4096 unsupported");
+  const unsigned grid = (unsigned)(groups < 2048 ? groups : 2048);  // 8 workgroups per CU, persistent over groups
+  hipLaunchKernelGGL(pool_bwd_pre_kernel, dim3(grid), dim3(256), S * sizeof(float), stream, d_out, y, w, t_dpre,
+                     q_a, dq_a, groups, S, Q, D);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
