@@ -11,7 +11,7 @@ import torch
 
 from ._lightning import LightningModuleBase
 from .dense_batch import to_dense_batch
-from .metrics import ranking_metrics
+from .metrics import aspect_metrics, ranking_metrics
 
 
 class AbstractRecommender(LightningModuleBase):
@@ -87,6 +87,17 @@ class AbstractRecommender(LightningModuleBase):
             m = ranking_metrics(torch.cat(outputs["preds"]), torch.cat(outputs["targets"]),
                                 torch.cat(outputs["cand_news_size"]), self.hparams.top_k_list)
             logs.update({f"{stage}/{k}": v for k, v in m.items()})
+            # test stage: aspect-based diversity / personalization of the recommendations
+            # (nrms_module.py:475-493: categories and sentiments of candidates vs clicked history)
+            for asp, ncls in (("categories", getattr(self, "num_categ_classes", None)),
+                              ("sentiments", getattr(self, "num_sent_classes", None))):
+                tk, hk = f"target_{asp}", f"hist_{asp}"
+                if ncls and outputs.get(tk) and outputs.get(hk) and outputs.get("hist_news_size") \
+                        and all(t.numel() for t in outputs[tk]) and all(t.numel() for t in outputs[hk]):
+                    a = aspect_metrics(torch.cat(outputs["preds"]), torch.cat(outputs[tk]), torch.cat(outputs[hk]),
+                                       torch.cat(outputs["cand_news_size"]), torch.cat(outputs["hist_news_size"]),
+                                       ncls, self.hparams.top_k_list, prefix="categ" if asp == "categories" else "sent")
+                    logs.update({f"{stage}/{k}": v for k, v in a.items()})
         for v in outputs.values():
             v.clear()
         self._loss_sums[stage] = [0.0, 0]

@@ -109,9 +109,15 @@ class LSTURModule(AbstractRecommender):
         if self.training and seed is None:
             seed = _draw_seed()                       # one draw per step; streams separate the dropouts
         news_vector = self.news_encoder(batch["x_all"], seed=seed)
-        hist_news_vector_agg, _ = to_dense_batch(news_vector[:n_hist], batch["batch_hist"], B,
+        return self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch, seed=seed)
+
+    def score_news_vectors(self, hist_news_vector: torch.Tensor, cand_news_vector: torch.Tensor, batch: Dict,
+                           seed: Optional[int] = None) -> torch.Tensor:
+        """lstur_module.py:280-303 from already-encoded news rows (see ``evaluation.NewsVectorCache``)."""
+        B = batch["batch_size"]
+        hist_news_vector_agg, _ = to_dense_batch(hist_news_vector, batch["batch_hist"], B,
                                                  batch["max_hist"], batch["hist_offsets"])
-        cand_news_vector_agg, _ = to_dense_batch(news_vector[n_hist:], batch["batch_cand"], B,
+        cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
                                                  batch["max_cand"], batch["cand_offsets"])
         hist_size = batch["hist_sizes"]               # == mask_hist row sums (lstur_module.py:287-290)
         user_vector = self.user_encoder(batch["user_idx"], hist_news_vector_agg, hist_size, seed=seed,

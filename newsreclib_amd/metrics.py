@@ -52,3 +52,48 @@ def ranking_metrics(preds: torch.Tensor, targets: torch.Tensor, cand_news_size: 
     else:
         out["auc"] = 0.0
     return out
+
+
+def aspect_metrics(preds: torch.Tensor, cand_aspects: torch.Tensor, hist_aspects: torch.Tensor,
+                   cand_news_size: torch.Tensor, hist_news_size: torch.Tensor, num_classes: int,
+                   top_k_list: Sequence[int] = (5, 10), prefix: str = "categ") -> Dict[str, float]:
+    """Aspect-based diversity and personalization of the top-k recommendations, mean over impressions --
+    the reference's ``Diversity`` / ``Personalization`` (metrics/diversity.py, metrics/personalization.py,
+    metrics/base.py:137-182 on top of metrics/functional.py:8-127), vectorised over impressions instead of
+    a Python loop per impression:
+
+    * diversity@k: entropy of the aspect distribution of the k highest-scored candidates / log(num_classes)
+      (``functional.py:36-46``: the counts are divided by num_classes and re-normalised by ``Categorical``);
+    * personalization@k: generalised Jaccard sum(min) / sum(max) between the aspect counts of those k
+      candidates and the aspect counts of the clicked history (``functional.py:85-127``);
+    * an impression whose candidate aspects sum to 0 scores 0 (``empty_target_action="neg"``).
+    Flat inputs in impression order (as ``model_step`` returns them) + the per-impression sizes."""
+    dev = preds.device
+    csz, hsz = cand_news_size.to(dev).long(), hist_news_size.to(dev).long()
+    B = csz.numel()
+    C = int(csz.max()) if B else 0
+    cmask = torch.arange(C, device=dev)[None, :] < csz[:, None]
+    p = preds.new_full((B, C), float("-inf")).float()
+    a = torch.zeros((B, C), dtype=torch.long, device=dev)
+    p[cmask], a[cmask] = preds.float(), cand_aspects.to(dev).long()
+    order = torch.argsort(p, dim=1, descending=True, stable=True)
+    a_sorted = torch.gather(a, 1, order)
+    valid_sorted = torch.gather(cmask, 1, order)
+    nonempty = (a * cmask).sum(1) > 0
+    hist_q = torch.repeat_interleave(torch.arange(B, device=dev), hsz)
+    hist_cnt = torch.zeros((B, num_classes), device=dev)
+    hist_cnt.index_put_((hist_q, hist_aspects.to(dev).long()), torch.ones(hist_q.numel(), device=dev), accumulate=True)
+    out = {}
+    log_nc = float(torch.log(torch.tensor(float(num_classes))))
+    for k in top_k_list:
+        take = valid_sorted & (torch.arange(C, device=dev)[None, :] < k)
+        cnt = torch.zeros((B, num_classes), device=dev)
+        cnt.scatter_add_(1, a_sorted, take.float())
+        prob = cnt / cnt.sum(1, keepdim=True).clamp_min(1.0)
+        ent = -(torch.where(prob > 0, prob * torch.log(prob.clamp_min(1e-38)), torch.zeros_like(prob))).sum(1)
+        div = torch.where(nonempty, ent / log_nc, torch.zeros_like(ent))
+        jac = torch.minimum(cnt, hist_cnt).sum(1) / torch.maximum(cnt, hist_cnt).sum(1).clamp_min(1e-38)
+        pers = torch.where(nonempty, jac, torch.zeros_like(jac))
+        out[f"{prefix}_div@{k}"] = float(div.mean()) if B else 0.0
+        out[f"{prefix}_pers@{k}"] = float(pers.mean()) if B else 0.0
+    return out

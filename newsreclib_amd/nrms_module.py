@@ -142,9 +142,16 @@ class NRMSModule(AbstractRecommender):
         n_hist = (hist_text if torch.is_tensor(hist_text) else next(iter(hist_text.values()))).shape[0]
         # one encoder call for history + candidate news (the reference makes two, :232,236)
         news_vector = self.news_encoder(batch["x_all"])
-        hist_news_vector_agg, _ = to_dense_batch(news_vector[:n_hist], batch["batch_hist"], B,
+        return self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch)
+
+    def score_news_vectors(self, hist_news_vector: torch.Tensor, cand_news_vector: torch.Tensor,
+                           batch: Dict) -> torch.Tensor:
+        """nrms_module.py:233-253 from already-encoded news rows (also the entry of the evaluation path that
+        encodes every unique news once, ``evaluation.NewsVectorCache``)."""
+        B = batch["batch_size"]
+        hist_news_vector_agg, _ = to_dense_batch(hist_news_vector, batch["batch_hist"], B,
                                                  batch["max_hist"], batch["hist_offsets"])
-        cand_news_vector_agg, _ = to_dense_batch(news_vector[n_hist:], batch["batch_cand"], B,
+        cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
                                                  batch["max_cand"], batch["cand_offsets"])
         user_vector = self.user_encoder(hist_news_vector_agg)
         scores = self.click_predictor(user_vector.unsqueeze(dim=1), cand_news_vector_agg.permute(0, 2, 1))
