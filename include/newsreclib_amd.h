@@ -149,6 +149,14 @@ int nrl_to_dense_batch_fwd(const float* x, const int64_t* offsets, int64_t batch
 int nrl_to_dense_batch_bwd(const float* d_dense, const int64_t* offsets, int64_t batch,
                            int64_t max_len, int32_t dim, int64_t n_rows, float* d_x, void* stream);
 
+/* ---- late fusion (late_fusion=True): user vector = mean of the clicked-news vectors, nrms_module.py:243-248 /
+ * lstur_module.py:295-296: hist (B, max_len, D) zero-padded dense history, offsets (B+1) as above ->
+ * user[b] = sum_h hist[b, h] / (offsets[b+1] - offsets[b]).  _bwd writes d_hist (B, max_len, D). */
+int nrl_hist_mean_fwd(const float* hist, const int64_t* offsets, int64_t batch, int64_t max_len,
+                      int32_t dim, float* user, void* stream);
+int nrl_hist_mean_bwd(const float* d_user, const int64_t* offsets, int64_t batch, int64_t max_len,
+                      int32_t dim, float* d_hist, void* stream);
+
 /* ---- click predictor: DotProduct.forward, click_predictor.py:9-11 as called at
  * nrms_module.py:251-253: user (B, D), cand (B, C, D) -> scores (B, C) -------------------------- */
 int nrl_dot_scores_fwd(const float* user, const float* cand, int64_t batch, int64_t n_cand,

@@ -79,6 +79,8 @@ SIGNATURES = {
     "nrl_to_dense_batch_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nrl_to_dense_batch_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_void_p,
                                          c_void_p]),
+    "nrl_hist_mean_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
+    "nrl_hist_mean_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nrl_dot_scores_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nrl_dot_scores_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p,
                                      c_void_p, c_void_p]),

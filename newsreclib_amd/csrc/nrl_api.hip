@@ -506,6 +506,18 @@ int nrl_to_dense_batch_bwd(const float* d_dense, const int64_t* offsets, int64_t
   return to_dense_bwd(d_dense, offsets, batch, max_len, dim, n_rows, d_x, (hipStream_t)stream);
 }
 
+int nrl_hist_mean_fwd(const float* hist, const int64_t* offsets, int64_t batch, int64_t max_len, int32_t dim,
+                      float* user, void* stream) {
+  NRL_REQUIRE(hist && offsets && user && batch >= 0 && max_len >= 0 && dim > 0, "hist_mean_fwd: bad arguments");
+  return hist_mean_fwd(hist, offsets, batch, max_len, dim, user, (hipStream_t)stream);
+}
+
+int nrl_hist_mean_bwd(const float* d_user, const int64_t* offsets, int64_t batch, int64_t max_len, int32_t dim,
+                      float* d_hist, void* stream) {
+  NRL_REQUIRE(d_user && offsets && d_hist && batch >= 0 && max_len >= 0 && dim > 0, "hist_mean_bwd: bad arguments");
+  return hist_mean_bwd(d_user, offsets, batch, max_len, dim, d_hist, (hipStream_t)stream);
+}
+
 int nrl_dot_scores_fwd(const float* user, const float* cand, int64_t batch, int64_t n_cand,
                        int32_t dim, float* scores, void* stream) {
   NRL_REQUIRE(user && cand && scores && batch >= 0 && n_cand >= 0 && dim > 0, "dot_scores_fwd: bad arguments");

@@ -39,6 +39,13 @@ int to_dense_fwd(const float* x, const int64_t* offsets, int64_t B, int64_t max_
 int to_dense_bwd(const float* d_dense, const int64_t* offsets, int64_t B, int64_t max_len, int D,
                  int64_t n_rows, float* d_x, hipStream_t stream);
 
+// late fusion (nrms_module.py:243-248): user[b] = sum_h hist[b, h, :] / size[b] over the zero-padded dense
+// history; _bwd: d_hist[b, h, :] = d_user[b, :] / size[b] for every slot h
+int hist_mean_fwd(const float* hist, const int64_t* offsets, int64_t B, int64_t max_len, int D, float* user,
+                  hipStream_t stream);
+int hist_mean_bwd(const float* d_user, const int64_t* offsets, int64_t B, int64_t max_len, int D, float* d_hist,
+                  hipStream_t stream);
+
 int dot_scores_fwd(const float* user, const float* cand, int64_t B, int64_t C, int D, float* scores,
                    hipStream_t stream);
 int dot_scores_bwd(const float* d_scores, const float* user, const float* cand, int64_t B, int64_t C,

@@ -638,6 +638,59 @@ int to_dense_bwd(const float* d_dense, const int64_t* offsets, int64_t B, int64_
 }
 
 // =============================================================================================
+// late fusion: mean of the clicked-news vectors (division by the TRUE history size, sum over all slots)
+// =============================================================================================
+__global__ void hist_mean_fwd_kernel(const float4* __restrict__ hist, const int64_t* __restrict__ offsets,
+                                     int64_t total4, int64_t max_len, int D4, float4* __restrict__ user) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / D4;
+    const int d4 = (int)(i % D4);
+    const float inv = 1.0f / (float)(offsets[b + 1] - offsets[b]);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t h = 0; h < max_len; ++h) {
+      const float4 v = hist[(b * max_len + h) * D4 + d4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    user[i] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
+__global__ void hist_mean_bwd_kernel(const float4* __restrict__ d_user, const int64_t* __restrict__ offsets,
+                                     int64_t total4, int64_t max_len, int D4, float4* __restrict__ d_hist) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % D4);
+    const int64_t b = (i / D4) / max_len;
+    const float inv = 1.0f / (float)(offsets[b + 1] - offsets[b]);
+    const float4 g = d_user[b * D4 + d4];
+    d_hist[i] = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+  }
+}
+
+int hist_mean_fwd(const float* hist, const int64_t* offsets, int64_t B, int64_t max_len, int D, float* user,
+                  hipStream_t stream) {
+  NRL_REQUIRE(D % 4 == 0, "hist_mean: dim must be a multiple of 4");
+  const int64_t total4 = B * (D / 4);
+  if (total4 == 0) return NRL_OK;
+  hipLaunchKernelGGL(hist_mean_fwd_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, stream, (const float4*)hist,
+                     offsets, total4, max_len, D / 4, (float4*)user);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int hist_mean_bwd(const float* d_user, const int64_t* offsets, int64_t B, int64_t max_len, int D, float* d_hist,
+                  hipStream_t stream) {
+  NRL_REQUIRE(D % 4 == 0, "hist_mean: dim must be a multiple of 4");
+  const int64_t total4 = B * max_len * (D / 4);
+  if (total4 == 0) return NRL_OK;
+  hipLaunchKernelGGL(hist_mean_bwd_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, stream, (const float4*)d_user,
+                     offsets, total4, max_len, D / 4, (float4*)d_hist);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =============================================================================================
 // scorer + loss
 // =============================================================================================
 // one wavefront per (b, c): scores[b, c] = <user[b], cand[b, c]>

@@ -13,6 +13,7 @@ from typing import Any, Dict, List, Optional
 
 import torch
 
+from . import ops
 from .abstract_recommender import AbstractRecommender
 from .click_predictor import CrossEntropyLoss, DotProduct
 from .dense_batch import to_dense_batch
@@ -65,8 +66,6 @@ class LSTURModule(AbstractRecommender):
         if dual_loss_training or loss != "cross_entropy_loss":
             raise NotImplementedError("newsreclib_amd.LSTURModule implements loss='cross_entropy_loss' "
                                       "(configs/model/lstur.yaml:6); sup_con / dual loss are out of scope")
-        if late_fusion:
-            raise NotImplementedError("late_fusion=True is not built yet")
         if use_plm:
             raise NotImplementedError("newsreclib_amd.LSTURModule covers use_plm=False (configs/model/lstur.yaml:13)")
         self.criterion = CrossEntropyLoss()
@@ -91,9 +90,10 @@ class LSTURModule(AbstractRecommender):
             else text_embed_dim
         categ_dim = categ_embed_dim * 2 if "category" in attributes2encode and "subcategory" in attributes2encode \
             else categ_embed_dim
-        self.user_encoder = UserEncoder(num_users=self.num_users, input_dim=text_dim + categ_dim,
-                                        user_masking_probability=user_masking_probability,
-                                        long_short_term_method=long_short_term_method)
+        if not late_fusion:                                     # lstur_module.py:213-218
+            self.user_encoder = UserEncoder(num_users=self.num_users, input_dim=text_dim + categ_dim,
+                                            user_masking_probability=user_masking_probability,
+                                            long_short_term_method=long_short_term_method)
         self.click_predictor = DotProduct()
         self._init_step_outputs(outputs)
 
@@ -120,7 +120,10 @@ class LSTURModule(AbstractRecommender):
         cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
                                                  batch["max_cand"], batch["cand_offsets"])
         hist_size = batch["hist_sizes"]               # == mask_hist row sums (lstur_module.py:287-290)
-        user_vector = self.user_encoder(batch["user_idx"], hist_news_vector_agg, hist_size, seed=seed,
-                                        min_hist_size=batch["min_hist"])
+        if not self.hparams.late_fusion:
+            user_vector = self.user_encoder(batch["user_idx"], hist_news_vector_agg, hist_size, seed=seed,
+                                            min_hist_size=batch["min_hist"])
+        else:                                         # lstur_module.py:295-296
+            user_vector = ops.HistMeanFn.apply(hist_news_vector_agg, batch["hist_offsets"])
         scores = self.click_predictor(user_vector.unsqueeze(dim=1), cand_news_vector_agg.permute(0, 2, 1))
         return scores

@@ -100,8 +100,6 @@ class NRMSModule(AbstractRecommender):
         if dual_loss_training or loss != "cross_entropy_loss":
             raise NotImplementedError("newsreclib_amd.NRMSModule implements loss='cross_entropy_loss' "
                                       "(configs/model/nrms.yaml:6); sup_con / dual loss are out of scope")
-        if late_fusion:
-            raise NotImplementedError("late_fusion=True is not built yet")
         self.criterion = CrossEntropyLoss()
 
         if not use_plm:
@@ -123,7 +121,8 @@ class NRMSModule(AbstractRecommender):
             concatenate_inputs=False, text_encoder=text_encoder, category_encoder=None,
             entity_encoder=None, combine_vectors=False, combine_type=None, input_dim=None,
             query_dim=None, output_dim=None)
-        self.user_encoder = UserEncoder(news_embed_dim=embed_dim, num_heads=num_heads, query_dim=query_dim)
+        if not late_fusion:                                     # nrms_module.py:165-171
+            self.user_encoder = UserEncoder(news_embed_dim=embed_dim, num_heads=num_heads, query_dim=query_dim)
         self.click_predictor = DotProduct()
         self._text_attr = next(iter(self.news_encoder.text_encoders.keys()))
 
@@ -153,6 +152,9 @@ class NRMSModule(AbstractRecommender):
                                                  batch["max_hist"], batch["hist_offsets"])
         cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
                                                  batch["max_cand"], batch["cand_offsets"])
-        user_vector = self.user_encoder(hist_news_vector_agg)
+        if not self.hparams.late_fusion:
+            user_vector = self.user_encoder(hist_news_vector_agg)
+        else:  # aggregate embeddings of clicked news (nrms_module.py:243-248)
+            user_vector = ops.HistMeanFn.apply(hist_news_vector_agg, batch["hist_offsets"])
         scores = self.click_predictor(user_vector.unsqueeze(dim=1), cand_news_vector_agg.permute(0, 2, 1))
         return scores

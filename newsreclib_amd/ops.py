@@ -204,6 +204,35 @@ class ToDenseBatchFn(torch.autograd.Function):
         return d_x, None, None, None
 
 
+class HistMeanFn(torch.autograd.Function):
+    """late fusion (nrms_module.py:243-248): (B, max_len, D) zero-padded history -> (B, D) mean over the TRUE
+    number of clicks."""
+
+    @staticmethod
+    def forward(ctx, hist, offsets):
+        lib = _lib.load()
+        hist = _chk(hist, torch.float32, "hist_news_vector")
+        offsets = _chk(offsets, torch.int64, "offsets")
+        B, H, D = hist.shape
+        user = torch.empty((B, D), dtype=torch.float32, device=hist.device)
+        _lib.check(lib.nrl_hist_mean_fwd(hist.data_ptr(), offsets.data_ptr(), B, H, D, user.data_ptr(), _stream()),
+                   "nrl_hist_mean_fwd")
+        ctx.save_for_backward(offsets)
+        ctx.shape = (B, H, D)
+        return user
+
+    @staticmethod
+    def backward(ctx, d_user):
+        lib = _lib.load()
+        (offsets,) = ctx.saved_tensors
+        B, H, D = ctx.shape
+        d_user = _chk(d_user, torch.float32, "d_user")
+        d_hist = torch.empty((B, H, D), dtype=torch.float32, device=d_user.device)
+        _lib.check(lib.nrl_hist_mean_bwd(d_user.data_ptr(), offsets.data_ptr(), B, H, D, d_hist.data_ptr(), _stream()),
+                   "nrl_hist_mean_bwd")
+        return d_hist, None
+
+
 class DotScoresFn(torch.autograd.Function):
     """``DotProduct.forward`` (click_predictor.py:9-11): user (B, D) x cand (B, C, D) -> (B, C)."""
 

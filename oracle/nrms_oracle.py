@@ -261,7 +261,8 @@ def ce_loss(scores: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
 
 
 def nrms_forward(batch: dict, params: Dict[str, torch.Tensor], num_heads: int = 15,
-                 p_drop: float = 0.0, seed: int = 0, fused_news_call: bool = True) -> dict:
+                 p_drop: float = 0.0, seed: int = 0, fused_news_call: bool = True,
+                 late_fusion: bool = False) -> dict:
     """``NRMSModule.forward`` (``nrms_module.py:230-255``) + the loss line (``:277,287-288``).
 
     batch keys: x_hist["title"] (N_hist, L) int64, batch_hist (N_hist,), x_cand["title"],
@@ -287,7 +288,10 @@ def nrms_forward(batch: dict, params: Dict[str, torch.Tensor], num_heads: int = 
     hist_vec, cand_vec = news[: ids_h.shape[0]], news[ids_h.shape[0]:]
     hist_dense, mask_hist = to_dense_batch(hist_vec, batch["batch_hist"], B)
     cand_dense, mask_cand = to_dense_batch(cand_vec, batch["batch_cand"], B)
-    user = user_encoder_fwd(hist_dense, params, num_heads)
+    if not late_fusion:
+        user = user_encoder_fwd(hist_dense, params, num_heads)
+    else:   # nrms_module.py:243-248: sum over the zero-padded slots / true history size
+        user = hist_dense.sum(dim=1) / mask_hist.sum(dim=1, keepdim=True).to(hist_dense.dtype)
     scores = click_scores(user, cand_dense)
     y_true, _ = to_dense_batch(batch["labels"], batch["batch_cand"], B)
     loss = ce_loss(scores, y_true)

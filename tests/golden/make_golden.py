@@ -102,7 +102,7 @@ def dense_batch_loops(x, batch, B):
     return torch.stack(rows), mask
 
 
-def ref_forward(model, batch, p_drop=0.0, seed=0):
+def ref_forward(model, batch, p_drop=0.0, seed=0, late_fusion=False):
     """nrms_module.py:230-255 + :277,287-288 glued around the imported components."""
     B = batch["batch_size"]
     ids_h, ids_c = batch["x_hist"]["title"], batch["x_cand"]["title"]
@@ -117,7 +117,11 @@ def ref_forward(model, batch, p_drop=0.0, seed=0):
     hist_dense, mask_hist = dense_batch_loops(hist_vec, batch["batch_hist"], B)
     cand_vec = model.news_encoder({"title": ids_c})
     cand_dense, mask_cand = dense_batch_loops(cand_vec, batch["batch_cand"], B)
-    user = model.user_encoder(hist_dense)
+    if not late_fusion:
+        user = model.user_encoder(hist_dense)
+    else:   # nrms_module.py:243-248
+        hist_size = torch.tensor([torch.where(mask_hist[i])[0].shape[0] for i in range(mask_hist.shape[0])])
+        user = torch.div(hist_dense.sum(dim=1), hist_size.unsqueeze(dim=-1))
     scores = model.click_predictor(user.unsqueeze(dim=1), cand_dense.permute(0, 2, 1))
     y_true, _ = dense_batch_loops(batch["labels"], batch["batch_cand"], B)
     loss = model.criterion(scores, y_true)
@@ -151,11 +155,12 @@ def grad_summary(model, full_embedding):
     return out
 
 
-def run_case(name, batch, vocab, param_seed, p_drop=0.0, seed=0, full_embedding=False, extra=None):
+def run_case(name, batch, vocab, param_seed, p_drop=0.0, seed=0, full_embedding=False, extra=None,
+             late_fusion=False):
     params = make_params(vocab, D, Q, seed=param_seed)
     model = RefNRMS(params)
     model.train()                      # dropout handled by injection; nothing else is mode-dependent
-    out = ref_forward(model, batch, p_drop, seed)
+    out = ref_forward(model, batch, p_drop, seed, late_fusion)
     out["loss"].backward()
     arrays = batch_arrays(batch)
     arrays.update(cfg_vocab=np.int64(vocab), cfg_param_seed=np.int64(param_seed),
@@ -299,6 +304,8 @@ def main():
     b32 = make_batch(32, vocab=2000, mode="ragged", seed=21)
     run_case("mind32_eval", b32, vocab=2000, param_seed=2)
     run_case("mind32_train", b32, vocab=2000, param_seed=2, p_drop=0.2, seed=99)
+    run_case("tiny_late_fusion", tiny_batch(), vocab=64, param_seed=1, p_drop=0.2, seed=7, full_embedding=True,
+             late_fusion=True)
     case_quirks()
     case_adam()
     case_plm()

@@ -27,6 +27,9 @@ def check_grads_against_golden(g, grads, rtol=2e-4, atol=2e-5):
     """grads: dict reference-state_dict-key -> tensor.  Compares norms, sums, samples, rows."""
     stride = int(g["cfg_sample_stride"])
     for key in [k[len("gnorm/"):] for k in g if k.startswith("gnorm/")]:
+        if key not in grads:                                 # late fusion: the unused user encoder has no gradient
+            assert float(g["gnorm/" + key]) == 0.0, key
+            continue
         gr = grads[key].detach().cpu().double()
         ref_norm = float(g["gnorm/" + key])
         assert abs(float(gr.norm()) - ref_norm) <= rtol * ref_norm + atol, (key, float(gr.norm()), ref_norm)
@@ -48,7 +51,7 @@ def check_grads_against_golden(g, grads, rtol=2e-4, atol=2e-5):
             assert float((gr[rows] - ref).abs().max()) <= 2e-4 * scale, key
 
 
-def build_module(params, p_drop=0.2, device="cuda", heads=15):
+def build_module(params, p_drop=0.2, device="cuda", heads=15, late_fusion=False):
     """NRMSModule (the product) loaded from a reference-keyed state dict."""
     from functools import partial
 
@@ -61,12 +64,14 @@ def build_module(params, p_drop=0.2, device="cuda", heads=15):
         dataset_attributes=["title", "abstract", "category"], attributes2encode=["title"],
         outputs={"train": ["preds", "targets", "cand_news_size"], "val": ["preds", "targets", "cand_news_size"],
                  "test": ["preds", "targets", "cand_news_size", "hist_news_size", "user_ids"]},
-        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False,
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=late_fusion,
         temperature=None, use_plm=False, pretrained_embeddings_path=None, plm_model=None, frozen_layers=None,
         embed_dim=D, num_heads=heads, query_dim=Q, dropout_probability=float(p_drop), top_k_list=[5, 10],
         num_categ_classes=18, num_sent_classes=3, save_recs=False, recs_fpath=None,
         optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
         pretrained_embeddings=torch.zeros_like(params[EMB_KEY]))
+    if late_fusion:                                         # no user encoder is built (nrms_module.py:165-171)
+        params = {k: v for k, v in params.items() if not k.startswith("user_encoder.")}
     missing = mod.load_state_dict(params, strict=True)      # reference checkpoint keys load as-is
     assert not missing.missing_keys and not missing.unexpected_keys
     return mod.to(device)

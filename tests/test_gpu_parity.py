@@ -552,3 +552,22 @@ def test_c_abi_reports_errors():
         ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
     with pytest.raises(RuntimeError, match="k % 4"):
         ops.linear(torch.zeros(4, 6, device=DEV), torch.zeros(4, 6, device=DEV))
+
+
+def test_late_fusion_matches_reference_golden(engine):
+    """late_fusion=True: no user encoder, user vector = mean of the clicked-news vectors (HIP kernel
+    nrl_hist_mean_fwd/bwd), against the golden made from the reference components."""
+    g = load_golden("tiny_late_fusion")
+    params = O.make_params(int(g["cfg_vocab"]), seed=int(g["cfg_param_seed"]))
+    mod = build_module(params, p_drop=float(g["cfg_p_drop"]), late_fusion=True)
+    assert not hasattr(mod, "user_encoder")
+    mod.train()
+    te = mod.news_encoder.text_encoders["title"]
+    orig = te.forward
+    te.forward = lambda text, seed=None, **kw: orig(text, seed=int(g["cfg_seed"]), **kw)
+    batch = batch_to(golden_batch(g), DEV)
+    loss, preds, *_ = mod.model_step(batch)
+    scale = max(1.0, float(np.abs(g["out_scores"]).max()))
+    assert abs(float(loss) - float(g["out_loss"])) <= 2e-4 * scale
+    loss.backward()
+    check_grads_against_golden(g, module_grads(mod), rtol=5e-4)

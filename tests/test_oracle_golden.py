@@ -29,6 +29,20 @@ def test_forward_and_grads_match_reference(name):
     check_grads_against_golden(g, grads)
 
 
+def test_late_fusion_matches_reference():
+    """late_fusion=True (nrms_module.py:243-248): user = sum of clicked-news vectors / history size."""
+    g = load_golden("tiny_late_fusion")
+    batch = golden_batch(g)
+    params = {k: v.clone().requires_grad_(True) for k, v in O.make_params(int(g["cfg_vocab"]), seed=int(g["cfg_param_seed"])).items()}
+    out = O.nrms_forward(batch, params, p_drop=float(g["cfg_p_drop"]), seed=int(g["cfg_seed"]), late_fusion=True)
+    assert np.abs(out["scores"].detach().numpy() - g["out_scores"]).max() <= 2e-5 * max(1.0, np.abs(g["out_scores"]).max())
+    assert abs(float(out["loss"]) - float(g["out_loss"])) <= 1e-4
+    out["loss"].backward()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+    grads[O.EMB_KEY][0] = 0.0
+    check_grads_against_golden(g, grads)
+
+
 def test_quirks_are_reproduced():
     """Seq-first user attention couples users of a batch; the pad token's row matters."""
     g = load_golden("quirks")
