@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 3
+#define NRL_ABI_VERSION 4
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -275,6 +275,46 @@ int nrl_gru_bwd(const NrlGruParams* p, const NrlGruGrads* g, const float* hist,
                 const int64_t* lengths, const float* h0, int64_t batch, int64_t max_len,
                 const float* d_out, float* d_hist, float* d_h0, void* ws, size_t ws_bytes,
                 void* stream);
+
+/* =================================================================================================
+ * Generic blocks of the sibling recommenders (NAML: news-view combination, user encoder, category encoder).
+ * ================================================================================================= */
+
+/* AdditiveAttention.forward, layers/attention.py:24-42: y (G, S, D) -> out (G, D),
+ *   t = tanh(y W_a^T + b_a); w = softmax_S(t . q_a); out = sum_s w_s y_s   (no mask).
+ * Field <-> state_dict key: att_weight linear.weight (Q, D), att_bias linear.bias (Q), att_query query (Q). */
+typedef struct NrlAddAttParams {
+  const float* att_weight;
+  const float* att_bias;
+  const float* att_query;
+  int32_t dim;       /* D, multiple of 4 */
+  int32_t query_dim; /* Q, multiple of 4 */
+} NrlAddAttParams;
+
+typedef struct NrlAddAttGrads { /* accumulators, kernels ADD */
+  float* att_weight;
+  float* att_bias;
+  float* att_query;
+} NrlAddAttGrads;
+
+size_t nrl_additive_attention_workspace_bytes(int64_t groups, int64_t len, int32_t dim, int32_t query_dim);
+int nrl_additive_attention_fwd(const NrlAddAttParams* p, const float* y, int64_t groups, int64_t len,
+                               int32_t save_for_backward, float* out, void* ws, size_t ws_bytes,
+                               void* stream);
+/* d_out (G, D) -> d_y (G, S, D) overwritten; adds into `g`.  `ws` must be the forward's workspace. */
+int nrl_additive_attention_bwd(const NrlAddAttParams* p, const NrlAddAttGrads* g, const float* y,
+                               int64_t groups, int64_t len, const float* d_out, float* d_y, void* ws,
+                               size_t ws_bytes, void* stream);
+
+/* act(A W^T + bias): nn.Linear followed by an activation (0 none, 1 tanh, 2 relu), e.g. the category
+ * encoder's F.relu(self.linear(x)), category.py:78-80.  a (M, K), w (N, K), c (M, N); N, K multiples of 4.
+ * _bwd: d_c (M, N) -> d_a (M, K) overwritten (may be NULL), d_w / d_bias ADDED; c = the forward output. */
+size_t nrl_linear_act_workspace_bytes(int64_t m, int32_t n, int32_t k);
+int nrl_linear_act_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k,
+                       int32_t act, float* c, void* ws, size_t ws_bytes, void* stream);
+int nrl_linear_act_bwd(const float* a, const float* w, const float* c, const float* d_c, int64_t m,
+                       int32_t n, int32_t k, int32_t act, float* d_a, float* d_w, float* d_bias,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---- building blocks exported for unit parity tests and reuse ------------------------------- */
 /* nn.Embedding lookup alone (bit-exact), text.py:224. */

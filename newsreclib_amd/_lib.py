@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -51,6 +51,15 @@ class NrlGruParams(ctypes.Structure):
 
 class NrlGruGrads(ctypes.Structure):
     _fields_ = [("weight_ih", c_void_p), ("weight_hh", c_void_p), ("bias_ih", c_void_p), ("bias_hh", c_void_p)]
+
+
+class NrlAddAttParams(ctypes.Structure):
+    _fields_ = [("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p),
+                ("dim", c_int32), ("query_dim", c_int32)]
+
+
+class NrlAddAttGrads(ctypes.Structure):
+    _fields_ = [("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/newsreclib_amd.h one to one
@@ -104,6 +113,16 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_gru_bwd": (c_int32, [POINTER(NrlGruParams), POINTER(NrlGruGrads), c_void_p, c_void_p, c_void_p, c_int64,
                               c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nrl_additive_attention_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    "nrl_additive_attention_fwd": (c_int32, [POINTER(NrlAddAttParams), c_void_p, c_int64, c_int64, c_int32, c_void_p,
+                                             c_void_p, c_size_t, c_void_p]),
+    "nrl_additive_attention_bwd": (c_int32, [POINTER(NrlAddAttParams), POINTER(NrlAddAttGrads), c_void_p, c_int64,
+                                             c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nrl_linear_act_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "nrl_linear_act_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    "nrl_linear_act_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_embedding_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "nrl_linear_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "nrl_linear_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,

@@ -575,3 +575,4 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
 }  // extern "C"
 
 #include "nrl_api_lstur.inc"
+#include "nrl_api_blocks.inc"

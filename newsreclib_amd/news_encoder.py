@@ -12,7 +12,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops, ops_lstur
+from . import ops, ops_blocks, ops_lstur
 from .attention import AdditiveAttention
 
 # dropout stream pair of each text attribute (fixed by NAME: the reference iterates its text encoders
@@ -107,9 +107,8 @@ class LinearEncoder(nn.Module):
                  freeze_pretrained_emb: bool, num_categories: int, embed_dim: Optional[int], use_dropout: bool,
                  dropout_probability: Optional[float], linear_transform: bool, output_dim: Optional[int]) -> None:
         super().__init__()
-        if use_dropout or linear_transform:
-            raise NotImplementedError("newsreclib_amd.LinearEncoder covers use_dropout=False, "
-                                      "linear_transform=False (the LSTUR category encoder)")
+        if use_dropout:
+            raise NotImplementedError("newsreclib_amd.LinearEncoder covers use_dropout=False (LSTUR, NAML)")
         if from_pretrained:
             assert isinstance(pretrained_embeddings, torch.Tensor)
             self.embedding_layer = nn.Embedding.from_pretrained(
@@ -118,10 +117,17 @@ class LinearEncoder(nn.Module):
             assert isinstance(embed_dim, int) and embed_dim > 0
             self.embedding_layer = nn.Embedding(num_embeddings=num_categories, embedding_dim=embed_dim, padding_idx=0)
         self.use_dropout, self.linear_transform = use_dropout, linear_transform
+        if self.linear_transform:
+            assert isinstance(output_dim, int)
+            self.linear = nn.Linear(in_features=self.embedding_layer.weight.shape[1], out_features=output_dim)
 
     def forward(self, category: torch.Tensor) -> torch.Tensor:
         w = self.embedding_layer.weight
-        return ops_lstur.EmbeddingRowsFn.apply(category, w, 0.0, 0, 0, _grad_bufs((w,)))
+        vec = ops_lstur.EmbeddingRowsFn.apply(category, w, 0.0, 0, 0, _grad_bufs((w,)))
+        if self.linear_transform:                                   # F.relu(self.linear(x)), category.py:78-80
+            lp = (self.linear.weight, self.linear.bias)
+            vec = ops_blocks.LinearActFn.apply(vec, *lp, "relu", _grad_bufs(lp))
+        return vec
 
 
 class PLM(nn.Module):
@@ -174,10 +180,11 @@ class PLM(nn.Module):
 class NewsEncoder(nn.Module):
     """Dispatches news attributes to their encoders and combines the vectors (news.py:134-183).
 
-    Built configurations: NRMS (one text attribute -> that encoder's output unchanged, news.py:159-160)
-    and LSTUR (ONE text encoder registered under every text attribute, a category encoder,
-    ``combine_type="concat"``, news.py:69-79,128,181).  Entity encoders and the ``add_att`` / ``linear``
-    combine layers belong to recommenders that are out of this build's scope (they raise).
+    Built configurations: NRMS (one text attribute -> that encoder's output unchanged, news.py:159-160),
+    LSTUR (ONE text encoder registered under every text attribute, a category encoder,
+    ``combine_type="concat"``, news.py:69-79,128,181) and NAML (``combine_type="add_att"``: additive
+    attention over the stacked view vectors, news.py:118-121,164-165).  Entity encoders and the ``linear``
+    combine layer belong to recommenders that are out of this build's scope (they raise).
 
     Text-vector order: the reference fills its ``ModuleDict`` from a Python ``set`` (news.py:72-77), so the
     title/abstract order of the concatenation depends on the process's string-hash seed.  Here it is
@@ -194,8 +201,8 @@ class NewsEncoder(nn.Module):
         self.concatenate_inputs = concatenate_inputs
         if entity_encoder is not None:
             raise NotImplementedError("newsreclib_amd.NewsEncoder: entity encoders are not built")
-        if combine_vectors and combine_type != "concat":
-            raise NotImplementedError("newsreclib_amd.NewsEncoder: combine_type must be 'concat' "
+        if combine_vectors and combine_type not in ("concat", "add_att"):
+            raise NotImplementedError("newsreclib_amd.NewsEncoder: combine_type must be 'concat' or 'add_att' "
                                       f"(got {combine_type!r})")
         self.encode_text = self.encode_category = self.encode_entity = False
         if ("title" in attributes2encode) or ("abstract" in attributes2encode):
@@ -219,6 +226,10 @@ class NewsEncoder(nn.Module):
             raise ValueError("several news attributes need combine_vectors=True")
         if combine_vectors:
             self.combine_type = combine_type
+            if combine_type == "add_att":                           # news.py:118-121
+                assert isinstance(input_dim, int) and input_dim > 0
+                assert isinstance(query_dim, int) and query_dim > 0
+                self.combine_layer = AdditiveAttention(input_dim=input_dim, query_dim=query_dim)
 
     def set_text_order(self, order) -> None:
         """Re-register the text encoders in the given attribute order (state_dict keys are unchanged)."""
@@ -241,4 +252,6 @@ class NewsEncoder(nn.Module):
             vectors += [encoder(news[name]) for name, encoder in self.category_encoders.items()]
         if len(vectors) == 1:
             return vectors[0]
+        if self.combine_type == "add_att":                   # news.py:164-165: attention over the stacked views
+            return self.combine_layer(torch.stack(vectors, dim=1))
         return torch.cat(vectors, dim=1)                     # news.py:128

@@ -1,0 +1,95 @@
+"""``torch.autograd.Function`` wrappers of the generic blocks of the C ABI (standalone additive attention,
+nn.Linear + activation).  Same conventions as ``ops.py``."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import NrlAddAttGrads, NrlAddAttParams
+from .ops import _chk, _grad_targets, _stream
+
+ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2}
+
+
+class AdditiveAttentionFn(torch.autograd.Function):
+    """``AdditiveAttention.forward`` (reference layers/attention.py:24-42): (G, S, D) -> (G, D)."""
+
+    @staticmethod
+    def forward(ctx, y, w_a, b_a, q_a, grad_bufs):
+        lib = _lib.load()
+        y = _chk(y, torch.float32, "input_vector")
+        params = [_chk(t, torch.float32, n) for t, n in zip((w_a, b_a, q_a), ("linear.weight", "linear.bias", "query"))]
+        if y.dim() != 3:
+            raise ValueError("newsreclib_amd: additive attention expects (groups, length, dim)")
+        G, S, D = y.shape
+        Q = params[0].shape[0]
+        if params[0].shape != (Q, D) or params[1].shape != (Q,) or params[2].shape != (Q,):
+            raise ValueError("newsreclib_amd: inconsistent additive-attention parameter shapes")
+        ap = NrlAddAttParams(*[p.data_ptr() for p in params], D, Q)
+        ws = torch.empty(max(lib.nrl_additive_attention_workspace_bytes(G, S, D, Q), 256), dtype=torch.uint8,
+                         device=y.device)
+        out = torch.empty((G, D), dtype=torch.float32, device=y.device)
+        save = any(ctx.needs_input_grad)
+        _lib.check(lib.nrl_additive_attention_fwd(ctypes.byref(ap), y.data_ptr(), G, S, int(save), out.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), _stream()), "nrl_additive_attention_fwd")
+        if save:
+            ctx.save_for_backward(y, *params)
+            ctx.ws, ctx.grad_bufs = ws, grad_bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        y, *params = ctx.saved_tensors
+        G, S, D = y.shape
+        Q = params[0].shape[0]
+        d_out = _chk(d_out, torch.float32, "d_out")
+        ap = NrlAddAttParams(*[p.data_ptr() for p in params], D, Q)
+        bufs, rets = _grad_targets(params, ctx.grad_bufs)
+        ag = NrlAddAttGrads(*[b.data_ptr() for b in bufs])
+        d_y = torch.empty_like(y)
+        _lib.check(lib.nrl_additive_attention_bwd(ctypes.byref(ap), ctypes.byref(ag), y.data_ptr(), G, S,
+                                                  d_out.data_ptr(), d_y.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(),
+                                                  _stream()), "nrl_additive_attention_bwd")
+        ctx.ws = None
+        return (d_y, *rets, None)
+
+
+class LinearActFn(torch.autograd.Function):
+    """``act(nn.Linear(x))``, act in {none, tanh, relu}: (M, K) -> (M, N)."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, act, grad_bufs):
+        lib = _lib.load()
+        a, w, bias = _chk(a, torch.float32, "input"), _chk(w, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
+        if a.dim() != 2 or w.dim() != 2 or a.shape[1] != w.shape[1] or bias.shape != (w.shape[0],):
+            raise ValueError("newsreclib_amd: inconsistent linear shapes")
+        M, K = a.shape
+        N = w.shape[0]
+        code = ACT[act]
+        ws = torch.empty(max(lib.nrl_linear_act_workspace_bytes(M, N, K), 256), dtype=torch.uint8, device=a.device)
+        c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _lib.check(lib.nrl_linear_act_fwd(a.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, code, c.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _stream()), "nrl_linear_act_fwd")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(a, w, bias, c)
+            ctx.ws, ctx.code, ctx.grad_bufs = ws, code, grad_bufs
+        return c
+
+    @staticmethod
+    def backward(ctx, d_c):
+        lib = _lib.load()
+        a, w, bias, c = ctx.saved_tensors
+        M, K = a.shape
+        N = w.shape[0]
+        d_c = _chk(d_c, torch.float32, "d_out")
+        bufs, rets = _grad_targets([w, bias], ctx.grad_bufs)
+        need_da = ctx.needs_input_grad[0]
+        d_a = torch.empty_like(a) if need_da else None
+        _lib.check(lib.nrl_linear_act_bwd(a.data_ptr(), w.data_ptr(), c.data_ptr(), d_c.data_ptr(), M, N, K, ctx.code,
+                                          d_a.data_ptr() if need_da else None, bufs[0].data_ptr(), bufs[1].data_ptr(),
+                                          ctx.ws.data_ptr(), ctx.ws.numel(), _stream()), "nrl_linear_act_bwd")
+        ctx.ws = None
+        return (d_a, rets[0], rets[1], None, None)

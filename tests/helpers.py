@@ -219,3 +219,44 @@ def build_lstur_module(cfg, params, device="cuda", p_drop=None, p_mask=None):
     assert not res.missing_keys and not res.unexpected_keys
     mod.news_encoder.set_text_order(list(cfg["text_order"]))
     return mod.to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# NAML fixtures
+# ---------------------------------------------------------------------------------------------
+NAML_CASES = ["naml_tiny_eval", "naml_tiny_train", "naml16_train"]
+
+
+def naml_golden_cfg(g):
+    cfg = {k: int(g["cfg_" + k]) for k in ("vocab", "n_categ", "D", "F", "W", "Q", "categ_dim")}
+    cfg.update(text_attrs=tuple(str(a) for a in g["cfg_text_attrs"]), text_order=tuple(str(a) for a in g["cfg_text_order"]),
+               p_drop=float(g["cfg_p_drop"]), seed=int(g["cfg_seed"]), param_seed=int(g["cfg_param_seed"]))
+    return cfg
+
+
+def naml_golden_params(cfg):
+    from oracle.naml_oracle import make_naml_params
+    return make_naml_params(cfg["vocab"], cfg["n_categ"], cfg["D"], cfg["F"], cfg["W"], cfg["Q"], cfg["categ_dim"],
+                            cfg["text_attrs"], seed=cfg["param_seed"])
+
+
+def build_naml_module(cfg, params, device="cuda"):
+    from functools import partial
+
+    from newsreclib_amd.naml_module import NAMLModule
+    from oracle.lstur_oracle import TEXT_PREFIX
+    mod = NAMLModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=list(cfg["text_attrs"]) + ["category"],
+        outputs={"train": ["preds", "targets", "cand_news_size"], "val": ["preds", "targets", "cand_news_size"],
+                 "test": ["preds", "targets", "cand_news_size", "hist_news_size", "user_ids"]},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False, temperature=None,
+        use_plm=False, pretrained_embeddings_path=None, plm_model=None, frozen_layers=None, text_embed_dim=cfg["D"],
+        num_heads=15, num_filters=cfg["F"], window_size=cfg["W"], query_dim=cfg["Q"], categ_embed_dim=cfg["categ_dim"],
+        dropout_probability=float(cfg["p_drop"]) if cfg["p_drop"] > 0 else 0.2, top_k_list=[5, 10],
+        num_categ_classes=cfg["n_categ"] - 1, num_sent_classes=3, save_recs=False, recs_fpath=None,
+        optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
+        pretrained_embeddings=torch.zeros_like(params[TEXT_PREFIX.format(cfg["text_attrs"][0]) + "embedding_layer.weight"]))
+    res = mod.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    mod.news_encoder.set_text_order(list(cfg["text_order"]))
+    return mod.to(device)
