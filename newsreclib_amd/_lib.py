@@ -137,6 +137,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64: it must be the HIP runtime of the process (it owns the device
+    # context, streams and allocator the C ABI is handed), so torch is loaded BEFORE this library binds to one.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension was not built (run `python -m newsreclib_amd._build` "
