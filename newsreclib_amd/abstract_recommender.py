@@ -31,10 +31,13 @@ class AbstractRecommender(LightningModuleBase):
     def model_step(self, batch: Dict) -> Tuple:
         batch = self._prepare(batch)
         B = batch["batch_size"]
-        scores = self.forward(batch)
+        out = self.forward(batch)
+        scores, aux = out if isinstance(out, tuple) else (out, None)
         y_true, _ = to_dense_batch(batch["labels"], batch["batch_cand"], B, batch["max_cand"],
                                    batch["cand_offsets"], batch["cand_flat_idx"])
         loss = self.criterion(scores, y_true.float())
+        if aux is not None:          # recommenders with an auxiliary task (TANR topic prediction)
+            loss = loss + self._aux_loss(batch, aux)
 
         # outputs for metric computation: gathering the valid slots in row-major order == the
         # reference's per-user concatenation (abstract_recommender.py:126-130), no loops, no syncs

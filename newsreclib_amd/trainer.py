@@ -141,6 +141,12 @@ class NRMSTrainer:
         self.module.train()
         loss = self.module.training_step(batch, 0)
         loss.backward()
+        # parameters whose gradient came through ordinary autograd (``.grad``: a transformer body, a small
+        # head fed through torch ops) rather than through a kernel writing ``main_grad``: fold them in
+        for p in self.flat.params:
+            if p.grad is not None:
+                p.main_grad.add_(p.grad)
+                p.grad = None
         scale = self.reduce.finish()
         self.opt.step(grad_scale=scale, zero_grad=True)
         return loss.detach()
