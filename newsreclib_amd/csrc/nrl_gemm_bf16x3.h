@@ -363,21 +363,7 @@ __global__ void __launch_bounds__(WM* WN * 64, OCC)
   else
     k_loop(std::false_type{});
 
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + r;
-      if (m < M) {
-        const typename Epi::Row rs = epi.row(m);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + (wn * TN + j) * 16 + l15;
-          if (n < N) epi(rs, m, n, acc[i][j][r]);
-        }
-      }
-    }
-  }
+  store_accumulators<TM, TN>(epi, acc, m0, n0, wm, wn, l15, g, M, N);
 }
 
 template <int WM, int WN, int TM, int TN, int DEEP = 0, int OCC = 1, class AOp, class BOp, class Epi>
