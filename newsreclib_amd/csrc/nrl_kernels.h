@@ -21,6 +21,10 @@ struct AttnGeom {
 bool attn_head_dim_supported(int dh);
 // o (rows, D); lse (groups, S) may be null in inference
 int attn_fwd(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream);
+// the same forward on the fp32 matrix cores (flash attention, nrl_attn_mfma.hip); attn_fwd routes S >= 64 here
+int attn_fwd_mfma(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream);
+int attn_bwd_mfma(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                  const AttnGeom& G, hipStream_t stream);
 // dqkv (rows, 3D) fully overwritten
 int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
              const AttnGeom& G, hipStream_t stream);

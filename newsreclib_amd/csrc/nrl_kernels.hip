@@ -9,6 +9,7 @@
 //  * pool_*: additive-attention softmax + weighted sum and its backward.
 //  * dense batching, dot-product scorer, probability-target cross entropy, dense Adam.
 #include <math.h>
+#include <stdlib.h>
 
 #include "nrl_kernels.h"
 
@@ -361,6 +362,13 @@ static int check_geom(const AttnGeom& G) {
 int attn_fwd(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream) {
   NRL_TRY(check_geom(G));
   if (G.groups == 0) return NRL_OK;
+  // long sequences (the seq-first attention across users / across the news of a PLM call) are genuinely dense:
+  // matrix cores.  NRL_ATTN_MFMA=0 keeps them on the vector-ALU kernel (A/B measurements).
+  static const bool use_mfma = [] {
+    const char* e = getenv("NRL_ATTN_MFMA");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  if (use_mfma && G.S >= 64) return attn_fwd_mfma(qkv, o, lse, G, stream);
   NRL_DISPATCH_DH(G.dh, {
     if (G.S <= 32) {
       constexpr int GPW = DH <= 32 ? 8 : 4;
@@ -380,6 +388,11 @@ int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* ls
   NRL_TRY(check_geom(G));
   NRL_REQUIRE(lse != nullptr, "attention backward needs the saved log-sum-exp");
   if (G.groups == 0) return NRL_OK;
+  static const bool use_mfma = [] {
+    const char* e = getenv("NRL_ATTN_MFMA");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  if (use_mfma && G.S >= 64) return attn_bwd_mfma(qkv, o, d_o, lse, dqkv, G, stream);
   NRL_DISPATCH_DH(G.dh, {
     if (G.S <= 32) {
       constexpr int GPW = DH <= 32 ? 8 : 4;

@@ -571,3 +571,39 @@ def test_late_fusion_matches_reference_golden(engine):
     assert abs(float(loss) - float(g["out_loss"])) <= 2e-4 * scale
     loss.backward()
     check_grads_against_golden(g, module_grads(mod), rtol=5e-4)
+
+
+@pytest.mark.parametrize("S,H,D,heads", [(64, 2, 60, 3), (100, 3, 96, 2), (129, 1, 64, 4), (300, 2, 128, 2), (77, 2, 64, 1)])
+def test_long_sequence_attention_on_matrix_cores(S, H, D, heads, engine):
+    """S >= 64 routes the attention forward to the fp32-MFMA flash kernel (nrl_attn_mfma.hip): the seq-first
+    block over (S, H, D) against the oracle, every supported head dim (20, 48, 16, 64), tails (S % 64 != 0),
+    and agreement with the vector-ALU kernel's saved statistics through the backward pass."""
+    from newsreclib_amd.user_encoder import UserEncoder
+    rng = np.random.default_rng(S + D)
+    Q = 32
+    t = lambda *s, scale=1.0: torch.from_numpy((rng.standard_normal(s) * scale).astype(np.float32))  # noqa: E731
+    P = O.USER_PREFIX
+    params = {P + "multihead_attention.in_proj_weight": t(3 * D, D, scale=D ** -0.5),
+              P + "multihead_attention.in_proj_bias": t(3 * D, scale=0.05),
+              P + "multihead_attention.out_proj.weight": t(D, D, scale=D ** -0.5),
+              P + "multihead_attention.out_proj.bias": t(D, scale=0.05),
+              P + "additive_attention.linear.weight": t(Q, D, scale=D ** -0.5),
+              P + "additive_attention.linear.bias": t(Q, scale=0.05), P + "additive_attention.query": t(Q, scale=0.1)}
+    hist = t(S, H, D, scale=0.7)
+    enc = UserEncoder(D, heads, Q)
+    enc.load_state_dict({k[len(P):]: v for k, v in params.items()})
+    enc = enc.to(DEV)
+    hg = hist.to(DEV).requires_grad_(True)
+    out = enc(hg)
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    hc = hist.clone().requires_grad_(True)
+    ref = O.user_encoder_fwd(hc, op, heads)
+    tol = 2e-5 if engine == "f32" else 1e-4
+    assert _maxerr(out, ref) <= tol * max(1.0, float(ref.abs().max()))
+    d_out = t(S, D)
+    out.backward(d_out.to(DEV))
+    ref.backward(d_out)
+    assert _maxerr(hg.grad, hc.grad) <= 5e-4 * max(1.0, float(hc.grad.abs().max()))
+    for k, p in enc.named_parameters():
+        rg = op[P + k].grad
+        assert _maxerr(p.grad, rg) <= 5e-4 * max(1.0, float(rg.abs().max())), k
