@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 4
+#define NRL_ABI_VERSION 5
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -129,17 +129,19 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
  * attention runs across the B rows of dim 0 for each slot of dim 1 (SURVEY.md headline fact 3), then
  * additive attention pools over dim 1.  With p_drop > 0 a dropout (stream0) is applied to the input
  * and another (stream0 + 1) between attention and pooling: that is exactly the tail of the PLM text
- * encoder, PLM.forward text.py:92-99, called with hist = last_hidden_state (N_news, L, D). */
+ * encoder, PLM.forward text.py:92-99, called with hist = last_hidden_state (N_news, L, D).
+ * input_dropout = 0 applies only the second one: the long-term branch of the CenNewsRec user encoder
+ * (user/cen_news_rec.py:66-72). */
 size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t embed_dim,
                                         int32_t num_heads, int32_t query_dim);
 int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t batch,
                          int64_t hist_len, double p_drop, uint64_t seed, uint32_t stream0,
-                         int32_t save_for_backward, float* out, void* ws, size_t ws_bytes,
-                         void* stream);
+                         int32_t input_dropout, int32_t save_for_backward, float* out, void* ws,
+                         size_t ws_bytes, void* stream);
 int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
                          int64_t batch, int64_t hist_len, double p_drop, uint64_t seed,
-                         uint32_t stream0, const float* d_out, float* d_hist, void* ws,
-                         size_t ws_bytes, void* stream);
+                         uint32_t stream0, int32_t input_dropout, const float* d_out, float* d_hist,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---- to_dense_batch (torch_geometric 2.3.0; call sites nrms_module.py:233,237,277-284) ---------
  * x (N, D) + offsets (B+1) int64 (prefix sums of the sorted assignment vector) ->
@@ -227,6 +229,25 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
                         int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed,
                         uint32_t stream0, const float* d_out, void* ws, size_t ws_bytes,
                         void* stream);
+
+/* CNNMHSAAddAtt.forward, text.py:291-309 (CenNewsRec): ids (N, L) -> out (N, F).
+ *   x = dropout(emb[ids]) (stream0); c = dropout(relu(conv1d(x))) (stream0 + 1, padding (W-1)/2);
+ *   self-attention over the L tokens of each news on the F conv features, dropout (stream0 + 2), additive
+ *   attention.  `cp` supplies conv_weight / conv_bias and the dims (its att_* fields are ignored); conv_weight
+ *   in the (F, W*D) layout of NrlCnnParams (k = t*D + d; nn.Conv1d stores (F, D, W): permute on the host);
+ *   `bp` is the attention block on embed_dim = F. */
+size_t nrl_cnn_mhsa_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t embed_dim,
+                                            int32_t num_filters, int32_t window, int32_t num_heads,
+                                            int32_t query_dim);
+int nrl_cnn_mhsa_encoder_fwd(const NrlCnnParams* cp, const NrlBlockParams* bp, const float* emb_table,
+                             int64_t vocab, const int64_t* ids, int64_t n_news, int32_t seq_len,
+                             double p_drop, uint64_t seed, uint32_t stream0, int32_t save_for_backward,
+                             float* out, void* ws, size_t ws_bytes, void* stream);
+int nrl_cnn_mhsa_encoder_bwd(const NrlCnnParams* cp, const NrlCnnGrads* cg, const NrlBlockParams* bp,
+                             const NrlBlockGrads* bg, float* d_emb_table, int64_t vocab,
+                             const int64_t* ids, const int64_t* sorted_positions, int64_t n_news,
+                             int32_t seq_len, double p_drop, uint64_t seed, uint32_t stream0,
+                             const float* d_out, void* ws, size_t ws_bytes, void* stream);
 
 /* nn.Embedding(padding_idx=0) lookup followed by a ROW mask: out[i] = table[ids[i]] * m(i),
  * m(i) in {0, 1/(1-p)} from dropout stream `stream_id` with flat index i (whole rows dropped).

@@ -455,8 +455,8 @@ size_t nrl_user_encoder_workspace_bytes(int64_t batch, int64_t hist_len, int32_t
 }
 
 int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t batch, int64_t hist_len,
-                         double p_drop, uint64_t seed, uint32_t stream0, int32_t save_for_backward,
-                         float* out, void* ws, size_t ws_bytes, void* stream) {
+                         double p_drop, uint64_t seed, uint32_t stream0, int32_t input_dropout,
+                         int32_t save_for_backward, float* out, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   NRL_REQUIRE(hist && out && batch > 0 && hist_len > 0, "user_encoder_fwd: bad arguments");
   NRL_REQUIRE(((uintptr_t)hist & 15) == 0, "hist must be 16-byte aligned");
@@ -465,19 +465,22 @@ int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t bat
   NRL_REQUIRE(p_drop == 0.0 || s.M * s.D < (1LL << 32), "activation too large for the 32-bit dropout index space");
   BlockWs w;
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
-  if (p_drop > 0.0) {
+  const Dropout d2 = make_dropout(p_drop, seed, stream0 + 1);
+  if (p_drop > 0.0 && input_dropout) {
     // seq-first block with dropouts around the attention = the PLM text encoder's tail (text.py:92-96)
-    const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
+    const Dropout d1 = make_dropout(p_drop, seed, stream0);
     return block_fwd(p, KCGather{hist, nullptr, s.M, s.D, d1, save_for_backward ? w.x : nullptr}, s, w, d2,
                      save_for_backward != 0, false, out, (hipStream_t)stream);
   }
-  return block_fwd(p, KCPlain{hist, s.D, s.M}, s, w, make_dropout(0.0, 0, 0), save_for_backward != 0, false, out,
-                   (hipStream_t)stream);
+  // no input dropout: NRMS user encoder (p_drop = 0) / CenNewsRec long-term branch (dropout after the
+  // attention only, user/cen_news_rec.py:66-70)
+  return block_fwd(p, KCPlain{hist, s.D, s.M}, s, w, d2, save_for_backward != 0, false, out, (hipStream_t)stream);
 }
 
 int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
                          int64_t batch, int64_t hist_len, double p_drop, uint64_t seed, uint32_t stream0,
-                         const float* d_out, float* d_hist, void* ws, size_t ws_bytes, void* stream) {
+                         int32_t input_dropout, const float* d_out, float* d_hist, void* ws, size_t ws_bytes,
+                         void* stream) {
   NRL_TRY(check_params(p));
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(hist && d_out && d_hist && batch > 0 && hist_len > 0, "user_encoder_bwd: bad arguments");
@@ -485,13 +488,14 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   const BlockShape s = user_shape(p, batch, hist_len);
   BlockWs w;
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
-  const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
+  const bool in_drop = p_drop > 0.0 && input_dropout;
+  const Dropout d1 = make_dropout(in_drop ? p_drop : 0.0, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
   NRL_TRY(block_planes(p, s, w, false, &bp, st));
   NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st));
   NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{d_hist, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
                      s.D, st));
-  return block_bwd_phase2(g, p_drop > 0.0 ? w.x : hist, s, w, st);
+  return block_bwd_phase2(g, in_drop ? w.x : hist, s, w, st);
 }
 
 int nrl_to_dense_batch_fwd(const float* x, const int64_t* offsets, int64_t batch, int64_t max_len,

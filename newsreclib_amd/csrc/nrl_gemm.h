@@ -152,21 +152,29 @@ struct EpiLinear {
   int act;            // 0 none, 1 tanh, 2 relu
   Dropout drop;
   int n_cols;  // logical row width for the dropout flat index
+  const float* gate_src = nullptr;  // (M, N) saved post-ReLU activation: output zeroed where gate_src <= 0
+                                    // (a dgrad flowing back into a ReLU, CNNMHSAAddAtt text.py:297-299)
   struct Row {
     float* out;
+    const float* gate;
     uint32_t idx0;
   };
-  __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc, (uint32_t)m * (uint32_t)n_cols}; }
+  __device__ __forceinline__ Row row(int64_t m) const {
+    return Row{c + m * ldc, gate_src != nullptr ? gate_src + m * ldc : nullptr, (uint32_t)m * (uint32_t)n_cols};
+  }
   __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
     if (bias != nullptr) v += bias[n];
     if (act == 1) v = tanhf(v);
     if (act == 2) v = fmaxf(v, 0.0f);
     if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n);
+    if (r.gate != nullptr && !(r.gate[n] > 0.0f)) v = 0.0f;
     r.out[n] = v;
   }
   // four consecutive columns n .. n + 3 of one row (n % 4 == 0): one 16-B store, one 16-B bias load
   static constexpr bool kVec4 = true;
-  __device__ __forceinline__ bool vec_ok() const { return (ldc & 3) == 0 && (((uintptr_t)c | (uintptr_t)bias) & 15) == 0; }
+  __device__ __forceinline__ bool vec_ok() const {
+    return (ldc & 3) == 0 && (((uintptr_t)c | (uintptr_t)bias | (uintptr_t)gate_src) & 15) == 0;
+  }
   __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
     if (bias != nullptr) {
       const float4 b = *reinterpret_cast<const float4*>(bias + n);
@@ -177,6 +185,11 @@ struct EpiLinear {
     if (drop.thresh != 0u) {
       const uint32_t idx = r.idx0 + (uint32_t)n;
       v.x *= drop.mult(idx); v.y *= drop.mult(idx + 1); v.z *= drop.mult(idx + 2); v.w *= drop.mult(idx + 3);
+    }
+    if (r.gate != nullptr) {
+      const float4 sv = *reinterpret_cast<const float4*>(r.gate + n);
+      v.x = sv.x > 0.f ? v.x : 0.f; v.y = sv.y > 0.f ? v.y : 0.f;
+      v.z = sv.z > 0.f ? v.z : 0.f; v.w = sv.w > 0.f ? v.w : 0.f;
     }
     *reinterpret_cast<float4*>(r.out + n) = v;
   }

@@ -98,6 +98,46 @@ class CNNAddAtt(nn.Module):
         return ops_lstur.CnnEncoderFn.apply(text, *params, p, seed or 0, stream0, _grad_bufs(params), order)
 
 
+class CNNMHSAAddAtt(nn.Module):
+    """Embedding lookup -> dropout -> Conv1d over tokens -> ReLU -> dropout -> multi-head self-attention over the
+    tokens of each news -> dropout -> additive attention (reference text.py:239-309, CenNewsRec) as one HIP
+    pipeline (``nrl_cnn_mhsa_encoder_fwd``/``_bwd``).  ``cnn`` is an ``nn.Conv1d`` as in the reference (weight
+    (F, D, W)); the kernels take the (F, W, D) order, so the weight is permuted on the way in (1.4 MB, plumbing)
+    and its gradient comes back through the same permutation."""
+
+    def __init__(self, pretrained_embeddings: torch.Tensor, embed_dim: int, num_filters: int, window_size: int,
+                 num_heads: int, query_dim: int, dropout_probability: float) -> None:
+        super().__init__()
+        if not isinstance(dropout_probability, float):
+            raise ValueError(
+                f"Expected keyword argument `dropout_probability` to be a `float` but got {dropout_probability}")
+        if window_size != 3:
+            raise NotImplementedError("the reference hard-codes padding=1 (text.py:283): only window_size=3 keeps the "
+                                      "token count, which the attention block needs")
+        self.embedding_layer = nn.Embedding.from_pretrained(
+            torch.as_tensor(pretrained_embeddings, dtype=torch.float32), freeze=False, padding_idx=0)
+        self.cnn = nn.Conv1d(in_channels=embed_dim, out_channels=num_filters, kernel_size=window_size, padding=1)
+        self.multihead_attention = nn.MultiheadAttention(embed_dim=num_filters, num_heads=num_heads)
+        self.additive_attention = AdditiveAttention(input_dim=num_filters, query_dim=query_dim)
+        self.dropout = nn.Dropout(dropout_probability)
+        self.num_heads = num_heads
+
+    def forward(self, text: torch.Tensor, seed: Optional[int] = None, order: Optional[torch.Tensor] = None,
+                stream0: int = 0) -> torch.Tensor:
+        p = float(self.dropout.p) if self.training else 0.0
+        if p > 0.0 and seed is None:
+            seed = _draw_seed()
+        mha, att = self.multihead_attention, self.additive_attention
+        w_c = self.cnn.weight.permute(0, 2, 1).contiguous().unsqueeze(1)      # (F, D, W) -> (F, 1, W, D)
+        block = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, att.linear.weight,
+                 att.linear.bias, att.query)
+        emb = self.embedding_layer.weight
+        bufs = (getattr(emb, "main_grad", None), None, getattr(self.cnn.bias, "main_grad", None)) + \
+            tuple(getattr(t, "main_grad", None) for t in block)
+        return ops_lstur.CnnMhsaEncoderFn.apply(text, emb, w_c, self.cnn.bias, *block, self.num_heads, p, seed or 0,
+                                                stream0, bufs if any(b is not None for b in bufs) else None, order)
+
+
 class LinearEncoder(nn.Module):
     """Category encoder (reference category.py:9-80) for the configuration the recommenders in scope use
     (LSTUR, lstur_module.py:173-183): a trainable ``nn.Embedding(padding_idx=0)`` lookup, no dropout, no

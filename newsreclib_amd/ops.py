@@ -136,7 +136,8 @@ class UserEncoderFn(torch.autograd.Function):
     """NRMS ``UserEncoder.forward`` (reference user/nrms.py:32-41): hist (B, H, D) -> (B, D)."""
 
     @staticmethod
-    def forward(ctx, hist, w_in, b_in, w_o, b_o, w_a, b_a, q_a, heads, grad_bufs, p_drop=0.0, seed=0):
+    def forward(ctx, hist, w_in, b_in, w_o, b_o, w_a, b_a, q_a, heads, grad_bufs, p_drop=0.0, seed=0,
+                input_dropout=True, stream0=0):
         lib = _lib.load()
         hist = _chk(hist, torch.float32, "hist_news_vector")
         params = [_chk(t, torch.float32, "user encoder parameter") for t in (w_in, b_in, w_o, b_o, w_a, b_a, q_a)]
@@ -150,12 +151,13 @@ class UserEncoderFn(torch.autograd.Function):
         ws_bytes = lib.nrl_user_encoder_workspace_bytes(B, H, D, heads, bp.query_dim)
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=hist.device)
         out = torch.empty((B, D), dtype=torch.float32, device=hist.device)
-        _lib.check(lib.nrl_user_encoder_fwd(ctypes.byref(bp), hist.data_ptr(), B, H, float(p_drop), int(seed), 0,
-                                            int(save), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-                   "nrl_user_encoder_fwd")
+        _lib.check(lib.nrl_user_encoder_fwd(ctypes.byref(bp), hist.data_ptr(), B, H, float(p_drop), int(seed),
+                                            int(stream0), int(bool(input_dropout)), int(save), out.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), _stream()), "nrl_user_encoder_fwd")
         if save:
             ctx.save_for_backward(hist, *params)
-            ctx.ws, ctx.heads, ctx.grad_bufs, ctx.drop = ws, heads, grad_bufs, (float(p_drop), int(seed))
+            ctx.ws, ctx.heads, ctx.grad_bufs = ws, heads, grad_bufs
+            ctx.drop = (float(p_drop), int(seed), int(stream0), int(bool(input_dropout)))
         return out
 
     @staticmethod
@@ -170,10 +172,11 @@ class UserEncoderFn(torch.autograd.Function):
         d_hist = torch.empty_like(hist)
         ws = ctx.ws
         _lib.check(lib.nrl_user_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), hist.data_ptr(), B, H,
-                                            ctx.drop[0], ctx.drop[1], 0, d_out.data_ptr(), d_hist.data_ptr(),
-                                            ws.data_ptr(), ws.numel(), _stream()), "nrl_user_encoder_bwd")
+                                            ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], d_out.data_ptr(),
+                                            d_hist.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "nrl_user_encoder_bwd")
         ctx.ws = None
-        return (d_hist, *rets, None, None, None, None)
+        return (d_hist, *rets, None, None, None, None, None, None)
 
 
 class ToDenseBatchFn(torch.autograd.Function):

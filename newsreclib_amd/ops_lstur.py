@@ -160,3 +160,59 @@ class GruFn(torch.autograd.Function):
                                    _stream()), "nrl_gru_bwd")
         ctx.ws = None
         return (d_hist, None, d_h0, *rets, None)
+
+
+class CnnMhsaEncoderFn(torch.autograd.Function):
+    """``CNNMHSAAddAtt.forward`` (reference text.py:291-309): ids (N, L) -> (N, F).  ``w_c`` in the
+    (F, 1, W, D) layout of ``CnnEncoderFn`` (the module permutes its ``nn.Conv1d`` weight (F, D, W))."""
+
+    @staticmethod
+    def forward(ctx, ids, emb, w_c, b_c, w_in, b_in, w_o, b_o, w_a, b_a, q_a, heads, p_drop, seed, stream0, grad_bufs,
+                order=None):
+        from .ops import _block_grads, _block_params
+        lib = _lib.load()
+        ids = _chk(ids, torch.int64, "ids")
+        params = [_chk(t, torch.float32, "cnn-mhsa encoder parameter") for t in
+                  (emb, w_c, b_c, w_in, b_in, w_o, b_o, w_a, b_a, q_a)]
+        emb, w_c, b_c = params[:3]
+        N, L = ids.shape
+        V, D = emb.shape
+        F_, _, W, _ = w_c.shape
+        bp = _block_params(params[3:], heads)
+        cp = NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), None, None, None, D, F_, W, bp.query_dim)
+        save = any(ctx.needs_input_grad)
+        ws = torch.empty(max(lib.nrl_cnn_mhsa_encoder_workspace_bytes(N, L, D, F_, W, heads, bp.query_dim), 256),
+                         dtype=torch.uint8, device=ids.device)
+        out = torch.empty((N, F_), dtype=torch.float32, device=ids.device)
+        _lib.check(lib.nrl_cnn_mhsa_encoder_fwd(ctypes.byref(cp), ctypes.byref(bp), emb.data_ptr(), V, ids.data_ptr(), N,
+                                                L, float(p_drop), int(seed), int(stream0), int(save), out.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), _stream()), "nrl_cnn_mhsa_encoder_fwd")
+        if save:
+            if order is None:
+                order = torch.argsort(ids.reshape(-1))
+            ctx.save_for_backward(ids, _chk(order, torch.int64, "order"), *params)
+            ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from .ops import _block_grads, _block_params
+        lib = _lib.load()
+        ids, order, *params = ctx.saved_tensors
+        emb, w_c, b_c = params[:3]
+        heads, p_drop, seed, stream0 = ctx.cfg
+        N, L = ids.shape
+        V, D = emb.shape
+        F_, _, W, _ = w_c.shape
+        d_out = _chk(d_out, torch.float32, "d_out")
+        bp = _block_params(params[3:], heads)
+        cp = NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), None, None, None, D, F_, W, bp.query_dim)
+        bufs, rets = _grad_targets(params, ctx.grad_bufs)
+        cg = NrlCnnGrads(bufs[1].data_ptr(), bufs[2].data_ptr(), None, None, None)
+        bg = _block_grads(bufs[3:])
+        _lib.check(lib.nrl_cnn_mhsa_encoder_bwd(ctypes.byref(cp), ctypes.byref(cg), ctypes.byref(bp), ctypes.byref(bg),
+                                                bufs[0].data_ptr(), V, ids.data_ptr(), order.data_ptr(), N, L, p_drop,
+                                                seed, stream0, d_out.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(),
+                                                _stream()), "nrl_cnn_mhsa_encoder_bwd")
+        ctx.ws = None
+        return (None, *rets, None, None, None, None, None, None)

@@ -310,3 +310,52 @@ def build_tanr_module(cfg, params, device="cuda"):
     res = mod.load_state_dict(params, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     return mod.to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# CenNewsRec fixtures
+# ---------------------------------------------------------------------------------------------
+CEN_CASES = ["cen_tiny_eval", "cen_tiny_train", "cen_tiny_late_fusion", "cen16_train"]
+
+
+def cen_golden_cfg(g):
+    cfg = {k: int(g["cfg_" + k]) for k in ("vocab", "D", "F", "W", "Q", "heads", "recent")}
+    cfg.update(p_drop=float(g["cfg_p_drop"]), seed=int(g["cfg_seed"]), param_seed=int(g["cfg_param_seed"]),
+               late_fusion=bool(int(g["cfg_late_fusion"])))
+    return cfg
+
+
+def cen_golden_params(cfg):
+    from oracle.cen_news_rec_oracle import make_cen_news_rec_params
+    return make_cen_news_rec_params(cfg["vocab"], cfg["D"], cfg["F"], cfg["W"], cfg["Q"], cfg["late_fusion"],
+                                    seed=cfg["param_seed"])
+
+
+def cen_golden_batch(g, device="cpu"):
+    t = lambda a: torch.as_tensor(a).to(device)  # noqa: E731
+    return {
+        "x_hist": {"title": t(g["in_title_hist"])}, "x_cand": {"title": t(g["in_title_cand"])},
+        "batch_hist": t(g["in_batch_hist"]), "batch_cand": t(g["in_batch_cand"]), "labels": t(g["in_labels"]),
+        "batch_size": int(g["in_batch_size"]), "user_ids": torch.arange(int(g["in_batch_size"])) + 1,
+    }
+
+
+def build_cen_module(cfg, params, device="cuda"):
+    from functools import partial
+
+    from newsreclib_amd.cen_news_rec_module import CenNewsRecModule
+    from oracle.cen_news_rec_oracle import TEXT
+    mod = CenNewsRecModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=["title"],
+        outputs={"train": ["preds", "targets", "cand_news_size"], "val": ["preds", "targets", "cand_news_size"],
+                 "test": ["preds", "targets", "cand_news_size", "hist_news_size", "user_ids"]},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=cfg["late_fusion"],
+        temperature=None, use_plm=False, pretrained_embeddings_path=None, plm_model=None, frozen_layers=None,
+        embed_dim=cfg["D"], num_heads=cfg["heads"], num_filters=cfg["F"], window_size=cfg["W"], query_dim=cfg["Q"],
+        dropout_probability=float(cfg["p_drop"]) if cfg["p_drop"] > 0 else 0.2, gru_hidden_dim=cfg["F"],
+        num_recent_news=cfg["recent"], top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3, save_recs=False,
+        recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
+        pretrained_embeddings=torch.zeros_like(params[TEXT + "embedding_layer.weight"]))
+    res = mod.load_state_dict(params, strict=True)          # reference checkpoint keys load as-is
+    assert not res.missing_keys and not res.unexpected_keys
+    return mod.to(device)

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--vocab", type=int, default=70000)
     ap.add_argument("--engine", default="bf16x3")
-    ap.add_argument("--model", default="lstur", choices=["lstur", "naml"])
+    ap.add_argument("--model", default="lstur", choices=["lstur", "naml", "cen"])
     args = ap.parse_args()
     from functools import partial
 
@@ -50,6 +50,17 @@ def main():
             num_filters=400, window_size=3, query_dim=200, categ_embed_dim=100, dropout_probability=0.2,
             top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3, save_recs=False, recs_fpath=None,
             optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None, pretrained_embeddings=emb).cuda()
+    if args.model == "cen":    # configs/model/cen_news_rec.yaml: title only, 400 filters, 20 heads, GRU 400 over 20 recent
+        from newsreclib_amd.cen_news_rec_module import CenNewsRecModule
+        mod = CenNewsRecModule(
+            dataset_attributes=["title", "abstract", "category"], attributes2encode=["title"],
+            outputs={"train": [], "val": [], "test": []}, dual_loss_training=False, dual_loss_coef=None,
+            loss="cross_entropy_loss", late_fusion=False, temperature=None, use_plm=False,
+            pretrained_embeddings_path=None, plm_model=None, frozen_layers=None, embed_dim=300, num_heads=20,
+            num_filters=400, window_size=3, query_dim=200, dropout_probability=0.2, gru_hidden_dim=400,
+            num_recent_news=20, top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3, save_recs=False,
+            recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
+            pretrained_embeddings=emb).cuda()
     trainer = NRMSTrainer(mod, lr=1e-4)
     batch = add_lstur_fields(make_batch(args.batch, vocab=args.vocab, mode="fixed", seed=1, device="cuda"), args.vocab,
                              19, 45215, 50, seed=2)
