@@ -69,7 +69,8 @@ class DeviceNewsTable:
             "user_ids": user_ids.to(dev) if user_ids is not None else ar + 1,
             "batch_size": B,
         }
-        batch["x_cand"]["news_ids"] = cand_idx
+        if "news_ids" not in self.attrs:            # no id column in the table: the row number stands in
+            batch["x_cand"]["news_ids"] = cand_idx
         return batch
 
 

@@ -32,18 +32,22 @@ def prepare_batch(batch: Dict) -> Dict:
     A collate function has these on the host for free (it builds ``batch_hist`` from the per-user
     list lengths, rec_dataset.py:289-293); computing them from the device vectors costs two syncs,
     so do it once per batch, outside the timed step."""
-    if "hist_offsets" in batch:
+    if "cand_flat_idx" in batch:
         return batch
-    B = int(batch["user_idx"].shape[0]) if "user_idx" in batch else int(batch["batch_hist"].max()) + 1
+    B = int(batch["batch_size"]) if "batch_size" in batch else (
+        int(batch["user_idx"].shape[0]) if "user_idx" in batch else int(batch["batch_hist"].max()) + 1)
     out = dict(batch)
     out["batch_size"] = B
     for key in ("hist", "cand"):
+        if key + "_offsets" in batch:       # a loader that knows the row lengths on the host supplies these
+            continue                        # (input_pipeline.build_batch): no device read-back at all
         off = ops.offsets_from_sorted_batch(batch["batch_" + key], B)
         out[key + "_offsets"] = off
         sizes = off[1:] - off[:-1]
         out["max_" + key] = int(sizes.max())
         out[key + "_sizes"] = sizes
-    out["min_hist"] = int(out["hist_sizes"].min())
+    if "min_hist" not in out:
+        out["min_hist"] = int(out["hist_sizes"].min())
     out["cand_flat_idx"] = dense_slot_index(batch["batch_cand"], out["cand_offsets"], out["max_cand"])
     # history + candidate token ids as the single encoder call sees them, and their id-sorted
     # visiting order for the embedding gradient (pure index bookkeeping, like the offsets above)
