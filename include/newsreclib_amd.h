@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 5
+#define NRL_ABI_VERSION 6
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -336,6 +336,36 @@ int nrl_linear_act_fwd(const float* a, const float* w, const float* bias, int64_
 int nrl_linear_act_bwd(const float* a, const float* w, const float* c, const float* d_c, int64_t m,
                        int32_t n, int32_t k, int32_t act, float* d_a, float* d_w, float* d_bias,
                        void* ws, size_t ws_bytes, void* stream);
+
+/* nn.MultiheadAttention(x, x, x) with batch_first=False on its own (no pooling): x (seq, batch, D) -> out
+ * (seq, batch, D), attention over the `seq` axis for every (batch column, head).  Replaces the call at
+ * user/mins.py:55-57 (which feeds (B, H, D), so seq = users, batch = history slots -- the NRMS quirk).
+ * `scale` multiplies q before q k^T; 0 selects torch's 1/sqrt(D / num_heads).  A caller that zero-pads the
+ * heads to a supported head dim (MINS: 50 -> 64) passes the un-padded 1/sqrt(50) here. */
+typedef struct NrlMhaParams {
+  const float* in_proj_weight;  /* (3D, D) rows [q; k; v] */
+  const float* in_proj_bias;    /* (3D) */
+  const float* out_proj_weight; /* (D, D) */
+  const float* out_proj_bias;   /* (D) */
+  int32_t embed_dim;            /* D, multiple of 4; D / num_heads in {16, 20, 32, 48, 64} */
+  int32_t num_heads;
+  float scale;
+  int32_t reserved;
+} NrlMhaParams;
+
+typedef struct NrlMhaGrads {
+  float* in_proj_weight;
+  float* in_proj_bias;
+  float* out_proj_weight;
+  float* out_proj_bias;
+} NrlMhaGrads;
+
+size_t nrl_mha_workspace_bytes(int64_t seq, int64_t batch, int32_t embed_dim, int32_t num_heads);
+int nrl_mha_fwd(const NrlMhaParams* p, const float* x, int64_t seq, int64_t batch, int32_t save_for_backward,
+                float* out, void* ws, size_t ws_bytes, void* stream);
+/* d_out (seq, batch, D) -> d_x overwritten; adds into `g`.  `ws` must be the forward's workspace. */
+int nrl_mha_bwd(const NrlMhaParams* p, const NrlMhaGrads* g, const float* x, int64_t seq, int64_t batch,
+                const float* d_out, float* d_x, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- building blocks exported for unit parity tests and reuse ------------------------------- */
 /* nn.Embedding lookup alone (bit-exact), text.py:224. */

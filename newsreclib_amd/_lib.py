@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -60,6 +60,17 @@ class NrlAddAttParams(ctypes.Structure):
 
 class NrlAddAttGrads(ctypes.Structure):
     _fields_ = [("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p)]
+
+
+class NrlMhaParams(ctypes.Structure):
+    _fields_ = [("in_proj_weight", c_void_p), ("in_proj_bias", c_void_p), ("out_proj_weight", c_void_p),
+                ("out_proj_bias", c_void_p), ("embed_dim", c_int32), ("num_heads", c_int32), ("scale", ctypes.c_float),
+                ("reserved", c_int32)]
+
+
+class NrlMhaGrads(ctypes.Structure):
+    _fields_ = [("in_proj_weight", c_void_p), ("in_proj_bias", c_void_p), ("out_proj_weight", c_void_p),
+                ("out_proj_bias", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/newsreclib_amd.h one to one
@@ -126,6 +137,11 @@ SIGNATURES = {
                                              c_void_p, c_size_t, c_void_p]),
     "nrl_additive_attention_bwd": (c_int32, [POINTER(NrlAddAttParams), POINTER(NrlAddAttGrads), c_void_p, c_int64,
                                              c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nrl_mha_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    "nrl_mha_fwd": (c_int32, [POINTER(NrlMhaParams), c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_size_t,
+                              c_void_p]),
+    "nrl_mha_bwd": (c_int32, [POINTER(NrlMhaParams), POINTER(NrlMhaGrads), c_void_p, c_int64, c_int64, c_void_p,
+                              c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_linear_act_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "nrl_linear_act_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),

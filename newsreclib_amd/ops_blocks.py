@@ -93,3 +93,49 @@ class LinearActFn(torch.autograd.Function):
                                           ctx.ws.data_ptr(), ctx.ws.numel(), _stream()), "nrl_linear_act_bwd")
         ctx.ws = None
         return (d_a, rets[0], rets[1], None, None)
+
+
+class MhaFn(torch.autograd.Function):
+    """``nn.MultiheadAttention(x, x, x)[0]`` with ``batch_first=False``: x (S, Bt, D) -> (S, Bt, D), attention over
+    S.  ``scale`` = the factor applied to q (None: 1/sqrt(D / heads))."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, b_in, w_o, b_o, heads, scale, grad_bufs):
+        from ._lib import NrlMhaParams
+        lib = _lib.load()
+        x = _chk(x, torch.float32, "input")
+        params = [_chk(t, torch.float32, n) for t, n in zip(
+            (w_in, b_in, w_o, b_o), ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias"))]
+        if x.dim() != 3:
+            raise ValueError("newsreclib_amd: multi-head attention expects (seq, batch, dim)")
+        S, Bt, D = x.shape
+        if params[0].shape != (3 * D, D) or params[1].shape != (3 * D,) or params[2].shape != (D, D) or \
+                params[3].shape != (D,):
+            raise ValueError("newsreclib_amd: inconsistent attention parameter shapes")
+        mp = NrlMhaParams(*[p.data_ptr() for p in params], D, int(heads), float(scale or 0.0), 0)
+        ws = torch.empty(max(lib.nrl_mha_workspace_bytes(S, Bt, D, int(heads)), 256), dtype=torch.uint8, device=x.device)
+        out = torch.empty_like(x)
+        save = any(ctx.needs_input_grad)
+        _lib.check(lib.nrl_mha_fwd(ctypes.byref(mp), x.data_ptr(), S, Bt, int(save), out.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), _stream()), "nrl_mha_fwd")
+        if save:
+            ctx.save_for_backward(x, *params)
+            ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (int(heads), float(scale or 0.0)), grad_bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from ._lib import NrlMhaGrads, NrlMhaParams
+        lib = _lib.load()
+        x, *params = ctx.saved_tensors
+        S, Bt, D = x.shape
+        heads, scale = ctx.cfg
+        d_out = _chk(d_out, torch.float32, "d_out")
+        mp = NrlMhaParams(*[p.data_ptr() for p in params], D, heads, scale, 0)
+        bufs, rets = _grad_targets(params, ctx.grad_bufs)
+        mg = NrlMhaGrads(*[b.data_ptr() for b in bufs])
+        d_x = torch.empty_like(x)
+        _lib.check(lib.nrl_mha_bwd(ctypes.byref(mp), ctypes.byref(mg), x.data_ptr(), S, Bt, d_out.data_ptr(),
+                                   d_x.data_ptr(), ctx.ws.data_ptr(), ctx.ws.numel(), _stream()), "nrl_mha_bwd")
+        ctx.ws = None
+        return (d_x, *rets, None, None, None)

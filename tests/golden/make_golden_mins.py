@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/mins_*.npz by running the REFERENCE's own MINS components (same rules as make_golden.py;
+fixtures hold inputs, seeds and reference outputs only).
+
+Imported from the reference: ``MHSAAddAtt`` (text.py:179-236), ``LinearEncoder`` with ``linear_transform``
+(category.py:9-82), ``NewsEncoder`` with ``combine_type="add_att"`` (news.py:9-183), MINS ``UserEncoder``
+(user/mins.py:9-86), ``DotProduct``.  ``MINSModule`` needs lightning / torch_geometric / torchmetrics, so its
+wiring (mins_module.py:131-198) and forward (:250-279) are restated around the imported components.
+
+Usage:  python tests/golden/make_golden_mins.py   (from the repo root)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from newsreclib.models.components.encoders.news.category import LinearEncoder  # noqa: E402
+from newsreclib.models.components.encoders.news.news import NewsEncoder  # noqa: E402
+from newsreclib.models.components.encoders.news.text import MHSAAddAtt  # noqa: E402
+from newsreclib.models.components.encoders.user.mins import UserEncoder  # noqa: E402
+from newsreclib.models.components.layers.click_predictor import DotProduct  # noqa: E402
+
+from newsreclib_amd.synthetic import add_lstur_fields, batch_from_sizes, make_batch  # noqa: E402
+from oracle.lstur_oracle import TEXT_PREFIX, TEXT_STREAMS, unique_params  # noqa: E402
+from oracle.mins_oracle import make_mins_params  # noqa: E402
+from oracle.nrms_oracle import dropout_multiplier  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SAMPLE_STRIDE = 97
+
+
+class Injected(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.mults, self.k = [], 0
+
+    def arm(self, mults):
+        self.mults, self.k = list(mults), 0
+
+    def forward(self, x):
+        if not self.mults:
+            return x
+        m = self.mults[self.k]
+        self.k += 1
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m
+
+
+class RefMINS(torch.nn.Module):
+    def __init__(self, params, cfg, text_attrs):
+        super().__init__()
+        pre = TEXT_PREFIX.format(text_attrs[0])
+        text_encoder = MHSAAddAtt(pretrained_embeddings=params[pre + "embedding_layer.weight"].numpy(),
+                                  embed_dim=cfg["D"], num_heads=cfg["heads"], query_dim=cfg["Q"],
+                                  dropout_probability=0.2)
+        category_encoder = LinearEncoder(pretrained_embeddings=None, from_pretrained=False, freeze_pretrained_emb=False,
+                                         num_categories=cfg["n_categ"], embed_dim=cfg["categ_dim"], use_dropout=False,
+                                         dropout_probability=None, linear_transform=True, output_dim=cfg["D"])
+        self.news_encoder = NewsEncoder(
+            dataset_attributes=["title", "abstract", "category"], attributes2encode=list(text_attrs) + ["category"],
+            concatenate_inputs=False, text_encoder=text_encoder, category_encoder=category_encoder, entity_encoder=None,
+            combine_vectors=True, combine_type="add_att", input_dim=cfg["D"], query_dim=cfg["Q"], output_dim=None)
+        self.user_encoder = UserEncoder(news_embed_dim=cfg["D"], query_dim=cfg["Q"], num_filters=cfg["D"],
+                                        num_gru_channels=cfg["channels"])
+        self.click_predictor = DotProduct()
+        res = self.load_state_dict(params, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        self.inj = Injected()
+        text_encoder.dropout = self.inj
+        self.criterion = torch.nn.CrossEntropyLoss()
+        self.text_order = list(self.news_encoder.text_encoders.keys())
+
+
+def dense_batch_loops(x, batch, B):
+    counts = [int((batch == b).sum()) for b in range(B)]
+    mx = max(counts)
+    rows, mask, start = [], torch.zeros(B, mx, dtype=torch.bool), 0
+    for b in range(B):
+        r = x.new_zeros((mx,) + tuple(x.shape[1:]))
+        if counts[b]:
+            r[: counts[b]] = x[start:start + counts[b]]
+            mask[b, : counts[b]] = True
+        rows.append(r)
+        start += counts[b]
+    return torch.stack(rows), mask
+
+
+def ref_forward(model, batch, cfg, p_drop, seed):
+    B = batch["batch_size"]
+    order = model.text_order
+    nh, nc = batch["x_hist"][order[0]].shape[0], batch["x_cand"][order[0]].shape[0]
+    if p_drop > 0:
+        mults = []
+        for lo, hi in ((0, nh), (nh, nh + nc)):
+            for a in order:
+                L = batch["x_hist"][a].shape[1]
+                s1, s2 = TEXT_STREAMS[a]
+                mults.append(dropout_multiplier(seed, s1, p_drop, (nh + nc, L, cfg["D"]))[lo:hi])
+                # the second dropout sees (L, N, D) (text.py:229-230)
+                mults.append(dropout_multiplier(seed, s2, p_drop, (nh + nc, L, cfg["D"]))[lo:hi].permute(1, 0, 2))
+        model.inj.arm(mults)
+    else:
+        model.inj.arm([])
+    hist_vec = model.news_encoder(batch["x_hist"])
+    hist_dense, mask_hist = dense_batch_loops(hist_vec, batch["batch_hist"], B)
+    cand_vec = model.news_encoder(batch["x_cand"])
+    cand_dense, _ = dense_batch_loops(cand_vec, batch["batch_cand"], B)
+    hist_size = torch.tensor([torch.where(mask_hist[i])[0].shape[0] for i in range(mask_hist.shape[0])])
+    user = model.user_encoder(hist_dense, hist_size)
+    scores = model.click_predictor(user.unsqueeze(dim=1), cand_dense.permute(0, 2, 1))
+    y_true, _ = dense_batch_loops(batch["labels"], batch["batch_cand"], B)
+    loss = model.criterion(scores, y_true)
+    return dict(hist_vec=hist_vec, cand_vec=cand_vec, user_vec=user, scores=scores, y_true=y_true, loss=loss)
+
+
+def run_case(name, batch, cfg, text_attrs=("title", "abstract"), param_seed=1, p_drop=0.0, seed=0, full_grads=False,
+             row_stride=1):
+    params = make_mins_params(cfg["vocab"], cfg["n_categ"], cfg["D"], cfg["Q"], cfg["categ_dim"], cfg["channels"],
+                              text_attrs, seed=param_seed)
+    model = RefMINS(params, cfg, text_attrs)
+    model.train()
+    out = ref_forward(model, batch, cfg, p_drop, seed)
+    out["loss"].backward()
+    arrays = {"in_batch_hist": batch["batch_hist"].numpy(), "in_batch_cand": batch["batch_cand"].numpy(),
+              "in_labels": batch["labels"].numpy(), "in_batch_size": np.int64(batch["batch_size"]),
+              "in_user_idx": batch["user_idx"].numpy()}
+    for part in ("hist", "cand"):
+        for k, v in batch["x_" + part].items():
+            arrays[f"in_{k}_{part}"] = v.numpy()
+    arrays.update({"cfg_" + k: np.int64(v) for k, v in cfg.items()})
+    arrays.update(cfg_param_seed=np.int64(param_seed), cfg_p_drop=np.float64(p_drop), cfg_seed=np.int64(seed),
+                  cfg_sample_stride=np.int64(SAMPLE_STRIDE), cfg_row_stride=np.int64(row_stride),
+                  cfg_text_attrs=np.array(list(text_attrs)), cfg_text_order=np.array(model.text_order))
+    for k in ("user_vec", "scores", "y_true", "loss"):
+        arrays["out_" + k] = out[k].detach().numpy()
+    for k in ("hist_vec", "cand_vec"):
+        arrays["out_" + k] = out[k].detach().numpy()[::row_stride].copy()
+    sd = model.state_dict(keep_vars=True)
+    for k in unique_params(params):
+        g = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        flat = g.detach().reshape(-1).double()
+        arrays["gnorm/" + k] = np.float64(flat.norm())
+        arrays["gsum/" + k] = np.float64(flat.sum())
+        if full_grads:
+            arrays["gfull/" + k] = g.detach().numpy()
+        elif k.endswith("embedding_layer.weight") and g.shape[0] > 64:
+            rows = torch.nonzero(g.abs().sum(1) > 0).reshape(-1)[:8]
+            arrays["grows_idx/" + k] = rows.numpy()
+            arrays["grows/" + k] = g[rows].detach().numpy()
+        else:
+            arrays["gsample/" + k] = g.detach().reshape(-1)[::SAMPLE_STRIDE].numpy().copy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: order={model.text_order} loss={float(out['loss'].detach()):.6f} "
+          f"scores{tuple(out['scores'].shape)} -> {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# head dims: text 48 / 3 = 16; user 48 / 4 channels = 12 (zero-padded to 16 by the product, GRU width 12)
+SMALL = dict(vocab=64, n_categ=7, D=48, Q=32, categ_dim=16, heads=3, channels=4)
+# the reference configuration: text 300 / 15 = 20; user 300 / 6 channels = 50 (padded to 64, GRU 50 -> 52)
+FULL = dict(vocab=2000, n_categ=19, D=300, Q=200, categ_dim=100, heads=15, channels=6)
+
+
+def tiny_batch(cfg):
+    labels = [0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1]
+    b = batch_from_sizes([1, 4, 2], [5, 10, 5], labels, vocab=cfg["vocab"], seed=11, L=12)
+    return add_lstur_fields(b, cfg["vocab"], cfg["n_categ"], 9, 20, seed=12)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    with torch.backends.mkldnn.flags(enabled=False):
+        run_case("mins_tiny_eval", tiny_batch(SMALL), SMALL, param_seed=1, full_grads=True)
+        run_case("mins_tiny_train", tiny_batch(SMALL), SMALL, param_seed=1, p_drop=0.2, seed=7, full_grads=True)
+        b16 = add_lstur_fields(make_batch(16, vocab=FULL["vocab"], mode="ragged", seed=23), FULL["vocab"],
+                               FULL["n_categ"], 200, 50, seed=24)
+        run_case("mins16_train", b16, FULL, param_seed=6, p_drop=0.2, seed=41, row_stride=9)
+
+
+if __name__ == "__main__":
+    main()

@@ -359,3 +359,44 @@ def build_cen_module(cfg, params, device="cuda"):
     res = mod.load_state_dict(params, strict=True)          # reference checkpoint keys load as-is
     assert not res.missing_keys and not res.unexpected_keys
     return mod.to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# MINS fixtures
+# ---------------------------------------------------------------------------------------------
+MINS_CASES = ["mins_tiny_eval", "mins_tiny_train", "mins16_train"]
+
+
+def mins_golden_cfg(g):
+    cfg = {k: int(g["cfg_" + k]) for k in ("vocab", "n_categ", "D", "Q", "categ_dim", "heads", "channels")}
+    cfg.update(text_attrs=tuple(str(a) for a in g["cfg_text_attrs"]), text_order=tuple(str(a) for a in g["cfg_text_order"]),
+               p_drop=float(g["cfg_p_drop"]), seed=int(g["cfg_seed"]), param_seed=int(g["cfg_param_seed"]))
+    return cfg
+
+
+def mins_golden_params(cfg):
+    from oracle.mins_oracle import make_mins_params
+    return make_mins_params(cfg["vocab"], cfg["n_categ"], cfg["D"], cfg["Q"], cfg["categ_dim"], cfg["channels"],
+                            cfg["text_attrs"], seed=cfg["param_seed"])
+
+
+def build_mins_module(cfg, params, device="cuda"):
+    from functools import partial
+
+    from newsreclib_amd.mins_module import MINSModule
+    from oracle.lstur_oracle import TEXT_PREFIX
+    mod = MINSModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=list(cfg["text_attrs"]) + ["category"],
+        outputs={"train": ["preds", "targets", "cand_news_size"], "val": ["preds", "targets", "cand_news_size"],
+                 "test": ["preds", "targets", "cand_news_size", "hist_news_size", "user_ids"]},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False, temperature=None,
+        use_plm=False, pretrained_embeddings_path=None, plm_model=None, frozen_layers=None, text_embed_dim=cfg["D"],
+        categ_embed_dim=cfg["categ_dim"], num_heads=cfg["heads"], query_dim=cfg["Q"],
+        dropout_probability=float(cfg["p_drop"]) if cfg["p_drop"] > 0 else 0.2, num_filters=cfg["D"],
+        num_gru_channels=cfg["channels"], top_k_list=[5, 10], num_categ_classes=cfg["n_categ"] - 1, num_sent_classes=3,
+        save_recs=False, recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
+        pretrained_embeddings=torch.zeros_like(params[TEXT_PREFIX.format(cfg["text_attrs"][0]) + "embedding_layer.weight"]))
+    res = mod.load_state_dict(params, strict=True)          # reference checkpoint keys load as-is
+    assert not res.missing_keys and not res.unexpected_keys
+    mod.news_encoder.set_text_order(list(cfg["text_order"]))
+    return mod.to(device)

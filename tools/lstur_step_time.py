@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--vocab", type=int, default=70000)
     ap.add_argument("--engine", default="bf16x3")
-    ap.add_argument("--model", default="lstur", choices=["lstur", "naml", "cen"])
+    ap.add_argument("--model", default="lstur", choices=["lstur", "naml", "cen", "mins"])
     args = ap.parse_args()
     from functools import partial
 
@@ -59,6 +59,17 @@ def main():
             pretrained_embeddings_path=None, plm_model=None, frozen_layers=None, embed_dim=300, num_heads=20,
             num_filters=400, window_size=3, query_dim=200, dropout_probability=0.2, gru_hidden_dim=400,
             num_recent_news=20, top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3, save_recs=False,
+            recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
+            pretrained_embeddings=emb).cuda()
+    if args.model == "mins":   # configs/model/mins.yaml: MHSA text encoder on title + abstract, 6 GRU channels
+        from newsreclib_amd.mins_module import MINSModule
+        mod = MINSModule(
+            dataset_attributes=["title", "abstract", "category"], attributes2encode=["title", "abstract", "category"],
+            outputs={"train": [], "val": [], "test": []}, dual_loss_training=False, dual_loss_coef=None,
+            loss="cross_entropy_loss", late_fusion=False, temperature=None, use_plm=False,
+            pretrained_embeddings_path=None, plm_model=None, frozen_layers=None, text_embed_dim=300,
+            categ_embed_dim=100, num_heads=15, query_dim=200, dropout_probability=0.2, num_filters=300,
+            num_gru_channels=6, top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3, save_recs=False,
             recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
             pretrained_embeddings=emb).cuda()
     trainer = NRMSTrainer(mod, lr=1e-4)
