@@ -172,6 +172,15 @@ int nrl_dot_scores_bwd(const float* d_scores, const float* user, const float* ca
 int nrl_ce_loss_fwd_bwd(const float* scores, const float* y_true, int64_t batch, int64_t n_cand,
                         float grad_scale, float* loss, float* d_scores, void* stream);
 
+/* ---- loss: SupConLoss over the score matrix, losses.py:6-40 as called at nrms_module.py:289-318 (on
+ * pytorch-metric-learning 2.2.0: GenericPairLoss.mat_based_loss, AvgNonZeroReducer).  Row b: positives = slots
+ * with y_true != 0, negatives = its other real candidates (slot < cand_sizes[b]); x = scores / temperature;
+ * loss_b = -mean_p(x_p - logsumexp over the row's real candidates); loss = mean of the loss_b > 0 (0 when the
+ * batch holds no positive or no negative pair).  Also writes d_scores = grad_scale * dloss/dscores (may be NULL). */
+int nrl_supcon_loss_fwd_bwd(const float* scores, const float* y_true, const int64_t* cand_sizes, int64_t batch,
+                            int64_t n_cand, float temperature, float grad_scale, float* loss, float* d_scores,
+                            void* stream);
+
 /* ---- optimizer: torch.optim.Adam(lr) dense step over a flat buffer, configs/model/nrms.yaml:49-52,
  * abstract_recommender.py:96.  `step` is the 1-based step count.  grad_scale multiplies g first
  * (1/world_size after a sum all-reduce).  zero_grad != 0 clears g after use. */

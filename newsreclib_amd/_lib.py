@@ -106,6 +106,8 @@ SIGNATURES = {
                                      c_void_p, c_void_p]),
     "nrl_ce_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
                                       c_void_p]),
+    "nrl_supcon_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, ctypes.c_float,
+                                          ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "nrl_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
                                 c_double, c_int64, c_float, c_int32, c_void_p]),
     "nrl_cnn_encoder_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),

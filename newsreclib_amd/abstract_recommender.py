@@ -23,6 +23,39 @@ class AbstractRecommender(LightningModuleBase):
         self._loss_sums = {"train": [0.0, 0], "val": [0.0, 0], "test": [0.0, 0]}
         self.val_loss_best = float("inf")
 
+    # -- reference: abstract_recommender.py:113-124 and the constructors' loss block (nrms_module.py:110-118) ----
+    def _get_loss(self, criterion: str):
+        from .click_predictor import CrossEntropyLoss, SupConLoss
+        if criterion == "cross_entropy_loss":
+            return CrossEntropyLoss()
+        if criterion == "sup_con_loss":
+            return SupConLoss()
+        if criterion == "dual_loss":
+            return CrossEntropyLoss(), SupConLoss()
+        raise ValueError(f"Loss not defined: {criterion}")
+
+    def _init_loss(self, loss: str, dual_loss_training: bool, dual_loss_coef) -> None:
+        if not dual_loss_training:
+            self.criterion = self._get_loss(loss)
+            if isinstance(self.criterion, tuple):
+                raise ValueError("loss='dual_loss' needs dual_loss_training=True")
+        else:
+            assert isinstance(dual_loss_coef, float)
+            self.ce_criterion, self.scl_criterion = self._get_loss(loss)
+
+    def _loss(self, scores: torch.Tensor, y_true: torch.Tensor, batch: Dict) -> torch.Tensor:
+        """nrms_module.py:286-328.  The positive / negative index lists the reference builds with per-user Python
+        loops (:290-304) are what ``SupConLoss`` derives from y_true and the candidate counts on the device."""
+        hp = self.hparams
+        if hp.loss == "cross_entropy_loss":
+            return self.criterion(scores, y_true)
+        sizes = batch["cand_sizes"]
+        if not hp.dual_loss_training:
+            return self.criterion(scores, y_true, sizes)
+        ce_loss = self.ce_criterion(scores, y_true)
+        scl_loss = self.scl_criterion(scores, y_true, sizes)
+        return (1 - hp.dual_loss_coef) * ce_loss + hp.dual_loss_coef * scl_loss
+
     # -- reference: abstract_recommender.py:110-111 ------------------------------------------------
     def _init_embedding(self, filepath: str) -> torch.Tensor:
         return torch.from_numpy(np.load(filepath)).float()
@@ -35,7 +68,7 @@ class AbstractRecommender(LightningModuleBase):
         scores, aux = out if isinstance(out, tuple) else (out, None)
         y_true, _ = to_dense_batch(batch["labels"], batch["batch_cand"], B, batch["max_cand"],
                                    batch["cand_offsets"], batch["cand_flat_idx"])
-        loss = self.criterion(scores, y_true.float())
+        loss = self._loss(scores, y_true.float(), batch)
         if aux is not None:          # recommenders with an auxiliary task (TANR topic prediction)
             loss = loss + self._aux_loss(batch, aux)
 

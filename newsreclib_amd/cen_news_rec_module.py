@@ -58,12 +58,9 @@ class CenNewsRecModule(AbstractRecommender):
         self.num_sent_classes = num_sent_classes + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if dual_loss_training or loss != "cross_entropy_loss":
-            raise NotImplementedError("newsreclib_amd.CenNewsRecModule implements loss='cross_entropy_loss'; "
-                                      "sup_con / dual loss are out of scope")
         if use_plm:
             raise NotImplementedError("newsreclib_amd.CenNewsRecModule covers use_plm=False")
-        self.criterion = CrossEntropyLoss()
+        self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
         assert isinstance(num_filters, int) and isinstance(window_size, int)
         if pretrained_embeddings is None:
             assert isinstance(pretrained_embeddings_path, str)

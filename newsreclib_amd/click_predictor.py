@@ -22,3 +22,16 @@ class CrossEntropyLoss(nn.Module):
 
     def forward(self, scores: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
         return ops.CrossEntropyFn.apply(scores, y_true, 1.0)
+
+
+class SupConLoss(nn.Module):
+    """The reference's ``SupConLoss`` (components/losses.py:6-40) applied to the score matrix as at
+    nrms_module.py:289-318, fused with its gradient.  ``temperature`` defaults to 0.1 as in the reference, which
+    builds the loss without arguments (abstract_recommender.py:117-120)."""
+
+    def __init__(self, temperature: float = 0.1) -> None:
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, scores: torch.Tensor, y_true: torch.Tensor, cand_sizes: torch.Tensor) -> torch.Tensor:
+        return ops.SupConFn.apply(scores, y_true, cand_sizes, self.temperature)

@@ -540,6 +540,14 @@ int nrl_ce_loss_fwd_bwd(const float* scores, const float* y_true, int64_t batch,
   return ce_loss_fwd_bwd(scores, y_true, batch, n_cand, grad_scale, loss, d_scores, (hipStream_t)stream);
 }
 
+int nrl_supcon_loss_fwd_bwd(const float* scores, const float* y_true, const int64_t* cand_sizes, int64_t batch,
+                            int64_t n_cand, float temperature, float grad_scale, float* loss, float* d_scores,
+                            void* stream) {
+  NRL_REQUIRE(scores && y_true && cand_sizes && loss, "supcon_loss: bad arguments");
+  return supcon_loss_fwd_bwd(scores, y_true, cand_sizes, batch, n_cand, temperature, grad_scale, loss, d_scores,
+                             (hipStream_t)stream);
+}
+
 int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
                   double beta1, double beta2, double eps, int64_t step, float grad_scale,
                   int32_t zero_grad, void* stream) {

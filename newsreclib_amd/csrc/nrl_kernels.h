@@ -54,6 +54,8 @@ int dot_scores_fwd(const float* user, const float* cand, int64_t B, int64_t C, i
                    hipStream_t stream);
 int dot_scores_bwd(const float* d_scores, const float* user, const float* cand, int64_t B, int64_t C,
                    int D, float* d_user, float* d_cand, hipStream_t stream);
+int supcon_loss_fwd_bwd(const float* scores, const float* y, const int64_t* sizes, int64_t B, int64_t C,
+                        float temperature, float grad_scale, float* loss, float* d_scores, hipStream_t stream);
 int ce_loss_fwd_bwd(const float* scores, const float* y, int64_t B, int64_t C, float grad_scale,
                     float* loss, float* d_scores, hipStream_t stream);
 

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "nrl_kernels.h"
+#include <cfloat>
 
 namespace nrl {
 
@@ -768,6 +769,90 @@ __global__ void __launch_bounds__(256)
   if ((tid & 63) == 0) red[tid >> 6] = local;
   __syncthreads();
   if (tid == 0) *loss = (red[0] + red[1] + red[2] + red[3]) * invB;
+}
+
+// =============================================================================================
+// supervised contrastive loss over the (B, C) score matrix (reference losses.py:6-40 on top of
+// pytorch-metric-learning 2.2.0's GenericPairLoss.mat_based_loss + AvgNonZeroReducer; index construction
+// nrms_module.py:289-304).  Row b: positives = {c : y != 0}, negatives = the other REAL candidates (c < size_b);
+// x = s / T;  loss_b = -(1 / (npos + tiny)) sum_{p} (x_p - logsumexp_{c < size_b} x_c);
+// loss = mean of the loss_b that are > 0.  One workgroup: B is a batch size.
+// =============================================================================================
+struct SupConRow {
+  float loss, lse, mx;
+  int npos, n;
+};
+
+__device__ __forceinline__ SupConRow supcon_row(const float* s, const float* y, int64_t C, int64_t n, float inv_t) {
+  SupConRow r;
+  r.n = (int)n;
+  // (the reference first shifts by the max of the whole row, pads included, and torch.logsumexp then shifts again
+  //  by the max of the kept entries; shifting once by the latter is the same value without the underflow window)
+  float mx = n > 0 ? -INFINITY : 0.f;
+  for (int64_t c = 0; c < n; ++c) mx = fmaxf(mx, s[c] * inv_t);
+  float sum = 0.f, possum = 0.f;
+  int npos = 0;
+  for (int64_t c = 0; c < n; ++c) {
+    const float x = s[c] * inv_t - mx;
+    sum += expf(x);
+    if (y[c] != 0.f) { ++npos; possum += x; }
+  }
+  for (int64_t c = n; c < C; ++c) npos += y[c] != 0.f;                 // (cannot happen with to_dense_batch labels)
+  r.mx = mx;
+  r.npos = npos;
+  r.lse = n > 0 ? logf(sum) : 0.f;                                     // masked logsumexp: empty set -> 0
+  r.loss = -(possum - (float)npos * r.lse) / ((float)npos + FLT_MIN);
+  return r;
+}
+
+__global__ void __launch_bounds__(256)
+    supcon_kernel(const float* __restrict__ scores, const float* __restrict__ y, const int64_t* __restrict__ sizes,
+                  int64_t B, int64_t C, float inv_t, float grad_scale, float* __restrict__ loss,
+                  float* __restrict__ d_scores) {
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x;
+  float lsum = 0.f, lcnt = 0.f, tpos = 0.f, tneg = 0.f;
+  for (int64_t b = tid; b < B; b += 256) {
+    const SupConRow r = supcon_row(scores + b * C, y + b * C, C, sizes[b], inv_t);
+    if (r.loss > 0.f) { lsum += r.loss; lcnt += 1.f; }
+    tpos += (float)r.npos;
+    tneg += (float)(r.n - r.npos);
+  }
+  float v[4] = {wave_sum(lsum), wave_sum(lcnt), wave_sum(tpos), wave_sum(tneg)};
+  if ((tid & 63) == 0)
+    for (int i = 0; i < 4; ++i) red[i][tid >> 6] = v[i];
+  __syncthreads();
+  float tot[4];
+  for (int i = 0; i < 4; ++i) tot[i] = red[i][0] + red[i][1] + red[i][2] + red[i][3];
+  // losses.py:13-15 (fewer than two pairs of either kind) and :20 (no positive or no negative pair): zero loss
+  const bool zero = (tot[2] <= 1.f && tot[3] <= 1.f) || !(tot[2] > 0.f && tot[3] > 0.f) || tot[1] < 1.f;
+  if (tid == 0) *loss = zero ? 0.f : tot[0] / tot[1];
+  if (d_scores == nullptr) return;
+  const float k = zero ? 0.f : inv_t * grad_scale / tot[1];
+  for (int64_t b = tid; b < B; b += 256) {
+    const float* s = scores + b * C;
+    const float* yy = y + b * C;
+    const int64_t n = sizes[b];
+    const SupConRow r = supcon_row(s, yy, C, n, inv_t);
+    const float live = (r.loss > 0.f) ? k / ((float)r.npos + FLT_MIN) : 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      float g = 0.f;
+      if (c < n && live != 0.f) {
+        const float p = expf(s[c] * inv_t - r.mx - r.lse);
+        g = ((float)r.npos * p - (yy[c] != 0.f ? 1.f : 0.f)) * live;
+      }
+      d_scores[b * C + c] = g;
+    }
+  }
+}
+
+int supcon_loss_fwd_bwd(const float* scores, const float* y, const int64_t* sizes, int64_t B, int64_t C,
+                        float temperature, float grad_scale, float* loss, float* d_scores, hipStream_t stream) {
+  NRL_REQUIRE(B > 0 && C > 0 && temperature > 0.f, "supcon: bad arguments");
+  hipLaunchKernelGGL(supcon_kernel, dim3(1), dim3(256), 0, stream, scores, y, sizes, B, C, 1.0f / temperature,
+                     grad_scale, loss, d_scores);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
 }
 
 int dot_scores_fwd(const float* user, const float* cand, int64_t B, int64_t C, int D, float* scores,

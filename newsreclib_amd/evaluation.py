@@ -138,7 +138,7 @@ class NewsVectorCache:
         scores = self.scores(hist_idx, hist_sizes, cand_idx, cand_sizes, user_idx)
         y_true, _ = to_dense_batch(meta["labels"], meta["batch_cand"], meta["batch_size"], meta["max_cand"],
                                    meta["cand_offsets"], meta["cand_flat_idx"])
-        loss = self.module.criterion(scores, y_true.float())
+        loss = self.module._loss(scores, y_true.float(), meta)
         preds = scores.reshape(-1)[meta["cand_flat_idx"]]
         empty = torch.empty(0, dtype=torch.int64, device=dev)
 

@@ -63,12 +63,9 @@ class LSTURModule(AbstractRecommender):
         self.num_users = num_users + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if dual_loss_training or loss != "cross_entropy_loss":
-            raise NotImplementedError("newsreclib_amd.LSTURModule implements loss='cross_entropy_loss' "
-                                      "(configs/model/lstur.yaml:6); sup_con / dual loss are out of scope")
         if use_plm:
             raise NotImplementedError("newsreclib_amd.LSTURModule covers use_plm=False (configs/model/lstur.yaml:13)")
-        self.criterion = CrossEntropyLoss()
+        self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
 
         if pretrained_embeddings is None:
             assert isinstance(pretrained_embeddings_path, str)

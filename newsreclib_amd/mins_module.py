@@ -57,12 +57,9 @@ class MINSModule(AbstractRecommender):
         self.num_sent_classes = num_sent_classes + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if dual_loss_training or loss != "cross_entropy_loss":
-            raise NotImplementedError("newsreclib_amd.MINSModule implements loss='cross_entropy_loss' "
-                                      "(configs/model/mins.yaml:5); sup_con / dual loss are out of scope")
         if use_plm:
             raise NotImplementedError("newsreclib_amd.MINSModule covers use_plm=False (configs/model/mins.yaml:11)")
-        self.criterion = CrossEntropyLoss()
+        self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
         if pretrained_embeddings is None:
             assert isinstance(pretrained_embeddings_path, str)
             pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)

@@ -59,12 +59,9 @@ class NAMLModule(AbstractRecommender):
         self.num_sent_classes = num_sent_classes + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if dual_loss_training or loss != "cross_entropy_loss":
-            raise NotImplementedError("newsreclib_amd.NAMLModule implements loss='cross_entropy_loss' "
-                                      "(configs/model/naml.yaml:6); sup_con / dual loss are out of scope")
         if use_plm:
             raise NotImplementedError("newsreclib_amd.NAMLModule covers use_plm=False (configs/model/naml.yaml:13)")
-        self.criterion = CrossEntropyLoss()
+        self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
         assert isinstance(num_filters, int) and isinstance(window_size, int)
         if pretrained_embeddings is None:
             assert isinstance(pretrained_embeddings_path, str)

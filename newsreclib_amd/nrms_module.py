@@ -101,10 +101,7 @@ class NRMSModule(AbstractRecommender):
         self.num_sent_classes = num_sent_classes + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if dual_loss_training or loss != "cross_entropy_loss":
-            raise NotImplementedError("newsreclib_amd.NRMSModule implements loss='cross_entropy_loss' "
-                                      "(configs/model/nrms.yaml:6); sup_con / dual loss are out of scope")
-        self.criterion = CrossEntropyLoss()
+        self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
 
         if not use_plm:
             # pretrained embeddings + contextualisation (nrms_module.py:122-135)

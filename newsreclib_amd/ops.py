@@ -287,6 +287,33 @@ class CrossEntropyFn(torch.autograd.Function):
         return d_scores * g, None, None
 
 
+class SupConFn(torch.autograd.Function):
+    """``SupConLoss()(embeddings=scores, indices_tuple=...)`` as called at nrms_module.py:289-318: scores, y_true
+    (B, C) dense, cand_sizes (B,) int64 = real candidates per row."""
+
+    @staticmethod
+    def forward(ctx, scores, y_true, cand_sizes, temperature):
+        lib = _lib.load()
+        scores = _chk(scores, torch.float32, "scores")
+        y_true = _chk(y_true, torch.float32, "y_true")
+        cand_sizes = _chk(cand_sizes, torch.int64, "cand_sizes")
+        B, C = scores.shape
+        if y_true.shape != (B, C) or cand_sizes.shape != (B,):
+            raise ValueError("newsreclib_amd: inconsistent sup-con loss shapes")
+        loss = torch.empty((), dtype=torch.float32, device=scores.device)
+        d_scores = torch.empty_like(scores)
+        _lib.check(lib.nrl_supcon_loss_fwd_bwd(scores.data_ptr(), y_true.data_ptr(), cand_sizes.data_ptr(), B, C,
+                                               float(temperature), 1.0, loss.data_ptr(), d_scores.data_ptr(),
+                                               _stream()), "nrl_supcon_loss_fwd_bwd")
+        ctx.save_for_backward(d_scores)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_scores,) = ctx.saved_tensors
+        return d_scores * g, None, None, None
+
+
 # ---- plain (non-autograd) entry points ----------------------------------------------------------
 def embedding_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()

@@ -59,12 +59,9 @@ class TANRModule(AbstractRecommender):
         self.num_sent_classes = num_sent_classes + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if dual_loss_training or loss != "cross_entropy_loss":
-            raise NotImplementedError("newsreclib_amd.TANRModule implements loss='cross_entropy_loss' "
-                                      "(configs/model/tanr.yaml:6); sup_con / dual loss are out of scope")
         if use_plm:
             raise NotImplementedError("newsreclib_amd.TANRModule covers use_plm=False (configs/model/tanr.yaml:13)")
-        self.criterion = CrossEntropyLoss()
+        self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
         self.topic_pred_loss = CrossEntropyLoss()
         assert isinstance(num_filters, int) and isinstance(window_size, int)
         if pretrained_embeddings is None:
