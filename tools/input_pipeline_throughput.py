@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Input-pipeline throughput at MINDsmall shape (65 k news, 150 k train impressions, <= 50 clicks, ~37 candidates
 of which ~1.5 clicked, 4 negatives per positive, B = 128): batches/s of ``TrainBatchLoader`` alone, of the NRMS
-train step on a pre-built batch, and of loader + train step together; plus the reference-shaped pandas collate
-(oracle/input_oracle.py, one core, ``num_workers: 0`` as in configs/data/mind_rec.yaml:66) on a bounded sample."""
+train step on a pre-built batch, and of loader + train step together.  (The reference-shaped pandas collate it is
+compared with is timed by tests/bench_collate_baseline.py -- the restatement is test infrastructure.)"""
 import argparse
 import os
 import sys
@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--batches", type=int, default=200)
     ap.add_argument("--vocab", type=int, default=70000)
-    ap.add_argument("--cpu-batches", type=int, default=3)
     args = ap.parse_args()
     import pandas as pd
 
@@ -29,8 +28,7 @@ def main():
     from newsreclib_amd.evaluation import DeviceNewsTable
     from newsreclib_amd.nrms_module import prepare_batch
     from newsreclib_amd.trainer import NRMSTrainer
-    from tests.helpers import build_module
-    from oracle import nrms_oracle as O
+    import bench
     rng = np.random.default_rng(0)
     n, m = args.news, args.impressions
     lens = np.clip(np.round(rng.normal(11.5, 3.5, n)), 3, 30).astype(int)
@@ -69,7 +67,8 @@ def main():
 
     loader_only(20)
     dt_load = timed(loader_only, args.batches)
-    mod = build_module(O.make_params(args.vocab, seed=1), p_drop=0.2)
+    bench.VOCAB = args.vocab
+    mod = bench.build_module(torch.device("cuda", 0))
     tr = NRMSTrainer(mod, lr=1e-4)
     fixed = prepare_batch(next(iter(loader)))
 
@@ -91,26 +90,6 @@ def main():
     print(f"loader alone      : {dt_load * 1e3:7.3f} ms/batch  {B / dt_load:9.0f} impressions/s")
     print(f"train step alone  : {dt_step * 1e3:7.3f} ms/batch  {B / dt_step:9.0f} impressions/s (ragged batch)")
     print(f"loader + step     : {dt_both * 1e3:7.3f} ms/batch  {B / dt_both:9.0f} impressions/s")
-    # reference-shaped host collate on a bounded sample (pandas .loc + concat + per-row pad), one core
-    from oracle import input_oracle as IO
-    news_df = pd.DataFrame({"tokenized_title": titles, "category_class": table.attrs["category"].cpu().numpy(),
-                            "subcategory_class": table.attrs["subcategory"].cpu().numpy()},
-                           index=[f"N{i + 1}" for i in range(n)])
-    hr, cr = bt.hist_rows.cpu().numpy(), bt.cand_rows.cpu().numpy()
-    idx = np.arange(B * args.cpu_batches)
-    bhv = pd.DataFrame({"uid": [f"U{i}" for i in idx], "user": idx,
-                        "history": [[f"N{r + 1}" for r in hr[hist_ptr[i]:hist_ptr[i + 1]]] for i in idx],
-                        "candidates": [[f"N{r + 1}" for r in cr[cand_ptr[i]:cand_ptr[i + 1]]] for i in idx],
-                        "labels": [list(labels[cand_ptr[i]:cand_ptr[i + 1]]) for i in idx]})
-    nrng = np.random.default_rng(0)
-    t = time.perf_counter()
-    for b in range(args.cpu_batches):
-        items = [IO.get_item(news_df, bhv, int(i), 50, IO.sample_candidates(np.array(bhv.iloc[int(i)]["labels"]), 4, nrng))
-                 for i in range(b * B, (b + 1) * B)]
-        IO.collate(items, ["title", "category"], 30)
-    dt_cpu = (time.perf_counter() - t) / args.cpu_batches
-    print(f"pandas collate    : {dt_cpu * 1e3:7.1f} ms/batch  {B / dt_cpu:9.0f} impressions/s "
-          f"(reference-shaped restatement, 1 core, {args.cpu_batches} batches)")
 
 
 if __name__ == "__main__":
