@@ -111,23 +111,26 @@ __device__ __forceinline__ void stage_rows(const float* src, int64_t stride, int
   }
 }
 
-// ---- S <= 32: two groups per wavefront (one per 32-lane half), GPW groups per workgroup ----------
-template <int DH, int GPW>
-__global__ void __launch_bounds__(GPW * 32)
+// ---- S <= LPG: LPG (32 or 64) lanes per group -- two groups per wavefront or one --, GPW groups per workgroup;
+// lane = query row (then key row), K/V (then Q/dO) of the group in LDS.  S in (32, 64) used to fall to the
+// one-workgroup-per-group kernel below, 3.5x slower per token (profiles/r01_mins_x3_kernel_stats.csv: the
+// 50-token abstracts of MINS) ---------------------------------------------------------------------------------
+template <int DH, int GPW, int LPG = 32>
+__global__ void __launch_bounds__(GPW * LPG)
     attn_fwd_small(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
                    const AttnGeom G) {
-  __shared__ float4 smem4[GPW * 2 * 32 * DH / 4];
-  const int tid = threadIdx.x, li = tid & 31, grp = tid >> 5;
+  __shared__ float4 smem4[GPW * 2 * LPG * DH / 4];
+  const int tid = threadIdx.x, li = tid % LPG, grp = tid / LPG;
   const int64_t g = (int64_t)blockIdx.x * GPW + grp;
   const bool gvalid = g < G.groups;
-  float* Ks = reinterpret_cast<float*>(smem4) + grp * (2 * 32 * DH);
-  float* Vs = Ks + 32 * DH;
+  float* Ks = reinterpret_cast<float*>(smem4) + grp * (2 * LPG * DH);
+  float* Vs = Ks + LPG * DH;
   const int64_t outer = gvalid ? g / G.heads : 0;
   const int head = gvalid ? (int)(g % G.heads) : 0;
   const float* qb = qkv + outer * G.q_outer + head * DH;
   if (gvalid) {
-    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ks, li, 32);
-    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Vs, li, 32);
+    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ks, li, LPG);
+    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Vs, li, LPG);
   }
   __syncthreads();
   if (gvalid && li < G.S) {
@@ -142,22 +145,22 @@ __global__ void __launch_bounds__(GPW * 32)
   }
 }
 
-template <int DH, int GPW>
-__global__ void __launch_bounds__(GPW * 32)
+template <int DH, int GPW, int LPG = 32>
+__global__ void __launch_bounds__(GPW * LPG)
     attn_bwd_small(const float* __restrict__ qkv, const float* __restrict__ o,
                    const float* __restrict__ d_o, const float* __restrict__ lse,
                    float* __restrict__ dqkv, const AttnGeom G) {
   // LDS per group: two row buffers (K,V in phase 1; scaled Q, dO in phase 2) + row statistics.
   // Re-using the buffers across the phases halves the footprint -> twice the resident waves.
-  constexpr int PER = 2 * 32 * DH + 64;
+  constexpr int PER = 2 * LPG * DH + 2 * LPG;
   __shared__ float4 smem4[GPW * PER / 4];
-  const int tid = threadIdx.x, li = tid & 31, grp = tid >> 5;
+  const int tid = threadIdx.x, li = tid % LPG, grp = tid / LPG;
   const int64_t g = (int64_t)blockIdx.x * GPW + grp;
   const bool gvalid = g < G.groups;
   float* Ra = reinterpret_cast<float*>(smem4) + grp * PER;
-  float* Rb = Ra + 32 * DH;
-  float* lse_s = Rb + 32 * DH;
-  float* dl_s = lse_s + 32;
+  float* Rb = Ra + LPG * DH;
+  float* lse_s = Rb + LPG * DH;
+  float* dl_s = lse_s + LPG;
   const int64_t outer = gvalid ? g / G.heads : 0;
   const int head = gvalid ? (int)(g % G.heads) : 0;
   const float* qb = qkv + outer * G.q_outer + head * DH;
@@ -166,8 +169,8 @@ __global__ void __launch_bounds__(GPW * 32)
   float* dqb = dqkv + outer * G.q_outer + head * DH;
   const bool active = gvalid && li < G.S;
   if (gvalid) {
-    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ra, li, 32);      // K
-    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Rb, li, 32);  // V
+    stage_rows<DH>(qb + G.D, G.q_seq, G.S, Ra, li, LPG);     // K
+    stage_rows<DH>(qb + 2 * G.D, G.q_seq, G.S, Rb, li, LPG); // V
   }
   __syncthreads();
   // phase 1: lane = query row -> dq, and the row statistics phase 2 needs
@@ -375,6 +378,10 @@ int attn_fwd(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStrea
       constexpr int GPW = DH <= 32 ? 8 : 4;
       hipLaunchKernelGGL((attn_fwd_small<DH, GPW>), dim3((unsigned)ceil_div(G.groups, GPW)),
                          dim3(GPW * 32), 0, stream, qkv, o, lse, G);
+    } else if (G.S <= 64) {
+      constexpr int GPW = DH <= 32 ? 4 : 2;
+      hipLaunchKernelGGL((attn_fwd_small<DH, GPW, 64>), dim3((unsigned)ceil_div(G.groups, GPW)),
+                         dim3(GPW * 64), 0, stream, qkv, o, lse, G);
     } else {
       hipLaunchKernelGGL((attn_fwd_general<DH>), dim3((unsigned)G.groups), dim3(256), 0, stream, qkv,
                          o, lse, G);
@@ -399,6 +406,10 @@ int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* ls
       constexpr int GPW = DH <= 32 ? 8 : 4;
       hipLaunchKernelGGL((attn_bwd_small<DH, GPW>), dim3((unsigned)ceil_div(G.groups, GPW)),
                          dim3(GPW * 32), 0, stream, qkv, o, d_o, lse, dqkv, G);
+    } else if (G.S <= 64) {
+      constexpr int GPW = DH <= 32 ? 4 : 2;
+      hipLaunchKernelGGL((attn_bwd_small<DH, GPW, 64>), dim3((unsigned)ceil_div(G.groups, GPW)),
+                         dim3(GPW * 64), 0, stream, qkv, o, d_o, lse, dqkv, G);
     } else {
       hipLaunchKernelGGL((attn_bwd_general<DH>), dim3((unsigned)G.groups), dim3(256), 0, stream, qkv,
                          o, d_o, lse, dqkv, G);

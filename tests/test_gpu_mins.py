@@ -25,7 +25,9 @@ def _tols(engine):
     return (2e-5, 2e-4) if engine == "f32" else (1e-4, 5e-4)
 
 
-@pytest.mark.parametrize("shape", [(5, 3, 48, 3), (128, 50, 300, 15), (70, 7, 384, 6), (1, 1, 32, 2)])
+@pytest.mark.parametrize("shape", [(5, 3, 48, 3), (128, 50, 300, 15), (70, 7, 384, 6), (1, 1, 32, 2),
+                                   # 32 < S < 64: the 64-lanes-per-group kernels, every head dim
+                                   (50, 9, 300, 15), (40, 5, 128, 2), (33, 4, 96, 2), (63, 3, 64, 2), (45, 3, 32, 2)])
 def test_mha_matches_oracle(shape, engine):
     from newsreclib_amd.ops_blocks import MhaFn
     from oracle.nrms_oracle import _mhsa_seq_first
