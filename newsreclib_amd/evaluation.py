@@ -75,7 +75,8 @@ class DeviceNewsTable:
 
 
 class NewsVectorCache:
-    """Encode-once evaluation of a drop-in recommender (``NRMSModule`` / ``LSTURModule``)."""
+    """Encode-once evaluation of a drop-in recommender (any of the module mirrors: NRMS, LSTUR, NAML, TANR,
+    CenNewsRec, MINS -- whatever exposes ``news_encoder`` and ``score_news_vectors``)."""
 
     def __init__(self, module, table: DeviceNewsTable, chunk: int = 16384):
         self.module, self.table, self.chunk = module, table, int(chunk)

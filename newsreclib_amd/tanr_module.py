@@ -87,20 +87,11 @@ class TANRModule(AbstractRecommender):
     # -- reference: tanr_module.py:258-286 -------------------------------------------------------------
     def forward(self, batch: Dict, seed: Optional[int] = None):
         batch = prepare_batch(batch)
-        B = batch["batch_size"]
         n_hist = batch["batch_hist"].shape[0]
         if self.training and seed is None:
             seed = _draw_seed()
         news_vector = self.news_encoder(batch["x_all"], seed=seed)        # rows: [history; candidates]
-        hist_news_vector_agg, _ = to_dense_batch(news_vector[:n_hist], batch["batch_hist"], B,
-                                                 batch["max_hist"], batch["hist_offsets"])
-        cand_news_vector_agg, _ = to_dense_batch(news_vector[n_hist:], batch["batch_cand"], B,
-                                                 batch["max_cand"], batch["cand_offsets"])
-        if not self.hparams.late_fusion:
-            user_vector = self.user_encoder(hist_news_vector_agg)
-        else:
-            user_vector = ops.HistMeanFn.apply(hist_news_vector_agg, batch["hist_offsets"])
-        scores = self.click_predictor(user_vector.unsqueeze(dim=1), cand_news_vector_agg.permute(0, 2, 1))
+        scores = self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch)
         # topic scores of every encoded news.  The reference orders the rows [candidates; history]
         # (tanr_module.py:284); the loss is a mean over rows, so the order only matters for the returned tensor.
         w, b = self.topic_predictor.weight, self.topic_predictor.bias
@@ -111,6 +102,21 @@ class TANRModule(AbstractRecommender):
         topic_all = ops_blocks.LinearActFn.apply(news_vector, wp, bp, "none", None)[:, :n_cls]
         topic_scores = torch.cat((topic_all[n_hist:], topic_all[:n_hist]), dim=0)
         return scores, topic_scores
+
+    def score_news_vectors(self, hist_news_vector: torch.Tensor, cand_news_vector: torch.Tensor,
+                           batch: Dict) -> torch.Tensor:
+        """User encoding + click scores from already-encoded news (tanr_module.py:262-282; also the entry of the
+        encode-once evaluation path, evaluation.NewsVectorCache)."""
+        B = batch["batch_size"]
+        hist_news_vector_agg, _ = to_dense_batch(hist_news_vector, batch["batch_hist"], B,
+                                                 batch["max_hist"], batch["hist_offsets"])
+        cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
+                                                 batch["max_cand"], batch["cand_offsets"])
+        if not self.hparams.late_fusion:
+            user_vector = self.user_encoder(hist_news_vector_agg)
+        else:
+            user_vector = ops.HistMeanFn.apply(hist_news_vector_agg, batch["hist_offsets"])
+        return self.click_predictor(user_vector.unsqueeze(dim=1), cand_news_vector_agg.permute(0, 2, 1))
 
     # -- reference: tanr_module.py:361-367 -------------------------------------------------------------
     def _aux_loss(self, batch: Dict, topic_scores: torch.Tensor) -> torch.Tensor:

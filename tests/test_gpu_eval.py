@@ -127,3 +127,45 @@ def test_lstur_cached_scores_equal_uncached_forward():
     with torch.no_grad():
         ref = mod.forward(batch)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("model", ["naml", "tanr", "cen", "mins"])
+def test_sibling_models_cached_scores_equal_uncached_forward(model):
+    """Encode-once evaluation through every sibling module mirror: scoring from the cached news vectors is
+    bit-identical to the module's own forward on the same batch."""
+    from newsreclib_amd.evaluation import DeviceNewsTable, NewsVectorCache
+    from tests import helpers as H
+    rng = np.random.default_rng(11)
+    n_news, vocab = 90, 120
+    if model == "naml":
+        from oracle.naml_oracle import make_naml_params
+        cfg = dict(vocab=vocab, n_categ=7, D=48, F=48, W=3, Q=32, categ_dim=16, text_attrs=("title", "abstract"),
+                   text_order=("title", "abstract"), p_drop=0.2)
+        mod = H.build_naml_module(cfg, make_naml_params(vocab, 7, 48, 48, 3, 32, 16, seed=5))
+    elif model == "tanr":
+        from oracle.tanr_oracle import make_tanr_params
+        cfg = dict(vocab=vocab, n_categ=7, D=48, F=48, W=3, Q=32, p_drop=0.2, coef=0.2)
+        mod = H.build_tanr_module(cfg, make_tanr_params(vocab, 7, 48, 48, 3, 32, seed=5))
+    elif model == "cen":
+        from oracle.cen_news_rec_oracle import make_cen_news_rec_params
+        cfg = dict(vocab=vocab, D=40, F=48, W=3, Q=32, heads=3, recent=3, p_drop=0.2, late_fusion=False)
+        mod = H.build_cen_module(cfg, make_cen_news_rec_params(vocab, 40, 48, 3, 32, seed=5))
+    else:
+        from oracle.mins_oracle import make_mins_params
+        cfg = dict(vocab=vocab, n_categ=7, D=48, Q=32, categ_dim=16, heads=3, channels=4,
+                   text_attrs=("title", "abstract"), text_order=("title", "abstract"), p_drop=0.2)
+        mod = H.build_mins_module(cfg, make_mins_params(vocab, 7, 48, 32, 16, 4, seed=5))
+    mod = mod.eval()
+    attrs = _table(rng, n_news, vocab, L=12, n_categ=7)
+    attrs["abstract"] = _table(rng, n_news, vocab, L=20)["title"]
+    table = DeviceNewsTable(attrs)
+    cache = NewsVectorCache(mod, table, chunk=32)
+    imps = _impressions(rng, 6, n_news, max_hist=8, max_cand=12)
+    hist, cand = torch.cat([i["hist"] for i in imps]), torch.cat([i["cand"] for i in imps])
+    hs, cs = torch.tensor([len(i["hist"]) for i in imps]), torch.tensor([len(i["cand"]) for i in imps])
+    got = cache.scores(hist, hs, cand, cs)
+    batch = table.build_batch(hist, hs, cand, cs, torch.cat([i["labels"] for i in imps]))
+    with torch.no_grad():
+        out = mod.forward(batch)
+    ref = out[0] if isinstance(out, tuple) else out
+    assert torch.equal(got, ref)
