@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .abstract_recommender import AbstractRecommender
-from .click_predictor import CrossEntropyLoss, DotProduct
+from .click_predictor import DotProduct
 from .dense_batch import to_dense_batch
 from .news_encoder import CNNAddAtt, LinearEncoder, NewsEncoder, _draw_seed
 from .nrms_module import prepare_batch

@@ -14,13 +14,13 @@ candidate news are encoded in ONE encoder call (row-independent, so identical re
 """
 from __future__ import annotations
 
-from typing import Any, Dict, List, Optional, Tuple
+from typing import Any, Dict, List, Optional
 
 import torch
 
 from . import ops
 from .abstract_recommender import AbstractRecommender
-from .click_predictor import CrossEntropyLoss, DotProduct
+from .click_predictor import DotProduct
 from .dense_batch import dense_slot_index, to_dense_batch
 from .news_encoder import PLM, MHSAAddAtt, NewsEncoder
 from .user_encoder import UserEncoder

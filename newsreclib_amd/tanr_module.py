@@ -17,7 +17,7 @@ from . import ops, ops_blocks
 from .abstract_recommender import AbstractRecommender
 from .click_predictor import CrossEntropyLoss, DotProduct
 from .dense_batch import to_dense_batch
-from .news_encoder import CNNAddAtt, NewsEncoder, _draw_seed, _grad_bufs
+from .news_encoder import CNNAddAtt, NewsEncoder, _draw_seed
 from .nrms_module import prepare_batch
 from .user_encoder_naml import UserEncoder
 

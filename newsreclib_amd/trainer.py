@@ -8,7 +8,7 @@ GPUs, "gloo" in the CPU tests of the communication logic.
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional
+from typing import Dict, Iterable, List
 
 import torch
 import torch.distributed as dist

@@ -22,7 +22,6 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
-import numpy as np
 import torch
 
 from .nrms_oracle import (additive_attention, ce_loss, click_scores, dropout_multiplier,

@@ -10,7 +10,7 @@ Dropout streams by attribute name as everywhere (title (0, 1), abstract (2, 3)):
 (N, L, D), second = post-attention over (N, L, D) (the reference holds (L, N, D) there, ``text.py:229-230``)."""
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence
+from typing import Sequence
 
 import torch
 

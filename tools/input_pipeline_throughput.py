@@ -22,7 +22,6 @@ def main():
     ap.add_argument("--batches", type=int, default=200)
     ap.add_argument("--vocab", type=int, default=70000)
     args = ap.parse_args()
-    import pandas as pd
 
     from newsreclib_amd import input_pipeline as IP
     from newsreclib_amd.evaluation import DeviceNewsTable
