@@ -5,6 +5,7 @@
 //   pat 2: 4 rows x 256 B
 //   pat 3: 1 row x 640 B on 40 of 64 lanes  (whole tile rows, e.g. after staging the tile through LDS)
 //   pat 4: 16 rows x 16 B... per lane dword  (the original 4-byte accumulator stores), for reference
+//   pat 5/6: the workgroup's 128 x 160 tile stored as ONE contiguous 80 KB chunk (a tile-contiguous activation layout)
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/store_probe tools/store_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,6 +21,17 @@ __global__ void __launch_bounds__(256) store_kernel(float* __restrict__ c, int64
   const int n0 = tile_n * 160;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float4 v = make_float4((float)lane, (float)wave, (float)tile_m, (float)tile_n);
+  if (PAT == 5 || PAT == 6) {
+    // same 80 KB per workgroup, but CONTIGUOUS in memory: pat 5 = tile-contiguous ("blocked") layout, the
+    // workgroup's tile is one 81920-byte chunk; pat 6 = the same chunks visited in a scrambled workgroup order
+    int64_t chunk = blockIdx.x;
+    if (PAT == 6) chunk = (int64_t)((uint64_t)blockIdx.x * 2654435761ull % (uint64_t)gridDim.x);
+    float4* base = reinterpret_cast<float4*>(c) + chunk * (128 * 160 / 4);
+    const int64_t total4 = M * (int64_t)N / 4;
+    for (int i = threadIdx.x; i < 128 * 160 / 4; i += 256)
+      if (chunk * (128 * 160 / 4) + i < total4) base[i] = v;
+    return;
+  }
   if (PAT == 3) {
     // wave w writes rows w, w+4, ...: 40 lanes x 16 B = one 640-byte row segment per instruction
     for (int r = wave; r < 128; r += 4) {
@@ -78,12 +90,13 @@ int main() {
   float* c;
   CK(hipMalloc(&c, M * 900 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
-  const char* names[5] = {"16 rows x  64 B (current)", " 8 rows x 128 B", " 4 rows x 256 B", " 1 row  x 640 B (40 lanes)",
-                          "dword stores (16 x 64 B x4)"};
+  const char* names[7] = {"16 rows x  64 B (current)", " 8 rows x 128 B", " 4 rows x 256 B", " 1 row  x 640 B (40 lanes)",
+                          "dword stores (16 x 64 B x4)", "tile-contiguous 80 KB chunks", "80 KB chunks, scrambled order"};
   for (int N : {900, 300}) {
     const double bytes = (double)M * (N / 4 * 4) * 4;
-    float t[5] = {run<0>(c, M, N, st), run<1>(c, M, N, st), run<2>(c, M, N, st), run<3>(c, M, N, st), run<4>(c, M, N, st)};
-    for (int p = 0; p < 5; ++p)
+    float t[7] = {run<0>(c, M, N, st), run<1>(c, M, N, st), run<2>(c, M, N, st), run<3>(c, M, N, st), run<4>(c, M, N, st),
+                  run<5>(c, M, N, st), run<6>(c, M, N, st)};
+    for (int p = 0; p < 7; ++p)
       printf("N=%d  %-28s median %7.3f ms  %7.1f GB/s\n", N, names[p], t[p], bytes / t[p] / 1e6);
   }
   return 0;
