@@ -88,11 +88,15 @@ float run(float* c, int64_t M, int N, hipStream_t st) {
 int main() {
   const int64_t M = 211200;
   float* c;
-  CK(hipMalloc(&c, M * 900 * 4));
+  CK(hipMalloc(&c, M * 1024 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
   const char* names[7] = {"16 rows x  64 B (current)", " 8 rows x 128 B", " 4 rows x 256 B", " 1 row  x 640 B (40 lanes)",
                           "dword stores (16 x 64 B x4)", "tile-contiguous 80 KB chunks", "80 KB chunks, scrambled order"};
-  for (int N : {900, 300}) {
+  const int64_t M1 = M;
+  for (int N : {900, 960, 928, 320, -300}) {
+    // N = -300: three (M, 300) planes back to back = one (3M, 300) matrix -- the same 760 MB as N = 900
+    const int64_t M = N < 0 ? 3 * M1 : M1;
+    if (N < 0) N = -N;
     const double bytes = (double)M * (N / 4 * 4) * 4;
     float t[7] = {run<0>(c, M, N, st), run<1>(c, M, N, st), run<2>(c, M, N, st), run<3>(c, M, N, st), run<4>(c, M, N, st),
                   run<5>(c, M, N, st), run<6>(c, M, N, st)};
