@@ -85,6 +85,9 @@ class NewsVectorCache:
     @torch.no_grad()
     def build(self) -> torch.Tensor:
         """news vectors (num_news, D) of the whole table, in chunks (the encoder workspace is O(rows))."""
+        if getattr(getattr(self.module, "hparams", None), "use_plm", False):
+            raise NotImplementedError("the PLM text encoder attends across the news of one call (text.py:92-96): "
+                                      "a news vector is not a function of the news alone and cannot be cached")
         was_training = self.module.training
         self.module.eval()
         enc = self.module.news_encoder

@@ -58,8 +58,8 @@ def prepare_batch(batch: Dict) -> Dict:
                 ids = torch.cat([h, c], dim=0)
                 out.setdefault("x_all", {})[attr] = ids
                 out["x_all"][attr + "_order"] = torch.argsort(ids.reshape(-1))
-            else:   # PLM tokenizer output: dict of (N, L) tensors (rec_dataset.py:180-190)
-                out.setdefault("x_all", {})[attr] = {k: torch.cat([h[k], c[k]], dim=0) for k in h.keys()}
+            # (PLM tokenizer output -- a dict of (N, L) tensors, rec_dataset.py:180-190 -- is NOT merged: the
+            #  two sides are padded to their own longest text and the PLM encoder must see them in separate calls)
     for attr in ("category", "subcategory"):
         if attr in batch["x_hist"] and attr in batch["x_cand"]:
             out.setdefault("x_all", {})[attr] = torch.cat([batch["x_hist"][attr], batch["x_cand"][attr]], dim=0)
@@ -140,7 +140,14 @@ class NRMSModule(AbstractRecommender):
         B = batch["batch_size"]
         hist_text = batch["x_hist"][self._text_attr]
         n_hist = (hist_text if torch.is_tensor(hist_text) else next(iter(hist_text.values()))).shape[0]
-        # one encoder call for history + candidate news (the reference makes two, :232,236)
+        if self.hparams.use_plm:
+            # the PLM encoder's seq-first attention runs ACROSS THE NEWS OF ONE CALL (text.py:92-96), so the two
+            # calls of the reference (:232,236) are NOT interchangeable with one call over [history; candidates]
+            hist_vec = self.news_encoder(batch["x_hist"])
+            cand_vec = self.news_encoder(batch["x_cand"])
+            return self.score_news_vectors(hist_vec, cand_vec, batch)
+        # rows of the MHSAAddAtt encoder are independent: one call for history + candidate news gives the same
+        # vectors as the reference's two (:232,236)
         news_vector = self.news_encoder(batch["x_all"])
         return self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch)
 

@@ -436,15 +436,14 @@ def test_nrms_module_with_plm_news_encoder_end_to_end(tmp_path, engine):
              "labels": torch.tensor([1., 0, 0, 0, 0] * 3), "user_ids": torch.arange(3) + 1,
              "user_idx": torch.arange(3)}
     scores = mod(batch_to(batch, DEV)).detach().cpu()
-    # oracle: one body call over [hist; cand] (attention across ALL news of the call, as the product does)
+    # oracle: TWO encoder calls as in the reference (nrms_module.py:232,236) -- the tail's seq-first attention
+    # runs across the news of ONE call, so history and candidates must not see each other
     body = AutoModel.from_pretrained(path).eval()
-    allt = {k: torch.cat([batch["x_hist"]["title"][k], batch["x_cand"]["title"][k]]) for k in ("input_ids", "attention_mask")}
     with torch.no_grad():
-        hidden = body(**allt)[0]
-        news = O.plm_tail_fwd(hidden, tail, PLM_HEADS)
-        nh = sum(hist_sizes)
-        hd, _ = O.to_dense_batch(news[:nh], batch["batch_hist"], 3)
-        cd, _ = O.to_dense_batch(news[nh:], batch["batch_cand"], 3)
+        hist_news = O.plm_tail_fwd(body(**batch["x_hist"]["title"])[0], tail, PLM_HEADS)
+        cand_news = O.plm_tail_fwd(body(**batch["x_cand"]["title"])[0], tail, PLM_HEADS)
+        hd, _ = O.to_dense_batch(hist_news, batch["batch_hist"], 3)
+        cd, _ = O.to_dense_batch(cand_news, batch["batch_cand"], 3)
         user = O.plm_tail_fwd(hd, utail, PLM_HEADS)         # same seq-first block = NRMS user encoder
         ref = O.click_scores(user, cd)
     err = float((scores - ref).abs().max())

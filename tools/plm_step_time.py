@@ -47,7 +47,7 @@ def main():
         ids = b[part]["title"].clamp_min(3)
         b[part]["title"] = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
     batch = prepare_batch(b)
-    n_news = batch["x_all"]["title"]["input_ids"].shape[0]
+    n_news = sum(batch[p]["title"]["input_ids"].shape[0] for p in ("x_hist", "x_cand"))
     trainer.step(batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
