@@ -16,6 +16,7 @@
 #include "nrl_gemm_bf16x3_dma.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
+#include "nrl_gru_fused.h"
 
 namespace nrl {
 
