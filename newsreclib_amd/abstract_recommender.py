@@ -56,6 +56,27 @@ class AbstractRecommender(LightningModuleBase):
         scl_loss = self.scl_criterion(scores, y_true, sizes)
         return (1 - hp.dual_loss_coef) * ce_loss + hp.dual_loss_coef * scl_loss
 
+    # -- the two news-encoder calls of every recommender's forward (e.g. nrms_module.py:232,236) ----
+    def _plm_text_encoder(self, plm_model, frozen_layers, embed_dim, num_heads, query_dim, dropout_probability):
+        """``PLM(use_mhsa=True, apply_reduce_dim=False)`` -- the configuration every recommender of the reference
+        builds under ``use_plm`` (e.g. lstur_module.py:158-170, naml_module.py:149-161)."""
+        from .news_encoder import PLM
+        assert isinstance(plm_model, str)
+        return PLM(plm_model=plm_model, frozen_layers=frozen_layers, embed_dim=embed_dim, use_mhsa=True,
+                   apply_reduce_dim=False, reduced_embed_dim=None, num_heads=num_heads, query_dim=query_dim,
+                   dropout_probability=dropout_probability)
+
+    def _encode_news(self, batch: Dict, seed=None):
+        """-> (history news vectors, candidate news vectors).  Row-independent text encoders see history and
+        candidates in ONE call (identical vectors, half the launches); the PLM encoder's seq-first attention
+        couples the news of a call (text.py:92-96), so there the reference's two calls are kept."""
+        if self.hparams.use_plm:
+            return (self.news_encoder(batch["x_hist"], seed=seed),
+                    self.news_encoder(batch["x_cand"], seed=seed, stream_base=4))
+        n_hist = batch["batch_hist"].shape[0]
+        news_vector = self.news_encoder(batch["x_all"], seed=seed)
+        return news_vector[:n_hist], news_vector[n_hist:]
+
     # -- reference: abstract_recommender.py:110-111 ------------------------------------------------
     def _init_embedding(self, filepath: str) -> torch.Tensor:
         return torch.from_numpy(np.load(filepath)).float()

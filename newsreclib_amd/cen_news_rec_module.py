@@ -58,16 +58,19 @@ class CenNewsRecModule(AbstractRecommender):
         self.num_sent_classes = num_sent_classes + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if use_plm:
-            raise NotImplementedError("newsreclib_amd.CenNewsRecModule covers use_plm=False")
         self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
-        assert isinstance(num_filters, int) and isinstance(window_size, int)
-        if pretrained_embeddings is None:
-            assert isinstance(pretrained_embeddings_path, str)
-            pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
-        text_encoder = CNNMHSAAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=embed_dim,
-                                     num_filters=num_filters, window_size=window_size, num_heads=num_heads,
-                                     query_dim=query_dim, dropout_probability=dropout_probability)
+        if use_plm:                                             # cen_news_rec_module.py:149-161; width :182
+            text_encoder = self._plm_text_encoder(plm_model, frozen_layers, embed_dim, num_heads, query_dim,
+                                                  dropout_probability)
+            num_filters = embed_dim
+        else:
+            assert isinstance(num_filters, int) and isinstance(window_size, int)
+            if pretrained_embeddings is None:
+                assert isinstance(pretrained_embeddings_path, str)
+                pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
+            text_encoder = CNNMHSAAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=embed_dim,
+                                         num_filters=num_filters, window_size=window_size, num_heads=num_heads,
+                                         query_dim=query_dim, dropout_probability=dropout_probability)
         self.news_encoder = NewsEncoder(
             dataset_attributes=dataset_attributes, attributes2encode=attributes2encode, concatenate_inputs=False,
             text_encoder=text_encoder, category_encoder=None, entity_encoder=None, combine_vectors=False,
@@ -85,11 +88,10 @@ class CenNewsRecModule(AbstractRecommender):
 
     def forward(self, batch: Dict, seed: Optional[int] = None) -> torch.Tensor:
         batch = prepare_batch(batch)
-        n_hist = batch["batch_hist"].shape[0]
         if self.training and seed is None:
             seed = _draw_seed()
-        news_vector = self.news_encoder(batch["x_all"], seed=seed)
-        return self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch, seed=seed)
+        hist_vec, cand_vec = self._encode_news(batch, seed)
+        return self.score_news_vectors(hist_vec, cand_vec, batch, seed=seed)
 
     def score_news_vectors(self, hist_news_vector: torch.Tensor, cand_news_vector: torch.Tensor, batch: Dict,
                            seed: Optional[int] = None) -> torch.Tensor:

@@ -63,16 +63,18 @@ class LSTURModule(AbstractRecommender):
         self.num_users = num_users + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if use_plm:
-            raise NotImplementedError("newsreclib_amd.LSTURModule covers use_plm=False (configs/model/lstur.yaml:13)")
         self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
 
-        if pretrained_embeddings is None:
-            assert isinstance(pretrained_embeddings_path, str)
-            pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
-        text_encoder = CNNAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=text_embed_dim,
-                                 num_filters=num_filters, window_size=window_size, query_dim=query_dim,
-                                 dropout_probability=dropout_probability)
+        if use_plm:                                             # lstur_module.py:158-170
+            text_encoder = self._plm_text_encoder(plm_model, frozen_layers, text_embed_dim, num_heads, query_dim,
+                                                  dropout_probability)
+        else:
+            if pretrained_embeddings is None:
+                assert isinstance(pretrained_embeddings_path, str)
+                pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
+            text_encoder = CNNAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=text_embed_dim,
+                                     num_filters=num_filters, window_size=window_size, query_dim=query_dim,
+                                     dropout_probability=dropout_probability)
         category_encoder = LinearEncoder(pretrained_embeddings=None, from_pretrained=False,
                                          freeze_pretrained_emb=False, num_categories=self.num_categ_classes,
                                          embed_dim=categ_embed_dim, use_dropout=False, dropout_probability=None,
@@ -102,11 +104,10 @@ class LSTURModule(AbstractRecommender):
     def forward(self, batch: Dict, seed: Optional[int] = None) -> torch.Tensor:
         batch = prepare_batch(batch)
         B = batch["batch_size"]
-        n_hist = batch["batch_hist"].shape[0]
         if self.training and seed is None:
             seed = _draw_seed()                       # one draw per step; streams separate the dropouts
-        news_vector = self.news_encoder(batch["x_all"], seed=seed)
-        return self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch, seed=seed)
+        hist_vec, cand_vec = self._encode_news(batch, seed)
+        return self.score_news_vectors(hist_vec, cand_vec, batch, seed=seed)
 
     def score_news_vectors(self, hist_news_vector: torch.Tensor, cand_news_vector: torch.Tensor, batch: Dict,
                            seed: Optional[int] = None) -> torch.Tensor:

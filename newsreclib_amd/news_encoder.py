@@ -206,7 +206,8 @@ class PLM(nn.Module):
         self.dropout = nn.Dropout(p=dropout_probability)
         self.num_heads = num_heads
 
-    def forward(self, text: Dict[str, torch.Tensor], seed: Optional[int] = None) -> torch.Tensor:
+    def forward(self, text: Dict[str, torch.Tensor], seed: Optional[int] = None, order=None,
+                stream0: int = 0) -> torch.Tensor:
         hidden = self.plm_model(**text)[0]                      # (N, L, D)
         p = float(self.dropout.p) if self.training else 0.0
         if p > 0.0 and seed is None:
@@ -214,7 +215,7 @@ class PLM(nn.Module):
         mha, att = self.multihead_attention, self.additive_attention
         params = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
                   att.linear.weight, att.linear.bias, att.query)
-        return ops.UserEncoderFn.apply(hidden, *params, self.num_heads, _grad_bufs(params), p, seed or 0)
+        return ops.UserEncoderFn.apply(hidden, *params, self.num_heads, _grad_bufs(params), p, seed or 0, True, stream0)
 
 
 class NewsEncoder(nn.Module):
@@ -276,7 +277,9 @@ class NewsEncoder(nn.Module):
         assert sorted(order) == sorted(self.text_encoders.keys())
         self.text_encoders = nn.ModuleDict({name: self.text_encoders[name] for name in order})
 
-    def forward(self, news: Dict[str, torch.Tensor], seed: Optional[int] = None) -> torch.Tensor:
+    def forward(self, news: Dict[str, torch.Tensor], seed: Optional[int] = None, stream_base: int = 0) -> torch.Tensor:
+        """``stream_base`` shifts the dropout streams of this call (a recommender that must make SEPARATE history /
+        candidate calls -- the PLM text encoder -- under one step seed gives the second call its own masks)."""
         vectors = []
         if self.encode_text:
             for name, encoder in self.text_encoders.items():
@@ -285,8 +288,8 @@ class NewsEncoder(nn.Module):
                     kw["seed"] = seed
                 if news.get(name + "_order") is not None:   # optional argsort of the flat ids (prepare_batch)
                     kw["order"] = news[name + "_order"]
-                if len(self.text_encoders) > 1:
-                    kw["stream0"] = TEXT_STREAMS[name]
+                if len(self.text_encoders) > 1 or stream_base:
+                    kw["stream0"] = TEXT_STREAMS[name] + stream_base
                 vectors.append(encoder(news[name], **kw))
         if self.encode_category:
             vectors += [encoder(news[name]) for name, encoder in self.category_encoders.items()]

@@ -59,17 +59,20 @@ class TANRModule(AbstractRecommender):
         self.num_sent_classes = num_sent_classes + 1
         if save_recs:
             assert isinstance(recs_fpath, str)
-        if use_plm:
-            raise NotImplementedError("newsreclib_amd.TANRModule covers use_plm=False (configs/model/tanr.yaml:13)")
         self._init_loss(loss, dual_loss_training, dual_loss_coef)      # CE / SupCon / dual
         self.topic_pred_loss = CrossEntropyLoss()
-        assert isinstance(num_filters, int) and isinstance(window_size, int)
-        if pretrained_embeddings is None:
-            assert isinstance(pretrained_embeddings_path, str)
-            pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
-        text_encoder = CNNAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=embed_dim,
-                                 num_filters=num_filters, window_size=window_size, query_dim=query_dim,
-                                 dropout_probability=dropout_probability)
+        if use_plm:                                             # tanr_module.py:154-166; widths :179,187,197
+            text_encoder = self._plm_text_encoder(plm_model, frozen_layers, embed_dim, num_heads, query_dim,
+                                                  dropout_probability)
+            num_filters = embed_dim
+        else:
+            assert isinstance(num_filters, int) and isinstance(window_size, int)
+            if pretrained_embeddings is None:
+                assert isinstance(pretrained_embeddings_path, str)
+                pretrained_embeddings = self._init_embedding(pretrained_embeddings_path)
+            text_encoder = CNNAddAtt(pretrained_embeddings=pretrained_embeddings, embed_dim=embed_dim,
+                                     num_filters=num_filters, window_size=window_size, query_dim=query_dim,
+                                     dropout_probability=dropout_probability)
         self.news_encoder = NewsEncoder(
             dataset_attributes=dataset_attributes, attributes2encode=attributes2encode, concatenate_inputs=False,
             text_encoder=text_encoder, category_encoder=None, entity_encoder=None, combine_vectors=False,
@@ -87,11 +90,12 @@ class TANRModule(AbstractRecommender):
     # -- reference: tanr_module.py:258-286 -------------------------------------------------------------
     def forward(self, batch: Dict, seed: Optional[int] = None):
         batch = prepare_batch(batch)
-        n_hist = batch["batch_hist"].shape[0]
         if self.training and seed is None:
             seed = _draw_seed()
-        news_vector = self.news_encoder(batch["x_all"], seed=seed)        # rows: [history; candidates]
-        scores = self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch)
+        hist_vec, cand_vec = self._encode_news(batch, seed)
+        n_hist = hist_vec.shape[0]
+        news_vector = torch.cat((hist_vec, cand_vec), dim=0)              # rows: [history; candidates]
+        scores = self.score_news_vectors(hist_vec, cand_vec, batch)
         # topic scores of every encoded news.  The reference orders the rows [candidates; history]
         # (tanr_module.py:284); the loss is a mean over rows, so the order only matters for the returned tensor.
         w, b = self.topic_predictor.weight, self.topic_predictor.bias

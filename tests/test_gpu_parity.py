@@ -606,3 +606,74 @@ def test_long_sequence_attention_on_matrix_cores(S, H, D, heads, engine):
     for k, p in enc.named_parameters():
         rg = op[P + k].grad
         assert _maxerr(p.grad, rg) <= 5e-4 * max(1.0, float(rg.abs().max())), k
+
+
+@pytest.mark.parametrize("model", ["lstur", "naml", "tanr", "mins", "cen"])
+def test_sibling_modules_with_plm_text_encoder(tmp_path, model):
+    """``use_plm=True`` through every sibling mirror: the PLM text encoder (pinned against the reference ``PLM`` by
+    plm_tiny.npz) is wired as in the reference -- TWO encoder calls, widths following the text vector -- and the
+    module's scores equal the composition of its own sub-modules called the reference's way; backward runs."""
+    from functools import partial
+
+    from tests.helpers import PLM_HEADS, PLM_Q, make_tiny_roberta
+    path = make_tiny_roberta(str(tmp_path))
+    common = dict(
+        dataset_attributes=["title", "abstract", "category"], outputs={"train": ["preds", "targets", "cand_news_size"], "val": [], "test": []},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False, temperature=None,
+        use_plm=True, pretrained_embeddings_path=None, plm_model=path, frozen_layers=[0], num_heads=PLM_HEADS,
+        query_dim=PLM_Q, dropout_probability=0.2, top_k_list=[5, 10], num_categ_classes=6, num_sent_classes=3,
+        save_recs=False, recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None)
+    two_text = ["title", "abstract", "category"]
+    if model == "lstur":
+        from newsreclib_amd.lstur_module import LSTURModule
+        mod = LSTURModule(attributes2encode=two_text, text_embed_dim=96, num_filters=96, window_size=3, categ_embed_dim=16,
+                          num_users=8, user_masking_probability=0.5, long_short_term_method="ini", **common)
+    elif model == "naml":
+        from newsreclib_amd.naml_module import NAMLModule
+        mod = NAMLModule(attributes2encode=two_text, text_embed_dim=96, num_filters=None, window_size=None,
+                         categ_embed_dim=16, **common)
+    elif model == "tanr":
+        from newsreclib_amd.tanr_module import TANRModule
+        mod = TANRModule(attributes2encode=["title"], embed_dim=96, num_filters=None, window_size=None,
+                         topic_pred_loss_coef=0.2, **common)
+    elif model == "mins":
+        from newsreclib_amd.mins_module import MINSModule
+        mod = MINSModule(attributes2encode=two_text, text_embed_dim=96, categ_embed_dim=16, num_filters=96,
+                         num_gru_channels=6, **common)
+    else:
+        from newsreclib_amd.cen_news_rec_module import CenNewsRecModule
+        mod = CenNewsRecModule(attributes2encode=["title"], embed_dim=96, num_filters=None, window_size=None,
+                               gru_hidden_dim=96, num_recent_news=2, **common)
+    mod = mod.to(DEV).eval()
+    rng = np.random.default_rng(5)
+    hist_sizes, cand_sizes = [2, 3, 1], [5, 5, 5]
+
+    def toks(n, L):
+        ids = rng.integers(3, 200, (n, L))
+        lens = rng.integers(3, L + 1, n)
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+        return {"input_ids": torch.from_numpy(np.where(m == 1, ids, 1)), "attention_mask": torch.from_numpy(m)}
+
+    def side(n):            # history and candidates are padded to DIFFERENT lengths, as the per-call tokenizer does
+        return {"title": toks(n, 8 + n % 3), "abstract": toks(n, 12 + n % 2), "category": torch.from_numpy(rng.integers(1, 7, n))}
+
+    batch = batch_to({"x_hist": side(sum(hist_sizes)), "x_cand": side(sum(cand_sizes)),
+                      "batch_hist": torch.repeat_interleave(torch.arange(3), torch.tensor(hist_sizes)),
+                      "batch_cand": torch.repeat_interleave(torch.arange(3), torch.tensor(cand_sizes)),
+                      "labels": torch.tensor([1., 0, 0, 0, 0] * 3), "user_ids": torch.arange(3) + 1,
+                      "user_idx": torch.tensor([1, 2, 3])}, DEV)
+    from newsreclib_amd.nrms_module import prepare_batch
+    pb = prepare_batch(batch)
+    out = mod.forward(pb)
+    scores = out[0] if isinstance(out, tuple) else out
+    with torch.no_grad():    # the reference's order of calls: news_encoder(x_hist), news_encoder(x_cand)
+        hv, cv = mod.news_encoder(pb["x_hist"]), mod.news_encoder(pb["x_cand"])
+        ref = mod.score_news_vectors(hv, cv, pb)
+    assert torch.equal(scores.detach(), ref)
+    assert scores.shape == (3, 5) and bool(torch.isfinite(scores).all())
+    mod.train()
+    loss = mod.model_step(pb)[0]
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in mod.parameters() if p.grad is not None)
+    body_grads = [p.grad for n, p in mod.named_parameters() if "plm_model" in n and p.grad is not None]
+    assert body_grads and any(float(g.abs().max()) > 0 for g in body_grads)
