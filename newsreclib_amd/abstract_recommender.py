@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from ._lightning import LightningModuleBase
-from .dense_batch import to_dense_batch
+from .dense_batch import dense_rows
 from .metrics import aspect_metrics, ranking_metrics
 
 
@@ -87,7 +87,7 @@ class AbstractRecommender(LightningModuleBase):
         B = batch["batch_size"]
         out = self.forward(batch)
         scores, aux = out if isinstance(out, tuple) else (out, None)
-        y_true, _ = to_dense_batch(batch["labels"], batch["batch_cand"], B, batch["max_cand"],
+        y_true = dense_rows(batch["labels"], batch["batch_cand"], B, batch["max_cand"],
                                    batch["cand_offsets"], batch["cand_flat_idx"])
         loss = self._loss(scores, y_true.float(), batch)
         if aux is not None:          # recommenders with an auxiliary task (TANR topic prediction)
@@ -97,8 +97,7 @@ class AbstractRecommender(LightningModuleBase):
         # reference's per-user concatenation (abstract_recommender.py:126-130), no loops, no syncs
         preds = scores.detach().reshape(-1)[batch["cand_flat_idx"]]
         targets = batch["labels"]
-        cand_news_size = batch["cand_offsets"][1:] - batch["cand_offsets"][:-1]
-        hist_news_size = batch["hist_offsets"][1:] - batch["hist_offsets"][:-1]
+        cand_news_size, hist_news_size = batch["cand_sizes"], batch["hist_sizes"]    # == the mask row sums (:331-345)
 
         def attr(side, name):
             v = batch["x_" + side].get(name)

@@ -14,7 +14,7 @@ import torch
 from . import ops
 from .abstract_recommender import AbstractRecommender
 from .click_predictor import DotProduct
-from .dense_batch import to_dense_batch
+from .dense_batch import dense_rows
 from .news_encoder import CNNMHSAAddAtt, NewsEncoder, _draw_seed
 from .nrms_module import prepare_batch
 from .user_encoder_cen_news_rec import UserEncoder
@@ -96,9 +96,9 @@ class CenNewsRecModule(AbstractRecommender):
     def score_news_vectors(self, hist_news_vector: torch.Tensor, cand_news_vector: torch.Tensor, batch: Dict,
                            seed: Optional[int] = None) -> torch.Tensor:
         B = batch["batch_size"]
-        hist_news_vector_agg, _ = to_dense_batch(hist_news_vector, batch["batch_hist"], B,
+        hist_news_vector_agg = dense_rows(hist_news_vector, batch["batch_hist"], B,
                                                  batch["max_hist"], batch["hist_offsets"])
-        cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
+        cand_news_vector_agg = dense_rows(cand_news_vector, batch["batch_cand"], B,
                                                  batch["max_cand"], batch["cand_offsets"])
         if not self.hparams.late_fusion:
             user_vector = self.user_encoder(hist_news_vector_agg, seed=seed)

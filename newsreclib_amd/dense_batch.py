@@ -14,25 +14,37 @@ def to_dense_batch(x: torch.Tensor, batch: torch.Tensor, batch_size: Optional[in
 
     ``batch_size`` / ``max_num_nodes`` / ``offsets`` may be supplied to avoid the two device->host
     syncs the shapes otherwise cost (the reference pays them inside torch_geometric)."""
+    batch_size, max_num_nodes, offsets = _resolve(batch, batch_size, max_num_nodes, offsets)
+    counts = offsets[1:] - offsets[:-1]
+    mask = torch.arange(max_num_nodes, device=x.device)[None, :] < counts[:, None]
+    return dense_rows(x, batch, batch_size, max_num_nodes, offsets, flat_idx), mask
+
+
+def _resolve(batch, batch_size, max_num_nodes, offsets):
     if batch_size is None:
         batch_size = int(batch.max()) + 1 if batch.numel() else 0
     if offsets is None:
         offsets = ops.offsets_from_sorted_batch(batch, batch_size)
     if max_num_nodes is None:
         max_num_nodes = int((offsets[1:] - offsets[:-1]).max()) if batch_size else 0
-    counts = offsets[1:] - offsets[:-1]
-    mask = torch.arange(max_num_nodes, device=x.device)[None, :] < counts[:, None]
+    return batch_size, max_num_nodes, offsets
+
+
+def dense_rows(x: torch.Tensor, batch: torch.Tensor, batch_size: Optional[int] = None,
+               max_num_nodes: Optional[int] = None, offsets: Optional[torch.Tensor] = None,
+               flat_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The dense tensor of ``to_dense_batch`` without the mask (every call site on the step path discards it, and
+    building it costs three small launches per call)."""
+    batch_size, max_num_nodes, offsets = _resolve(batch, batch_size, max_num_nodes, offsets)
     if x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0:
-        dense = ops.ToDenseBatchFn.apply(x, offsets, batch_size, max_num_nodes)
-    else:
-        # label / category vectors: (N,) of any dtype -- tiny index bookkeeping, not arithmetic;
-        # explicit slot indices instead of a boolean-mask store (which would sync the host)
-        if flat_idx is None:
-            flat_idx = dense_slot_index(batch, offsets, max_num_nodes)
-        dense = x.new_zeros((batch_size * max_num_nodes,) + tuple(x.shape[1:]))
-        dense[flat_idx] = x
-        dense = dense.view((batch_size, max_num_nodes) + tuple(x.shape[1:]))
-    return dense, mask
+        return ops.ToDenseBatchFn.apply(x, offsets, batch_size, max_num_nodes)
+    # label / category vectors: (N,) of any dtype -- tiny index bookkeeping, not arithmetic;
+    # explicit slot indices instead of a boolean-mask store (which would sync the host)
+    if flat_idx is None:
+        flat_idx = dense_slot_index(batch, offsets, max_num_nodes)
+    dense = x.new_zeros((batch_size * max_num_nodes,) + tuple(x.shape[1:]))
+    dense[flat_idx] = x
+    return dense.view((batch_size, max_num_nodes) + tuple(x.shape[1:]))
 
 
 def dense_slot_index(batch: torch.Tensor, offsets: torch.Tensor, max_num_nodes: int) -> torch.Tensor:

@@ -24,7 +24,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import ops
-from .dense_batch import to_dense_batch
+from .dense_batch import dense_rows
 from .nrms_module import prepare_batch
 
 TEXT_ATTRS = ("title", "abstract")
@@ -140,7 +140,7 @@ class NewsVectorCache:
         dev = self.table.device
         meta = self._meta(hist_sizes, cand_sizes, labels, user_idx, user_ids)
         scores = self.scores(hist_idx, hist_sizes, cand_idx, cand_sizes, user_idx)
-        y_true, _ = to_dense_batch(meta["labels"], meta["batch_cand"], meta["batch_size"], meta["max_cand"],
+        y_true = dense_rows(meta["labels"], meta["batch_cand"], meta["batch_size"], meta["max_cand"],
                                    meta["cand_offsets"], meta["cand_flat_idx"])
         loss = self.module._loss(scores, y_true.float(), meta)
         preds = scores.reshape(-1)[meta["cand_flat_idx"]]

@@ -16,7 +16,7 @@ import torch
 from . import ops
 from .abstract_recommender import AbstractRecommender
 from .click_predictor import DotProduct
-from .dense_batch import to_dense_batch
+from .dense_batch import dense_rows
 from .news_encoder import CNNAddAtt, LinearEncoder, NewsEncoder, _draw_seed
 from .nrms_module import prepare_batch
 from .user_encoder_lstur import UserEncoder
@@ -113,9 +113,9 @@ class LSTURModule(AbstractRecommender):
                            seed: Optional[int] = None) -> torch.Tensor:
         """lstur_module.py:280-303 from already-encoded news rows (see ``evaluation.NewsVectorCache``)."""
         B = batch["batch_size"]
-        hist_news_vector_agg, _ = to_dense_batch(hist_news_vector, batch["batch_hist"], B,
+        hist_news_vector_agg = dense_rows(hist_news_vector, batch["batch_hist"], B,
                                                  batch["max_hist"], batch["hist_offsets"])
-        cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
+        cand_news_vector_agg = dense_rows(cand_news_vector, batch["batch_cand"], B,
                                                  batch["max_cand"], batch["cand_offsets"])
         hist_size = batch["hist_sizes"]               # == mask_hist row sums (lstur_module.py:287-290)
         if not self.hparams.late_fusion:

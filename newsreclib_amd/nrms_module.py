@@ -21,7 +21,7 @@ import torch
 from . import ops
 from .abstract_recommender import AbstractRecommender
 from .click_predictor import DotProduct
-from .dense_batch import dense_slot_index, to_dense_batch
+from .dense_batch import dense_rows, dense_slot_index
 from .news_encoder import PLM, MHSAAddAtt, NewsEncoder
 from .user_encoder import UserEncoder
 
@@ -156,9 +156,9 @@ class NRMSModule(AbstractRecommender):
         """nrms_module.py:233-253 from already-encoded news rows (also the entry of the evaluation path that
         encodes every unique news once, ``evaluation.NewsVectorCache``)."""
         B = batch["batch_size"]
-        hist_news_vector_agg, _ = to_dense_batch(hist_news_vector, batch["batch_hist"], B,
+        hist_news_vector_agg = dense_rows(hist_news_vector, batch["batch_hist"], B,
                                                  batch["max_hist"], batch["hist_offsets"])
-        cand_news_vector_agg, _ = to_dense_batch(cand_news_vector, batch["batch_cand"], B,
+        cand_news_vector_agg = dense_rows(cand_news_vector, batch["batch_cand"], B,
                                                  batch["max_cand"], batch["cand_offsets"])
         if not self.hparams.late_fusion:
             user_vector = self.user_encoder(hist_news_vector_agg)

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops_blocks
-from .dense_batch import to_dense_batch
+from .dense_batch import dense_rows
 from .nrms_module import NRMSModule, prepare_batch
 
 
@@ -95,9 +95,9 @@ class SentiRecModule(NRMSModule):
         # (:348-352) the predictor's scores are replaced by the labels before the L1 loss: exactly 0
         sent_labels = torch.cat((batch["x_cand"]["sentiment_score"], batch["x_hist"]["sentiment_score"]))
         loss = self.hparams.sent_pred_loss_coef * self.sent_pred_loss(sent_labels.flatten(), sent_labels)
-        sent_hist, _ = to_dense_batch(batch["x_hist"]["sentiment_score"], batch["batch_hist"], B, batch["max_hist"],
+        sent_hist = dense_rows(batch["x_hist"]["sentiment_score"], batch["batch_hist"], B, batch["max_hist"],
                                       batch["hist_offsets"])
-        sent_cand, _ = to_dense_batch(batch["x_cand"]["sentiment_score"], batch["batch_cand"], B, batch["max_cand"],
+        sent_cand = dense_rows(batch["x_cand"]["sentiment_score"], batch["batch_cand"], B, batch["max_cand"],
                                       batch["cand_offsets"], batch["cand_flat_idx"])
         user_mean_sent_score = sent_hist.sum(dim=1) / batch["hist_sizes"].to(sent_hist.dtype)          # :360-362
         sent_div_loss = torch.relu(user_mean_sent_score.unsqueeze(dim=-1) * sent_cand * scores).mean()  # :363
