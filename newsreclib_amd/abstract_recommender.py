@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from ._lightning import LightningModuleBase
+from . import ops
 from .dense_batch import dense_rows
 from .metrics import aspect_metrics, ranking_metrics
 
@@ -75,7 +76,7 @@ class AbstractRecommender(LightningModuleBase):
                     self.news_encoder(batch["x_cand"], seed=seed, stream_base=4))
         n_hist = batch["batch_hist"].shape[0]
         news_vector = self.news_encoder(batch["x_all"], seed=seed)
-        return news_vector[:n_hist], news_vector[n_hist:]
+        return ops.split_rows(news_vector, n_hist)
 
     # -- reference: abstract_recommender.py:110-111 ------------------------------------------------
     def _init_embedding(self, filepath: str) -> torch.Tensor:

@@ -149,7 +149,7 @@ class NRMSModule(AbstractRecommender):
         # rows of the MHSAAddAtt encoder are independent: one call for history + candidate news gives the same
         # vectors as the reference's two (:232,236)
         news_vector = self.news_encoder(batch["x_all"])
-        return self.score_news_vectors(news_vector[:n_hist], news_vector[n_hist:], batch)
+        return self.score_news_vectors(*ops.split_rows(news_vector, n_hist), batch)
 
     def score_news_vectors(self, hist_news_vector: torch.Tensor, cand_news_vector: torch.Tensor,
                            batch: Dict) -> torch.Tensor:

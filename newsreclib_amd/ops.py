@@ -314,6 +314,24 @@ class SupConFn(torch.autograd.Function):
         return d_scores * g, None, None, None
 
 
+class SplitRowsFn(torch.autograd.Function):
+    """(x[:n], x[n:]) whose backward is ONE concatenation.  (Plain slicing makes autograd zero-fill two full-size
+    gradients, copy a slice into each and add them: five launches where one does.)"""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = int(n)
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, g_head, g_tail):
+        return torch.cat((g_head, g_tail), dim=0), None
+
+
+def split_rows(x: torch.Tensor, n: int):
+    return SplitRowsFn.apply(x, n) if x.requires_grad else (x[:n], x[n:])
+
+
 # ---- plain (non-autograd) entry points ----------------------------------------------------------
 def embedding_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()

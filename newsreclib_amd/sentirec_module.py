@@ -21,7 +21,7 @@ from typing import Any, Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops_blocks
+from . import ops, ops_blocks
 from .dense_batch import dense_rows
 from .nrms_module import NRMSModule, prepare_batch
 
@@ -77,7 +77,7 @@ class SentiRecModule(NRMSModule):
         else:
             n_hist = batch["batch_hist"].shape[0]
             news_vector = self.news_encoder(batch["x_all"])
-            hist_vec, cand_vec = news_vector[:n_hist], news_vector[n_hist:]
+            hist_vec, cand_vec = ops.split_rows(news_vector, n_hist)
         scores = self.score_news_vectors(hist_vec, cand_vec, batch)
         w, b = self.sent_predictor.weight, self.sent_predictor.bias
         n_cls = w.shape[0]
