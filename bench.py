@@ -179,6 +179,20 @@ def main():
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "gemm_engine": args.engine},
             "roofline": roof,
         }
+        if world == 1:
+            # the forward-only (evaluation-mode) rate of the same workload, outside the timed region
+            mod.eval()
+            with torch.no_grad():
+                for i in range(3):
+                    mod.forward(batches[i % N_BATCHES])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(20):
+                    mod.forward(batches[i % N_BATCHES])
+                torch.cuda.synchronize()
+            fdt = (time.perf_counter() - t1) / 20
+            mod.train()
+            out["forward_only"] = {"value": round(B_PER_GPU / fdt, 1), "unit": "impressions/s", "ms": round(fdt * 1e3, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
