@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 6
+#define NRL_ABI_VERSION 7
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -57,7 +57,9 @@ typedef struct NrlBlockParams {
   int32_t embed_dim;  /* D, multiple of 4 */
   int32_t num_heads;  /* D / num_heads in {16, 20, 32, 48, 64} */
   int32_t query_dim;  /* Q, multiple of 4 */
-  int32_t reserved;
+  int32_t gemm_engine; /* projection engine of THIS call: 0 = process default (nrl_set_gemm_engine),
+                        * 1 = exact fp32, 2 = bf16x3.  A backward must be given the value its forward ran under
+                        * (the bf16 weight planes in the workspace exist only under bf16x3). */
 } NrlBlockParams;
 
 /* Gradient accumulators, same shapes as NrlBlockParams; kernels ADD into them (callers zero
@@ -75,7 +77,8 @@ typedef struct NrlBlockGrads {
 int nrl_abi_version(void);
 const char* nrl_last_error(void);
 
-/* ---- projection GEMM engine (process-wide; the same entry points serve both) ------------------
+/* ---- projection GEMM engine: the process DEFAULT, used by calls whose params carry gemm_engine == 0 and by the
+ * entry points whose params have no such field (the same entry points serve both engines) ------
  *   0 = exact fp32: v_mfma_f32_16x16x4_f32, bitwise an fmaf chain (the reference's arithmetic type)
  *   1 = "bf16x3" (default): fp32 operands split a = hi + lo (two bf16), three bf16 MFMAs per product
  *       (hi*hi + hi*lo + lo*hi) with fp32 accumulation; ~2^-16 relative per product, scores within
@@ -359,7 +362,7 @@ typedef struct NrlMhaParams {
   int32_t embed_dim;            /* D, multiple of 4; D / num_heads in {16, 20, 32, 48, 64} */
   int32_t num_heads;
   float scale;
-  int32_t reserved;
+  int32_t gemm_engine;          /* as NrlBlockParams.gemm_engine */
 } NrlMhaParams;
 
 typedef struct NrlMhaGrads {

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -19,7 +19,7 @@ class NrlBlockParams(ctypes.Structure):
         ("in_proj_weight", c_void_p), ("in_proj_bias", c_void_p),
         ("out_proj_weight", c_void_p), ("out_proj_bias", c_void_p),
         ("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p),
-        ("embed_dim", c_int32), ("num_heads", c_int32), ("query_dim", c_int32), ("reserved", c_int32),
+        ("embed_dim", c_int32), ("num_heads", c_int32), ("query_dim", c_int32), ("gemm_engine", c_int32),
     ]
 
 
@@ -65,7 +65,7 @@ class NrlAddAttGrads(ctypes.Structure):
 class NrlMhaParams(ctypes.Structure):
     _fields_ = [("in_proj_weight", c_void_p), ("in_proj_bias", c_void_p), ("out_proj_weight", c_void_p),
                 ("out_proj_bias", c_void_p), ("embed_dim", c_int32), ("num_heads", c_int32), ("scale", ctypes.c_float),
-                ("reserved", c_int32)]
+                ("gemm_engine", c_int32)]
 
 
 class NrlMhaGrads(ctypes.Structure):
@@ -197,6 +197,20 @@ def set_gemm_engine(name: str) -> None:
 def get_gemm_engine() -> str:
     code = load().nrl_get_gemm_engine()
     return {v: k for k, v in ENGINES.items()}[code]
+
+
+def engine_code() -> int:
+    """The per-call engine value (1 = f32, 2 = bf16x3) of the current process default: captured by every
+    autograd forward and handed to its backward, so a default changed in between cannot mix engines."""
+    return load().nrl_get_gemm_engine() + 1
+
+
+def require_engine(code: int, what: str) -> None:
+    """Backward of an entry point whose params carry no per-call engine: refuse to run under another engine
+    than the forward did (the saved workspace holds that engine's weight planes / layouts)."""
+    if engine_code() != code:
+        raise RuntimeError(f"newsreclib_amd: the GEMM engine changed between the forward and the backward of {what}; "
+                           "set the engine before the forward and keep it until the backward has run")
 
 
 def check(rc: int, what: str) -> None:

@@ -4,10 +4,12 @@
 lstur_module.py:308-410 -- identical apart from the class name)."""
 from __future__ import annotations
 
-from typing import Any, Dict, Tuple
+import json
+from typing import Any, Dict, List, Tuple
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from ._lightning import LightningModuleBase
 from . import ops
@@ -135,12 +137,37 @@ class AbstractRecommender(LightningModuleBase):
         self._track("test", loss)
         self.test_step_outputs = self._collect_step_outputs(self.test_step_outputs, locals())
 
+    # -- data-parallel epoch ends: every rank sees every rank's step outputs -------------------------
+    @staticmethod
+    def _world() -> int:
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _gather_outputs(self, outputs: Dict[str, list]) -> Dict[str, list]:
+        """All-gather the per-rank step outputs (ragged, so as objects; epoch-end only) and concatenate them in
+        rank order.  The reference's torchmetrics objects synchronise their states across DDP ranks at compute()
+        (SURVEY.md section 5); with plain floats logged here the gather is explicit.  Impressions keep their own
+        group: the reference restarts its `indexes` at 0 on every rank (nrms_module.py:385,429,487), which would
+        merge unrelated impressions under torchmetrics' sync -- that collision is not reproduced."""
+        if self._world() == 1:
+            return outputs
+        local = {k: [t.detach().cpu() for t in v if torch.is_tensor(t)] for k, v in outputs.items()}
+        gathered: List[Dict[str, list]] = [None] * self._world()
+        dist.all_gather_object(gathered, local)
+        dev = self.device
+        return {k: [t.to(dev) for part in gathered for t in part.get(k, [])] for k in outputs}
+
     def _epoch_end(self, stage: str, outputs: Dict[str, list]) -> Dict[str, float]:
         s = self._loss_sums[stage]
         logs = {}
+        if self._world() > 1:
+            tot = torch.tensor([float(s[0]), float(s[1])], dtype=torch.float64, device=self.device)
+            dist.all_reduce(tot)                       # mean over the steps of ALL ranks (MeanMetric sync)
+            s = [float(tot[0]), int(tot[1])]
         if s[1]:
             logs[f"{stage}/loss"] = float(s[0]) / s[1]
-        if outputs.get("preds"):
+        local_outputs = outputs
+        outputs = self._gather_outputs(outputs)
+        if outputs.get("preds") and outputs.get("targets") and outputs.get("cand_news_size"):
             m = ranking_metrics(torch.cat(outputs["preds"]), torch.cat(outputs["targets"]),
                                 torch.cat(outputs["cand_news_size"]), self.hparams.top_k_list)
             logs.update({f"{stage}/{k}": v for k, v in m.items()})
@@ -155,11 +182,43 @@ class AbstractRecommender(LightningModuleBase):
                                        torch.cat(outputs["cand_news_size"]), torch.cat(outputs["hist_news_size"]),
                                        ncls, self.hparams.top_k_list, prefix="categ" if asp == "categories" else "sent")
                     logs.update({f"{stage}/{k}": v for k, v in a.items()})
-        for v in outputs.values():
+        if stage == "test" and getattr(self.hparams, "save_recs", False) and outputs.get("user_ids") \
+                and outputs.get("cand_news_ids") and outputs.get("preds"):
+            # nrms_module.py:520-531
+            recs = self._get_recommendations(user_ids=torch.cat(outputs["user_ids"]),
+                                             news_ids=torch.cat(outputs["cand_news_ids"]),
+                                             scores=torch.cat(outputs["preds"]),
+                                             cand_news_size=torch.cat(outputs["cand_news_size"]))
+            if self._world() == 1 or dist.get_rank() == 0:
+                self._save_recommendations(recommendations=recs, fpath=self.hparams.recs_fpath)
+        elif stage == "test" and getattr(self.hparams, "save_recs", False):
+            raise RuntimeError("save_recs=True needs `user_ids`, `cand_news_ids`, `preds` and `cand_news_size` among "
+                               "outputs.test (configs/model/nrms.yaml lists them)")
+        for v in local_outputs.values():
             v.clear()
         self._loss_sums[stage] = [0.0, 0]
         self.log_dict(logs, on_step=False, on_epoch=True, prog_bar=True, logger=True)
         return logs
+
+    # -- reference: abstract_recommender.py:159-193 ------------------------------------------------
+    def _get_recommendations(self, user_ids: torch.Tensor, news_ids: torch.Tensor, scores: torch.Tensor,
+                             cand_news_size: torch.Tensor) -> Dict[str, Dict[str, float]]:
+        """{"U<user id>": {"N<news id>": score, ...}, ...}; a user seen in several impressions keeps ONE entry per
+        news, the later score overwriting the earlier, as the reference's dictionary fill does."""
+        sizes = cand_news_size.detach().cpu()
+        users = torch.repeat_interleave(user_ids.detach().cpu(), sizes).tolist()
+        news = news_ids.detach().cpu().tolist()
+        vals = scores.detach().cpu().tolist()
+        if not (len(users) == len(news) == len(vals)):
+            raise ValueError("recommendations: user / news / score vectors disagree in length")
+        recs: Dict[str, Dict[str, float]] = {}
+        for u, n, v in zip(users, news, vals):
+            recs.setdefault(f"U{u}", {})[f"N{n}"] = v
+        return recs
+
+    def _save_recommendations(self, recommendations: Dict[str, Dict[str, float]], fpath: str) -> None:
+        with open(fpath, "w") as f:
+            json.dump(recommendations, f)
 
     def on_train_epoch_end(self) -> None:
         self._epoch_end("train", self.training_step_outputs)

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <utility>
 #include <vector>
 
@@ -87,7 +88,21 @@ struct ProfScope {
 #define X3_DMA_TILE_Q 4, 2, 2, 7, 2  // 128 x 224, 8 waves: Q = 200 in one column tile (0.32 -> 0.24 ms)
 
 enum { ENGINE_F32 = 0, ENGINE_BF16X3 = 1 };
-static int g_engine = ENGINE_BF16X3;
+// Engine selection.  The per-call choice (NrlBlockParams.gemm_engine / NrlMhaParams.gemm_engine: 1 = f32,
+// 2 = bf16x3) wins; 0 means "the process default" (nrl_set_gemm_engine).  The value a call runs under is
+// fixed at its entry (EngineScope) and kept thread-local, so a concurrent nrl_set_gemm_engine on another
+// thread cannot change it halfway through a call.
+static std::atomic<int> g_default_engine{ENGINE_BF16X3};
+static thread_local int t_engine = -1;
+static inline int cur_engine() { return t_engine >= 0 ? t_engine : g_default_engine.load(std::memory_order_relaxed); }
+struct EngineScope {
+  int prev;
+  explicit EngineScope(int per_call) : prev(t_engine) {
+    t_engine = per_call > 0 ? per_call - 1 : g_default_engine.load(std::memory_order_relaxed);
+  }
+  ~EngineScope() { t_engine = prev; }
+};
+static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 // A/B switch for measurements: NRL_X3_DMA=0 keeps every bf16x3 GEMM on the register-staged kernel
 static const bool g_x3_dma = [] {
   const char* e = getenv("NRL_X3_DMA");
@@ -159,6 +174,7 @@ static int check_params(const NrlBlockParams* p) {
   NRL_REQUIRE(p != nullptr, "params struct is null");
   NRL_REQUIRE(p->in_proj_weight && p->in_proj_bias && p->out_proj_weight && p->out_proj_bias &&
                   p->att_weight && p->att_bias && p->att_query, "null parameter pointer");
+  NRL_REQUIRE(engine_field_ok(p->gemm_engine), "gemm_engine must be 0 (default), 1 (f32) or 2 (bf16x3)");
   NRL_REQUIRE(p->embed_dim > 0 && p->embed_dim % 4 == 0, "embed_dim must be a positive multiple of 4");
   NRL_REQUIRE(p->query_dim > 0 && p->query_dim % 4 == 0, "query_dim must be a positive multiple of 4");
   NRL_REQUIRE(p->num_heads > 0 && p->embed_dim % p->num_heads == 0, "embed_dim must be divisible by num_heads");
@@ -198,7 +214,7 @@ static bool big_tiles(int64_t M, int N) { return ceil_div(M, 256) * ceil_div(N, 
 template <class AOp, class Epi>
 static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int N, int K,
                     bool q_tile, hipStream_t st) {
-  if (g_engine == ENGINE_BF16X3) {
+  if (cur_engine() == ENGINE_BF16X3) {
     const KCSplit b{sw.hi, sw.lo, sw.ld, N};
     if constexpr (!std::is_same<AOp, KCGather>::value) if (g_x3_dma) {
       // (the gathered operand keeps the register-staged kernel: its dropout hash would be re-evaluated by
@@ -220,7 +236,7 @@ template <class Epi>
 static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int Nw,
                       int Kw, hipStream_t st) {
   const KCPlain a{dy, Nw, M};
-  if (g_engine == ENGINE_BF16X3) {
+  if (cur_engine() == ENGINE_BF16X3) {
     const KCSplit b{sw.hi_t, sw.lo_t, sw.ld_t, Kw};
     if (g_x3_dma) return launch_gemm_bf16x3_dma<X3_DMA_TILE>(a, b, epi, M, Kw, Nw, st);
     if (big_tiles(M, Kw)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, Kw, Nw, 1, st);
@@ -234,7 +250,7 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
                       hipStream_t st) {
   const RCPlain a{dy, I, I, 0}, b{x, J, J, 1};
   const EpiAtomicWB epi{dW, J, db, J};
-  if (g_engine == ENGINE_BF16X3) {
+  if (cur_engine() == ENGINE_BF16X3) {
     // ~1.6k rows per k-split (profiles/r01_gemm_bf16x3_probe.txt): the split's operand slices are
     // re-read by all of its tiles from ONE XCD's L2 (split -> XCD mapping in the kernel)
     auto splits = [&](int bm) {
@@ -261,7 +277,7 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
   const int D = s.D, Q = s.Q;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
   BlockPlanes bp;
-  NRL_TRY(block_planes(P, s, w, g_engine == ENGINE_BF16X3, &bp, st));
+  NRL_TRY(block_planes(P, s, w, cur_engine() == ENGINE_BF16X3, &bp, st));
   // q|k|v = x W_in^T + b_in           (text.py:229 / user/nrms.py:34; torch in-projection)
   {
     ProfScope prof(st, prof_in_proj ? 2.0 * (double)s.M * 3.0 * D * D : 0.0);
@@ -380,10 +396,10 @@ int nrl_prof_read(double* total_ms, int64_t* launches, double* total_flops) {
 
 int nrl_set_gemm_engine(int32_t engine) {
   NRL_REQUIRE(engine == ENGINE_F32 || engine == ENGINE_BF16X3, "unknown GEMM engine %d", engine);
-  g_engine = engine;
+  g_default_engine.store(engine);
   return NRL_OK;
 }
-int nrl_get_gemm_engine(void) { return g_engine; }
+int nrl_get_gemm_engine(void) { return g_default_engine.load(); }
 
 uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream) { return dropout_key(seed, stream); }
 
@@ -403,6 +419,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
                          uint64_t seed, uint32_t stream0, int32_t save_for_backward, float* out,
                          void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
+  const EngineScope engine_scope(p->gemm_engine);
   NRL_REQUIRE(emb_table && ids && out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_fwd: bad arguments");
   NRL_REQUIRE(((uintptr_t)emb_table & 15) == 0, "embedding table must be 16-byte aligned");
   NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
@@ -421,6 +438,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
                          int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed, uint32_t stream0,
                          const float* d_out, int32_t phase, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
+  const EngineScope engine_scope(p->gemm_engine);
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(d_emb_table && ids && d_out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_bwd: bad arguments");
   NRL_REQUIRE(phase >= 0 && phase <= 2, "news_encoder_bwd: phase must be 0 (all), 1 or 2");
@@ -459,6 +477,7 @@ int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t bat
                          double p_drop, uint64_t seed, uint32_t stream0, int32_t input_dropout,
                          int32_t save_for_backward, float* out, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
+  const EngineScope engine_scope(p->gemm_engine);
   NRL_REQUIRE(hist && out && batch > 0 && hist_len > 0, "user_encoder_fwd: bad arguments");
   NRL_REQUIRE(((uintptr_t)hist & 15) == 0, "hist must be 16-byte aligned");
   NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
@@ -483,6 +502,7 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
                          int32_t input_dropout, const float* d_out, float* d_hist, void* ws, size_t ws_bytes,
                          void* stream) {
   NRL_TRY(check_params(p));
+  const EngineScope engine_scope(p->gemm_engine);
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(hist && d_out && d_hist && batch > 0 && hist_len > 0, "user_encoder_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -573,7 +593,7 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
   NRL_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0, "linear_fwd: operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const EpiLinear epi{c, n, bias, 0, make_dropout(0.0, 0, 0), n};
-  if (ws == nullptr || g_engine != ENGINE_BF16X3)
+  if (ws == nullptr || cur_engine() != ENGINE_BF16X3)
     return launch_gemm<NRL_TILE>(KCPlain{a, k, m}, KCPlain{w, k, n}, epi, m, n, k, 1, st);
   NRL_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
   if (ws_bytes < nrl_linear_workspace_bytes(n, k)) {

@@ -25,9 +25,12 @@ def ranking_metrics(preds: torch.Tensor, targets: torch.Tensor, cand_news_size: 
     t_sorted = torch.gather(t, 1, order)
     ranks = torch.arange(1, p.shape[1] + 1, device=p.device, dtype=torch.float32)[None, :]
     has_pos = t.sum(1) > 0
-    # MRR: reciprocal rank of the first relevant item, mean over queries with a positive
+    # MRR: reciprocal rank of the first relevant item.  torchmetrics' retrieval metrics default to
+    # empty_target_action="neg": an impression WITHOUT a positive counts as 0 and stays in the mean
+    # (RetrievalMRR() / RetrievalNormalizedDCG(top_k=k) at nrms_module.py:186,190 take that default).
     first = torch.where(t_sorted > 0, ranks, torch.full_like(ranks, float("inf"))).min(1).values
-    mrr = (1.0 / first)[has_pos].mean() if has_pos.any() else preds.new_tensor(0.0)
+    rr = torch.where(has_pos, 1.0 / first, torch.zeros_like(first))
+    mrr = rr.mean() if rr.numel() else preds.new_tensor(0.0)
     out = {"mrr": float(mrr)}
     disc = 1.0 / torch.log2(ranks + 1.0)
     ideal = torch.sort(t, dim=1, descending=True).values
@@ -35,7 +38,7 @@ def ranking_metrics(preds: torch.Tensor, targets: torch.Tensor, cand_news_size: 
         dcg = (t_sorted[:, :k] * disc[:, :k]).sum(1)
         idcg = (ideal[:, :k] * disc[:, :k]).sum(1)
         ndcg = torch.where(idcg > 0, dcg / idcg.clamp_min(1e-12), torch.zeros_like(dcg))
-        out[f"ndcg@{k}"] = float(ndcg[has_pos].mean()) if has_pos.any() else 0.0
+        out[f"ndcg@{k}"] = float(ndcg.mean()) if ndcg.numel() else 0.0      # 0 for impressions without a positive
     # global AUROC over all (score, label) pairs, as torchmetrics' binary AUROC without indexes
     pos, neg = preds[targets > 0], preds[targets <= 0]
     if pos.numel() and neg.numel():

@@ -36,12 +36,13 @@ class AdditiveAttentionFn(torch.autograd.Function):
                                                   ws.data_ptr(), ws.numel(), _stream()), "nrl_additive_attention_fwd")
         if save:
             ctx.save_for_backward(y, *params)
-            ctx.ws, ctx.grad_bufs = ws, grad_bufs
+            ctx.ws, ctx.grad_bufs, ctx.engine = ws, grad_bufs, _lib.engine_code()
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
+        _lib.require_engine(ctx.engine, "additive attention")
         y, *params = ctx.saved_tensors
         G, S, D = y.shape
         Q = params[0].shape[0]
@@ -75,12 +76,13 @@ class LinearActFn(torch.autograd.Function):
                                           ws.data_ptr(), ws.numel(), _stream()), "nrl_linear_act_fwd")
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(a, w, bias, c)
-            ctx.ws, ctx.code, ctx.grad_bufs = ws, code, grad_bufs
+            ctx.ws, ctx.code, ctx.grad_bufs, ctx.engine = ws, code, grad_bufs, _lib.engine_code()
         return c
 
     @staticmethod
     def backward(ctx, d_c):
         lib = _lib.load()
+        _lib.require_engine(ctx.engine, "linear + activation")
         a, w, bias, c = ctx.saved_tensors
         M, K = a.shape
         N = w.shape[0]
@@ -112,7 +114,8 @@ class MhaFn(torch.autograd.Function):
         if params[0].shape != (3 * D, D) or params[1].shape != (3 * D,) or params[2].shape != (D, D) or \
                 params[3].shape != (D,):
             raise ValueError("newsreclib_amd: inconsistent attention parameter shapes")
-        mp = NrlMhaParams(*[p.data_ptr() for p in params], D, int(heads), float(scale or 0.0), 0)
+        engine = _lib.engine_code()
+        mp = NrlMhaParams(*[p.data_ptr() for p in params], D, int(heads), float(scale or 0.0), engine)
         ws = torch.empty(max(lib.nrl_mha_workspace_bytes(S, Bt, D, int(heads)), 256), dtype=torch.uint8, device=x.device)
         out = torch.empty_like(x)
         save = any(ctx.needs_input_grad)
@@ -120,7 +123,7 @@ class MhaFn(torch.autograd.Function):
                                    ws.numel(), _stream()), "nrl_mha_fwd")
         if save:
             ctx.save_for_backward(x, *params)
-            ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (int(heads), float(scale or 0.0)), grad_bufs
+            ctx.ws, ctx.cfg, ctx.grad_bufs, ctx.engine = ws, (int(heads), float(scale or 0.0)), grad_bufs, engine
         return out
 
     @staticmethod
@@ -131,7 +134,7 @@ class MhaFn(torch.autograd.Function):
         S, Bt, D = x.shape
         heads, scale = ctx.cfg
         d_out = _chk(d_out, torch.float32, "d_out")
-        mp = NrlMhaParams(*[p.data_ptr() for p in params], D, heads, scale, 0)
+        mp = NrlMhaParams(*[p.data_ptr() for p in params], D, heads, scale, ctx.engine)
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         mg = NrlMhaGrads(*[b.data_ptr() for b in bufs])
         d_x = torch.empty_like(x)

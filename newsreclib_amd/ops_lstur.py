@@ -53,11 +53,13 @@ class CnnEncoderFn(torch.autograd.Function):
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (float(p_drop), int(seed), int(stream0)), grad_bufs
+            ctx.engine = _lib.engine_code()
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
+        _lib.require_engine(ctx.engine, "the CNN text encoder")
         ids, order, *params = ctx.saved_tensors
         emb = params[0]
         p_drop, seed, stream0 = ctx.cfg
@@ -139,12 +141,13 @@ class GruFn(torch.autograd.Function):
         if save:
             ctx.save_for_backward(hist, lengths, *params)
             ctx.has_h0 = h0 is not None
-            ctx.ws, ctx.grad_bufs = ws, grad_bufs
+            ctx.ws, ctx.grad_bufs, ctx.engine = ws, grad_bufs, _lib.engine_code()
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
+        _lib.require_engine(ctx.engine, "the GRU")
         hist, lengths, *params = ctx.saved_tensors
         B, T, Din = hist.shape
         Hd = params[1].shape[1]
@@ -178,7 +181,8 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
         N, L = ids.shape
         V, D = emb.shape
         F_, _, W, _ = w_c.shape
-        bp = _block_params(params[3:], heads)
+        engine = _lib.engine_code()
+        bp = _block_params(params[3:], heads, engine)
         cp = NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), None, None, None, D, F_, W, bp.query_dim)
         save = any(ctx.needs_input_grad)
         ws = torch.empty(max(lib.nrl_cnn_mhsa_encoder_workspace_bytes(N, L, D, F_, W, heads, bp.query_dim), 256),
@@ -192,6 +196,7 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
                 order = torch.argsort(ids.reshape(-1))
             ctx.save_for_backward(ids, _chk(order, torch.int64, "order"), *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
+            ctx.engine = engine
         return out
 
     @staticmethod
@@ -205,7 +210,7 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
         V, D = emb.shape
         F_, _, W, _ = w_c.shape
         d_out = _chk(d_out, torch.float32, "d_out")
-        bp = _block_params(params[3:], heads)
+        bp = _block_params(params[3:], heads, ctx.engine)
         cp = NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), None, None, None, D, F_, W, bp.query_dim)
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         cg = NrlCnnGrads(bufs[1].data_ptr(), bufs[2].data_ptr(), None, None, None)

@@ -139,7 +139,9 @@ class NRMSTrainer:
 
     def step(self, batch: Dict) -> torch.Tensor:
         self.module.train()
-        loss = self.module.training_step(batch, 0)
+        # model_step directly: training_step would append preds / targets to training_step_outputs every step, and
+        # nothing here runs the epoch-end hook that clears them (use `epoch_end()` for the epoch metrics instead)
+        loss = self.module.model_step(batch)[0]
         loss.backward()
         # parameters whose gradient came through ordinary autograd (``.grad``: a transformer body, a small
         # head fed through torch ops) rather than through a kernel writing ``main_grad``: fold them in

@@ -260,3 +260,108 @@ def test_aspect_metrics_match_per_impression_restatement():
     m = aspect_metrics(torch.tensor([0.9, 0.8, 0.1]), torch.tensor([1, 2, 3]), torch.tensor([1, 1]),
                        torch.tensor([3]), torch.tensor([2]), 4, [2])
     assert abs(m["categ_div@2"] - 0.5) <= 1e-6 and abs(m["categ_pers@2"] - 1.0 / 3.0) <= 1e-6
+
+
+def test_ranking_metrics_count_impressions_without_a_positive_as_zero():
+    """torchmetrics' RetrievalMRR / RetrievalNormalizedDCG default to empty_target_action="neg" (the reference
+    builds them with defaults, nrms_module.py:186,190): an all-negative impression scores 0 and STAYS in the mean."""
+    from newsreclib_amd.metrics import ranking_metrics
+    preds = torch.tensor([0.9, 0.1, 0.5, 0.2, 0.8, 0.3, 0.7, 0.6])
+    targets = torch.tensor([1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0])
+    m = ranking_metrics(preds, targets, torch.tensor([3, 3, 2]), [5])
+    assert abs(m["mrr"] - (1.0 + 0.5 + 0.0) / 3) < 1e-6
+    assert abs(m["ndcg@5"] - (1.0 + 1.0 / np.log2(3) + 0.0) / 3) < 1e-6
+
+
+def test_save_recs_writes_the_recommendations_file(tmp_path):
+    """abstract_recommender.py:159-193 / nrms_module.py:520-531: {"U<user>": {"N<news>": score}}; a later score of
+    the same (user, news) overwrites the earlier one."""
+    import json
+    fpath = str(tmp_path / "recs.json")
+    mod = _module(save_recs=True, recs_fpath=fpath,
+                  outputs={"train": [], "val": [],
+                           "test": ["preds", "targets", "cand_news_size", "user_ids", "cand_news_ids"]})
+    out = mod.test_step_outputs
+    out["preds"] += [torch.tensor([0.5, 0.25, 0.75]), torch.tensor([1.5, -1.0])]
+    out["targets"] += [torch.tensor([1.0, 0.0, 0.0]), torch.tensor([0.0, 1.0])]
+    out["cand_news_size"] += [torch.tensor([2, 1]), torch.tensor([2])]
+    out["user_ids"] += [torch.tensor([7, 9]), torch.tensor([7])]
+    out["cand_news_ids"] += [torch.tensor([11, 12, 13]), torch.tensor([11, 14])]
+    mod.on_test_epoch_end()
+    got = json.load(open(fpath))
+    assert got == {"U7": {"N11": 1.5, "N12": 0.25, "N14": -1.0}, "U9": {"N13": 0.75}}
+    assert all(len(v) == 0 for v in mod.test_step_outputs.values())
+    # a configuration that cannot produce the file fails loudly instead of silently writing nothing
+    bad = _module(save_recs=True, recs_fpath=fpath, outputs={"train": [], "val": [], "test": ["preds"]})
+    bad.test_step_outputs["preds"].append(torch.tensor([0.1]))
+    with pytest.raises(RuntimeError, match="save_recs"):
+        bad.on_test_epoch_end()
+
+
+_EPOCH_SYNC_SCRIPT = r"""
+import os, sys, json, torch, torch.distributed as dist
+from functools import partial
+sys.path.insert(0, os.environ["REPO"])
+from newsreclib_amd.nrms_module import NRMSModule
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+def module():
+    return NRMSModule(dataset_attributes=["title"], attributes2encode=["title"],
+        outputs={"train": [], "val": ["preds", "targets", "cand_news_size"], "test": []},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False, temperature=None,
+        use_plm=False, pretrained_embeddings_path=None, plm_model=None, frozen_layers=None, embed_dim=300, num_heads=15,
+        query_dim=200, dropout_probability=0.2, top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3,
+        save_recs=False, recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None,
+        pretrained_embeddings=torch.randn(16, 300))
+g = torch.Generator().manual_seed(5)
+sizes = [torch.tensor([3, 5, 2]), torch.tensor([4, 6]), torch.tensor([7]), torch.tensor([2, 2, 9])]   # 4 "steps"
+preds = [torch.randn(int(s.sum()), generator=g) for s in sizes]
+targets = [(torch.rand(int(s.sum()), generator=g) < 0.3).float() for s in sizes]
+losses = [0.7, 0.5, 0.9, 0.3]
+def feed(mod, steps):
+    for i in steps:
+        mod.val_step_outputs["preds"].append(preds[i]); mod.val_step_outputs["targets"].append(targets[i])
+        mod.val_step_outputs["cand_news_size"].append(sizes[i]); mod._track("val", torch.tensor(losses[i]))
+# rank r owns steps r, r + 2 (what a DistributedSampler shard looks like); every rank must log the metrics of ALL
+# impressions and the mean loss of ALL steps
+shard = module(); feed(shard, [rank, rank + 2])
+got = shard._epoch_end("val", shard.val_step_outputs)
+dist.destroy_process_group()                      # the single-process reference below must not gather
+whole = module(); feed(whole, [0, 1, 2, 3])
+ref = whole._epoch_end("val", whole.val_step_outputs)
+assert got.keys() == ref.keys(), (got, ref)
+for k in ref:
+    # the global AUC and the per-impression means do not depend on the impression ORDER (rank-major here)
+    assert abs(got[k] - ref[k]) < 1e-6, (k, got[k], ref[k])
+assert all(len(v) == 0 for v in shard.val_step_outputs.values())
+print("OK", rank)
+"""
+
+
+def test_epoch_end_metrics_cover_every_rank_two_processes_gloo(tmp_path):
+    """Under data parallelism every rank logs the loss / AUC / MRR / nDCG of ALL ranks' impressions (what the
+    reference's torchmetrics objects do by synchronising their states), not of its own shard."""
+    _run_two_ranks(tmp_path, _EPOCH_SYNC_SCRIPT, "epoch_sync.py")
+
+
+def test_per_call_engine_field_and_backward_guard():
+    """The GEMM engine a forward ran under travels with the call (NrlBlockParams.gemm_engine / autograd ctx); entry
+    points without the field refuse a backward under another engine."""
+    from newsreclib_amd import _lib
+    lib = _lib.load()
+    before = _lib.get_gemm_engine()
+    try:
+        _lib.set_gemm_engine("f32")
+        code = _lib.engine_code()
+        assert code == 1
+        _lib.set_gemm_engine("bf16x3")
+        assert _lib.engine_code() == 2
+        with pytest.raises(RuntimeError, match="engine changed"):
+            _lib.require_engine(code, "a test call")
+        _lib.require_engine(2, "a test call")
+        bp = _lib.NrlBlockParams(1, 1, 1, 1, 1, 1, 1, 300, 15, 200, 3)       # bad per-call engine value
+        rc = lib.nrl_news_encoder_fwd(bp, None, 1, None, 0, 30, 0.0, 0, 0, 0, None, None, 0, None)
+        assert rc == -1 and b"gemm_engine" in lib.nrl_last_error()
+    finally:
+        _lib.set_gemm_engine(before)
