@@ -10,11 +10,18 @@ backward, (N > 1: RCCL all-reduce of the flat gradient), dense Adam -- dropout a
 Workload at every N (weak scaling): BASELINE.json configs[1], B = 128 impressions per GPU,
 H = 50 clicks, C = 5 candidates, L = 30 tokens, V = 70,000, D = 300, 15 heads, Q = 200.
 Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU
+over RCCL), so the same command line works with and without an external launcher.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -81,6 +88,21 @@ def cpu_baseline(time_budget_s=20.0):
                       f"CPU, {cores} threads"}
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (reference multi-GPU leg:
+    configs/trainer/ddp.yaml:4 `strategy: ddp`, one process per device)."""
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this node has {have}")
+    with socket.socket() as sock:                       # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,12 +113,13 @@ def main():
                     help="projection-GEMM engine: exact fp32 MFMA, or fp32 via 3 bf16 MFMAs per product")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -107,7 +130,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI
 
     from newsreclib_amd import _lib
-    from newsreclib_amd.nrms_module import prepare_batch
+    from newsreclib_amd.nrms_module import attach_layout, prepare_batch
     from newsreclib_amd.synthetic import make_batch
     from newsreclib_amd.trainer import NRMSTrainer
     lib = _lib.load()
@@ -116,8 +139,12 @@ def main():
     mod = build_module(device)
     trainer = NRMSTrainer(mod, lr=LR)
     # impressions shard on the user axis: rank r owns its own B_PER_GPU impressions (seed by rank)
-    batches = [prepare_batch(make_batch(B_PER_GPU, VOCAB, "fixed", seed=1234 + 1000 * i + rank, device=device))
+    # what a collate function hands over: the RecommendationBatch tensors in HBM plus the row-length metadata it
+    # has on the host anyway (offsets, max sizes).  The per-step device work on the ids -- concatenating history
+    # and candidate ids and the argsort the embedding gradient needs -- happens INSIDE every timed step.
+    batches = [attach_layout(make_batch(B_PER_GPU, VOCAB, "fixed", seed=1234 + 1000 * i + rank, device=device))
                for i in range(N_BATCHES)]
+    assert all("x_all" not in b for b in batches)
 
     def barrier():
         if distributed:
@@ -128,11 +155,21 @@ def main():
         trainer.step(batches[i % N_BATCHES])
     barrier()
     lib.nrl_prof_enable(1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         trainer.step(batches[i % N_BATCHES])
+        marks[i + 1].record()                    # per-step boundary on the step's own stream (for the median)
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    # what the id bookkeeping inside the step costs (measured after the timed region)
+    t1 = time.perf_counter()
+    for i in range(20):
+        prepare_batch(batches[i % N_BATCHES])
+    torch.cuda.synchronize()
+    prepare_ms = (time.perf_counter() - t1) / 20 * 1e3
     tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     lib.nrl_prof_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(flops))
     lib.nrl_prof_enable(0)
@@ -170,7 +207,10 @@ def main():
         out = {
             "metric": "impressions/sec (train step) NRMS MINDsmall-shape", "value": round(value, 1),
             "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "median_ms_per_step": round(statistics.median(step_ms), 4), "prepare_ms": round(prepare_ms, 4),
+            "rccl_ranks": dist.get_world_size() if distributed else 1,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.engine == "f32" else "f32 (projections: 3xbf16 split MFMA)",
             "data": "synthetic",
             "config": {"workload": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDsmall-shaped train step: "
@@ -193,6 +233,21 @@ def main():
             fdt = (time.perf_counter() - t1) / 20
             mod.train()
             out["forward_only"] = {"value": round(B_PER_GPU / fdt, 1), "unit": "impressions/s", "ms": round(fdt * 1e3, 4)}
+        if world == 1 and args.engine != "f32":
+            # the exact-fp32 projection engine on the same workload (extra key, outside the timed region)
+            _lib.set_gemm_engine("f32")
+            for i in range(3):
+                trainer.step(batches[i % N_BATCHES])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n32 = max(10, min(args.steps, 30))
+            for i in range(n32):
+                trainer.step(batches[i % N_BATCHES])
+            torch.cuda.synchronize()
+            d32 = (time.perf_counter() - t1) / n32
+            _lib.set_gemm_engine(args.engine)
+            out["f32_engine"] = {"value": round(B_PER_GPU / d32, 1), "unit": "impressions/s",
+                                 "ms_per_step": round(d32 * 1e3, 4), "dtype": "f32 (v_mfma_f32_16x16x4_f32 projections)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
@@ -201,4 +256,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

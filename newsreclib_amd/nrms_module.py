@@ -26,12 +26,12 @@ from .news_encoder import PLM, MHSAAddAtt, NewsEncoder
 from .user_encoder import UserEncoder
 
 
-def prepare_batch(batch: Dict) -> Dict:
+def attach_layout(batch: Dict) -> Dict:
     """Attach the ragged-layout metadata the forward needs (offsets, max lengths, batch size).
 
     A collate function has these on the host for free (it builds ``batch_hist`` from the per-user
-    list lengths, rec_dataset.py:289-293); computing them from the device vectors costs two syncs,
-    so do it once per batch, outside the timed step."""
+    list lengths, rec_dataset.py:289-293; ``input_pipeline.build_batch`` supplies them); computing
+    them from the device vectors costs two syncs, so a loader does it once per batch, outside the step."""
     if "cand_flat_idx" in batch:
         return batch
     B = int(batch["batch_size"]) if "batch_size" in batch else (
@@ -49,8 +49,17 @@ def prepare_batch(batch: Dict) -> Dict:
     if "min_hist" not in out:
         out["min_hist"] = int(out["hist_sizes"].min())
     out["cand_flat_idx"] = dense_slot_index(batch["batch_cand"], out["cand_offsets"], out["max_cand"])
-    # history + candidate token ids as the single encoder call sees them, and their id-sorted
-    # visiting order for the embedding gradient (pure index bookkeeping, like the offsets above)
+    return out
+
+
+def prepare_batch(batch: Dict) -> Dict:
+    """``attach_layout`` + the per-step device work on the token ids: history and candidate ids as the single
+    encoder call sees them, and their id-sorted visiting order for the embedding gradient (the sort the reference
+    pays inside ``embedding_dense_backward``).  No host sync; part of the train step (bench.py times it)."""
+    out = attach_layout(batch)
+    if "x_all" in out:
+        return out
+    out = dict(out)
     for attr in ("title", "abstract"):
         if attr in batch["x_hist"] and attr in batch["x_cand"]:
             h, c = batch["x_hist"][attr], batch["x_cand"][attr]

@@ -187,8 +187,21 @@ def test_module_matches_reference_golden(name):
     # pin the dropout seed to the one the golden masks were drawn with
     orig = te.forward
     te.forward = lambda text, seed=None, **kw: orig(text, seed=int(g["cfg_seed"]), **kw)
-    loss, preds, targets, cand_size, *_ = mod.model_step(batch)
+    loss, preds, targets, cand_size, hist_size, *_ = mod.model_step(batch)
     scores = mod.forward(batch)
+    # model_step's outputs against the reference's per-user loops (abstract_recommender.py:126-130,
+    # nrms_module.py:331-345) restated in the oracle: preds = cat_n scores[n][mask_cand[n]] of the REFERENCE's
+    # scores, cand_news_size / hist_news_size = the mask row sums
+    cpu = golden_batch(g)
+    B = int(cpu["batch_hist"].max()) + 1
+    _, mask_cand = O.to_dense_batch(cpu["labels"], cpu["batch_cand"], B)
+    _, mask_hist = O.to_dense_batch(cpu["batch_hist"].float(), cpu["batch_hist"], B)
+    ref_preds = O.collect_model_outputs(torch.from_numpy(g["out_scores"]), mask_cand)
+    assert preds.shape == ref_preds.shape and _maxerr(preds, ref_preds) <= 2e-4
+    assert torch.equal(preds, scores.detach()[mask_cand.to(DEV)])            # same elements, same order
+    assert torch.equal(cand_size.cpu(), mask_cand.sum(1)) and torch.equal(hist_size.cpu(), mask_hist.sum(1))
+    ref_targets = O.collect_model_outputs(O.to_dense_batch(cpu["labels"], cpu["batch_cand"], B)[0], mask_cand)
+    assert torch.equal(targets.cpu(), ref_targets)
     err_s = float(np.abs(scores.detach().cpu().numpy() - g["out_scores"]).max())
     err_l = abs(float(loss) - float(g["out_loss"]))
     print(f"{name}: scores max abs err {err_s:.3e}, loss err {err_l:.3e}")
@@ -282,6 +295,61 @@ def test_full_size_properties_b128():
     sizes = (rag["cand_offsets"][1:] - rag["cand_offsets"][:-1])
     pad = torch.arange(sr.shape[1], device=DEV)[None, :] >= sizes[:, None]
     assert pad.any() and (sr[pad] == 0).all()
+
+
+_FULL_ORACLE = {}
+
+
+def _full_size_oracle(train: bool):
+    """One B=128, V=70k step of the CPU oracle (a few seconds on the box's host cores), shared by both engines."""
+    if train not in _FULL_ORACLE:
+        from newsreclib_amd.synthetic import make_batch
+        params = O.make_params(70_000, seed=42)
+        batch = make_batch(128, 70_000, "fixed", seed=1234)
+        orc = O.NRMSOracle(params, num_heads=15, p_drop=0.2)
+        if train:
+            out, grads = orc.loss_and_grads(batch, True, seed=4242)
+        else:
+            with torch.no_grad():
+                out, grads = orc.forward(batch, False), None
+        _FULL_ORACLE[train] = (params, batch, {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}, grads)
+    return _FULL_ORACLE[train]
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train_injected_mask"])
+def test_full_size_b128_v70k_matches_oracle(train, engine):
+    """BASELINE configs[1] AT FULL SIZE (B=128, H=50, C=5, L=30, V=70,000) against the CPU oracle: scores, loss
+    and -- in train mode, under the oracle's own dropout draw (same counter-based masks) -- every parameter
+    gradient.  Contract: scores within 1e-3; observed errors are printed."""
+    params, batch, ref, ref_grads = _full_size_oracle(train)
+    mod = build_module(params, p_drop=0.2)
+    mod.train(train)
+    te = mod.news_encoder.text_encoders["title"]
+    orig = te.forward
+    te.forward = lambda text, seed=None, **kw: orig(text, seed=4242, **kw)
+    dev_batch = batch_to(batch, DEV)
+    loss, preds, *_ = mod.model_step(dev_batch)
+    scores = mod.forward(dev_batch)
+    err_s, err_l = _maxerr(scores, ref["scores"]), abs(float(loss) - float(ref["loss"]))
+    print(f"full size [{engine}, train={train}]: scores max abs err {err_s:.3e} (|scores| max "
+          f"{float(ref['scores'].abs().max()):.2f}), loss err {err_l:.3e}")
+    assert err_s <= TOL and err_l <= TOL
+    assert err_s <= _eng_tol(engine, 5e-5, 5e-4)
+    if not train:
+        return
+    loss.backward()
+    worst = 0.0
+    for k, got in module_grads(mod).items():
+        want = ref_grads[k]
+        scale = max(1e-3, float(want.abs().max()))
+        d = (got.detach().cpu() - want).abs()
+        if k.endswith("in_proj_bias"):                 # zero-true-gradient key bias: rounding noise on both sides
+            d[300:600] = 0
+        rel = float(d.max()) / scale
+        worst = max(worst, rel)
+        nrm = abs(float(got.norm()) - float(want.norm())) / max(1e-6, float(want.norm()))
+        assert rel <= _eng_tol(engine, 2e-4, 1e-3) and nrm <= 1e-3, (k, rel, nrm)
+    print(f"full size [{engine}]: worst gradient error relative to the parameter's largest gradient {worst:.3e}")
 
 
 def test_embedding_gradient_hot_token_and_both_scatter_paths():
@@ -496,6 +564,39 @@ mod = build_module(params, p_drop=0.2, device="cuda:0")
 tr = NRMSTrainer(mod, lr=1e-3)
 assert tr.reduce.head == 2000 * 300 and mod.news_encoder.text_encoders["title"].table_grad_hook is not None
 batch = prepare_batch(make_batch(8, 2000, "ragged", seed=100 + rank, device="cuda:0"))   # rank-specific impressions
+# -- the reduced gradient == the MEAN of the per-rank ORACLE gradients (what reference DDP hands its optimizer;
+#    SURVEY.md section 8e), each rank's oracle run on its own sub-batch under its own dropout draw
+te = mod.news_encoder.text_encoders["title"]
+plain_fwd = te.forward
+te.forward = lambda text, seed=None, **kw: plain_fwd(text, seed=500 + rank, **kw)
+mod.train()
+loss0 = mod.model_step(batch)[0]
+loss0.backward()
+scale = tr.reduce.finish()
+assert scale == 0.5
+got = (tr.flat.grad * scale).cpu()
+mean = None
+for r in range(2):
+    orc = O.NRMSOracle(params, num_heads=15, p_drop=0.2)
+    out_r, grads_r = orc.loss_and_grads(make_batch(8, 2000, "ragged", seed=100 + r), True, seed=500 + r)
+    if r == rank:
+        assert abs(float(loss0) - float(out_r["loss"])) <= 1e-3, (float(loss0), float(out_r["loss"]))
+    mean = grads_r if mean is None else {k: (mean[k] + grads_r[k]) / 2 for k in mean}
+names = [k for k, _ in mod.named_parameters()]
+assert len(names) == len(tr.flat.params)
+worst = 0.0
+for k, p, off in zip(names, tr.flat.params, tr.flat.offsets):
+    g = got[off:off + p.numel()].view_as(p)
+    ref_g = mean[k]
+    d = (g - ref_g).abs()
+    if k.endswith("in_proj_bias"):
+        d[300:600] = 0          # key bias: exactly-zero true gradient, rounding noise on both sides
+    tol = 2e-4 * max(1.0, float(ref_g.abs().max()))
+    assert float(d.max()) <= tol, (k, float(d.max()), tol)
+    worst = max(worst, float(d.max()))
+print("reduced gradient vs mean of per-rank oracle gradients: max abs err", worst)
+tr.flat.grad.zero_()
+te.forward = plain_fwd
 fired = []
 orig = tr.reduce.start_head
 tr.reduce.start_head = lambda g=None: (fired.append(1), orig(g))[1]
