@@ -87,6 +87,14 @@ const char* nrl_last_error(void);
 int nrl_set_gemm_engine(int32_t engine);
 int nrl_get_gemm_engine(void);
 
+/* ---- kernel-selection switches for A/B measurements and the equivalence tests (process-wide, diagnostic; the
+ * environment variables NRL_NEWS_FUSED / NRL_ROWPANEL / NRL_X3_DMA = 0 set the same flags at load time).  All paths
+ * compute the same function; a forward and its backward must run under the same setting.
+ *   "news_fused": gather + in-projection + token attention of the news encoder in one kernel (bf16x3 engine,
+ *                 L <= 32, D = 20 * heads in [288, 316]);  "rowpanel": row-panel kernel for the N <= 320 projections;
+ *   "x3_dma": LDS-DMA staged tiled GEMMs. */
+int nrl_set_option(const char* name, int32_t value);
+
 /* ---- measurement hook (bench.py "roofline"): HIP-event timing of the dominant kernel, the
  * in-projection GEMM with the fused embedding gather, recorded on the launch stream.  The ProfScope
  * only wraps news-encoder forward launches; total_flops sums 2*M*3D*D per launch. */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "nrl_last_error": (c_char_p, []),
     "nrl_set_gemm_engine": (c_int32, [c_int32]),
     "nrl_get_gemm_engine": (c_int32, []),
+    "nrl_set_option": (c_int32, [c_char_p, c_int32]),
     "nrl_prof_enable": (c_int32, [c_int32]),
     "nrl_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "nrl_dropout_key": (c_uint32, [c_uint64, c_uint32]),
@@ -197,6 +198,11 @@ def set_gemm_engine(name: str) -> None:
 def get_gemm_engine() -> str:
     code = load().nrl_get_gemm_engine()
     return {v: k for k, v in ENGINES.items()}[code]
+
+
+def set_option(name: str, value: bool) -> None:
+    """Kernel-selection switch ("news_fused", "rowpanel", "x3_dma") for A/B measurements and equivalence tests."""
+    check(load().nrl_set_option(name.encode(), int(bool(value))), "nrl_set_option")
 
 
 def engine_code() -> int:

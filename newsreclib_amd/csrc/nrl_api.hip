@@ -15,6 +15,8 @@
 #include "nrl_gemm.h"
 #include "nrl_gemm_bf16x3.h"
 #include "nrl_gemm_bf16x3_dma.h"
+#include "nrl_rowpanel.h"
+#include "nrl_news_fused.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
 #include "nrl_gru_fused.h"
@@ -104,8 +106,20 @@ struct EngineScope {
 };
 static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 // A/B switch for measurements: NRL_X3_DMA=0 keeps every bf16x3 GEMM on the register-staged kernel
-static const bool g_x3_dma = [] {
+static bool g_x3_dma = [] {
   const char* e = getenv("NRL_X3_DMA");
+  return !(e != nullptr && e[0] == '0');
+}();
+
+// A/B switch: NRL_ROWPANEL=0 keeps the narrow (N <= 320) forward / dgrad projections on the tiled kernels
+static bool g_rowpanel = [] {
+  const char* e = getenv("NRL_ROWPANEL");
+  return !(e != nullptr && e[0] == '0');
+}();
+
+// A/B switch: NRL_NEWS_FUSED=0 keeps the news encoder's gather + in-projection + attention as separate kernels
+static bool g_news_fused = [] {
+  const char* e = getenv("NRL_NEWS_FUSED");
   return !(e != nullptr && e[0] == '0');
 }();
 
@@ -128,7 +142,25 @@ struct BlockShape {
 struct BlockWs {
   float *x, *qkv, *o, *y, *t, *w, *lse, *dy, *dqkv, *d_o;
   uint16_t* planes;  // bf16 hi/lo planes of the three weights (bf16x3 engine)
+  uint16_t* rp;      // fragment-ordered weight images of the row-panel GEMMs (nrl_rowpanel.h)
 };
+
+// the five narrow projections of the block that run on the row-panel kernel: forward out-projection and
+// additive-attention linear, and the three activation-gradient GEMMs
+struct BlockRp {
+  RpImage out_f, att_f, att_d, out_d, in_d, in_heads;
+  bool on = false;
+};
+static bool block_rp_ok(int D, int Q) { return g_rowpanel && rp_nblk_supported(D) && rp_nblk_supported(Q); }
+static size_t block_rp_elems(int D, int Q) {
+  if (!block_rp_ok(D, Q)) return 0;
+  const int nd = rp_nblk_for(D), nq = rp_nblk_for(Q);
+  return rp_image_elems(nd, rp_kblocks(D, false)) * 2      // out fwd (N = D, K = D), out dgrad (N = D, K = D)
+         + rp_image_elems(nq, rp_kblocks(D, false))         // att fwd (N = Q, K = D)
+         + rp_image_elems(nd, rp_kblocks(Q, false))         // att dgrad (N = D, K = Q)
+         + rp_image_elems(nd, rp_kblocks(3 * D, false))     // in dgrad (N = D, K = 3D)
+         + rp_image_elems((D / 20) * 4, NF_KB);             // per-head q|k|v image of the fused news encoder
+}
 
 static size_t plane_elems(int D, int Q) {
   return split_weight_elems(3 * D, D) + split_weight_elems(D, D) + split_weight_elems(Q, D);
@@ -144,6 +176,7 @@ static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
   n += al((size_t)M);              // w
   n += al((size_t)M * heads);      // lse
   n += al((plane_elems(D, Q) + 1) / 2);  // bf16 weight planes
+  n += al((block_rp_elems(D, Q) + 1) / 2);
   return n;
 }
 
@@ -167,6 +200,7 @@ static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x,
   out->w = take((size_t)s.M);
   out->lse = take((size_t)s.M * s.heads);
   out->planes = reinterpret_cast<uint16_t*>(take((plane_elems(s.D, s.Q) + 1) / 2));
+  out->rp = reinterpret_cast<uint16_t*>(take((block_rp_elems(s.D, s.Q) + 1) / 2));
   return NRL_OK;
 }
 
@@ -187,11 +221,12 @@ static int check_params(const NrlBlockParams* p) {
 
 struct BlockPlanes {
   SplitWeight in, out, att;
+  BlockRp rp;
 };
 
 // carve (and, in the forward, fill) the bf16 planes of the block's three weights
 static int block_planes(const NrlBlockParams* P, const BlockShape& s, const BlockWs& w, bool fill,
-                        BlockPlanes* bp, hipStream_t st) {
+                        BlockPlanes* bp, hipStream_t st, int fused_heads = 0) {
   const int D = s.D, Q = s.Q;
   uint16_t* p = w.planes;
   const float* ws[3] = {P->in_proj_weight, P->out_proj_weight, P->att_weight};
@@ -205,7 +240,42 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
     }
     p += split_weight_elems(ns[i], D);
   }
+  // row-panel images (bf16x3 engine): carved always, built by the forward in ONE small launch
+  bp->rp.on = block_rp_ok(D, Q) && cur_engine() == ENGINE_BF16X3;
+  if (bp->rp.on) {
+    const int nd = rp_nblk_for(D), nq = rp_nblk_for(Q);
+    uint16_t* q = w.rp;
+    RpImageJobs jobs;
+    rp_jobs_init(&jobs);
+    auto add = [&](RpImage* im, const float* src, int64_t sn, int64_t sk, int N, int K, int nblk) {
+      im->img = q; im->nblk = nblk; im->kblocks = rp_kblocks(K, false);
+      if (fill) rp_jobs_add(&jobs, src, sn, sk, N, K, nullptr, q, nblk);
+      q += rp_image_elems(nblk, im->kblocks);
+    };
+    add(&bp->rp.out_f, P->out_proj_weight, D, 1, D, D, nd);       // y = o W_o^T: element (n, k) = W_o[n][k]
+    add(&bp->rp.att_f, P->att_weight, D, 1, Q, D, nq);            // t = y W_a^T
+    add(&bp->rp.att_d, P->att_weight, 1, D, D, Q, nd);            // dy = d_pre W_a: (n, k) = W_a[k][n]
+    add(&bp->rp.out_d, P->out_proj_weight, 1, D, D, D, nd);       // d_o = dy W_o
+    add(&bp->rp.in_d, P->in_proj_weight, 1, D, D, 3 * D, nd);     // dx = dqkv W_in
+    if (fused_heads > 0) {                                          // nrl_news_fused.h
+      bp->rp.in_heads.img = q; bp->rp.in_heads.nblk = fused_heads * 4; bp->rp.in_heads.kblocks = NF_KB;
+      if (fill) rp_jobs_add_qkv_heads(&jobs, P->in_proj_weight, D, P->in_proj_bias, q, fused_heads, D / fused_heads);
+      q += rp_image_elems(fused_heads * 4, NF_KB);
+    }
+    if (fill) NRL_TRY(rp_jobs_launch(jobs, st));
+  }
   return NRL_OK;
+}
+
+template <class AOp, class Epi>
+static int rp_dispatch(const AOp& a, const RpImage& b, const Epi& epi, int64_t M, int N, int K, hipStream_t st) {
+  switch (b.nblk) {
+    case 13: return launch_rp_gemm<13>(a, b, epi, M, N, K, st);
+    case 19: return launch_rp_gemm<19>(a, b, epi, M, N, K, st);
+    case 20: return launch_rp_gemm<20>(a, b, epi, M, N, K, st);
+  }
+  set_error("row-panel GEMM: no instantiation for %d column blocks", b.nblk);
+  return NRL_E_INVALID;
 }
 
 static bool big_tiles(int64_t M, int N) { return ceil_div(M, 256) * ceil_div(N, 160) >= 512; }
@@ -213,8 +283,10 @@ static bool big_tiles(int64_t M, int N) { return ceil_div(M, 256) * ceil_div(N, 
 // C = epi(A W^T): nn.Linear forward.  W (N, K) fp32 in place / its bf16 planes.
 template <class AOp, class Epi>
 static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int N, int K,
-                    bool q_tile, hipStream_t st) {
+                    bool q_tile, hipStream_t st, const RpImage* rp = nullptr) {
   if (cur_engine() == ENGINE_BF16X3) {
+    if constexpr (std::is_same<AOp, KCPlain>::value)
+      if (rp != nullptr && rp->img != nullptr) return rp_dispatch(a, *rp, epi, M, N, K, st);
     const KCSplit b{sw.hi, sw.lo, sw.ld, N};
     if constexpr (!std::is_same<AOp, KCGather>::value) if (g_x3_dma) {
       // (the gathered operand keeps the register-staged kernel: its dropout hash would be re-evaluated by
@@ -234,9 +306,10 @@ static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const E
 // dX = epi(dY W): dY (M, Nw), W (Nw, Kw) -> (M, Kw)
 template <class Epi>
 static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int Nw,
-                      int Kw, hipStream_t st) {
+                      int Kw, hipStream_t st, const RpImage* rp = nullptr) {
   const KCPlain a{dy, Nw, M};
   if (cur_engine() == ENGINE_BF16X3) {
+    if (rp != nullptr && rp->img != nullptr) return rp_dispatch(a, *rp, epi, M, Kw, Nw, st);
     const KCSplit b{sw.hi_t, sw.lo_t, sw.ld_t, Kw};
     if (g_x3_dma) return launch_gemm_bf16x3_dma<X3_DMA_TILE>(a, b, epi, M, Kw, Nw, st);
     if (big_tiles(M, Kw)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, Kw, Nw, 1, st);
@@ -270,11 +343,14 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
   return launch_gemm<NRL_TILE_W>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 64, 160), st);
 }
 
+static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const BlockWs& w, const BlockPlanes& bp,
+                          Dropout drop2, float* out, hipStream_t st);
+
 // forward of the shared block given an A-operand accessor for the in-projection
 template <class AOp>
 static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape& s, const BlockWs& w,
                      Dropout drop2, bool save, bool prof_in_proj, float* out, hipStream_t st) {
-  const int D = s.D, Q = s.Q;
+  const int D = s.D;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
   BlockPlanes bp;
   NRL_TRY(block_planes(P, s, w, cur_engine() == ENGINE_BF16X3, &bp, st));
@@ -286,12 +362,21 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
   }
   // per (group, head): softmax(q k^T / sqrt(dh)) v
   NRL_TRY(attn_fwd(w.qkv, w.o, save ? w.lse : nullptr, s.geom, st));
+  return block_fwd_tail(P, s, w, bp, drop2, out, st);
+}
+
+// out-projection -> dropout -> additive attention, from the attention output w.o
+static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const BlockWs& w, const BlockPlanes& bp,
+                          Dropout drop2, float* out, hipStream_t st) {
+  const int D = s.D, Q = s.Q;
+  const Dropout nodrop = make_dropout(0.0, 0, 0);
   // y = dropout(o W_o^T + b_o)        (out-projection, text.py:229-230)
   NRL_TRY(gemm_fwd(KCPlain{w.o, D, s.M}, P->out_proj_weight, bp.out,
-                   EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, false, st));
+                   EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, false, st,
+                   bp.rp.on ? &bp.rp.out_f : nullptr));
   // t = tanh(y W_a^T + b_a)           (attention.py:34)
   NRL_TRY(gemm_fwd(KCPlain{w.y, D, s.M}, P->att_weight, bp.att, EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q},
-                   s.M, Q, D, true, st));
+                   s.M, Q, D, true, st, bp.rp.on ? &bp.rp.att_f : nullptr));
   // w = softmax(t . q_a); out = sum w y   (attention.py:37-40)
   NRL_TRY(pool_fwd(w.t, P->att_query, w.y, s.pool_groups, s.pool_len, Q, D, w.w, out, st));
   return NRL_OK;
@@ -308,9 +393,11 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
   // additive attention backward: t -> d_pre in place, dq_a
   NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st));
   // dy = (d_pre W_a + w * d_out) * dropout2
-  NRL_TRY(gemm_dgrad(w.t, P->att_weight, bp.att, EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, Q, D, st));
+  NRL_TRY(gemm_dgrad(w.t, P->att_weight, bp.att, EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, Q, D, st,
+                     bp.rp.on ? &bp.rp.att_d : nullptr));
   // d_o = dy W_o
-  NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{w.d_o, D}, s.M, D, D, st));
+  NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{w.d_o, D}, s.M, D, D, st,
+                     bp.rp.on ? &bp.rp.out_d : nullptr));
   // attention backward -> dqkv
   NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
   return NRL_OK;
@@ -333,6 +420,12 @@ static int check_grads(const NrlBlockGrads* g) {
                   g->out_proj_bias && g->att_weight && g->att_bias && g->att_query,
               "null gradient pointer");
   return NRL_OK;
+}
+
+// the fused front half applies to the reference's news-encoder geometry under the bf16x3 engine
+static bool news_fused_on(const BlockShape& s, int L) {
+  return g_news_fused && cur_engine() == ENGINE_BF16X3 && block_rp_ok(s.D, s.Q) && s.dh == 20 &&
+         news_fused_ok(L, s.D, s.heads);
 }
 
 static BlockShape news_shape(const NrlBlockParams* p, int64_t n_news, int L) {
@@ -401,6 +494,17 @@ int nrl_set_gemm_engine(int32_t engine) {
 }
 int nrl_get_gemm_engine(void) { return g_default_engine.load(); }
 
+int nrl_set_option(const char* name, int32_t value) {
+  NRL_REQUIRE(name != nullptr, "set_option: null name");
+  bool* flag = !strcmp(name, "news_fused") ? &g_news_fused
+               : !strcmp(name, "rowpanel") ? &g_rowpanel
+               : !strcmp(name, "x3_dma")   ? &g_x3_dma
+                                           : nullptr;
+  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, rowpanel, x3_dma)", name);
+  *flag = value != 0;
+  return NRL_OK;
+}
+
 uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream) { return dropout_key(seed, stream); }
 
 int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, uint32_t stream,
@@ -429,6 +533,23 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
   BlockWs w;
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
+  if (news_fused_on(s, seq_len)) {
+    // gather + in-projection + token attention in ONE kernel (nrl_news_fused.h): q|k|v are never read back
+    hipStream_t st = (hipStream_t)stream;
+    BlockPlanes bp;
+    NRL_TRY(block_planes(p, s, w, true, &bp, st, s.heads));
+    NewsFusedArgs a;
+    a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
+    a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.o = w.o;
+    a.x_save = save_for_backward ? w.x : nullptr;
+    a.qkv_save = save_for_backward ? w.qkv : nullptr;
+    a.lse = save_for_backward ? w.lse : nullptr;
+    {
+      ProfScope prof(st, 2.0 * (double)s.M * 3.0 * s.D * s.D + 4.0 * (double)s.M * seq_len * s.D);
+      NRL_TRY(launch_news_fused_fwd(a, st));
+    }
+    return block_fwd_tail(p, s, w, bp, d2, out, st);
+  }
   KCGather a_in{emb_table, ids, s.M, s.D, d1, save_for_backward ? w.x : nullptr};
   return block_fwd(p, a_in, s, w, d2, save_for_backward != 0, true, out, (hipStream_t)stream);
 }
@@ -457,7 +578,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
       // dx is materialised (in the now dead d_o buffer) and reduced in id-sorted order: no hot-row contention
       float* dx = w.d_o;
       NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{dx, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
-                         s.D, st));
+                         s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
       NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));
     } else {
       NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiScatter{d_emb_table, ids, s.D, d1}, s.M, 3 * s.D,
@@ -515,7 +636,7 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   NRL_TRY(block_planes(p, s, w, false, &bp, st));
   NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st));
   NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{d_hist, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
-                     s.D, st));
+                     s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
   return block_bwd_phase2(g, in_drop ? w.x : hist, s, w, st);
 }
 

@@ -1,0 +1,341 @@
+// Fused front half of the NRMS news encoder (gfx950):  token ids -> attention output `o`
+//
+//   x = dropout(E[ids])                         text.py:224-225   (bit-exact gather, counter-based mask)
+//   q|k|v = x W_in^T + b_in                     text.py:229       (bf16x3 on the matrix cores, K = D (+ bias column))
+//   o[:, head] = softmax(q k^T / sqrt(dh)) v    nn.MultiheadAttention, per (news, head), no mask
+//
+// One wavefront owns ONE news (L <= 32 tokens = 2 MFMA row blocks).  Its post-dropout embedding rows are
+// gathered ONCE, split to (hi, lo) bf16 ONCE and kept in registers as MFMA A fragments (160 VGPRs at
+// D <= 316) for all heads -- the tiled in-projection GEMM re-read and re-split every row for each of its
+// six column tiles, wrote q|k|v (3.6 KB per token) to HBM and the attention kernel read it back.  Per head the
+// 64 image columns [q 20 | k 20 | v 20 | 0] of W_in stream through a 5-slot LDS ring as fragment-ordered 16 KB
+// chunks (rp_weight_image_kernel with the head remap; the bias rides in the image as column K = D against a
+// ones column on the A side), the 32 x 64 result goes accumulators -> a private LDS image, and the 32 x 32
+// attention of that head runs on the matrix cores straight from it:
+//   S^T = K Q^T   (bf16x3; the accumulator layout of S^T -- lane (query, g) holds keys {4g.., 16+4g..} -- IS the
+//                  A-operand layout of P V under the key permutation kappa(g, e), so P never leaves registers)
+//   softmax over the keys of a query = 8 in-register values + two cross-lane steps (xor 16, 32)
+//   O = P V       (bf16x3, V fragments read k-strided from the image)
+// Only `o` (and, for training, q|k|v + log-sum-exp + x for the existing backward kernels) leaves the chip.
+//
+// Workgroup = 8 wavefronts = 8 news, two waves per SIMD (<= 256 VGPRs); LDS = 80 KB weight ring + 8 x 8.5 KB
+// images.  Sync: one barrier per 16 KB chunk (slot reuse) + one `vmcnt(0)` per head; the DMA of head h + 1's
+// chunk c is issued right after chunk c of head h has been consumed, so it has the rest of the head to land.
+#pragma once
+#include "nrl_rowpanel.h"
+
+namespace nrl {
+
+constexpr int NF_WAVES = 8;        // news per workgroup
+constexpr int NF_KB = 10;          // k-blocks of 32: D + 1 (bias column) <= 320
+constexpr int NF_IMG_LD = 68;      // floats per row of the private q|k|v image (64 + pad: conflict-free C-layout stores)
+constexpr int NF_IMG_FLOATS = 32 * NF_IMG_LD;
+constexpr int NF_RING = 5 * 16384;  // one head = 5 chunks of (2 k-blocks x 4 column blocks x hi|lo) KiB
+
+struct NewsFusedArgs {
+  const float* table;       // (V, D)
+  const int64_t* ids;       // (n_news, L)
+  const uint16_t* img;      // rp image: nblk = heads * 4, kblocks = NF_KB, bias at k = D
+  int64_t n_news;
+  int L, D, heads, dh;      // dh == 20
+  float scale;              // 1 / sqrt(dh)
+  Dropout drop1;
+  float* o;                 // (n_news * L, D)
+  float* x_save;            // (n_news * L, D) post-dropout rows, or null
+  float* qkv_save;          // (n_news * L, 3D) packed q|k|v (unscaled q), or null
+  float* lse;               // (n_news * heads, L) or null
+};
+
+__device__ __forceinline__ float nf_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+
+template <int DH, bool SAVE>
+__global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
+  static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NF_RING + NF_WAVES * NF_IMG_FLOATS * 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  float* const image = reinterpret_cast<float*>(smem + NF_RING) + wave * NF_IMG_FLOATS;
+
+  const int L = P.L, D = P.D, heads = P.heads;
+  const int nblk = heads * 4;
+  const int64_t news = (int64_t)blockIdx.x * NF_WAVES + wave;
+  const bool news_ok = news < P.n_news;
+  const int64_t row0 = (news_ok ? news : 0) * L;        // first token row of this wave's news
+
+  // ---- weight DMA: chunk c of head h = k-blocks 2c, 2c + 1 x column blocks 4h .. 4h + 3 x (hi, lo): 16 pieces of
+  // 1 KiB, two per wave.  LDS slot c holds [kbi][nb][plane][lane * 16].
+  auto issue_chunk = [&](int h, int c) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int piece = wave * 2 + q;                    // 0..15 = (kbi, nb, plane)
+      const int kbi = piece >> 3, nb = (piece >> 1) & 3, plane = piece & 1;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) +
+                                 ((size_t)(((2 * c + kbi) * nblk + h * 4 + nb) * 2 + plane)) * 1024 + lane * 16;
+      glds16_asm(src, smem_base + (uint32_t)c * 16384u + (uint32_t)piece * 1024u);
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < 5; ++c) issue_chunk(0, c);
+
+  // ---- gather + dropout + split: the A fragments of this news, resident for all heads ------------------
+  // All 40 row loads of a lane are issued before the first is consumed (branch-free: counted waits, one memory
+  // latency per news instead of one per k-block); the raw registers turn into the fragments in place.
+  bf16x8 ah[2][NF_KB], al[2][NF_KB];
+  {
+    float4 raw[2][NF_KB][2];
+    bool okr[2];
+    int64_t growr[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int t = rb * 16 + l15;
+      okr[rb] = news_ok && t < L;
+      growr[rb] = row0 + (okr[rb] ? t : 0);
+      const float* rowp = P.table + P.ids[growr[rb]] * (int64_t)D;
+#pragma unroll
+      for (int kb = 0; kb < NF_KB; ++kb) {
+        const int k = kb * 32 + 8 * g;
+        // k-blocks 0 .. NF_KB - 2 lie inside every supported D (>= 288); only the last one needs clamping
+        const int k0 = (kb < NF_KB - 1 || k < D) ? k : D - 4;
+        const int k1 = (kb < NF_KB - 1 || k + 4 < D) ? k + 4 : D - 4;
+        raw[rb][kb][0] = *reinterpret_cast<const float4*>(rowp + k0);
+        raw[rb][kb][1] = *reinterpret_cast<const float4*>(rowp + k1);
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const uint32_t idx0 = (uint32_t)growr[rb] * (uint32_t)D;
+      const float live = okr[rb] ? 1.0f : 0.0f;
+#pragma unroll
+      for (int kb = 0; kb < NF_KB; ++kb) {
+        const int k = kb * 32 + 8 * g;
+        float4 v0 = raw[rb][kb][0], v1 = raw[rb][kb][1];
+        const bool in0 = kb < NF_KB - 1 || k < D, in1 = kb < NF_KB - 1 || k + 4 < D;
+        const float m0 = in0 ? live : 0.0f, m1 = in1 ? live : 0.0f;
+        const uint32_t idx = idx0 + (uint32_t)k;
+        // (p == 0: thresh 0, scale 1 -> every multiplier is 1; no branch on it)
+        v0.x *= m0 * P.drop1.mult(idx);     v0.y *= m0 * P.drop1.mult(idx + 1);
+        v0.z *= m0 * P.drop1.mult(idx + 2); v0.w *= m0 * P.drop1.mult(idx + 3);
+        v1.x *= m1 * P.drop1.mult(idx + 4); v1.y *= m1 * P.drop1.mult(idx + 5);
+        v1.z *= m1 * P.drop1.mult(idx + 6); v1.w *= m1 * P.drop1.mult(idx + 7);
+        if constexpr (SAVE) {
+          if (okr[rb]) {
+            if (in0) *reinterpret_cast<float4*>(P.x_save + growr[rb] * D + k) = v0;
+            if (in1) *reinterpret_cast<float4*>(P.x_save + growr[rb] * D + k + 4) = v1;
+          }
+        }
+        // ones column at k == D: the bias row of the image is added by the matrix cores (D % 4 == 0)
+        if (kb == NF_KB - 1) {
+          if (k == D) v0.x = 1.0f;
+          if (k + 4 == D) v1.x = 1.0f;
+        }
+        rp_split8(v0, v1, ah[rb][kb], al[rb][kb]);
+      }
+    }
+  }
+
+  const float* const ring = reinterpret_cast<const float*>(smem);
+  (void)ring;
+  for (int h = 0; h < heads; ++h) {
+    // every chunk of head h was issued while head h - 1 ran: landed for this wave, then (barrier) for all
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int hn = h + 1 < heads ? h + 1 : h;            // last head: re-issue its own chunks (uniform control flow)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const unsigned char* slot = smem + c * 16384 + lane * 16;
+#pragma unroll
+      for (int kbi = 0; kbi < 2; ++kbi) {
+        const int kb = 2 * c + kbi;
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {                   // two column blocks at a time: 4 independent accumulators
+          bf16x8 bh[2], bl[2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            bh[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2) * 1024);
+            bl[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2 + 1) * 1024);
+          }
+#pragma unroll
+          for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+                acc[i][2 * np + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    pass == 1 ? al[i][kb] : ah[i][kb], pass == 0 ? bl[jj] : bh[jj], acc[i][2 * np + jj], 0, 0, 0);
+        }
+      }
+      // all waves are done with slot c: refill it with the same chunk of the next head
+      __builtin_amdgcn_s_barrier();
+      issue_chunk(hn, c);
+    }
+
+    // ---- accumulators -> private image [token][q 20 | k 20 | v 20 | 0 4] -----------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) image[(i * 16 + 4 * g + r) * NF_IMG_LD + nb * 16 + l15] = acc[i][nb][r];
+
+    // ---- save q|k|v for the backward kernels: (row, 3D) layout, q at head*dh, k at D + .., v at 2D + .. ---
+    // (the output base pointers are made opaque per head: hipcc otherwise hoists the per-pass store addresses out
+    //  of the head loop and spills them)
+    // wave-uniform bases + 32-bit lane offsets (scalar-base addressing)
+    float* qkv_out = P.qkv_save + row0 * (int64_t)(3 * D);
+    float* o_out = P.o + row0 * (int64_t)D;
+    asm volatile("" : "+s"(qkv_out), "+s"(o_out));
+    if (SAVE && news_ok) {
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {              // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
+        const int slot_i = pass * 64 + lane;
+        const int row = slot_i >> 4, ch = slot_i & 15;
+        if (ch < 15 && row < L) {
+          const int part = ch / 5, c4 = ch - part * 5;
+          const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + part * DH + 4 * c4);
+          *reinterpret_cast<float4*>(qkv_out + (row * 3 * D + part * D + h * DH + 4 * c4)) = v;
+        }
+      }
+    }
+
+    // ---- S^T = K Q^T on the matrix cores ---------------------------------------------------------------
+    auto frag8 = [&](int row, int col0, float mul, bf16x8& hi, bf16x8& lo) {
+      // 8 consecutive features 8g .. 8g + 7 of `row` (features >= dh are zero)
+      float4 v0 = f4zero(), v1 = f4zero();
+      if (g < 2) {
+        v0 = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + col0 + 8 * g);
+        v1 = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + col0 + 8 * g + 4);
+      } else if (g == 2) {
+        v0 = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + col0 + 16);
+      }
+      v0.x *= mul; v0.y *= mul; v0.z *= mul; v0.w *= mul;
+      v1.x *= mul; v1.y *= mul; v1.z *= mul; v1.w *= mul;
+      rp_split8(v0, v1, hi, lo);
+    };
+    bf16x8 kh[2], kl[2], qh[2], ql[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      frag8(b * 16 + l15, DH, 1.0f, kh[b], kl[b]);
+      frag8(b * 16 + l15, 0, P.scale, qh[b], ql[b]);
+    }
+    f32x4 s[2][2];                                         // [key block][query block]
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) s[jb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+          s[jb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? kl[jb] : kh[jb], pass == 0 ? ql[ib] : qh[ib],
+                                                              s[jb][ib], 0, 0, 0);
+    // lane (query = ib * 16 + l15, g) holds keys jb * 16 + 4g + r: softmax over all L keys of the query
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      float e[8];
+      float m = -INFINITY;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = jb * 16 + 4 * g + r;
+          e[jb * 4 + r] = key < L ? s[jb][ib][r] : -INFINITY;
+          m = fmaxf(m, e[jb * 4 + r]);
+        }
+      m = fmaxf(m, nf_shfl_xor(m, 16));
+      m = fmaxf(m, nf_shfl_xor(m, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        e[q] = expf(e[q] - m);                             // masked keys: exp(-inf) = 0
+        sum += e[q];
+      }
+      sum += nf_shfl_xor(sum, 16);
+      sum += nf_shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      if (SAVE && news_ok && g == 0 && ib * 16 + l15 < L)
+        P.lse[(news * heads + h) * L + ib * 16 + l15] = m + logf(sum);
+      // A fragment of P V: slot e of lane group g <-> key kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4)
+      rp_split8(make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv),
+                make_float4(e[4] * inv, e[5] * inv, e[6] * inv, e[7] * inv), ph[ib], pl[ib]);
+    }
+    // B fragments of V under the same key permutation: lane (d = db * 16 + l15, g) <- V[kappa(g, e)][d]
+    bf16x8 vh[2], vl[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int d = db * 16 + l15;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int key = (q < 4) ? 4 * g + q : 16 + 4 * g + (q - 4);
+        v[q] = d < DH ? image[key * NF_IMG_LD + 2 * DH + d] : 0.f;
+      }
+      rp_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), vh[db], vl[db]);
+    }
+    f32x4 oacc[2][2];                                      // [query block][feature block]
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[ib][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          oacc[ib][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? pl[ib] : ph[ib], pass == 0 ? vl[db] : vh[db],
+                                                                 oacc[ib][db], 0, 0, 0);
+    // O -> image (over the q columns, dead by now) -> 16-byte row stores into o[:, head * dh ..]
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (db * 16 + l15 < DH) image[(ib * 16 + 4 * g + r) * NF_IMG_LD + db * 16 + l15] = oacc[ib][db][r];
+    if (news_ok) {
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {               // 32 rows x 5 float4 = 160 slots
+        const int slot_i = pass * 64 + lane;
+        const int row = slot_i / 5, c4 = slot_i - row * 5;
+        if (slot_i < 160 && row < L)
+          *reinterpret_cast<float4*>(o_out + (row * D + h * DH + 4 * c4)) =
+              *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4);
+      }
+    }
+  }
+  // outstanding re-issued DMA of the last head must not outlive the workgroup's LDS allocation
+  wait_vmcnt<0>();
+}
+
+static inline bool news_fused_ok(int L, int D, int heads) {
+  // (the k-loop is unrolled for exactly NF_KB k-blocks: 288 <= D <= 316; the reference configuration is D = 300)
+  return L >= 1 && L <= 32 && D % 4 == 0 && rp_kblocks(D, true) == NF_KB && heads > 0 && D == heads * 20;
+}
+
+static inline int launch_news_fused_fwd(const NewsFusedArgs& a, hipStream_t st) {
+  if (a.n_news <= 0) return NRL_OK;
+  const int64_t blocks = ceil_div(a.n_news, NF_WAVES);
+  NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
+  if (a.x_save != nullptr && a.qkv_save != nullptr && a.lse != nullptr) {
+    hipLaunchKernelGGL((news_fused_fwd_kernel<20, true>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+  } else {
+    NRL_REQUIRE(a.x_save == nullptr && a.qkv_save == nullptr && a.lse == nullptr,
+                "fused news encoder: save all of x / q|k|v / lse or none");
+    hipLaunchKernelGGL((news_fused_fwd_kernel<20, false>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+  }
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+}  // namespace nrl

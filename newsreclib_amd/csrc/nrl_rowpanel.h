@@ -1,0 +1,298 @@
+// "Row-panel" bf16x3 GEMM for the narrow projections of the NRMS block (gfx950):
+//
+//     C (M x N) = epi( A (M x K) * B ),   N <= 320,  any K
+//
+// One wavefront owns 32 rows x ALL N columns of the output (accumulators: 2 x N/16 MFMA blocks in
+// registers).  That turns the three costs that bound the tiled kernels (nrl_gemm_bf16x3*.h,
+// 15-27 % matrix-core occupancy) into rounding errors:
+//   * the fp32 -> (hi, lo) bf16 split of an activation fragment happens ONCE per (row block, k block)
+//     and feeds 3 * N/16 MFMAs (57 at N = 300); in the 128 x 160 tiles the same fragment was split by
+//     every column tile and every wave column (4-12 x redundant VALU work, 15 MFMAs per split);
+//   * A never passes through LDS: a lane loads the 8 consecutive k of its row straight from global
+//     (two 16-B loads per fragment, one k-block ahead), so LDS carries only the weights;
+//   * the weights are laid out ONCE per step by `rp_weight_images` in MFMA-fragment order
+//     ([k block][n block][hi|lo][lane][8 bf16]): a k-block is one contiguous chunk that travels
+//     global -> LDS by `global_load_lds_dwordx4` with no address arithmetic, and a fragment read is one
+//     conflict-free ds_read_b128 at lane * 16.
+// Per k-block a wave issues 2 * N/16 ds_read_b128 and 6 * N/16 MFMAs (16 cycles each): LDS and VALU
+// sit far below the matrix pipe.  Two 4-wave workgroups share a CU (2-slot LDS ring of <= 40 KB chunks
+// each), so one workgroup's epilogue / barrier waits hide under the other's MFMAs.
+//
+// Arithmetic: identical to nrl_gemm_bf16x3.h (a = hi + lo, products hi*hi + hi*lo + lo*hi, fp32
+// accumulate, lo terms first); outputs differ from the tiled kernel only by the accumulation order over k
+// (the same k order, in fact: k-blocks ascending), i.e. they are bit-identical in practice.
+#pragma once
+#include "nrl_gemm_bf16x3_dma.h"
+
+namespace nrl {
+
+// ---- weight images -----------------------------------------------------------------------------------
+// element (n, k) of the logical B^T (n = output column, k = reduction index) is src[n * sn + k * sk];
+// k == K reads bias[n] when bias != nullptr (the "ones column": the A side then supplies 1.0 at k == K, so
+// the bias is added by the matrix cores); everything outside (N, K [+ 1]) is zero.
+struct RpImageJob {
+  const float* src;
+  const float* bias;
+  uint16_t* img;
+  int64_t sn, sk;
+  int N, K, nblk, kblocks;
+  // optional row remap for the fused news encoder (nrl_news_fused.h): logical column n of the image is
+  // row `remap_base[n / remap_w] * ... ` -- see rp_image_row()
+  int heads, dh;  // heads > 0: per-head packed q|k|v image (n = head * 64 + {q: 0..dh-1, k: dh.., v: 2dh..})
+};
+constexpr int RP_MAX_JOBS = 8;
+struct RpImageJobs {
+  RpImageJob job[RP_MAX_JOBS];
+  int count;
+  int64_t first_thread[RP_MAX_JOBS + 1];  // prefix sums of kblocks * nblk * 64
+};
+
+static inline int rp_kblocks(int K, bool bias) { return (K + (bias ? 1 : 0) + 31) / 32; }
+static inline size_t rp_image_elems(int nblk, int kblocks) { return (size_t)kblocks * nblk * 1024; }  // uint16
+
+// logical source row of image column n (or -1: zero column)
+__device__ __forceinline__ int rp_image_row(const RpImageJob& J, int n) {
+  if (J.heads <= 0) return n < J.N ? n : -1;
+  const int head = n >> 6, c = n & 63;       // 64 image columns per head: q | k | v | pad
+  if (head >= J.heads || c >= 3 * J.dh) return -1;
+  const int part = c / J.dh, d = c - part * J.dh;
+  return part * (J.heads * J.dh) + head * J.dh + d;   // rows [Wq; Wk; Wv] of in_proj_weight
+}
+
+__global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs jobs) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (tid >= jobs.first_thread[jobs.count]) return;
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < RP_MAX_JOBS; ++q)
+    if (q < jobs.count && tid >= jobs.first_thread[q]) j = q;
+  const RpImageJob& J = jobs.job[j];
+  const int64_t t = tid - jobs.first_thread[j];
+  const int lane = (int)(t & 63);
+  const int nb = (int)((t >> 6) % J.nblk), kb = (int)((t >> 6) / J.nblk);
+  const int n = nb * 16 + (lane & 15), k0 = kb * 32 + 8 * (lane >> 4);
+  const int row = rp_image_row(J, n);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    float x = 0.f;
+    if (row >= 0) {
+      if (k < J.K)
+        x = J.src[row * J.sn + k * J.sk];
+      else if (k == J.K && J.bias != nullptr)
+        x = J.bias[row];
+    }
+    v[e] = x;
+  }
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], h[q], l[q]);
+  uint4* dst = reinterpret_cast<uint4*>(J.img) + ((int64_t)(kb * J.nblk + nb) * 2) * 64 + lane;
+  dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  dst[64] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+static inline void rp_jobs_init(RpImageJobs* js) { js->count = 0; js->first_thread[0] = 0; }
+static inline RpImageJob* rp_jobs_add(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int K,
+                                      const float* bias, uint16_t* img, int nblk) {
+  RpImageJob& J = js->job[js->count];
+  J.src = src; J.bias = bias; J.img = img; J.sn = sn; J.sk = sk; J.N = N; J.K = K; J.nblk = nblk;
+  J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0;
+  js->first_thread[js->count + 1] = js->first_thread[js->count] + (int64_t)J.kblocks * nblk * 64;
+  js->count += 1;
+  return &J;
+}
+// per-head packed in-projection image for the fused news encoder: 64 image columns per head = [q | k | v | 0] rows of
+// in_proj_weight (3D, D), the bias as column K = D
+static inline RpImageJob* rp_jobs_add_qkv_heads(RpImageJobs* js, const float* w_in, int D, const float* b_in,
+                                                uint16_t* img, int heads, int dh) {
+  RpImageJob* J = rp_jobs_add(js, w_in, D, 1, heads * 64, D, b_in, img, heads * 4);
+  J->heads = heads;
+  J->dh = dh;
+  return J;
+}
+static inline int rp_jobs_launch(const RpImageJobs& js, hipStream_t st) {
+  if (js.count == 0) return NRL_OK;
+  const int64_t total = js.first_thread[js.count];
+  hipLaunchKernelGGL(rp_weight_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, js);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// handle of a built image
+struct RpImage {
+  const uint16_t* img = nullptr;
+  int nblk = 0, kblocks = 0;
+};
+
+// one fragment (8 consecutive k of one row) fp32 -> packed bf16 (hi, lo)
+__device__ __forceinline__ void rp_split8(const float4& v0, const float4& v1, bf16x8& hi, bf16x8& lo) {
+  uint32_t h[4], l[4];
+  split_pair(v0.x, v0.y, h[0], l[0]);
+  split_pair(v0.z, v0.w, h[1], l[1]);
+  split_pair(v1.x, v1.y, h[2], l[2]);
+  split_pair(v1.z, v1.w, h[3], l[3]);
+  hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+// ---- kernel ------------------------------------------------------------------------------------------
+// WAVES wavefronts x 32 rows each; NBLK = ceil(N / 16) column blocks per wave; LDS ring of 2 k-block chunks.
+template <int NBLK, int WAVES, class AOp, class Epi>
+__global__ void __launch_bounds__(WAVES * 64, 2)
+    rp_gemm_kernel(const AOp A, const uint16_t* __restrict__ img, const Epi epi, const int64_t M, const int N,
+                   const int K, const int kblocks) {
+  constexpr int CHUNK = NBLK * 2048;          // bytes of one k-block of the image
+  constexpr int PIECES = 2 * NBLK;            // 1-KiB pieces per chunk
+  constexpr int G = (PIECES + WAVES - 1) / WAVES;
+  static_assert(AOp::kLayout == SRC_KC, "A: fp32 k-contiguous rows");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * CHUNK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * (WAVES * 32);
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // this wave's share of a chunk: pieces wave, wave + WAVES, ... (clamped: a duplicate rewrites the same bytes)
+  auto issue = [&](int kb, int slot) {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(img) + (size_t)kb * CHUNK + lane * 16;
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      int piece = wave + c * WAVES;
+      piece = piece < PIECES ? piece : PIECES - 1;
+      glds16_asm(src + piece * 1024, smem_base + (uint32_t)slot * CHUNK + (uint32_t)piece * 1024u);
+    }
+  };
+
+  typename AOp::State st[2];
+  int64_t rowi[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    rowi[i] = m0 + wave * 32 + i * 16 + l15;
+    st[i] = A.init(rowi[i]);
+  }
+  auto load_raw = [&](int kb, float4 (&r)[2][2]) {
+    const int k = kb * 32 + 8 * g;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      r[i][0] = A.load(st[i], k, K);
+      r[i][1] = A.load(st[i], k + 4, K);
+    }
+  };
+  auto convert = [&](int kb, float4 (&r)[2][2], bf16x8 (&ah)[2], bf16x8 (&al)[2]) {
+    const int k = kb * 32 + 8 * g;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      A.finish(r[i][0], st[i], rowi[i], k, K, true);
+      A.finish(r[i][1], st[i], rowi[i], k + 4, K, true);
+      rp_split8(r[i][0], r[i][1], ah[i], al[i]);
+    }
+  };
+
+  f32x4 acc[2][NBLK];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // B fragments of column-block pair p are fetched while the 12 MFMAs of pair p - 1 run (two named fragment
+  // sets; hipcc on its own fetches each fragment right before its first MFMA and waits lgkmcnt(0) there, which
+  // exposes the LDS latency every 2-4 MFMAs).  Inside a pair the three split products go pass by pass over four
+  // independent accumulators, so dependent MFMAs are 64 cycles apart.
+  constexpr int NPAIR = (NBLK + 1) / 2;
+  auto read_pair = [&](const unsigned char* base, int p, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * p + jj < NBLK ? 2 * p + jj : NBLK - 1;
+      bh[jj] = *reinterpret_cast<const bf16x8*>(base + j * 2048);
+      bl[jj] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + 1024);
+    }
+  };
+  auto mfma_pair = [&](int p, const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const bf16x8 (&bh)[2],
+                       const bf16x8 (&bl)[2]) {
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (2 * p + jj < NBLK)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][2 * p + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
+                                                                        pass == 0 ? bl[jj] : bh[jj], acc[i][2 * p + jj], 0, 0, 0);
+  };
+  auto mfma_chunk = [&](int slot, const bf16x8 (&ah)[2], const bf16x8 (&al)[2]) {
+    const unsigned char* base = smem + slot * CHUNK + lane * 16;
+    bf16x8 bh0[2], bl0[2], bh1[2], bl1[2];
+    read_pair(base, 0, bh0, bl0);
+#pragma unroll
+    for (int p = 0; p < NPAIR; p += 2) {
+      if (p + 1 < NPAIR) read_pair(base, p + 1, bh1, bl1);
+      mfma_pair(p, ah, al, bh0, bl0);
+      if (p + 1 < NPAIR) {
+        if (p + 2 < NPAIR) read_pair(base, p + 2, bh0, bl0);
+        mfma_pair(p + 1, ah, al, bh1, bl1);
+      }
+    }
+    // pin the interleave: 4 fragment reads, then the 12 (last pair of an odd NBLK: 6) MFMAs they overlap with
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+      if (p + 1 < NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      if (2 * p + 1 < NBLK) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      }
+    }
+  };
+
+  // k-loop.  The (hi, lo) fragments of k-block kb are loop-carried; the raw loads of k-block kb + 1 are issued at
+  // the top of iteration kb and converted at its END, behind ~1800 cycles of MFMAs -- hipcc's own wait for them
+  // (a vmcnt(0): it cannot see the asm DMA) then finds both the loads and the chunk DMA long landed.
+  bf16x8 ah[2], al[2];
+  {
+    float4 r0[2][2];
+    issue(0, 0);
+    load_raw(0, r0);
+    convert(0, r0, ah, al);
+  }
+  for (int kb = 0; kb < kblocks; ++kb) {
+    // chunk kb has landed for THIS wave (it was issued one iteration ago) ...
+    wait_vmcnt<0>();
+    // ... and after the barrier for every wave; everyone has also finished reading the other slot
+    __builtin_amdgcn_s_barrier();
+    // the last iteration re-issues its own chunk into the idle slot and re-loads its own rows: uniform control
+    // flow instead of a branch (one redundant chunk per workgroup)
+    const int kn = kb + 1 < kblocks ? kb + 1 : kb;
+    float4 r[2][2];
+    issue(kn, (kb + 1) & 1);
+    load_raw(kn, r);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(kb & 1, ah, al);
+    __builtin_amdgcn_sched_barrier(0);
+    convert(kn, r, ah, al);
+  }
+
+  store_accumulators<2, NBLK>(epi, acc, m0, 0, wave, 0, l15, g, M, N);
+}
+
+template <int NBLK, int WAVES = 4, class AOp, class Epi>
+int launch_rp_gemm(const AOp& A, const RpImage& B, const Epi& epi, int64_t M, int N, int K, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
+  NRL_REQUIRE(B.img != nullptr && B.nblk == NBLK && N <= NBLK * 16 && B.kblocks * 32 >= K, "row-panel GEMM: image / shape mismatch");
+  const int64_t blocks = ceil_div(M, WAVES * 32);
+  NRL_REQUIRE(blocks < (1LL << 31), "gemm grid too large");
+  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, stream, A,
+                     B.img, epi, M, N, K, B.kblocks);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+static inline bool rp_nblk_supported(int N) { return N > 0 && N <= 320; }
+// NBLK instantiations: 13 (N <= 208: the additive-attention projection, Q = 200), 19 (N <= 304: D = 300), 20
+static inline int rp_nblk_for(int N) { return N <= 208 ? 13 : (N <= 304 ? 19 : 20); }
+
+}  // namespace nrl

@@ -114,6 +114,61 @@ def test_news_encoder_fwd_and_bwd_vs_oracle(p_drop):
         assert e <= 2e-4 * scale, k
 
 
+@pytest.mark.parametrize("N,L,p_drop", [(1, 30, 0.0), (7, 30, 0.2), (8, 30, 0.2), (9, 17, 0.2), (65, 32, 0.0),
+                                        (300, 30, 0.2), (13, 1, 0.0)])
+def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
+    """The fused gather + in-projection + attention kernel (nrl_news_fused.h, bf16x3 engine) against the separate
+    kernels it replaces AND against the oracle: news vectors, every parameter gradient (through the q|k|v, x and
+    log-sum-exp it saves for the unchanged backward kernels); partial workgroups (N % 8 != 0), short and full
+    32-token titles, a one-token title."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.news_encoder import MHSAAddAtt
+    if engine != "bf16x3":
+        pytest.skip("the fused kernel belongs to the bf16x3 engine")
+    params = _news_params(vocab=97, seed=N)
+    gen = torch.Generator().manual_seed(N * 31 + L)
+    ids = torch.randint(1, 97, (N, L), generator=gen)
+    if L > 4:
+        ids[::2, L - 3:] = 0                      # padded tails (id 0 is an ordinary row)
+    d_out = torch.randn(N, 300, generator=gen)
+    res = {}
+    for fused in (True, False):
+        _lib.set_option("news_fused", fused)
+        try:
+            enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
+            enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+            enc = enc.to(DEV)
+            enc.train(p_drop > 0)
+            out = enc(ids.to(DEV), seed=99)
+            out.backward(d_out.to(DEV))
+            with torch.no_grad():
+                enc.eval()
+                out_eval = enc(ids.to(DEV))          # the no-save variant of the kernel
+            res[fused] = (out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in enc.named_parameters()},
+                          out_eval.cpu())
+        finally:
+            _lib.set_option("news_fused", True)
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith(O.NEWS_PREFIX)}
+    m1 = m2 = None
+    if p_drop > 0:
+        m1 = O.dropout_multiplier(99, 0, p_drop, (N, L, 300))
+        m2 = O.dropout_multiplier(99, 1, p_drop, (N, L, 300))
+    ref = O.news_encoder_fwd(ids, op, 15, m1, m2)
+    ref.backward(d_out)
+    e_sep, e_ref = _maxerr(res[True][0], res[False][0]), _maxerr(res[True][0], ref)
+    print(f"fused N={N} L={L} p={p_drop}: vs separate kernels {e_sep:.3e}, vs oracle {e_ref:.3e}")
+    assert e_sep <= 5e-5 and e_ref <= 1e-4
+    if p_drop == 0:
+        assert _maxerr(res[True][2], res[True][0]) <= 1e-6      # eval (no-save) variant == train variant at p = 0
+    for k, gf in res[True][1].items():
+        rg = op[O.NEWS_PREFIX + k].grad.clone()
+        if k == "embedding_layer.weight":
+            rg[0].zero_()
+        scale = max(1.0, float(rg.abs().max()))
+        assert _maxerr(gf, res[False][1][k]) <= 1e-4 * scale, k
+        assert _maxerr(gf, rg) <= 2e-4 * scale, k
+
+
 @pytest.mark.parametrize("B,H", [(3, 4), (5, 50), (40, 7), (130, 3)])
 def test_user_encoder_fwd_and_bwd_vs_oracle(B, H):
     from newsreclib_amd.user_encoder import UserEncoder
