@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region (profiling runs): skip forward_only / f32_engine / cpu_baseline")
     ap.add_argument("--engine", choices=["f32", "bf16x3"], default="bf16x3",
                     help="projection-GEMM engine: exact fp32 MFMA, or fp32 via 3 bf16 MFMAs per product")
     args = ap.parse_args()
@@ -219,7 +221,7 @@ def main():
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "gemm_engine": args.engine},
             "roofline": roof,
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the forward-only (evaluation-mode) rate of the same workload, outside the timed region
             mod.eval()
             with torch.no_grad():
@@ -233,7 +235,7 @@ def main():
             fdt = (time.perf_counter() - t1) / 20
             mod.train()
             out["forward_only"] = {"value": round(B_PER_GPU / fdt, 1), "unit": "impressions/s", "ms": round(fdt * 1e3, 4)}
-        if world == 1 and args.engine != "f32":
+        if world == 1 and args.engine != "f32" and not args.no_extras:
             # the exact-fp32 projection engine on the same workload (extra key, outside the timed region)
             _lib.set_gemm_engine("f32")
             for i in range(3):
@@ -248,7 +250,7 @@ def main():
             _lib.set_gemm_engine(args.engine)
             out["f32_engine"] = {"value": round(B_PER_GPU / d32, 1), "unit": "impressions/s",
                                  "ms_per_step": round(d32 * 1e3, 4), "dtype": "f32 (v_mfma_f32_16x16x4_f32 projections)"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:

@@ -48,7 +48,9 @@ struct NewsFusedArgs {
 
 __device__ __forceinline__ float nf_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 
-template <int DH, bool SAVE>
+// ABL (tools/nf_probe.hip only; product code uses 0): 1 = no attention phase, 2 = no in-projection MFMAs,
+// 4 = no weight DMA, 8 = no o / q|k|v / lse stores
+template <int DH, bool SAVE, int ABL = 0>
 __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
   static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NF_RING + NF_WAVES * NF_IMG_FLOATS * 4];
@@ -77,8 +79,10 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       glds16_asm(src, smem_base + (uint32_t)c * 16384u + (uint32_t)piece * 1024u);
     }
   };
+  if constexpr (!(ABL & 4)) {
 #pragma unroll
-  for (int c = 0; c < 5; ++c) issue_chunk(0, c);
+    for (int c = 0; c < 5; ++c) issue_chunk(0, c);
+  }
 
   // ---- gather + dropout + split: the A fragments of this news, resident for all heads ------------------
   // All 40 row loads of a lane are issued before the first is consumed (branch-free: counted waits, one memory
@@ -136,8 +140,25 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
     }
   }
 
-  const float* const ring = reinterpret_cast<const float*>(smem);
-  (void)ring;
+  // image (q columns = O, column 60 = log-sum-exp of the query) of head `hp` -> global, 16-byte row stores
+  auto flush_o = [&](int hp) {
+    if (!news_ok || (ABL & 8)) return;
+    float* o_out = P.o + row0 * (int64_t)D;             // wave-uniform base + 32-bit lane offsets
+    // (the lane id is made opaque here: hipcc otherwise hoists every pass's address arithmetic out of the head
+    //  loop and spills it -- the MFMA phase has no registers to spare)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {               // 32 rows x 5 float4 = 160 slots
+      const int slot_i = pass * 64 + ln;
+      const int row = slot_i / 5, c4 = slot_i - row * 5;
+      if (slot_i < 160 && row < L)
+        *reinterpret_cast<float4*>(o_out + (row * D + hp * DH + 4 * c4)) =
+            *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4);
+    }
+    if (SAVE && ln < L) P.lse[(news * heads + hp) * L + ln] = image[ln * NF_IMG_LD + 60];
+  };
+
   for (int h = 0; h < heads; ++h) {
     // every chunk of head h was issued while head h - 1 ran: landed for this wave, then (barrier) for all
     wait_vmcnt<0>();
@@ -148,33 +169,55 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int hn = h + 1 < heads ? h + 1 : h;            // last head: re-issue its own chunks (uniform control flow)
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
+    // 20 steps per head = (chunk c, k-block kbi, column-block pair np); the B fragments of step t + 1 are fetched
+    // before the 12 MFMAs of step t (two named fragment sets -- hipcc alone fetches each pair right before its
+    // first MFMA and waits lgkmcnt(0) there, exposing the LDS latency every 2-4 MFMAs).  Reading ahead across a
+    // chunk boundary is safe: the barrier there only guards the REFILL of the slot just finished.
+    auto read_step = [&](int t, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) {
+      const int c = t >> 2, kbi = (t >> 1) & 1, np = t & 1;
       const unsigned char* slot = smem + c * 16384 + lane * 16;
 #pragma unroll
-      for (int kbi = 0; kbi < 2; ++kbi) {
-        const int kb = 2 * c + kbi;
-#pragma unroll
-        for (int np = 0; np < 2; ++np) {                   // two column blocks at a time: 4 independent accumulators
-          bf16x8 bh[2], bl[2];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            bh[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2) * 1024);
-            bl[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2 + 1) * 1024);
-          }
-#pragma unroll
-          for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int i = 0; i < 2; ++i)
-                acc[i][2 * np + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    pass == 1 ? al[i][kb] : ah[i][kb], pass == 0 ? bl[jj] : bh[jj], acc[i][2 * np + jj], 0, 0, 0);
-        }
+      for (int jj = 0; jj < 2; ++jj) {
+        bh[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2) * 1024);
+        bl[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2 + 1) * 1024);
       }
-      // all waves are done with slot c: refill it with the same chunk of the next head
-      __builtin_amdgcn_s_barrier();
-      issue_chunk(hn, c);
+    };
+    auto mfma_step = [&](int t, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
+      const int kb = t >> 1, np = t & 1;
+      if constexpr (ABL & 2) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(bh[jj]), "v"(bl[jj]));
+        return;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][2 * np + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                pass == 1 ? al[i][kb] : ah[i][kb], pass == 0 ? bl[jj] : bh[jj], acc[i][2 * np + jj], 0, 0, 0);
+    };
+    bf16x8 bh0[2], bl0[2], bh1[2], bl1[2];
+    read_step(0, bh0, bl0);
+#pragma unroll
+    for (int t = 0; t < 20; t += 2) {
+      read_step(t + 1, bh1, bl1);
+      mfma_step(t, bh0, bl0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      if (t + 2 < 20) read_step(t + 2, bh0, bl0);
+      mfma_step(t + 1, bh1, bl1);
+      if (t + 2 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      if ((t & 3) == 2) {
+        // steps 4c .. 4c + 3 done: all waves are finished with slot c -> refill it with chunk c of the next head
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 4)) issue_chunk(hn, t >> 2);
+        if (t == 2 && h > 0) flush_o(h - 1);              // the previous head's O, under this head's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 
     // ---- accumulators -> private image [token][q 20 | k 20 | v 20 | 0 4] -----------------------------
@@ -190,12 +233,13 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
     //  of the head loop and spills them)
     // wave-uniform bases + 32-bit lane offsets (scalar-base addressing)
     float* qkv_out = P.qkv_save + row0 * (int64_t)(3 * D);
-    float* o_out = P.o + row0 * (int64_t)D;
-    asm volatile("" : "+s"(qkv_out), "+s"(o_out));
-    if (SAVE && news_ok) {
+    asm volatile("" : "+s"(qkv_out));
+    if (SAVE && news_ok && !(ABL & 8)) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
 #pragma unroll
       for (int pass = 0; pass < 8; ++pass) {              // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
-        const int slot_i = pass * 64 + lane;
+        const int slot_i = pass * 64 + ln;
         const int row = slot_i >> 4, ch = slot_i & 15;
         if (ch < 15 && row < L) {
           const int part = ch / 5, c4 = ch - part * 5;
@@ -205,6 +249,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       }
     }
 
+    if constexpr (ABL & 1) continue;
     // ---- S^T = K Q^T on the matrix cores ---------------------------------------------------------------
     auto frag8 = [&](int row, int col0, float mul, bf16x8& hi, bf16x8& lo) {
       // 8 consecutive features 8g .. 8g + 7 of `row` (features >= dh are zero)
@@ -263,8 +308,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       sum += nf_shfl_xor(sum, 16);
       sum += nf_shfl_xor(sum, 32);
       const float inv = 1.0f / sum;
-      if (SAVE && news_ok && g == 0 && ib * 16 + l15 < L)
-        P.lse[(news * heads + h) * L + ib * 16 + l15] = m + logf(sum);
+      if (SAVE && g == 0) image[(ib * 16 + l15) * NF_IMG_LD + 60] = m + logf(sum);   // -> flush_o of the next head
       // A fragment of P V: slot e of lane group g <-> key kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4)
       rp_split8(make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv),
                 make_float4(e[4] * inv, e[5] * inv, e[6] * inv, e[7] * inv), ph[ib], pl[ib]);
@@ -303,17 +347,11 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (db * 16 + l15 < DH) image[(ib * 16 + 4 * g + r) * NF_IMG_LD + db * 16 + l15] = oacc[ib][db][r];
-    if (news_ok) {
-#pragma unroll
-      for (int pass = 0; pass < 3; ++pass) {               // 32 rows x 5 float4 = 160 slots
-        const int slot_i = pass * 64 + lane;
-        const int row = slot_i / 5, c4 = slot_i - row * 5;
-        if (slot_i < 160 && row < L)
-          *reinterpret_cast<float4*>(o_out + (row * D + h * DH + 4 * c4)) =
-              *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4);
-      }
-    }
+    // (the global stores of O / lse are issued by `flush_o` during the NEXT head's MFMA phase: the head-top
+    //  vmcnt(0) that the weight DMA needs would otherwise also wait out these stores' full latency -- 0.15 ms of
+    //  0.64 at B = 128, tools/nf_probe.hip)
   }
+  flush_o(heads - 1);
   // outstanding re-issued DMA of the last head must not outlive the workgroup's LDS allocation
   wait_vmcnt<0>();
 }
@@ -323,16 +361,17 @@ static inline bool news_fused_ok(int L, int D, int heads) {
   return L >= 1 && L <= 32 && D % 4 == 0 && rp_kblocks(D, true) == NF_KB && heads > 0 && D == heads * 20;
 }
 
+template <int ABL = 0>
 static inline int launch_news_fused_fwd(const NewsFusedArgs& a, hipStream_t st) {
   if (a.n_news <= 0) return NRL_OK;
   const int64_t blocks = ceil_div(a.n_news, NF_WAVES);
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   if (a.x_save != nullptr && a.qkv_save != nullptr && a.lse != nullptr) {
-    hipLaunchKernelGGL((news_fused_fwd_kernel<20, true>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+    hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
   } else {
     NRL_REQUIRE(a.x_save == nullptr && a.qkv_save == nullptr && a.lse == nullptr,
                 "fused news encoder: save all of x / q|k|v / lse or none");
-    hipLaunchKernelGGL((news_fused_fwd_kernel<20, false>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+    hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
   }
   NRL_LAUNCH_CHECK();
   return NRL_OK;

@@ -1,0 +1,100 @@
+// Probe (not product code): timing + ablations of the fused news-encoder front half (nrl_news_fused.h) at the
+// BASELINE configs[1] shape (7040 news x 30 tokens, D = 300, 15 heads, V = 70000).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Inewsreclib_amd/csrc tools/nf_probe.hip -o tools/bin/nf_probe
+#include <stdarg.h>
+
+#include <vector>
+
+#include "nrl_news_fused.h"
+
+namespace nrl {
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "\n");
+}
+}  // namespace nrl
+using namespace nrl;
+
+#define CK(x)                                                \
+  do {                                                       \
+    hipError_t e = (x);                                      \
+    if (e != hipSuccess) {                                   \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); \
+      exit(1);                                               \
+    }                                                        \
+  } while (0)
+
+template <class F>
+static float time_ms(F f, hipStream_t st, int reps = 20) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) f();
+  CK(hipEventRecord(a, st));
+  for (int i = 0; i < reps; ++i) f();
+  CK(hipEventRecord(b, st));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 7040;
+  const int L = 30, D = 300, H = 15, V = 70000;
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  float *table, *w, *b, *o, *x, *qkv, *lse;
+  int64_t* ids;
+  uint16_t* img;
+  CK(hipMalloc(&table, (size_t)V * D * 4));
+  CK(hipMalloc(&w, (size_t)3 * D * D * 4));
+  CK(hipMalloc(&b, (size_t)3 * D * 4));
+  CK(hipMalloc(&o, (size_t)N * L * D * 4));
+  CK(hipMalloc(&x, (size_t)N * L * D * 4));
+  CK(hipMalloc(&qkv, (size_t)N * L * 3 * D * 4));
+  CK(hipMalloc(&lse, (size_t)N * H * L * 4));
+  CK(hipMalloc(&ids, (size_t)N * L * 8));
+  CK(hipMalloc(&img, rp_image_elems(H * 4, NF_KB) * 2));
+  {
+    uint32_t s = 777;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+    std::vector<float> h((size_t)V * D);
+    for (auto& v : h) v = rnd();
+    CK(hipMemcpy(table, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> hw((size_t)3 * D * D);
+    for (auto& v : hw) v = rnd() * 0.06f;
+    CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> hb(3 * D);
+    for (auto& v : hb) v = rnd() * 0.1f;
+    CK(hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    std::vector<int64_t> hi((size_t)N * L);
+    for (auto& v : hi) { s = s * 1664525u + 1013904223u; const double u = (s >> 8) / 16777216.0; v = 1 + (int64_t)((V - 1) * u * u * u); }
+    CK(hipMemcpy(ids, hi.data(), hi.size() * 8, hipMemcpyHostToDevice));
+  }
+  RpImageJobs jobs;
+  rp_jobs_init(&jobs);
+  rp_jobs_add_qkv_heads(&jobs, w, D, b, img, H, 20);
+  rp_jobs_launch(jobs, st);
+  NewsFusedArgs a;
+  a.table = table; a.ids = ids; a.img = img; a.n_news = N; a.L = L; a.D = D; a.heads = H; a.dh = 20;
+  a.scale = 1.0f / sqrtf(20.f); a.drop1 = make_dropout(0.2, 5, 0); a.o = o;
+  NewsFusedArgs as = a;
+  as.x_save = x; as.qkv_save = qkv; as.lse = lse;
+  a.x_save = nullptr; a.qkv_save = nullptr; a.lse = nullptr;
+  const double gf = 2.0 * N * L * 3.0 * D * D * 1e-9;
+  auto report = [&](const char* name, float ms) { printf("%-46s %.3f ms  (%.0f TF fp32-equiv in-projection)\n", name, ms, gf / ms); fflush(stdout); };
+  report("eval  (no saves)", time_ms([&] { launch_news_fused_fwd<0>(a, st); }, st));
+  report("train (x, q|k|v, lse saved)", time_ms([&] { launch_news_fused_fwd<0>(as, st); }, st));
+  report("eval  no attention phase", time_ms([&] { launch_news_fused_fwd<1>(a, st); }, st));
+  report("eval  no in-projection MFMAs", time_ms([&] { launch_news_fused_fwd<2>(a, st); }, st));
+  report("eval  no attention, no MFMAs", time_ms([&] { launch_news_fused_fwd<3>(a, st); }, st));
+  report("eval  no weight DMA", time_ms([&] { launch_news_fused_fwd<4>(a, st); }, st));
+  report("eval  no stores", time_ms([&] { launch_news_fused_fwd<8>(a, st); }, st));
+  report("train no stores in the head loop", time_ms([&] { launch_news_fused_fwd<8>(as, st); }, st));
+  report("eval  no attention, no MFMAs, no DMA", time_ms([&] { launch_news_fused_fwd<7>(a, st); }, st));
+  return 0;
+}
