@@ -169,7 +169,7 @@ def main():
     # what the id bookkeeping inside the step costs (measured after the timed region)
     t1 = time.perf_counter()
     for i in range(20):
-        prepare_batch(batches[i % N_BATCHES])
+        prepare_batch(batches[i % N_BATCHES], VOCAB)
     torch.cuda.synchronize()
     prepare_ms = (time.perf_counter() - t1) / 20 * 1e3
     tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()

@@ -108,6 +108,14 @@ uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream);
 int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, uint32_t stream,
                      void* stream_handle);
 
+/* ---- token-id grouping for the embedding-table gradient (embedding_dense_backward, text.py:215-217,224) -----
+ * order (n) int64 <- the positions 0..n-1 of the flat id vector in ascending id order, ties in position order
+ * (stable radix sort over ceil(log2 vocab) key bits; == torch.argsort(ids, stable=True)).  This is the
+ * `sorted_positions` argument of the *_encoder_bwd entry points. */
+size_t nrl_sort_positions_workspace_bytes(int64_t n, int64_t vocab);
+int nrl_sort_positions(const int64_t* ids, int64_t n, int64_t vocab, int64_t* order, void* ws, size_t ws_bytes,
+                       void* stream);
+
 /* ---- news encoder: MHSAAddAtt.forward, text.py:222-236 (behind NewsEncoder.forward,
  * news.py:134-160) ------------------------------------------------------------------------------
  * ids (N, L) int64 -> out (N, D).  Embedding gather (bit-exact; id 0 is an ordinary row,

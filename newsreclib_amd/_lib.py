@@ -84,6 +84,8 @@ SIGNATURES = {
     "nrl_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "nrl_dropout_key": (c_uint32, [c_uint64, c_uint32]),
     "nrl_dropout_mask": (c_int32, [c_void_p, c_int64, c_double, c_uint64, c_uint32, c_void_p]),
+    "nrl_sort_positions_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "nrl_sort_positions": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_news_encoder_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32]),
     "nrl_news_encoder_fwd": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                        c_double, c_uint64, c_uint32, c_int32, c_void_p, c_void_p, c_size_t,

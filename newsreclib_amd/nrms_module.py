@@ -52,7 +52,7 @@ def attach_layout(batch: Dict) -> Dict:
     return out
 
 
-def prepare_batch(batch: Dict) -> Dict:
+def prepare_batch(batch: Dict, vocab: Optional[int] = None) -> Dict:
     """``attach_layout`` + the per-step device work on the token ids: history and candidate ids as the single
     encoder call sees them, and their id-sorted visiting order for the embedding gradient (the sort the reference
     pays inside ``embedding_dense_backward``).  No host sync; part of the train step (bench.py times it)."""
@@ -66,7 +66,7 @@ def prepare_batch(batch: Dict) -> Dict:
             if torch.is_tensor(h):
                 ids = torch.cat([h, c], dim=0)
                 out.setdefault("x_all", {})[attr] = ids
-                out["x_all"][attr + "_order"] = torch.argsort(ids.reshape(-1))
+                out["x_all"][attr + "_order"] = ops.sort_positions(ids, vocab)    # 3-pass radix sort on the id bits
             # (PLM tokenizer output -- a dict of (N, L) tensors, rec_dataset.py:180-190 -- is NOT merged: the
             #  two sides are padded to their own longest text and the PLM encoder must see them in separate calls)
     for attr in ("category", "subcategory"):
@@ -139,13 +139,14 @@ class NRMSModule(AbstractRecommender):
         self._init_step_outputs(outputs)
         assert hp is not None
 
-    @staticmethod
-    def _prepare(batch: Dict) -> Dict:
-        return prepare_batch(batch)
+    def _prepare(self, batch: Dict) -> Dict:
+        te = self.news_encoder.text_encoders[self._text_attr]
+        emb = getattr(te, "embedding_layer", None)
+        return prepare_batch(batch, emb.weight.shape[0] if emb is not None else None)
 
     # -- reference: nrms_module.py:230-255 ---------------------------------------------------------
     def forward(self, batch: Dict) -> torch.Tensor:
-        batch = prepare_batch(batch)
+        batch = self._prepare(batch)
         B = batch["batch_size"]
         hist_text = batch["x_hist"][self._text_attr]
         n_hist = (hist_text if torch.is_tensor(hist_text) else next(iter(hist_text.values()))).shape[0]

@@ -94,7 +94,7 @@ class NewsEncoderFn(torch.autograd.Function):
             if order is None:
                 # id-sorted visiting order for the table gradient (index bookkeeping on the int64 ids;
                 # `prepare_batch` precomputes it once per batch so the step does not pay the sort)
-                order = torch.argsort(ids.reshape(-1))
+                order = sort_positions(ids, V)
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
@@ -375,6 +375,21 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
     _lib.check(lib.nrl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
                                  exp_avg_sq.data_ptr(), param.numel(), lr, betas[0], betas[1], eps,
                                  int(step), float(grad_scale), int(zero_grad), _stream()), "nrl_adam_step")
+
+
+def sort_positions(ids: torch.Tensor, vocab: Optional[int] = None) -> torch.Tensor:
+    """Positions of the flat id vector in ascending id order (stable) == ``torch.argsort(ids.reshape(-1),
+    stable=True)``: the visiting order of the embedding-table gradient.  ``vocab`` (exclusive upper bound of the
+    ids) limits the radix sort to ceil(log2 vocab) key bits; None sorts all 32."""
+    lib = _lib.load()
+    flat = _chk(ids, torch.int64, "ids").reshape(-1)
+    n = flat.numel()
+    v = int(vocab) if vocab else (1 << 32)
+    order = torch.empty(n, dtype=torch.int64, device=flat.device)
+    ws = torch.empty(max(lib.nrl_sort_positions_workspace_bytes(n, v), 256), dtype=torch.uint8, device=flat.device)
+    _lib.check(lib.nrl_sort_positions(flat.data_ptr(), n, v, order.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "nrl_sort_positions")
+    return order
 
 
 def offsets_from_sorted_batch(batch: torch.Tensor, batch_size: int) -> torch.Tensor:

@@ -44,6 +44,20 @@ def test_dropout_mask_bit_exact():
     assert ops.dropout_mask(1000, 0.0, 1, 1, DEV).all()
 
 
+def test_sort_positions_equals_stable_argsort():
+    """The 3-pass radix sort that orders the embedding-gradient visits == torch.argsort(stable=True), bit for bit
+    (ties keep position order), with and without the vocabulary bound, incl. n = 0 and a single hot id."""
+    from newsreclib_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for n, vocab in [(211_200, 70_000), (1, 5), (777, 150_000), (4096, 2), (100_000, 1 << 20)]:
+        ids = torch.randint(0, vocab, (n,), generator=g)
+        ids[: n // 3] = 7 % vocab
+        ref = torch.argsort(ids, stable=True)
+        assert torch.equal(ops.sort_positions(ids.to(DEV), vocab).cpu(), ref)
+        assert torch.equal(ops.sort_positions(ids.to(DEV)).cpu(), ref)
+    assert ops.sort_positions(torch.empty(0, dtype=torch.int64, device=DEV), 10).numel() == 0
+
+
 def test_embedding_gather_bit_exact():
     from newsreclib_amd import ops
     g = torch.Generator().manual_seed(0)
