@@ -34,10 +34,7 @@ B_PER_GPU, VOCAB, L, H, C, D, HEADS, Q, P_DROP, LR = 128, 70_000, 30, 50, 5, 300
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= vector) peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBPS = 8000.0                 # HBM3E spec (6.3 TB/s achievable)
-# algorithmic HBM bytes of ONE in-projection forward launch: ids + gathered
-# embedding rows + qkv written + post-dropout x written for the weight gradient
 M_ROWS = B_PER_GPU * (H + C) * L
-IN_PROJ_ALGO_BYTES = M_ROWS * 8 + M_ROWS * D * 4 + M_ROWS * 3 * D * 4 + M_ROWS * D * 4
 N_BATCHES = 4                          # distinct pre-generated batches cycled through
 
 
@@ -185,26 +182,44 @@ def main():
         value = world * B_PER_GPU * args.steps / dt
         avg_s = tot_ms.value * 1e-3 / max(1, launches.value)
         tflops = (flops.value / max(1, launches.value)) / avg_s / 1e12 if avg_s > 0 else None
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"pmc_in_proj_fwd_{args.engine}.json")
+        # The dominant kernel of the step and its ALGORITHMIC work (no materialised
+        # intermediates): per launch it needs the ids (8 B per token) and the gathered embedding rows (1200 B per
+        # token) -- 0.255 GB at B = 128 -- and 2*M*3D*D (+ the per-head L x L attention it now contains) FLOPs.
+        algo_bytes = M_ROWS * 8 + M_ROWS * D * 4
+        fused = args.engine == "bf16x3" and os.environ.get("NRL_NEWS_FUSED", "1") != "0"
+        pmc_name = "pmc_news_fused_fwd_bf16x3.json" if fused else f"pmc_in_proj_fwd_{args.engine}.json"
+        traffic, step_bytes = None, None
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            j = json.load(open(pmc))
+            traffic, step_bytes = j.get("hbm_bytes_per_launch"), j.get("hbm_bytes_per_step")
         if args.engine == "f32":
-            # exact fp32 MFMA: intensity 90 FLOP/B >> ridge 25 -> MFMA-bound
+            # exact fp32 MFMA: intensity (114 GFLOP / 0.255 GB) >> ridge 25 FLOP/B -> MFMA-bound
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<4,2,2,5,16,KCGather,KCPlain,EpiLinear> (in-projection "
                                               "forward with fused embedding gather + dropout)",
                     "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4)}
         else:
-            # bf16x3: 3 bf16 MFMA products per fp32 product -> 342 GFLOP issued on a 2.5 PF pipe (0.14 ms)
-            # vs 1.27 GB over 8 TB/s (0.16 ms): the HBM roofline is the binding one for this kernel
-            gbps = IN_PROJ_ALGO_BYTES / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "gemm_bf16x3_kernel<4,2,4,5,KCGather,KCSplit,EpiLinear> (in-projection "
-                                             "forward with fused embedding gather + dropout)",
-                    "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(gbps / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": IN_PROJ_ALGO_BYTES,
-                    "mfma_view": {"algorithmic_fp32_TFLOPs": round(tflops, 1),
-                                  "issued_bf16_TFLOPs": round(3 * tflops, 1), "bf16_peak": BF16_MFMA_PEAK_TFLOPS}}
+            # bf16x3: every fp32 product is three bf16 MFMA products; against section 8(d)'s bytes the binding
+            # roofline is the matrix pipe (3 x 122 GFLOP on 2.5 PF = 0.146 ms vs 0.255 GB over 8 TB/s = 0.032 ms)
+            name = ("news_fused_fwd_kernel<20, true> (embedding gather + dropout + in-projection + per-head token "
+                    "attention in one launch)") if fused else \
+                   "gemm_bf16x3_kernel<4,2,4,5,KCGather,KCSplit,EpiLinear> (in-projection forward with fused gather)"
+            issued = 3.0 * tflops
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(issued, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(issued / BF16_MFMA_PEAK_TFLOPS, 4),
+                    "algorithmic_fp32_TFLOPs": round(tflops, 1),
+                    "hbm_view": {"algorithmic_GBps": round(algo_bytes / avg_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBPS,
+                                 "frac": round(algo_bytes / avg_s / 1e9 / HBM_PEAK_GBPS, 4)}}
+        roof["algorithmic_bytes_per_launch"] = algo_bytes
+        # whole step against the survey's algorithmic model: 4.49 GFLOP and 11.7 MB per impression (fp32-equivalent)
+        step_s = dt / args.steps
+        step_flops = 4.49e9 * B_PER_GPU
+        roof["step"] = {"algorithmic_flops": step_flops, "algorithmic_bytes": 11.7e6 * B_PER_GPU,
+                        "counter_bytes": step_bytes,
+                        "frac_of_fp32_mfma_peak": round(step_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "frac_of_bf16x3_peak": round(3 * step_flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "frac_of_hbm_peak_algorithmic": round(11.7e6 * B_PER_GPU / step_s / 1e9 / HBM_PEAK_GBPS, 4)}
         roof.update({"traffic": traffic, "launches": launches.value, "avg_launch_ms": round(avg_s * 1e3, 4)})
         out = {
             "metric": "impressions/sec (train step) NRMS MINDsmall-shape", "value": round(value, 1),

@@ -28,10 +28,17 @@ enum { SRC_SPLIT = 2 };
 __device__ __forceinline__ uint32_t pack_bf16(__bf16 a, __bf16 b) {
   return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
 }
+// (a, b) -> packed (hi_a | hi_b << 16), (lo_a | lo_b << 16).  Written on two-element vectors so that hipcc emits ONE
+// v_cvt_pk_bf16_f32 per pair and a packed subtract: 5 VALU per pair (the scalar `(__bf16)a` form costs ~10: one
+// convert per element with a zero second source, shifts and an sdwa merge).  Same round-to-nearest-even values.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const __bf16 ha = (__bf16)a, hb = (__bf16)b;
-  hi = pack_bf16(ha, hb);
-  lo = pack_bf16((__bf16)(a - (float)ha), (__bf16)(b - (float)hb));
+  const bf16x2_t h = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  const bf16x2_t l = __builtin_convertvector(f32x2_t{a - ha, b - hb}, bf16x2_t);
+  lo = __builtin_bit_cast(uint32_t, l);
 }
 
 // pre-split weight, zero padded past K to a multiple of 32.  The hi and lo halves of one k-tile are

@@ -9,7 +9,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --engine $ENGINE"
+BENCH="python $R/bench.py --steps 10 --warmup 3 --no-extras --engine $ENGINE"
+export NRL_PROFILE_STEPS=13
 # 1. per-kernel time (kernel trace + stats only)
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/${TAG}_trace -o $TAG -- $BENCH > $OUT/${TAG}_trace.log 2>&1
 # 2./3. HBM traffic counters, each in its own pass (TCC slot limits), no other trace domains

@@ -63,8 +63,25 @@ for k, ctrs in per.items():
         # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines
         e["mfma_busy_frac"] = (e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (e["SQ_BUSY_CYCLES"] / 32.0)
     summary[k] = e
+# counter traffic of one whole step: sum over kernels of (bytes per launch x launches per step); the PMC passes
+# ran `steps_profiled` steps (env NRL_PROFILE_STEPS, default 13 = 10 timed + 3 warm-up)
+steps_profiled = float(os.environ.get("NRL_PROFILE_STEPS", "13"))
+step_bytes = 0.0
+for k, e in summary.items():
+    if "hbm_bytes_per_launch" in e:
+        n_launch = max(len(per[k].get("FETCH_SIZE", [])), len(per[k].get("WRITE_SIZE", [])))
+        e["launches_per_step"] = round(n_launch / steps_profiled, 2)
+        step_bytes += e["hbm_bytes_per_launch"] * n_launch / steps_profiled
+summary["_step"] = {"hbm_bytes_per_step": step_bytes, "steps_profiled": steps_profiled}
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 for k, e in summary.items():
+    if "news_fused_fwd_kernel" in k and "true" in k and "hbm_bytes_per_launch" in e:
+        json.dump({"kernel": k, "hbm_bytes_per_launch": round(e["hbm_bytes_per_launch"]),
+                   "hbm_bytes_per_step": round(step_bytes), "mfma_busy_frac": e.get("mfma_busy_frac"),
+                   "raw_FETCH_SIZE_KiB": e.get("FETCH_SIZE"), "raw_WRITE_SIZE_KiB": e.get("WRITE_SIZE"),
+                   "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 half-count), write = WRITE_SIZE x 1024",
+                   "source": f"{tag}_pmc_summary.json"},
+                  open(os.path.join(out_dir, f"pmc_news_fused_fwd_{engine}.json"), "w"), indent=1)
     if "KCGather" in k and "hbm_bytes_per_launch" in e:
         json.dump({"kernel": k, "hbm_bytes_per_launch": round(e["hbm_bytes_per_launch"]),
                    "raw_FETCH_SIZE_KiB": e.get("FETCH_SIZE"), "raw_WRITE_SIZE_KiB": e.get("WRITE_SIZE"),
@@ -72,4 +89,4 @@ for k, e in summary.items():
                    "source": f"{tag}_pmc_summary.json"},
                   open(os.path.join(out_dir, f"pmc_in_proj_fwd_{engine}.json"), "w"), indent=1)
 print(json.dumps({k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in e.items()}
-                  for k, e in summary.items() if "gemm" in k}, indent=1)[:3000])
+                  for k, e in summary.items() if "gemm" in k or "fused" in k or k == "_step"}, indent=1)[:4000])
