@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 7
+#define NRL_ABI_VERSION 8
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -131,14 +131,17 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
 /* Backward of the above (autograd of text.py:222-236 incl. embedding_dense_backward with
  * padding_idx=0: rows of id 0 receive no gradient).  d_out (N, D).  Adds into `g` and into
  * d_emb_table (vocab, D).  `ws` must be the workspace the forward filled.
+ * emb_table: the table the forward read (unchanged since).  On the fused path (bf16x3 engine, reference geometry)
+ * the forward does NOT save q|k|v: the backward re-gathers the rows and recomputes them per head inside the
+ * attention-backward kernel (nrl_news_fused.h); NULL is accepted only where that path is off.
  * sorted_positions: optional (may be NULL) argsort of the flat (N*L) id vector; when given, the
  * table gradient is reduced in id-sorted order (one atomic per (id, 64-row segment)) instead of one
  * atomic per element -- frequent tokens otherwise serialise on their row.
  * phase: 0 = whole backward; 1 = activation-gradient chain + table gradient only; 2 = the three
  * weight/bias-gradient GEMMs only (call 1 then 2: a data-parallel caller starts the all-reduce of the
  * table gradient, >96 % of the bytes, between them so it overlaps the weight-gradient GEMMs). */
-int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
-                         int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
+int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* emb_table,
+                         float* d_emb_table, int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
                          int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed,
                          uint32_t stream0, const float* d_out, int32_t phase, void* ws,
                          size_t ws_bytes, void* stream);

@@ -123,6 +123,12 @@ static bool g_news_fused = [] {
   return !(e != nullptr && e[0] == '0');
 }();
 
+// NRL_NEWS_FUSED_BWD=0: the forward saves q|k|v and the separate attention-backward kernel reads them
+static bool g_news_fused_bwd = [] {
+  const char* e = getenv("NRL_NEWS_FUSED_BWD");
+  return !(e != nullptr && e[0] == '0');
+}();
+
 static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {
   const int64_t tiles = ceil_div(rows_out, bm) * ceil_div(cols_out, bn);
   int64_t s = ceil_div(2048, tiles);
@@ -388,7 +394,8 @@ static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const Bl
 //            in-projection dgrad -> table gradient / d_hist)
 //   phase 2: the three weight(+bias)-gradient GEMMs, which only READ saved activations/gradients.
 static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, const BlockShape& s, const BlockWs& w,
-                            const BlockPlanes& bp, Dropout drop2, const float* d_out, hipStream_t st) {
+                            const BlockPlanes& bp, Dropout drop2, const float* d_out, hipStream_t st,
+                            bool attention_elsewhere = false) {
   const int D = s.D, Q = s.Q;
   // additive attention backward: t -> d_pre in place, dq_a
   NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st));
@@ -399,7 +406,7 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
   NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{w.d_o, D}, s.M, D, D, st,
                      bp.rp.on ? &bp.rp.out_d : nullptr));
   // attention backward -> dqkv
-  NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+  if (!attention_elsewhere) NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
   return NRL_OK;
 }
 
@@ -497,10 +504,11 @@ int nrl_get_gemm_engine(void) { return g_default_engine.load(); }
 int nrl_set_option(const char* name, int32_t value) {
   NRL_REQUIRE(name != nullptr, "set_option: null name");
   bool* flag = !strcmp(name, "news_fused") ? &g_news_fused
+               : !strcmp(name, "news_fused_bwd") ? &g_news_fused_bwd
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma
                                            : nullptr;
-  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, rowpanel, x3_dma)", name);
+  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, rowpanel, x3_dma)", name);
   *flag = value != 0;
   return NRL_OK;
 }
@@ -542,7 +550,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
     a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.o = w.o;
     a.x_save = save_for_backward ? w.x : nullptr;
-    a.qkv_save = save_for_backward ? w.qkv : nullptr;
+    a.qkv_save = (save_for_backward && !g_news_fused_bwd) ? w.qkv : nullptr;   // else recomputed in the backward
     a.lse = save_for_backward ? w.lse : nullptr;
     {
       ProfScope prof(st, 2.0 * (double)s.M * 3.0 * s.D * s.D + 4.0 * (double)s.M * seq_len * s.D);
@@ -554,8 +562,8 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
   return block_fwd(p, a_in, s, w, d2, save_for_backward != 0, true, out, (hipStream_t)stream);
 }
 
-int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float* d_emb_table,
-                         int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
+int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* emb_table,
+                         float* d_emb_table, int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
                          int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed, uint32_t stream0,
                          const float* d_out, int32_t phase, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
@@ -570,9 +578,20 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, float*
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
-  NRL_TRY(block_planes(p, s, w, false, &bp, st));  // filled by the forward; weights unchanged since
+  const bool fused = news_fused_on(s, seq_len) && g_news_fused_bwd;
+  NRL_TRY(block_planes(p, s, w, false, &bp, st, fused ? s.heads : 0));  // filled by the forward; weights unchanged since
   if (phase != 2) {
-    NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st));
+    NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st, fused));
+    if (fused) {
+      // q|k|v recomputed per head + the attention backward on the matrix cores in one kernel (nrl_news_fused.h)
+      NewsFusedBwdArgs a;
+      NRL_REQUIRE(emb_table != nullptr && ((uintptr_t)emb_table & 15) == 0,
+                  "news_encoder_bwd: emb_table (16-byte aligned) is needed to recompute q|k|v");
+      a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
+      a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.d_o = w.d_o; a.lse = w.lse;
+      a.dqkv = w.dqkv;
+      NRL_TRY(launch_news_fused_bwd(a, st));
+    }
     // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
     if (sorted_positions != nullptr) {
       // dx is materialised (in the now dead d_o buffer) and reduced in id-sorted order: no hot-row contention

@@ -115,7 +115,7 @@ class NewsEncoderFn(torch.autograd.Function):
         bg = _block_grads(bufs[1:])
         ws = ctx.ws
         def run(phase):
-            _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), bufs[0].data_ptr(), V,
+            _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), emb.data_ptr(), bufs[0].data_ptr(), V,
                                                 ids.data_ptr(), order.data_ptr(), N, L, p_drop, seed, stream0,
                                                 d_out.data_ptr(), phase, ws.data_ptr(), ws.numel(), _stream()),
                        "nrl_news_encoder_bwd")

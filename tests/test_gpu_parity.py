@@ -146,8 +146,11 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
         ids[::2, L - 3:] = 0                      # padded tails (id 0 is an ordinary row)
     d_out = torch.randn(N, 300, generator=gen)
     res = {}
-    for fused in (True, False):
-        _lib.set_option("news_fused", fused)
+    # "full": fused forward + fused backward (q|k|v recomputed per head, never in HBM); True: fused forward that saves
+    # q|k|v for the separate attention-backward kernel; False: every stage its own kernel
+    for fused in ("full", True, False):
+        _lib.set_option("news_fused", bool(fused))
+        _lib.set_option("news_fused_bwd", fused == "full")
         try:
             enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
             enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
@@ -162,6 +165,7 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
                           out_eval.cpu())
         finally:
             _lib.set_option("news_fused", True)
+            _lib.set_option("news_fused_bwd", True)
     op = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith(O.NEWS_PREFIX)}
     m1 = m2 = None
     if p_drop > 0:
@@ -174,6 +178,8 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
     assert e_sep <= 5e-5 and e_ref <= 1e-4
     if p_drop == 0:
         assert _maxerr(res[True][2], res[True][0]) <= 1e-6      # eval (no-save) variant == train variant at p = 0
+    assert torch.equal(res["full"][0], res[True][0])            # same forward kernel, with / without the q|k|v save
+    worst = 0.0
     for k, gf in res[True][1].items():
         rg = op[O.NEWS_PREFIX + k].grad.clone()
         if k == "embedding_layer.weight":
@@ -181,6 +187,10 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
         scale = max(1.0, float(rg.abs().max()))
         assert _maxerr(gf, res[False][1][k]) <= 1e-4 * scale, k
         assert _maxerr(gf, rg) <= 2e-4 * scale, k
+        e_full = _maxerr(res["full"][1][k], rg)
+        worst = max(worst, e_full / scale)
+        assert e_full <= 2e-4 * scale, (k, e_full, scale)
+    print(f"   recomputing backward: worst gradient error vs oracle {worst:.3e} (relative to the largest gradient)")
 
 
 @pytest.mark.parametrize("B,H", [(3, 4), (5, 50), (40, 7), (130, 3)])
@@ -460,7 +470,8 @@ def test_embedding_gradient_hot_token_and_both_scatter_paths():
     bufs = [torch.zeros_like(p) for p in prm]
     bg = ops._block_grads(bufs[1:])
     dg = d_out.to(DEV)
-    _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), bufs[0].data_ptr(), 50, idg.data_ptr(),
+    _lib.check(lib.nrl_news_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), prm[0].data_ptr(), bufs[0].data_ptr(), 50,
+                                        idg.data_ptr(),
                                         None, 70, 30, 0.0, 0, 0, dg.data_ptr(), 0, ws.data_ptr(), nbytes, st), "bwd")
     assert _maxerr(bufs[0], ref) <= 2e-4 * scale
 
