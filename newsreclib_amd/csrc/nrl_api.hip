@@ -123,10 +123,14 @@ static bool g_news_fused = [] {
   return !(e != nullptr && e[0] == '0');
 }();
 
-// NRL_NEWS_FUSED_BWD=0: the forward saves q|k|v and the separate attention-backward kernel reads them
+// NRL_NEWS_FUSED_BWD=1 (or nrl_set_option("news_fused_bwd", 1)): the forward does not save q|k|v; the backward
+// recomputes them per head inside the matrix-core attention backward (news_fused_bwd_kernel).  OFF by default:
+// measured at B = 128 it removes 1.9 GB of HBM traffic per step but costs time (the kernel holds the 160-VGPR
+// embedding fragments through the attention backward and spills: 1.69 ms against 0.60 ms for attn_bwd_small plus
+// 0.22 ms of q|k|v stores in the forward; step 5.56 vs 4.76 ms, profiles/r02_fused_bwd_ab.txt).
 static bool g_news_fused_bwd = [] {
   const char* e = getenv("NRL_NEWS_FUSED_BWD");
-  return !(e != nullptr && e[0] == '0');
+  return e != nullptr && e[0] == '1';
 }();
 
 static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {

@@ -165,7 +165,7 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
                           out_eval.cpu())
         finally:
             _lib.set_option("news_fused", True)
-            _lib.set_option("news_fused_bwd", True)
+            _lib.set_option("news_fused_bwd", False)
     op = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith(O.NEWS_PREFIX)}
     m1 = m2 = None
     if p_drop > 0:
