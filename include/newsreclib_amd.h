@@ -109,9 +109,9 @@ int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, ui
                      void* stream_handle);
 
 /* ---- token-id grouping for the embedding-table gradient (embedding_dense_backward, text.py:215-217,224) -----
- * order (n) int64 <- the positions 0..n-1 of the flat id vector in ascending id order, ties in position order
- * (stable radix sort over ceil(log2 vocab) key bits; == torch.argsort(ids, stable=True)).  This is the
- * `sorted_positions` argument of the *_encoder_bwd entry points. */
+ * order (n) int64 <- the positions 0..n-1 of the flat id vector grouped by ASCENDING id (counting sort over the
+ * vocabulary: LDS-merged histogram, scan, scatter; ids must lie in [0, vocab), vocab <= 2^20).  The order inside one
+ * id's run is unspecified.  This is the `sorted_positions` argument of the *_encoder_bwd entry points. */
 size_t nrl_sort_positions_workspace_bytes(int64_t n, int64_t vocab);
 int nrl_sort_positions(const int64_t* ids, int64_t n, int64_t vocab, int64_t* order, void* ws, size_t ws_bytes,
                        void* stream);

@@ -242,16 +242,19 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
   const float* ws[3] = {P->in_proj_weight, P->out_proj_weight, P->att_weight};
   const int ns[3] = {3 * D, D, Q};
   SplitWeight* outs[3] = {&bp->in, &bp->out, &bp->att};
+  // row-panel images (bf16x3 engine): carved always, built by the forward in ONE small launch
+  bp->rp.on = block_rp_ok(D, Q) && cur_engine() == ENGINE_BF16X3;
   for (int i = 0; i < 3; ++i) {
-    if (fill) {
+    // planes nobody reads are not built: with the row-panel kernels on, the out-projection / additive-attention
+    // planes; with the fused news encoder, the in-projection ones too (its dgrad runs on the row-panel image)
+    const bool needed = i == 0 ? !(fused_heads > 0 && bp->rp.on) : !bp->rp.on;
+    if (fill && needed) {
       NRL_TRY(split_weight(ws[i], ns[i], D, p, outs[i], st));
     } else {
       *outs[i] = split_weight_view(p, ns[i], D);
     }
     p += split_weight_elems(ns[i], D);
   }
-  // row-panel images (bf16x3 engine): carved always, built by the forward in ONE small launch
-  bp->rp.on = block_rp_ok(D, Q) && cur_engine() == ENGINE_BF16X3;
   if (bp->rp.on) {
     const int nd = rp_nblk_for(D), nq = rp_nblk_for(Q);
     uint16_t* q = w.rp;
@@ -605,7 +608,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));
     } else {
       NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiScatter{d_emb_table, ids, s.D, d1}, s.M, 3 * s.D,
-                         s.D, st));
+                         s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
     }
   }
   if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, s, w, st));

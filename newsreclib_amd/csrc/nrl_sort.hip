@@ -1,27 +1,104 @@
 // Token-id grouping for the embedding-table gradient (embedding_dense_backward of text.py:215-217,224): the
-// positions of the flat (N * L) id vector in id-sorted order.  torch.argsort on int64 runs a 14-pass merge sort
-// (0.125 ms of a 5 ms step at B = 128); ids are < vocab, so a stable LSD radix sort over ceil(log2 vocab) bits of
-// a 32-bit key does it in 3 passes.  Stable => deterministic order inside a token's segment.
-#include <string.h>
-
-#include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
+// positions of the flat (N * L) id vector in ascending id order.
+//
+// torch.argsort on int64 runs a 14-pass merge sort, and so does rocPRIM's radix_sort_pairs at this size (it
+// dispatches to its merge sort below ~1 M keys: 40 launches, 0.23 ms of a 5 ms step at B = 128,
+// profiles/r02_x3_kernel_stats.csv).  The ids are < vocab, so this is a COUNTING sort in three launches:
+//   1. per workgroup, equal ids are merged in an LDS hash table (a Zipf-head token fills 13 % of a batch: one
+//      global atomic per (workgroup, id) instead of one per occurrence); the atomic's return value is the
+//      workgroup's base inside the id's run, the LDS counter the position inside the workgroup;
+//   2. exclusive scan of the vocab-sized histogram inside 1024-entry blocks (+ block totals);
+//   3. order[prefix of the block totals + start[id] + rank] = position.
+// Ids ascend; the order INSIDE an id's run follows the arrival order of the workgroups' atomics (the consumer
+// reduces a run with fp32 adds and atomics, whose order is not fixed either).
 #include "nrl_common.h"
 
 namespace nrl {
 
-struct IdKey {
-  __host__ __device__ uint32_t operator()(const int64_t& v) const { return (uint32_t)v; }
-};
+constexpr int CS_THREADS = 256, CS_SLOTS = 512;
 
-static unsigned key_bits(int64_t vocab) {
-  unsigned b = 1;
-  while (b < 32 && ((int64_t)1 << b) < vocab) ++b;
-  return b;
+__global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __restrict__ ids, int64_t n, int* __restrict__ hist,
+                                                            int* __restrict__ rank) {
+  __shared__ int keys[CS_SLOTS], cnt[CS_SLOTS], base[CS_SLOTS];
+  const int tid = threadIdx.x;
+  for (int s = tid; s < CS_SLOTS; s += CS_THREADS) {
+    keys[s] = -1;
+    cnt[s] = 0;
+  }
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * CS_THREADS + tid;
+  int slot = 0, lrank = 0;
+  if (p < n) {
+    const int id = (int)ids[p];
+    slot = (int)(((uint32_t)id * 0x9E3779B1u) >> 23) & (CS_SLOTS - 1);
+    while (true) {                                        // <= 256 distinct ids per workgroup in 512 slots
+      const int prev = atomicCAS(&keys[slot], -1, id);
+      if (prev == -1 || prev == id) break;
+      slot = (slot + 1) & (CS_SLOTS - 1);
+    }
+    lrank = atomicAdd(&cnt[slot], 1);
+  }
+  __syncthreads();
+  for (int s = tid; s < CS_SLOTS; s += CS_THREADS)
+    if (keys[s] != -1) base[s] = atomicAdd(&hist[keys[s]], cnt[s]);
+  __syncthreads();
+  if (p < n) rank[p] = base[slot] + lrank;
+}
+
+// hist (vocab) -> exclusive prefix sums INSIDE each 1024-entry block (in place) + the block totals
+__global__ void __launch_bounds__(1024) cs_scan_kernel(int* __restrict__ hist, int vocab, int* __restrict__ totals) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * 1024 + tid;
+  const int c = i < vocab ? hist[i] : 0;
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int wbase = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) wbase += w < wave ? wsum[w] : 0;
+  if (i < vocab) hist[i] = wbase + incl - c;
+  if (tid == 1023) totals[blockIdx.x] = wbase + incl;
+}
+
+// order[block prefix + start-in-block[id] + rank] = position; the prefix of the <= 1024 block totals is rebuilt per
+// workgroup in LDS (a few hundred cached loads)
+__global__ void __launch_bounds__(256) cs_scatter_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                         const int* __restrict__ start, const int* __restrict__ totals,
+                                                         int nblocks, const int* __restrict__ rank,
+                                                         int64_t* __restrict__ order) {
+  __shared__ int pre[1024];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < 1024; b += 256) pre[b] = b < nblocks ? totals[b] : 0;
+  __syncthreads();
+  if (tid < 64) {                                        // one wave: exclusive scan of 1024 totals, 16 per lane
+    int loc[16], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      loc[q] = sum;
+      sum += pre[tid * 16 + q];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (tid >= off) incl += v;
+    }
+    const int lbase = incl - sum;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pre[tid * 16 + q] = lbase + loc[q];
+  }
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+  if (p < n) {
+    const int id = (int)ids[p];
+    order[pre[id >> 10] + start[id] + rank[p]] = p;
+  }
 }
 
 }  // namespace nrl
@@ -30,30 +107,35 @@ using namespace nrl;
 extern "C" {
 
 size_t nrl_sort_positions_workspace_bytes(int64_t n, int64_t vocab) {
-  size_t temp = 0;
-  auto keys_in = rocprim::make_transform_iterator((const int64_t*)nullptr, IdKey{});
-  (void)rocprim::radix_sort_pairs(nullptr, temp, keys_in, (uint32_t*)nullptr, rocprim::counting_iterator<int64_t>(0),
-                                  (int64_t*)nullptr, (size_t)(n > 0 ? n : 1), 0u, key_bits(vocab), (hipStream_t)0);
-  return align_up(temp, 256) + align_up((size_t)(n > 0 ? n : 1) * sizeof(uint32_t), 256);
+  return align_up((size_t)(vocab > 0 ? vocab : 1) * sizeof(int), 256) + align_up((size_t)(n > 0 ? n : 1) * sizeof(int), 256) +
+         4096;  // + block totals
 }
 
 int nrl_sort_positions(const int64_t* ids, int64_t n, int64_t vocab, int64_t* order, void* ws, size_t ws_bytes,
                        void* stream) {
-  NRL_REQUIRE(n >= 0 && vocab > 0 && vocab <= ((int64_t)1 << 32), "sort_positions: bad arguments");
+  NRL_REQUIRE(n >= 0 && n < (1LL << 31) && vocab > 0 && vocab <= (1LL << 20),
+              "sort_positions: bad arguments (n < 2^31, 0 < vocab <= 2^20)");
   if (n == 0) return NRL_OK;
   NRL_REQUIRE(ids && order, "sort_positions: null argument");
   NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
-  const size_t keys_bytes = align_up((size_t)n * sizeof(uint32_t), 256);
   if (ws_bytes < nrl_sort_positions_workspace_bytes(n, vocab)) {
     set_error("workspace too small: %zu bytes", ws_bytes);
     return NRL_E_WORKSPACE;
   }
-  uint32_t* keys_out = (uint32_t*)ws;
-  void* temp = (unsigned char*)ws + keys_bytes;
-  size_t temp_bytes = ws_bytes - keys_bytes;
-  auto keys_in = rocprim::make_transform_iterator(ids, IdKey{});
-  NRL_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rocprim::counting_iterator<int64_t>(0), order,
-                                    (size_t)n, 0u, key_bits(vocab), (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  int* hist = (int*)ws;
+  int* rank = (int*)((unsigned char*)ws + align_up((size_t)vocab * sizeof(int), 256));
+  int* totals = (int*)((unsigned char*)rank + align_up((size_t)n * sizeof(int), 256));
+  const int sblocks = (int)ceil_div(vocab, 1024);
+  NRL_HIP(hipMemsetAsync(hist, 0, (size_t)vocab * sizeof(int), st));
+  const unsigned blocks = (unsigned)ceil_div(n, CS_THREADS);
+  hipLaunchKernelGGL(cs_rank_kernel, dim3(blocks), dim3(CS_THREADS), 0, st, ids, n, hist, rank);
+  NRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cs_scan_kernel, dim3((unsigned)sblocks), dim3(1024), 0, st, hist, (int)vocab, totals);
+  NRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cs_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, ids, n, hist, totals, sblocks,
+                     rank, order);
+  NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
 

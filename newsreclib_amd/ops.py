@@ -378,17 +378,20 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
 
 
 def sort_positions(ids: torch.Tensor, vocab: Optional[int] = None) -> torch.Tensor:
-    """Positions of the flat id vector in ascending id order (stable) == ``torch.argsort(ids.reshape(-1),
-    stable=True)``: the visiting order of the embedding-table gradient.  ``vocab`` (exclusive upper bound of the
-    ids) limits the radix sort to ceil(log2 vocab) key bits; None sorts all 32."""
-    lib = _lib.load()
+    """Positions of the flat id vector grouped by ascending id: the visiting order of the embedding-table gradient
+    (what ``embedding_dense_backward`` gets from its own sort).  With ``vocab`` (exclusive upper bound of the ids) a
+    three-launch counting sort in the HIP library; the order INSIDE one id's run is unspecified.  Without it,
+    ``torch.argsort`` (index bookkeeping on int64, no arithmetic)."""
     flat = _chk(ids, torch.int64, "ids").reshape(-1)
     n = flat.numel()
-    v = int(vocab) if vocab else (1 << 32)
+    if not vocab or vocab > (1 << 20):
+        return torch.argsort(flat, stable=True)
+    lib = _lib.load()
     order = torch.empty(n, dtype=torch.int64, device=flat.device)
-    ws = torch.empty(max(lib.nrl_sort_positions_workspace_bytes(n, v), 256), dtype=torch.uint8, device=flat.device)
-    _lib.check(lib.nrl_sort_positions(flat.data_ptr(), n, v, order.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-               "nrl_sort_positions")
+    ws = torch.empty(max(lib.nrl_sort_positions_workspace_bytes(n, int(vocab)), 256), dtype=torch.uint8,
+                     device=flat.device)
+    _lib.check(lib.nrl_sort_positions(flat.data_ptr(), n, int(vocab), order.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _stream()), "nrl_sort_positions")
     return order
 
 

@@ -44,17 +44,20 @@ def test_dropout_mask_bit_exact():
     assert ops.dropout_mask(1000, 0.0, 1, 1, DEV).all()
 
 
-def test_sort_positions_equals_stable_argsort():
-    """The 3-pass radix sort that orders the embedding-gradient visits == torch.argsort(stable=True), bit for bit
-    (ties keep position order), with and without the vocabulary bound, incl. n = 0 and a single hot id."""
+def test_sort_positions_groups_every_position_by_ascending_id():
+    """The counting sort that orders the embedding-gradient visits: a permutation of 0..n-1 whose ids ascend (the
+    order inside one id's run is free), incl. a hot id filling a third of the vector, vocab = 2 and n = 0."""
     from newsreclib_amd import ops
     g = torch.Generator().manual_seed(1)
-    for n, vocab in [(211_200, 70_000), (1, 5), (777, 150_000), (4096, 2), (100_000, 1 << 20)]:
+    for n, vocab in [(211_200, 70_000), (1, 5), (777, 150_000), (4096, 2), (100_000, 1 << 20), (300, 1), (5000, 1025)]:
         ids = torch.randint(0, vocab, (n,), generator=g)
         ids[: n // 3] = 7 % vocab
-        ref = torch.argsort(ids, stable=True)
-        assert torch.equal(ops.sort_positions(ids.to(DEV), vocab).cpu(), ref)
-        assert torch.equal(ops.sort_positions(ids.to(DEV)).cpu(), ref)
+        order = ops.sort_positions(ids.to(DEV), vocab).cpu()
+        assert torch.equal(torch.sort(order).values, torch.arange(n))
+        srt = ids[order]
+        assert bool((srt[1:] >= srt[:-1]).all())
+        assert torch.equal(srt, torch.sort(ids).values)
+    assert torch.equal(ops.sort_positions(ids.to(DEV)).cpu(), torch.argsort(ids, stable=True))   # no bound: torch
     assert ops.sort_positions(torch.empty(0, dtype=torch.int64, device=DEV), 10).numel() == 0
 
 
