@@ -39,6 +39,9 @@ struct RpImageJob {
   // optional row remap for the fused news encoder (nrl_news_fused.h): logical column n of the image is
   // row `remap_base[n / remap_w] * ... ` -- see rp_image_row()
   int heads, dh;  // heads > 0: per-head packed q|k|v image (n = head * 64 + {q: 0..dh-1, k: dh.., v: 2dh..})
+  // conv_w > 0: the tap-reversed conv weight of the CNN dgrad (nrl_conv.h): element (n = d, k = t' * F + f) is
+  // src[(f * W + (W - 1 - t')) * N + d], src = Wc (F, W * N)
+  int conv_f, conv_w;
 };
 constexpr int RP_MAX_JOBS = 8;
 struct RpImageJobs {
@@ -78,8 +81,14 @@ __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs 
     const int k = k0 + e;
     float x = 0.f;
     if (row >= 0) {
-      if (k < J.K)
-        x = J.src[row * J.sn + k * J.sk];
+      if (k < J.K) {
+        if (J.conv_w > 0) {
+          const int tr = k / J.conv_f, f = k - tr * J.conv_f;
+          x = J.src[((int64_t)f * J.conv_w + (J.conv_w - 1 - tr)) * J.N + row];
+        } else {
+          x = J.src[row * J.sn + k * J.sk];
+        }
+      }
       else if (k == J.K && J.bias != nullptr)
         x = J.bias[row];
     }
@@ -98,7 +107,7 @@ static inline RpImageJob* rp_jobs_add(RpImageJobs* js, const float* src, int64_t
                                       const float* bias, uint16_t* img, int nblk) {
   RpImageJob& J = js->job[js->count];
   J.src = src; J.bias = bias; J.img = img; J.sn = sn; J.sk = sk; J.N = N; J.K = K; J.nblk = nblk;
-  J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0;
+  J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0; J.conv_f = 0; J.conv_w = 0;
   js->first_thread[js->count + 1] = js->first_thread[js->count] + (int64_t)J.kblocks * nblk * 64;
   js->count += 1;
   return &J;

@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--engine", default="bf16x3")
     args = ap.parse_args()
     from newsreclib_amd import _lib
-    from newsreclib_amd.nrms_module import prepare_batch
+    from newsreclib_amd.nrms_module import attach_layout
     from newsreclib_amd.synthetic import make_batch
     from newsreclib_amd.trainer import NRMSTrainer
     _lib.set_gemm_engine(args.engine)
@@ -48,7 +48,7 @@ def main():
         bench.VOCAB = vocab
         mod = bench.build_module(dev)
         tr = NRMSTrainer(mod, lr=1e-4)
-        batches = [prepare_batch(make_batch(B, vocab, mode, seed=1234 + i, device=dev)) for i in range(4)]
+        batches = [attach_layout(make_batch(B, vocab, mode, seed=1234 + i, device=dev)) for i in range(4)]   # id concat + grouping run inside the step, as in bench.py
         it = iter(range(10 ** 9))
         dt_train = timed(lambda: tr.step(batches[next(it) % 4]), args.steps, args.warmup)
         mod.eval()
