@@ -85,6 +85,81 @@ def cpu_baseline(time_budget_s=20.0):
                       f"CPU, {cores} threads"}
 
 
+def _timed_steps(trainer, batch, steps, warmup):
+    for _ in range(warmup):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_lstur(device, batch_size=128, steps=15):
+    """BASELINE.json configs[4]: LSTUR (CNN news encoder, title 30 + abstract 50 tokens, 300 filters, window 3, category
+    embedding 100, GRU 700 user encoder, 45,215 users) train step under the same click_predictor API, B = 128."""
+    from functools import partial
+
+    from newsreclib_amd.lstur_module import LSTURModule
+    from newsreclib_amd.nrms_module import attach_layout
+    from newsreclib_amd.synthetic import add_lstur_fields, make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    torch.manual_seed(0)
+    mod = LSTURModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=["title", "abstract", "category"],
+        outputs={"train": [], "val": [], "test": []}, dual_loss_training=False, dual_loss_coef=None,
+        loss="cross_entropy_loss", late_fusion=False, temperature=None, use_plm=False,
+        pretrained_embeddings_path=None, plm_model=None, frozen_layers=None, text_embed_dim=300, num_heads=15,
+        num_filters=300, window_size=3, query_dim=200, categ_embed_dim=100, dropout_probability=0.2,
+        num_users=45214, user_masking_probability=0.5, long_short_term_method="ini", top_k_list=[5, 10],
+        num_categ_classes=18, num_sent_classes=3, save_recs=False, recs_fpath=None,
+        optimizer=partial(torch.optim.Adam, lr=LR), scheduler=None,
+        pretrained_embeddings=torch.randn(VOCAB, 300) * 0.3).to(device)
+    trainer = NRMSTrainer(mod, lr=LR)
+    batch = attach_layout(add_lstur_fields(make_batch(batch_size, VOCAB, "fixed", seed=1234, device=device), VOCAB))
+    dt = _timed_steps(trainer, batch, steps, 3)
+    return {"value": round(batch_size / dt, 1), "unit": "impressions/s", "ms_per_step": round(dt * 1e3, 3),
+            "config": "LSTUR MINDsmall-shaped train step, B=128, title 30 + abstract 50 tokens, GRU 700 (BASELINE.json configs[4])"}
+
+
+def extra_plm(device, batch_size=8, steps=3):
+    """BASELINE.json configs[3]: NRMS with the PLM news encoder (roberta-base SHAPE, random init -- no network for the
+    checkpoint; d = 768, 16 heads, L = 96, layers 0-7 frozen), B = 8 as in the reference's experiment file.  The
+    transformer body is HF on PyTorch-ROCm (third-party); the encoder tail, user encoder, scorer, loss and Adam are
+    this library's."""
+    import tempfile
+    from functools import partial
+
+    from transformers import RobertaConfig, RobertaModel
+
+    from newsreclib_amd.nrms_module import NRMSModule, prepare_batch
+    from newsreclib_amd.synthetic import make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    torch.manual_seed(0)
+    cfg = RobertaConfig(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                        intermediate_size=3072, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
+                        bos_token_id=0, eos_token_id=2)
+    tmp = tempfile.mkdtemp()
+    RobertaModel(cfg, add_pooling_layer=False).save_pretrained(tmp)
+    mod = NRMSModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=["title"],
+        outputs={"train": [], "val": [], "test": []}, dual_loss_training=False, dual_loss_coef=None,
+        loss="cross_entropy_loss", late_fusion=False, temperature=None, use_plm=True, pretrained_embeddings_path=None,
+        plm_model=tmp, frozen_layers=list(range(8)), embed_dim=768, num_heads=16, query_dim=200,
+        dropout_probability=0.2, top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3, save_recs=False,
+        recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-5), scheduler=None).to(device)
+    trainer = NRMSTrainer(mod, lr=1e-5)
+    b = make_batch(batch_size, vocab=50000, mode="fixed", seed=1, L=96, device=device)
+    for part in ("x_hist", "x_cand"):          # tokenizer-style inputs (rec_dataset.py:180-190)
+        ids = b[part]["title"].clamp_min(3)
+        b[part]["title"] = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    dt = _timed_steps(trainer, prepare_batch(b), steps, 1)
+    return {"value": round(batch_size / dt, 2), "unit": "impressions/s", "ms_per_step": round(dt * 1e3, 1),
+            "config": "NRMS-PLM train step, roberta-base-shaped random body (HF on PyTorch-ROCm), d=768, 16 heads, L=96, "
+                      "B=8 (BASELINE.json configs[3])"}
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (reference multi-GPU leg:
     configs/trainer/ddp.yaml:4 `strategy: ddp`, one process per device)."""
@@ -265,6 +340,16 @@ def main():
             _lib.set_gemm_engine(args.engine)
             out["f32_engine"] = {"value": round(B_PER_GPU / d32, 1), "unit": "impressions/s",
                                  "ms_per_step": round(d32 * 1e3, 4), "dtype": "f32 (v_mfma_f32_16x16x4_f32 projections)"}
+        if world == 1 and not args.no_extras:
+            # the other single-GPU configurations of BASELINE.json, driver-timed (outside the timed region)
+            del trainer, mod, batches
+            torch.cuda.empty_cache()
+            for key, fn in (("lstur", extra_lstur), ("plm", extra_plm)):
+                try:
+                    out[key] = fn(device)
+                except Exception as e:                     # an extra must never cost the headline line
+                    out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
