@@ -148,7 +148,7 @@ __device__ __forceinline__ void rp_split8(const float4& v0, const float4& v1, bf
 
 // ---- kernel ------------------------------------------------------------------------------------------
 // WAVES wavefronts x 32 rows each; NBLK = ceil(N / 16) column blocks per wave; LDS ring of 2 k-block chunks.
-template <int NBLK, int WAVES, class AOp, class Epi>
+template <int NBLK, int WAVES, class AOp, class Epi, int DEEP = 0>
 __global__ void __launch_bounds__(WAVES * 64, 2)
     rp_gemm_kernel(const AOp A, const uint16_t* __restrict__ img, const Epi epi, const int64_t M, const int N,
                    const int K, const int kblocks) {
@@ -262,39 +262,68 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
   // the top of iteration kb and converted at its END, behind ~1800 cycles of MFMAs -- hipcc's own wait for them
   // (a vmcnt(0): it cannot see the asm DMA) then finds both the loads and the chunk DMA long landed.
   bf16x8 ah[2], al[2];
-  {
-    float4 r0[2][2];
-    issue(0, 0);
-    load_raw(0, r0);
-    convert(0, r0, ah, al);
-  }
-  for (int kb = 0; kb < kblocks; ++kb) {
-    // chunk kb has landed for THIS wave (it was issued one iteration ago) ...
-    wait_vmcnt<0>();
-    // ... and after the barrier for every wave; everyone has also finished reading the other slot
-    __builtin_amdgcn_s_barrier();
-    // the last iteration re-issues its own chunk into the idle slot and re-loads its own rows: uniform control
-    // flow instead of a branch (one redundant chunk per workgroup)
-    const int kn = kb + 1 < kblocks ? kb + 1 : kb;
-    float4 r[2][2];
-    issue(kn, (kb + 1) & 1);
-    load_raw(kn, r);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_chunk(kb & 1, ah, al);
-    __builtin_amdgcn_sched_barrier(0);
-    convert(kn, r, ah, al);
+  if constexpr (DEEP) {
+    // two k-blocks of raw A loads in flight (two NAMED register sets, loop unrolled by two): the rows of k-block
+    // kb + 2 are requested at the top of iteration kb and converted at the end of iteration kb + 1.  The chunk DMA
+    // of an iteration is issued BEFORE its four row loads, so `vmcnt(4)` at the top of the next iteration covers it.
+    float4 ra[2][2], rb[2][2];
+    auto clampk = [&](int k) { return k < kblocks ? k : kblocks - 1; };
+    {
+      float4 r0[2][2];
+      issue(0, 0);
+      load_raw(0, r0);
+      load_raw(clampk(1), ra);
+      convert(0, r0, ah, al);
+    }
+    auto step = [&](int kb, float4 (&cur)[2][2], float4 (&nxt)[2][2]) {
+      wait_vmcnt<4>();
+      __builtin_amdgcn_s_barrier();
+      issue(clampk(kb + 1), (kb + 1) & 1);
+      load_raw(clampk(kb + 2), nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk(kb & 1, ah, al);
+      __builtin_amdgcn_sched_barrier(0);
+      convert(clampk(kb + 1), cur, ah, al);
+    };
+    for (int kb = 0; kb < kblocks; kb += 2) {
+      step(kb, ra, rb);
+      if (kb + 1 < kblocks) step(kb + 1, rb, ra);
+    }
+  } else {
+    {
+      float4 r0[2][2];
+      issue(0, 0);
+      load_raw(0, r0);
+      convert(0, r0, ah, al);
+    }
+    for (int kb = 0; kb < kblocks; ++kb) {
+      // chunk kb has landed for THIS wave (it was issued one iteration ago) ...
+      wait_vmcnt<0>();
+      // ... and after the barrier for every wave; everyone has also finished reading the other slot
+      __builtin_amdgcn_s_barrier();
+      // the last iteration re-issues its own chunk into the idle slot and re-loads its own rows: uniform control
+      // flow instead of a branch (one redundant chunk per workgroup)
+      const int kn = kb + 1 < kblocks ? kb + 1 : kb;
+      float4 r[2][2];
+      issue(kn, (kb + 1) & 1);
+      load_raw(kn, r);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk(kb & 1, ah, al);
+      __builtin_amdgcn_sched_barrier(0);
+      convert(kn, r, ah, al);
+    }
   }
 
   store_accumulators<2, NBLK>(epi, acc, m0, 0, wave, 0, l15, g, M, N);
 }
 
-template <int NBLK, int WAVES = 4, class AOp, class Epi>
+template <int NBLK, int WAVES = 4, int DEEP = 0, class AOp, class Epi>
 int launch_rp_gemm(const AOp& A, const RpImage& B, const Epi& epi, int64_t M, int N, int K, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
   NRL_REQUIRE(B.img != nullptr && B.nblk == NBLK && N <= NBLK * 16 && B.kblocks * 32 >= K, "row-panel GEMM: image / shape mismatch");
   const int64_t blocks = ceil_div(M, WAVES * 32);
   NRL_REQUIRE(blocks < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, stream, A,
+  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, stream, A,
                      B.img, epi, M, N, K, B.kblocks);
   NRL_LAUNCH_CHECK();
   return NRL_OK;

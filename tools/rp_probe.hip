@@ -45,7 +45,7 @@ static float time_ms(F f, hipStream_t st, int reps = 20) {
   return ms / reps;
 }
 
-template <int NBLK, int WAVES>
+template <int NBLK, int WAVES, int DEEP = 0>
 static void run_case(const char* name, int kind, int N, int K, float* a, float* w, float* bias, float* c, float* c2,
                      uint16_t* planes, uint16_t* img, hipStream_t st) {
   // kind 0: dgrad C = A (M, K) * W (K, N) with EpiStore; kind 1: forward C = A W^T (W (N, K)) + bias, dropout
@@ -71,8 +71,8 @@ static void run_case(const char* name, int kind, int N, int K, float* a, float* 
     else launch_gemm_bf16x3_dma<2, 2, 4, 5, 2>(A, B, el, M, N, K, st);
   };
   auto new_k = [&]() {
-    if (kind == 0) launch_rp_gemm<NBLK, WAVES>(A, im, EpiStore{c2, N}, M, N, K, st);
-    else launch_rp_gemm<NBLK, WAVES>(A, im, el2, M, N, K, st);
+    if (kind == 0) launch_rp_gemm<NBLK, WAVES, DEEP>(A, im, EpiStore{c2, N}, M, N, K, st);
+    else launch_rp_gemm<NBLK, WAVES, DEEP>(A, im, el2, M, N, K, st);
   };
   CK(hipMemsetAsync(c, 0, (size_t)M * N * 4, st));
   CK(hipMemsetAsync(c2, 0xFF, (size_t)M * N * 4, st));
@@ -123,7 +123,10 @@ int main() {
     CK(hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
   }
   run_case<19, 4>("out-proj fwd", 1, 300, 300, a, w, bias, c, c2, planes, img, st);
-  run_case<19, 8>("out-proj fwd", 1, 300, 300, a, w, bias, c, c2, planes, img, st);
+  run_case<19, 4, 1>("out-proj fwd  DEEP", 1, 300, 300, a, w, bias, c, c2, planes, img, st);
+  run_case<19, 4, 1>("in-proj dgrad DEEP", 0, 300, 900, a, w, bias, c, c2, planes, img, st);
+  run_case<13, 4, 1>("add-att fwd   DEEP", 1, 200, 300, a, w, bias, c, c2, planes, img, st);
+  run_case<19, 4, 1>("add-att dgrad DEEP", 0, 300, 200, a, w, bias, c, c2, planes, img, st);
   run_case<13, 4>("add-att fwd", 1, 200, 300, a, w, bias, c, c2, planes, img, st);
   run_case<13, 8>("add-att fwd", 1, 200, 300, a, w, bias, c, c2, planes, img, st);
   run_case<19, 4>("in-proj dgrad", 0, 300, 900, a, w, bias, c, c2, planes, img, st);
