@@ -16,6 +16,7 @@
 #include "nrl_gemm_bf16x3.h"
 #include "nrl_gemm_bf16x3_dma.h"
 #include "nrl_rowpanel.h"
+#include "nrl_gemm_ws.h"
 #include "nrl_news_fused.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
@@ -131,6 +132,13 @@ static bool g_news_fused = [] {
 static bool g_news_fused_bwd = [] {
   const char* e = getenv("NRL_NEWS_FUSED_BWD");
   return e != nullptr && e[0] == '1';
+}();
+
+// NRL_WGRAD_WS=0: the large (I > 512) weight gradient back on the register-staged kernel (default: the
+// wave-specialised one, nrl_gemm_ws.h, 32 k-splits = one workgroup per CU: 4.81 -> 4.72 ms/step at B = 128)
+static bool g_wgrad_ws = [] {
+  const char* e = getenv("NRL_WGRAD_WS");
+  return !(e != nullptr && e[0] == '0');
 }();
 
 static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {
@@ -346,6 +354,10 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
       const int64_t max_s = ceil_div(M, 256);
       return (int)(sp > max_s ? max_s : (sp < 1 ? 1 : sp));
     };
+    if (I > 512 && g_wgrad_ws) {
+      static const int ws_splits = [] { const char* e = getenv("NRL_WGRAD_WS_SPLITS"); return e ? atoi(e) : 32; }();
+      return launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, M >= (int64_t)ws_splits * 512 ? ws_splits : splits(256), st);
+    }
     if (I > 512) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, I, J + 1, M, splits(256), st);
     // small outputs: LDS-DMA staged, transposition at the fragment read (0.35 -> 0.30 ms at 300 x 300;
     // the 900-row gradient is faster register-staged, profiles/r01_gemm_x3_dma_probe.txt)
@@ -512,6 +524,7 @@ int nrl_set_option(const char* name, int32_t value) {
   NRL_REQUIRE(name != nullptr, "set_option: null name");
   bool* flag = !strcmp(name, "news_fused") ? &g_news_fused
                : !strcmp(name, "news_fused_bwd") ? &g_news_fused_bwd
+               : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma
                                            : nullptr;

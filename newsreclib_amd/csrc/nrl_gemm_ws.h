@@ -65,7 +65,7 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
     // ko = lane >> 4): a lane loads the float4 of rows 8 ko .. 8 ko + 7 for its 4 output rows (each load
     // instruction of the wave covers 4 k-rows x 256 contiguous bytes) and writes, per output row and plane, ONE
     // 16-byte chunk = its 8 consecutive k as bf16.
-    constexpr int WT_A = BM / 64, WT_B = (BN + 63) / 64;       // wave-tasks per operand
+    constexpr int WT_A = (BM + 63) / 64, WT_B = (BN + 63) / 64;       // wave-tasks per operand
     constexpr int NT_L = (WT_A + WT_B + NL - 1) / NL;           // wave-tasks per loader wave
     const int rq = lane & 15, ko = lane >> 4;
     struct Stage {
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
       t_isb[q] = wt >= WT_A;
       const int local = (t_isb[q] ? wt - WT_A : wt) * 64 + 4 * rq;
       t_row[q] = (t_isb[q] ? (int64_t)n0 : m0) + local;
-      if (t_isb[q] && local >= BN) t_on[q] = false;            // BN % 64 != 0: the last B wave-task is partial
+      if (local >= (t_isb[q] ? BN : BM)) t_on[q] = false;       // tile rows % 64 != 0: the last wave-task is partial
     }
     auto load_tiles = [&](int64_t k0, Stage& S) {
 #pragma unroll

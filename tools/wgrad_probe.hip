@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "nrl_gemm_bf16x3_dma.h"
-#include "experimental/nrl_gemm_ws.h"
+#include "nrl_gemm_ws.h"
 
 namespace nrl {
 void set_error(const char* fmt, ...) {
