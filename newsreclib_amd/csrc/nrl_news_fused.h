@@ -44,6 +44,7 @@ struct NewsFusedArgs {
   float* x_save;            // (n_news * L, D) post-dropout rows, or null
   float* qkv_save;          // (n_news * L, 3D) packed q|k|v (unscaled q), or null (news_fused_bwd_kernel recomputes them)
   float* lse;               // (n_news * heads, L) or null
+  int full_wgs;             // workgroups [0, full_wgs) own 8 news each, the rest 4 (set by the launcher: tail balancing)
 };
 
 __device__ __forceinline__ float nf_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
@@ -63,8 +64,14 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
 
   const int L = P.L, D = P.D, heads = P.heads;
   const int nblk = heads * 4;
-  const int64_t news = (int64_t)blockIdx.x * NF_WAVES + wave;
-  const bool news_ok = news < P.n_news;
+  // Tail balancing: a workgroup costs the same with 1 or 8 news (every wave streams all the weights), so the last,
+  // partly filled round of 8-news workgroups (7040 news = 3.44 rounds of 256) is replaced by 4-news workgroups whose
+  // waves have a SIMD to themselves; their other four waves only keep the barrier / DMA protocol going.
+  const bool half_wg = (int)blockIdx.x >= P.full_wgs;
+  const int64_t news = half_wg ? (int64_t)P.full_wgs * NF_WAVES + (int64_t)((int)blockIdx.x - P.full_wgs) * 4 + wave
+                               : (int64_t)blockIdx.x * NF_WAVES + wave;
+  const bool wave_active = !half_wg || wave < 4;
+  const bool news_ok = wave_active && news < P.n_news;
   const int64_t row0 = (news_ok ? news : 0) * L;        // first token row of this wave's news
 
   // ---- weight DMA: chunk c of head h = k-blocks 2c, 2c + 1 x column blocks 4h .. 4h + 3 x (hi, lo): 16 pieces of
@@ -82,6 +89,20 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
   if constexpr (!(ABL & 4)) {
 #pragma unroll
     for (int c = 0; c < 5; ++c) issue_chunk(0, c);
+  }
+  if (!wave_active) {
+    // idle wave of a 4-news workgroup: same barriers, same share of the weight DMA, nothing else
+    for (int h = 0; h < heads; ++h) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const int hn = h + 1 < heads ? h + 1 : h;
+      for (int c = 0; c < 5; ++c) {
+        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 4)) issue_chunk(hn, c);
+      }
+    }
+    wait_vmcnt<0>();
+    return;
   }
 
   // ---- gather + dropout + split: the A fragments of this news, resident for all heads ------------------
@@ -362,9 +383,21 @@ static inline bool news_fused_ok(int L, int D, int heads) {
 }
 
 template <int ABL = 0>
-static inline int launch_news_fused_fwd(const NewsFusedArgs& a, hipStream_t st) {
-  if (a.n_news <= 0) return NRL_OK;
-  const int64_t blocks = ceil_div(a.n_news, NF_WAVES);
+static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t st) {
+  if (a_in.n_news <= 0) return NRL_OK;
+  NewsFusedArgs a = a_in;
+  // full rounds of 8-news workgroups over the 256 CUs; what is left goes to 4-news workgroups if that fits one round
+  constexpr int64_t CUS = 256;
+  const int64_t full = (a.n_news / NF_WAVES) / CUS * CUS;
+  const int64_t rem = a.n_news - full * NF_WAVES;
+  int64_t blocks;
+  if (rem > 0 && rem <= 4 * CUS) {
+    a.full_wgs = (int)full;
+    blocks = full + ceil_div(rem, 4);
+  } else {
+    blocks = ceil_div(a.n_news, NF_WAVES);
+    a.full_wgs = (int)blocks;
+  }
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   if (a.x_save != nullptr && a.lse != nullptr) {       // training: x + lse (+ q|k|v unless the backward recomputes them)
     hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
