@@ -48,6 +48,18 @@ struct NewsFusedArgs {
 };
 
 __device__ __forceinline__ float nf_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+// lane ^ 16 / lane ^ 32 exchanges on the gfx950 row / half swaps: one VALU op + a select instead of a ds_bpermute
+// round trip through the LDS crossbar (tools/nf_probe.hip: the softmax's four dependent exchanges per query block)
+__device__ __forceinline__ float nf_xor16(float v, int lane) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (lane & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float nf_xor32(float v, int lane) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (lane & 32) ? r[0] : r[1]);
+}
 
 // ABL (tools/nf_probe.hip only; product code uses 0): 1 = no attention phase, 2 = no in-projection MFMAs,
 // 4 = no weight DMA, 8 = no o / q|k|v / lse stores
@@ -318,17 +330,20 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
           e[jb * 4 + r] = key < L ? s[jb][ib][r] : -INFINITY;
           m = fmaxf(m, e[jb * 4 + r]);
         }
-      m = fmaxf(m, nf_shfl_xor(m, 16));
-      m = fmaxf(m, nf_shfl_xor(m, 32));
+      m = fmaxf(m, nf_xor16(m, lane));
+      m = fmaxf(m, nf_xor32(m, lane));
+      // exp(s - m) as one fma + v_exp_f32 (2^x, 1 ulp): |s - m| stays far below the 2^-24 |x| the pre-scaling adds
+      constexpr float LOG2E = 1.4426950408889634f;
+      const float m2 = m * LOG2E;
       float sum = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        e[q] = expf(e[q] - m);                             // masked keys: exp(-inf) = 0
+        e[q] = __builtin_amdgcn_exp2f(fmaf(e[q], LOG2E, -m2));   // masked keys: 2^(-inf) = 0
         sum += e[q];
       }
-      sum += nf_shfl_xor(sum, 16);
-      sum += nf_shfl_xor(sum, 32);
-      const float inv = 1.0f / sum;
+      sum += nf_xor16(sum, lane);
+      sum += nf_xor32(sum, lane);
+      const float inv = __builtin_amdgcn_rcpf(sum);
       if (SAVE && g == 0) image[(ib * 16 + l15) * NF_IMG_LD + 60] = m + logf(sum);   // -> flush_o of the next head
       // A fragment of P V: slot e of lane group g <-> key kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4)
       rp_split8(make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv),

@@ -15,7 +15,10 @@
 
 namespace nrl {
 
-constexpr int CS_THREADS = 256, CS_SLOTS = 512;
+// 2048 positions per workgroup: the RETURNING global atomics of one hot id (the padding id, a Zipf head) are
+// serialised by the L2 at ~100 ns each, so their count -- one per (workgroup, id) -- is what the kernel's time follows
+// (256 positions per workgroup: 825 workgroups, 82 us at B = 128; 2048: 104 workgroups)
+constexpr int CS_THREADS = 256, CS_ITEMS = 8, CS_BLOCK = CS_THREADS * CS_ITEMS, CS_SLOTS = 2 * CS_BLOCK;
 
 __global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __restrict__ ids, int64_t n, int* __restrict__ hist,
                                                             int* __restrict__ rank) {
@@ -26,23 +29,34 @@ __global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __re
     cnt[s] = 0;
   }
   __syncthreads();
-  const int64_t p = (int64_t)blockIdx.x * CS_THREADS + tid;
-  int slot = 0, lrank = 0;
-  if (p < n) {
-    const int id = (int)ids[p];
-    slot = (int)(((uint32_t)id * 0x9E3779B1u) >> 23) & (CS_SLOTS - 1);
-    while (true) {                                        // <= 256 distinct ids per workgroup in 512 slots
-      const int prev = atomicCAS(&keys[slot], -1, id);
-      if (prev == -1 || prev == id) break;
-      slot = (slot + 1) & (CS_SLOTS - 1);
+  const int64_t p0 = (int64_t)blockIdx.x * CS_BLOCK + tid;
+  int slot[CS_ITEMS], lrank[CS_ITEMS];
+#pragma unroll
+  for (int q = 0; q < CS_ITEMS; ++q) {
+    const int64_t p = p0 + q * CS_THREADS;
+    slot[q] = 0;
+    lrank[q] = 0;
+    if (p < n) {
+      const int id = (int)ids[p];
+      int s = (int)(((uint32_t)id * 0x9E3779B1u) >> 20) & (CS_SLOTS - 1);
+      while (true) {                                      // <= CS_BLOCK distinct ids per workgroup in 2 x CS_BLOCK slots
+        const int prev = atomicCAS(&keys[s], -1, id);
+        if (prev == -1 || prev == id) break;
+        s = (s + 1) & (CS_SLOTS - 1);
+      }
+      slot[q] = s;
+      lrank[q] = atomicAdd(&cnt[s], 1);
     }
-    lrank = atomicAdd(&cnt[slot], 1);
   }
   __syncthreads();
   for (int s = tid; s < CS_SLOTS; s += CS_THREADS)
     if (keys[s] != -1) base[s] = atomicAdd(&hist[keys[s]], cnt[s]);
   __syncthreads();
-  if (p < n) rank[p] = base[slot] + lrank;
+#pragma unroll
+  for (int q = 0; q < CS_ITEMS; ++q) {
+    const int64_t p = p0 + q * CS_THREADS;
+    if (p < n) rank[p] = base[slot[q]] + lrank[q];
+  }
 }
 
 // hist (vocab) -> exclusive prefix sums INSIDE each 1024-entry block (in place) + the block totals
@@ -128,7 +142,7 @@ int nrl_sort_positions(const int64_t* ids, int64_t n, int64_t vocab, int64_t* or
   int* totals = (int*)((unsigned char*)rank + align_up((size_t)n * sizeof(int), 256));
   const int sblocks = (int)ceil_div(vocab, 1024);
   NRL_HIP(hipMemsetAsync(hist, 0, (size_t)vocab * sizeof(int), st));
-  const unsigned blocks = (unsigned)ceil_div(n, CS_THREADS);
+  const unsigned blocks = (unsigned)ceil_div(n, CS_BLOCK);
   hipLaunchKernelGGL(cs_rank_kernel, dim3(blocks), dim3(CS_THREADS), 0, st, ids, n, hist, rank);
   NRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(cs_scan_kernel, dim3((unsigned)sblocks), dim3(1024), 0, st, hist, (int)vocab, totals);
