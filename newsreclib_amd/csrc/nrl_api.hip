@@ -134,6 +134,13 @@ static bool g_news_fused_bwd = [] {
   return e != nullptr && e[0] == '1';
 }();
 
+// NRL_NEWS_ATTN_MFMA=0: the fused forward saves q|k|v as packed rows and the backward runs attn_bwd_small (fp32 VALU).
+// Default: head-major slabs + news_attn_bwd_kernel (matrix cores), nrl_news_fused.h.
+static bool g_news_attn_mfma = [] {
+  const char* e = getenv("NRL_NEWS_ATTN_MFMA");
+  return !(e != nullptr && e[0] == '0');
+}();
+
 // NRL_WGRAD_WS=0: the large (I > 512) weight gradient back on the register-staged kernel (default: the
 // wave-specialised one, nrl_gemm_ws.h, 32 k-splits = one workgroup per CU: 4.81 -> 4.72 ms/step at B = 128)
 static bool g_wgrad_ws = [] {
@@ -166,7 +173,7 @@ struct BlockWs {
 // the five narrow projections of the block that run on the row-panel kernel: forward out-projection and
 // additive-attention linear, and the three activation-gradient GEMMs
 struct BlockRp {
-  RpImage out_f, att_f, att_d, out_d, in_d, in_heads;
+  RpImage out_f, att_f, att_d, out_d, in_d, in_heads, in_d_hp;
   bool on = false;
 };
 static bool block_rp_ok(int D, int Q) { return g_rowpanel && rp_nblk_supported(D) && rp_nblk_supported(Q); }
@@ -177,18 +184,25 @@ static size_t block_rp_elems(int D, int Q) {
          + rp_image_elems(nq, rp_kblocks(D, false))         // att fwd (N = Q, K = D)
          + rp_image_elems(nd, rp_kblocks(Q, false))         // att dgrad (N = D, K = Q)
          + rp_image_elems(nd, rp_kblocks(3 * D, false))     // in dgrad (N = D, K = 3D)
-         + rp_image_elems((D / 20) * 4, NF_KB);             // per-head q|k|v image of the fused news encoder
+         + rp_image_elems((D / 20) * 4, NF_KB)              // per-head q|k|v image of the fused news encoder
+         + rp_image_elems(nd, (D / 20) * 2);                // its in-projection dgrad over head planes (K' = heads * 64)
 }
 
 static size_t plane_elems(int D, int Q) {
   return split_weight_elems(3 * D, D) + split_weight_elems(D, D) + split_weight_elems(Q, D);
 }
 
+// q|k|v: packed rows (M, 3D), or -- dh = 20, the fused news path -- head-major slabs of 64 floats per (token, head)
+static size_t qkv_elems(int64_t M, int D, int heads) {
+  const size_t packed = (size_t)M * 3 * D, slabs = (size_t)M * heads * 64;
+  return (D == heads * 20 && slabs > packed) ? slabs : packed;
+}
+
 static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
   auto al = [](size_t n) { return align_up(n, 64); };
   size_t n = 0;
   if (with_x) n += al((size_t)M * D);
-  n += al((size_t)M * 3 * D) * 2;  // qkv, dqkv
+  n += al(qkv_elems(M, D, heads)) * 2;  // qkv, dqkv
   n += al((size_t)M * D) * 4;      // o, y, dy, d_o (later dx)
   n += al((size_t)M * Q);          // t / d_pre
   n += al((size_t)M);              // w
@@ -208,8 +222,8 @@ static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x,
   float* p = (float*)ws;
   auto take = [&](size_t n) { float* r = p; p += align_up(n, 64); return r; };
   out->x = with_x ? take((size_t)s.M * s.D) : nullptr;
-  out->qkv = take((size_t)s.M * 3 * s.D);
-  out->dqkv = take((size_t)s.M * 3 * s.D);
+  out->qkv = take(qkv_elems(s.M, s.D, s.heads));
+  out->dqkv = take(qkv_elems(s.M, s.D, s.heads));
   out->o = take((size_t)s.M * s.D);
   out->y = take((size_t)s.M * s.D);
   out->dy = take((size_t)s.M * s.D);
@@ -282,14 +296,37 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
       bp->rp.in_heads.img = q; bp->rp.in_heads.nblk = fused_heads * 4; bp->rp.in_heads.kblocks = NF_KB;
       if (fill) rp_jobs_add_qkv_heads(&jobs, P->in_proj_weight, D, P->in_proj_bias, q, fused_heads, D / fused_heads);
       q += rp_image_elems(fused_heads * 4, NF_KB);
+      // dx = dqkv W_in with dqkv in head planes (KCSlab): reduction index head * 64 + c
+      bp->rp.in_d_hp.img = q; bp->rp.in_d_hp.nblk = nd; bp->rp.in_d_hp.kblocks = fused_heads * 2;
+      if (fill) rp_jobs_add_kheads(&jobs, P->in_proj_weight, 1, D, D, fused_heads, D / fused_heads, q, nd);
+      q += rp_image_elems(nd, fused_heads * 2);
     }
     if (fill) NRL_TRY(rp_jobs_launch(jobs, st));
   }
   return NRL_OK;
 }
 
+// epilogues with a `stream` switch can write large outputs with the streaming hint (nrl_gemm.h).  OFF by default: the
+// row-panel GEMMs are not store-bound (whole step 4.20 ms either way at B = 128); NRL_STREAM_MB=<n> streams outputs of
+// >= n MB for A/B runs.
+template <class T, class = void>
+struct HasStream : std::false_type {};
+template <class T>
+struct HasStream<T, std::void_t<decltype(std::declval<T&>().stream)>> : std::true_type {};
+template <class Epi>
+static Epi with_stream(Epi e, int64_t M, int N) {
+  static const int64_t thresh = [] {
+    const char* env = getenv("NRL_STREAM_MB");
+    const int64_t mb = env != nullptr ? atoll(env) : 0;
+    return mb <= 0 ? (int64_t)1 << 62 : mb << 20;
+  }();
+  if constexpr (HasStream<Epi>::value) e.stream = (M * N * (int64_t)sizeof(float) >= thresh) ? 1 : 0;
+  return e;
+}
+
 template <class AOp, class Epi>
-static int rp_dispatch(const AOp& a, const RpImage& b, const Epi& epi, int64_t M, int N, int K, hipStream_t st) {
+static int rp_dispatch(const AOp& a, const RpImage& b, const Epi& epi_in, int64_t M, int N, int K, hipStream_t st) {
+  const Epi epi = with_stream(epi_in, M, N);
   switch (b.nblk) {
     case 13: return launch_rp_gemm<13>(a, b, epi, M, N, K, st);
     case 19: return launch_rp_gemm<19>(a, b, epi, M, N, K, st);
@@ -303,8 +340,9 @@ static bool big_tiles(int64_t M, int N) { return ceil_div(M, 256) * ceil_div(N, 
 
 // C = epi(A W^T): nn.Linear forward.  W (N, K) fp32 in place / its bf16 planes.
 template <class AOp, class Epi>
-static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int N, int K,
+static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const Epi& epi_in, int64_t M, int N, int K,
                     bool q_tile, hipStream_t st, const RpImage* rp = nullptr) {
+  const Epi epi = with_stream(epi_in, M, N);
   if (cur_engine() == ENGINE_BF16X3) {
     if constexpr (std::is_same<AOp, KCPlain>::value)
       if (rp != nullptr && rp->img != nullptr) return rp_dispatch(a, *rp, epi, M, N, K, st);
@@ -326,8 +364,9 @@ static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const E
 
 // dX = epi(dY W): dY (M, Nw), W (Nw, Kw) -> (M, Kw)
 template <class Epi>
-static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, const Epi& epi, int64_t M, int Nw,
+static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, const Epi& epi_in, int64_t M, int Nw,
                       int Kw, hipStream_t st, const RpImage* rp = nullptr) {
+  const Epi epi = with_stream(epi_in, M, Kw);
   const KCPlain a{dy, Nw, M};
   if (cur_engine() == ENGINE_BF16X3) {
     if (rp != nullptr && rp->img != nullptr) return rp_dispatch(a, *rp, epi, M, Kw, Nw, st);
@@ -430,13 +469,23 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
 }
 
 static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const BlockShape& s, const BlockWs& w,
-                            hipStream_t st) {
+                            hipStream_t st, bool dqkv_head_planes = false) {
   const int D = s.D, Q = s.Q;
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
   NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
   // dW_o += dy^T o ; db_o += colsum(dy)
   NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
+  if (dqkv_head_planes) {
+    // dqkv in head planes (news_attn_bwd_kernel): 64 output rows per head, remapped to [Wq; Wk; Wv] rows on the way out
+    static const int ws_splits = [] { const char* e = getenv("NRL_WGRAD_WS_SPLITS"); return e ? atoi(e) : 32; }();
+    const int Ip = s.heads * 64;
+    int64_t sp = s.M >= (int64_t)ws_splits * 512 ? ws_splits : ceil_div(s.M, 1664);
+    if (sp < 1) sp = 1;
+    return launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(RCSlab{w.dqkv, Ip}, RCPlain{x_rows, D, D, 1},
+                                                EpiAtomicWBHeads{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh},
+                                                Ip, D + 1, s.M, (int)sp, st);
+  }
   NRL_TRY(gemm_wgrad(w.dqkv, 3 * D, x_rows, D, G->in_proj_weight, G->in_proj_bias, s.M, st));
   return NRL_OK;
 }
@@ -524,11 +573,12 @@ int nrl_set_option(const char* name, int32_t value) {
   NRL_REQUIRE(name != nullptr, "set_option: null name");
   bool* flag = !strcmp(name, "news_fused") ? &g_news_fused
                : !strcmp(name, "news_fused_bwd") ? &g_news_fused_bwd
+               : !strcmp(name, "news_attn_mfma") ? &g_news_attn_mfma
                : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma
                                            : nullptr;
-  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, rowpanel, x3_dma)", name);
+  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, wgrad_ws, rowpanel, x3_dma)", name);
   *flag = value != 0;
   return NRL_OK;
 }
@@ -571,6 +621,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.o = w.o;
     a.x_save = save_for_backward ? w.x : nullptr;
     a.qkv_save = (save_for_backward && !g_news_fused_bwd) ? w.qkv : nullptr;   // else recomputed in the backward
+    a.qkv_head_major = g_news_attn_mfma ? 1 : 0;
     a.lse = save_for_backward ? w.lse : nullptr;
     {
       ProfScope prof(st, 2.0 * (double)s.M * 3.0 * s.D * s.D + 4.0 * (double)s.M * seq_len * s.D);
@@ -599,9 +650,17 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
   const bool fused = news_fused_on(s, seq_len) && g_news_fused_bwd;
-  NRL_TRY(block_planes(p, s, w, false, &bp, st, fused ? s.heads : 0));  // filled by the forward; weights unchanged since
+  const bool slabs = news_fused_on(s, seq_len) && !g_news_fused_bwd && g_news_attn_mfma;   // what the forward saved
+  NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
   if (phase != 2) {
-    NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st, fused));
+    NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st, fused || slabs));
+    if (slabs) {
+      // token attention backward on the matrix cores from the head-major q|k|v slabs (nrl_news_fused.h)
+      NewsAttnBwdArgs a;
+      a.qkv_hm = w.qkv; a.d_o = w.d_o; a.lse = w.lse; a.dqkv = w.dqkv; a.n_news = n_news; a.L = seq_len; a.D = s.D;
+      a.heads = s.heads; a.scale = s.geom.scale; a.hpw = 1;
+      NRL_TRY(launch_news_attn_bwd(a, st));
+    }
     if (fused) {
       // q|k|v recomputed per head + the attention backward on the matrix cores in one kernel (nrl_news_fused.h)
       NewsFusedBwdArgs a;
@@ -613,18 +672,21 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       NRL_TRY(launch_news_fused_bwd(a, st));
     }
     // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
+    const KCSlab dq_hp{w.dqkv, s.M};
     if (sorted_positions != nullptr) {
       // dx is materialised (in the now dead d_o buffer) and reduced in id-sorted order: no hot-row contention
       float* dx = w.d_o;
-      NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{dx, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
-                         s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
+      const EpiLinear epi{dx, s.D, nullptr, 0, d1, s.D};
+      if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
+      else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
       NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));
     } else {
-      NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiScatter{d_emb_table, ids, s.D, d1}, s.M, 3 * s.D,
-                         s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
+      const EpiScatter epi{d_emb_table, ids, s.D, d1};
+      if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
+      else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
     }
   }
-  if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, s, w, st));
+  if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, s, w, st, slabs));
   return NRL_OK;
 }
 

@@ -32,6 +32,20 @@ enum { SRC_KC = 0, SRC_RC = 1 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// 16-byte store with the streaming (non-temporal) hint.  A write-once activation far larger than the 32 MB of L2 gains
+// nothing from write-allocate: with plain stores the attention backward's 0.81 GB of dqkv slabs ran at 2.4 TB/s
+// (0.57 ms for the kernel), with the hint the kernel's whole 1.9 GB of traffic moves at 5.3 TB/s (0.37 ms;
+// tools/nf_probe.hip, profiles/r02_news_fused_probe.txt).
+__device__ __forceinline__ void store4_stream(float* p, const float4& v) {
+  typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(nt_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f32x4*>(p));
+}
+__device__ __forceinline__ void store4(float* p, const float4& v, int stream) {
+  if (stream) store4_stream(p, v);
+  else *reinterpret_cast<float4*>(p) = v;
+}
+
+
 // 16-byte constants an LDS-DMA lane is pointed at instead of predicating the load (out-of-range rows /
 // k, and the virtual ones-column of a weight-gradient operand)
 __device__ const float nrl_dma_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -65,6 +79,32 @@ struct KCPlain {
   }
   // address form of `load` (LDS-DMA staging fetches it without touching VGPRs)
   __device__ __forceinline__ const float* src(const State& s, int k, int K) const { return s.ptr + (k < K ? k : K - 4); }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
+    if (!s.ok || k >= kend) v = f4zero();
+  }
+};
+
+// "head-plane" activation of the fused news path (nrl_news_fused.h): logical element (row m, k' = head * 64 + c) of
+// a (rows x heads * 64) matrix lives at p[(head * rows + m) * 64 + c] -- one (rows x 64) row-major plane per head,
+// so the L rows x 64 floats of a (news, head) pair are ONE contiguous slab for the attention kernels that produce it
+// (80-byte pieces of packed (rows, 3D) rows cost them 0.4 ms of partial-line writes at B = 128) and a k-block of 32
+// is still 128 contiguous bytes per row for the GEMMs that consume it.
+struct KCSlab {
+  static constexpr int kLayout = SRC_KC;
+  const float* p;
+  int64_t rows;
+  struct State {
+    const float* ptr;
+    bool ok;
+  };
+  __device__ __forceinline__ State init(int64_t r) const {
+    const bool ok = r < rows;
+    return State{p + (ok ? r : 0) * 64, ok};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
+    const int kc = k < K ? k : K - 4;
+    return *reinterpret_cast<const float4*>(s.ptr + (int64_t)(kc >> 6) * rows * 64 + (kc & 63));
+  }
   __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
     if (!s.ok || k >= kend) v = f4zero();
   }
@@ -138,6 +178,21 @@ struct RCPlain {
   }
 };
 
+// the same head-plane matrix read k-major (weight gradient: k = activation row, r = logical column head * 64 + c)
+struct RCSlab {
+  static constexpr int kLayout = SRC_RC;
+  const float* p;
+  int64_t rows;   // logical columns: heads * 64
+  struct State {};
+  __device__ __forceinline__ float4 load(int64_t k, int64_t r, int64_t K) const {
+    const int64_t rc = r < rows ? r : rows - 4;
+    return *reinterpret_cast<const float4*>(p + ((rc >> 6) * K + (k < K ? k : K - 1)) * 64 + (rc & 63));
+  }
+  __device__ __forceinline__ void finish(float4& v, int64_t k, int64_t r, int64_t kend) const {
+    if (k >= kend || r >= rows) v = f4zero();
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // epilogues: `row(m)` is evaluated once per output row a lane owns (per-row loads / index math),
 // `operator()(row_state, m, n, v)` once per valid element.
@@ -154,6 +209,7 @@ struct EpiLinear {
   int n_cols;  // logical row width for the dropout flat index
   const float* gate_src = nullptr;  // (M, N) saved post-ReLU activation: output zeroed where gate_src <= 0
                                     // (a dgrad flowing back into a ReLU, CNNMHSAAddAtt text.py:297-299)
+  int stream = 0;                   // 1: streaming stores (store4_stream)
   struct Row {
     float* out;
     const float* gate;
@@ -191,7 +247,7 @@ struct EpiLinear {
       v.x = sv.x > 0.f ? v.x : 0.f; v.y = sv.y > 0.f ? v.y : 0.f;
       v.z = sv.z > 0.f ? v.z : 0.f; v.w = sv.w > 0.f ? v.w : 0.f;
     }
-    *reinterpret_cast<float4*>(r.out + n) = v;
+    store4(r.out + n, v, stream);
   }
 };
 
@@ -199,6 +255,7 @@ struct EpiLinear {
 struct EpiStore {
   float* c;
   int64_t ldc;
+  int stream = 0;
   struct Row {
     float* out;
   };
@@ -206,9 +263,7 @@ struct EpiStore {
   __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const { r.out[n] = v; }
   static constexpr bool kVec4 = true;
   __device__ __forceinline__ bool vec_ok() const { return (ldc & 3) == 0 && ((uintptr_t)c & 15) == 0; }
-  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
-    *reinterpret_cast<float4*>(r.out + n) = v;
-  }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const { store4(r.out + n, v, stream); }
 };
 
 // additive-attention backward, fused: dy = (v + w[m] * d_out[group(m)][n]) * dropout(m, n)
@@ -222,6 +277,7 @@ struct EpiPoolBwd {
   int group_len;       // rows per group
   Dropout drop;
   const float* relu_src = nullptr;  // (M, N) post-ReLU(-dropout) activation: gradient gated by src > 0
+  int stream = 0;
   struct Row {
     float* out;
     const float* g;
@@ -255,7 +311,7 @@ struct EpiPoolBwd {
       v.x = sv.x > 0.f ? v.x : 0.f; v.y = sv.y > 0.f ? v.y : 0.f;
       v.z = sv.z > 0.f ? v.z : 0.f; v.w = sv.w > 0.f ? v.w : 0.f;
     }
-    *reinterpret_cast<float4*>(r.out + n) = v;
+    store4(r.out + n, v, stream);
   }
 };
 
@@ -286,6 +342,34 @@ struct EpiAtomicWB {
       atomicAdd(r.out + n, v);
     else if (n == n_w && db != nullptr)
       atomicAdd(db + m, v);
+  }
+};
+
+// EpiAtomicWB for a head-plane left operand: output row m = head * 64 + c is row part * (heads * dh) + head * dh + d
+// of the packed in-projection weight gradient (c = part * dh + d < 3 dh; the 64 - 3 dh pad rows are dropped)
+struct EpiAtomicWBHeads {
+  float* dw;
+  int64_t ldc;
+  float* db;  // may be null
+  int n_w;
+  int heads, dh;
+  struct Row {
+    float* out;
+    int64_t m;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const {
+    const int head = (int)(m >> 6), c = (int)(m & 63);
+    if (head >= heads || c >= 3 * dh) return Row{nullptr, 0};
+    const int part = c / dh, d = c - part * dh;
+    const int64_t r = (int64_t)part * heads * dh + head * dh + d;
+    return Row{dw + r * ldc, r};
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    if (r.out == nullptr) return;
+    if (n < n_w)
+      atomicAdd(r.out + n, v);
+    else if (n == n_w && db != nullptr)
+      atomicAdd(db + r.m, v);
   }
 };
 

@@ -42,7 +42,11 @@ struct NewsFusedArgs {
   Dropout drop1;
   float* o;                 // (n_news * L, D)
   float* x_save;            // (n_news * L, D) post-dropout rows, or null
-  float* qkv_save;          // (n_news * L, 3D) packed q|k|v (unscaled q), or null (news_fused_bwd_kernel recomputes them)
+  float* qkv_save;          // q|k|v (unscaled q) for the backward, or null (news_fused_bwd_kernel recomputes them):
+                            //   qkv_head_major == 0: (n_news * L, 3D) packed rows (attn_bwd_small's layout)
+                            //   qkv_head_major == 1: (n_news, heads, L, 64) = the private image rows [q | k | v | 0 4],
+                            //                        one contiguous L x 256 B slab per (news, head) (news_attn_bwd_kernel)
+  int qkv_head_major;
   float* lse;               // (n_news * heads, L) or null
   int full_wgs;             // workgroups [0, full_wgs) own 8 news each, the rest 4 (set by the launcher: tail balancing)
 };
@@ -61,12 +65,42 @@ __device__ __forceinline__ float nf_xor32(float v, int lane) {
   return __builtin_bit_cast(float, (lane & 32) ? r[0] : r[1]);
 }
 
+// Branch-free fragment readers of the per-wave images (dh = 20).  Lanes whose features fall outside the head read a
+// valid neighbouring address and are zeroed by their multiplier (hipcc turns `cond ? load : 0` into exec-masked
+// branches: 47 of them in the attention backward, each with its own waitcnt drain).
+//   nf_frag8: features 8g .. 8g + 7 of one row (rowp = row base + first column of the part), times mul
+__device__ __forceinline__ void nf_frag8(const float* rowp, int g, float mul, bf16x8& hi, bf16x8& lo) {
+  const int c = g < 3 ? 8 * g : 0;
+  float4 v0 = *reinterpret_cast<const float4*>(rowp + c);
+  float4 v1 = *reinterpret_cast<const float4*>(rowp + c + 4);
+  const float m0 = g < 3 ? mul : 0.f, m1 = g < 2 ? mul : 0.f;
+  v0.x *= m0; v0.y *= m0; v0.z *= m0; v0.w *= m0;
+  v1.x *= m1; v1.y *= m1; v1.z *= m1; v1.w *= m1;
+  rp_split8(v0, v1, hi, lo);
+}
+//   nf_kfrag: B operand of a product over rows -- lane (d, g) <- rows kappa(g, e), e = 0..7, of column d
+//   (colp = image + first column of the part + d; mk = d < dh ? mul : 0)
+__device__ __forceinline__ void nf_kfrag(const float* colp, int ld, int g, float mk, bf16x8& hi, bf16x8& lo) {
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int rowk = (q < 4) ? 4 * g + q : 16 + 4 * g + (q - 4);
+    v[q] = colp[rowk * ld] * mk;
+  }
+  rp_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+}
+
 // ABL (tools/nf_probe.hip only; product code uses 0): 1 = no attention phase, 2 = no in-projection MFMAs,
-// 4 = no weight DMA, 8 = no o / q|k|v / lse stores
+// 4 = no weight DMA, 8 = no o / q|k|v / lse stores, 16 = streaming saves, 32 = streaming `o` stores
 template <int DH, bool SAVE, int ABL = 0>
 __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
   static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NF_RING + NF_WAVES * NF_IMG_FLOATS * 4];
+  // plain (write-allocate) stores: this kernel is not store-bound and the L2 merges the 80-byte `o` pieces; streaming
+  // saves measured slower (train 0.62-0.65 vs 0.60 ms, tools/nf_probe.hip).  ABL 16 / 32 select the streaming forms.
+  constexpr int NT = (ABL & 16) ? 1 : 0;
+  constexpr int NT_O = (ABL & 32) ? 1 : 0;
+  // (+ 16 bytes: the masked lanes of the last wave's V-fragment reads run 3 floats past its image)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NF_RING + NF_WAVES * NF_IMG_FLOATS * 4 + 16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -159,8 +193,8 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
         v1.z *= m1 * P.drop1.mult(idx + 6); v1.w *= m1 * P.drop1.mult(idx + 7);
         if constexpr (SAVE) {
           if (okr[rb]) {
-            if (in0) *reinterpret_cast<float4*>(P.x_save + growr[rb] * D + k) = v0;
-            if (in1) *reinterpret_cast<float4*>(P.x_save + growr[rb] * D + k + 4) = v1;
+            if (in0) store4(P.x_save + growr[rb] * D + k, v0, NT);
+            if (in1) store4(P.x_save + growr[rb] * D + k + 4, v1, NT);
           }
         }
         // ones column at k == D: the bias row of the image is added by the matrix cores (D % 4 == 0)
@@ -186,8 +220,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       const int slot_i = pass * 64 + ln;
       const int row = slot_i / 5, c4 = slot_i - row * 5;
       if (slot_i < 160 && row < L)
-        *reinterpret_cast<float4*>(o_out + (row * D + hp * DH + 4 * c4)) =
-            *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4);
+        store4(o_out + (row * D + hp * DH + 4 * c4), *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4), NT_O);
     }
     if (SAVE && ln < L) P.lse[(news * heads + hp) * L + ln] = image[ln * NF_IMG_LD + 60];
   };
@@ -266,42 +299,42 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
     //  of the head loop and spills them)
     // wave-uniform bases + 32-bit lane offsets (scalar-base addressing)
     float* qkv_out = P.qkv_save + row0 * (int64_t)(3 * D);
+    if (P.qkv_head_major) qkv_out = P.qkv_save + ((news_ok ? news : 0) * heads + h) * (int64_t)L * 64;
     asm volatile("" : "+s"(qkv_out));
     if (SAVE && P.qkv_save != nullptr && news_ok && !(ABL & 8)) {
       int ln = lane;
       asm volatile("" : "+v"(ln));
+      if (P.qkv_head_major) {
+        // whole image rows: 1 KiB per pass, every 128-byte line written in full (the packed-row form below writes
+        // 80-byte pieces at a 3.6 KB stride)
 #pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {              // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
-        const int slot_i = pass * 64 + ln;
-        const int row = slot_i >> 4, ch = slot_i & 15;
-        if (ch < 15 && row < L) {
-          const int part = ch / 5, c4 = ch - part * 5;
-          const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + part * DH + 4 * c4);
-          *reinterpret_cast<float4*>(qkv_out + (row * 3 * D + part * D + h * DH + 4 * c4)) = v;
+        for (int pass = 0; pass < 8; ++pass) {
+          const int slot_i = pass * 64 + ln;
+          const int row = slot_i >> 4, ch = slot_i & 15;
+          if (row < L)
+            store4(qkv_out + 4 * slot_i, *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * ch), NT);
+        }
+      } else {
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {            // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
+          const int slot_i = pass * 64 + ln;
+          const int row = slot_i >> 4, ch = slot_i & 15;
+          if (ch < 15 && row < L) {
+            const int part = ch / 5, c4 = ch - part * 5;
+            const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + part * DH + 4 * c4);
+            *reinterpret_cast<float4*>(qkv_out + (row * 3 * D + part * D + h * DH + 4 * c4)) = v;
+          }
         }
       }
     }
 
     if constexpr (ABL & 1) continue;
     // ---- S^T = K Q^T on the matrix cores ---------------------------------------------------------------
-    auto frag8 = [&](int row, int col0, float mul, bf16x8& hi, bf16x8& lo) {
-      // 8 consecutive features 8g .. 8g + 7 of `row` (features >= dh are zero)
-      float4 v0 = f4zero(), v1 = f4zero();
-      if (g < 2) {
-        v0 = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + col0 + 8 * g);
-        v1 = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + col0 + 8 * g + 4);
-      } else if (g == 2) {
-        v0 = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + col0 + 16);
-      }
-      v0.x *= mul; v0.y *= mul; v0.z *= mul; v0.w *= mul;
-      v1.x *= mul; v1.y *= mul; v1.z *= mul; v1.w *= mul;
-      rp_split8(v0, v1, hi, lo);
-    };
     bf16x8 kh[2], kl[2], qh[2], ql[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      frag8(b * 16 + l15, DH, 1.0f, kh[b], kl[b]);
-      frag8(b * 16 + l15, 0, P.scale, qh[b], ql[b]);
+      nf_frag8(image + (b * 16 + l15) * NF_IMG_LD + DH, g, 1.0f, kh[b], kl[b]);
+      nf_frag8(image + (b * 16 + l15) * NF_IMG_LD, g, P.scale, qh[b], ql[b]);
     }
     f32x4 s[2][2];                                         // [key block][query block]
 #pragma unroll
@@ -354,13 +387,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       const int d = db * 16 + l15;
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int key = (q < 4) ? 4 * g + q : 16 + 4 * g + (q - 4);
-        v[q] = d < DH ? image[key * NF_IMG_LD + 2 * DH + d] : 0.f;
-      }
-      rp_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), vh[db], vl[db]);
+      nf_kfrag(image + 2 * DH + d, NF_IMG_LD, g, d < DH ? 1.0f : 0.f, vh[db], vl[db]);
     }
     f32x4 oacc[2][2];                                      // [query block][feature block]
 #pragma unroll
@@ -421,6 +448,327 @@ static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t s
                 "fused news encoder: save x and lse (and optionally q|k|v), or nothing");
     hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
   }
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+
+// =====================================================================================================
+// Token-attention backward on the matrix cores from the forward's head-major q|k|v slabs:
+//   (q|k|v slab of (news, head): L x 256 B contiguous, d_o, lse) -> dq|dk|dv slab of the head's plane of `dqkv`
+//
+// Replaces attn_bwd_small for the fused news path (fp32 VALU, 80-byte strided q|k|v reads: 2.4 GB of HBM traffic for
+// 1.77 GB of operands, 0.58 ms at B = 128 -- profiles/r02_x3_kernel_stats.csv).  One wavefront owns `hpw` consecutive
+// heads of one news; per head the 32 x 64 slab goes registers -> a private LDS image (rows padded to 68 floats) and the
+// whole 32 x 32 backward runs as in news_fused_bwd_kernel below:
+//   S = Q K^T, S^T = K Q^T, dP = dO V^T, dP^T = V dO^T     (both orientations: an accumulator block holds 4 rows x 1
+//   P = exp(S - lse), delta = rowsum(P o dP), dS = P o (dP - delta)   column per lane = the A-operand layout of the
+//   dV = P^T dO,  dK = dS^T (scale Q),  dQ = scale dS K             next product under the slot permutation kappa)
+// The next head's slab / d_o slice / lse are in flight (registers) during the current head's arithmetic.  No
+// workgroup-level synchronisation: every LDS byte is private to its wave.
+struct NewsAttnBwdArgs {
+  const float* qkv_hm;  // (n_news, heads, L, 64)
+  const float* d_o;     // (n_news * L, D)
+  const float* lse;     // (n_news * heads, L)
+  float* dqkv;          // head planes (heads, n_news * L, 64) = [dq | dk | dv | 0 4] rows (KCSlab / RCSlab, nrl_gemm.h):
+                        // the L rows of a (news, head) pair are one contiguous slab, written in full 128-byte lines
+  int64_t n_news;
+  int L, D, heads;
+  float scale;
+  int hpw;              // heads per wave (divides heads)
+};
+
+constexpr int NAB_WAVES = 4;
+constexpr int NAB_DO_FLOATS = 32 * 20;
+constexpr int NAB_VEC_FLOATS = 64;                         // [0, 32): lse of the query, [32, 64): delta of the query
+constexpr int NAB_WAVE_FLOATS = NF_IMG_FLOATS + NAB_DO_FLOATS + NAB_VEC_FLOATS;
+
+// ABL (tools/nf_probe.hip only): 1 = no dqkv stores, 2 = no arithmetic (slab -> image -> stores), 4 = no prefetch loads,
+// 8 = plain instead of streaming stores
+template <int DH, int OCC, int ABL = 0>
+__global__ void __launch_bounds__(NAB_WAVES * 64, OCC) news_attn_bwd_kernel(const NewsAttnBwdArgs P) {
+  static_assert(DH == 20, "image packing assumes dh = 20");
+  __shared__ __attribute__((aligned(16))) float smem[NAB_WAVES * NAB_WAVE_FLOATS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  float* const image = smem + wave * NAB_WAVE_FLOATS;
+  float* const dO_s = image + NF_IMG_FLOATS;              // [32][20]
+  float* const vec = dO_s + NAB_DO_FLOATS;                // lse | delta
+
+  const int L = P.L, D = P.D, heads = P.heads, hpw = P.hpw;
+  const int groups = heads / hpw;
+  const int64_t unit = (int64_t)blockIdx.x * NAB_WAVES + wave;
+  const int64_t news = unit / groups;
+  if (news >= P.n_news) return;
+  const int h0 = (int)(unit - news * groups) * hpw;
+  const int64_t row0 = news * L;
+  const float* const do_base = P.d_o + row0 * (int64_t)D;
+
+  // slab (8 float4 per lane), d_o slice (32 x 20, rows >= L zero) and lse of head `hd`: global -> registers
+  auto get_head_inputs = [&](int hd, float4 (&qv)[8], float4 (&dv)[3], float& ls) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const float* slab = P.qkv_hm + (news * heads + hd) * (int64_t)L * 64;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int slot_i = pass * 64 + ln;
+      const bool ok = (slot_i >> 4) < L;
+      qv[pass] = *reinterpret_cast<const float4*>(slab + (ok ? 4 * slot_i : 0));
+      if (!ok) qv[pass] = f4zero();
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      const int slot_i = pass * 64 + ln;
+      const int row = slot_i / 5, c4 = slot_i - row * 5;
+      const bool ok = slot_i < 160 && row < L;
+      dv[pass] = *reinterpret_cast<const float4*>(do_base + (ok ? row * D + hd * DH + 4 * c4 : 0));
+      if (!ok) dv[pass] = f4zero();
+    }
+    const bool lok = ln < L;
+    ls = P.lse[(news * heads + hd) * L + (lok ? ln : 0)];
+    if (!lok) ls = 1e30f;                                  // pad queries: P = exp(s - 1e30) = 0
+  };
+  auto put_head_inputs = [&](const float4 (&qv)[8], const float4 (&dv)[3], float ls) {
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int slot_i = pass * 64 + lane;
+      *reinterpret_cast<float4*>(image + (slot_i >> 4) * NF_IMG_LD + 4 * (slot_i & 15)) = qv[pass];
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      const int slot_i = pass * 64 + lane;
+      if (slot_i < 160) *reinterpret_cast<float4*>(dO_s + 4 * slot_i) = dv[pass];
+    }
+    if (lane < 32) vec[lane] = ls;
+  };
+  {
+    float4 qv[8], dv[3];
+    float ls;
+    get_head_inputs(h0, qv, dv, ls);
+    put_head_inputs(qv, dv, ls);
+  }
+
+  for (int hh = 0; hh < hpw; ++hh) {
+    const int h = h0 + hh;
+    const int hn = hh + 1 < hpw ? h + 1 : h;
+    float4 nx_qv[8], nx_dv[3];
+    float nx_ls;
+    if constexpr (ABL & 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) nx_qv[i] = f4zero();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) nx_dv[i] = f4zero();
+      nx_ls = 0.f;
+    } else {
+      get_head_inputs(hn, nx_qv, nx_dv, nx_ls);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (!(ABL & 2)) {
+
+    auto frag8 = [&](const float* src, int ld, int row, int col0, float mul, bf16x8& hi, bf16x8& lo) {
+      nf_frag8(src + row * ld + col0, g, mul, hi, lo);
+    };
+    auto kfrag = [&](const float* src, int ld, int col0, int db, float mul, bf16x8& hi, bf16x8& lo) {
+      const int d = db * 16 + l15;
+      nf_kfrag(src + col0 + d, ld, g, d < DH ? mul : 0.f, hi, lo);
+    };
+    auto mm3 = [&](f32x4& c, const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b_hi, const bf16x8& b_lo) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, c, 0, 0, 0);
+    };
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // ---- scores in both orientations: s[ib][jb] = (queries x keys), sT[jb][ib] = (keys x queries) --------
+    f32x4 s[2][2], sT[2][2];
+    {
+      bf16x8 qh[2], ql[2], kh[2], kl[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        frag8(image, NF_IMG_LD, b * 16 + l15, 0, P.scale, qh[b], ql[b]);
+        frag8(image, NF_IMG_LD, b * 16 + l15, DH, 1.0f, kh[b], kl[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          s[a][b] = z4; sT[a][b] = z4;
+          mm3(s[a][b], qh[a], ql[a], kh[b], kl[b]);
+          mm3(sT[a][b], kh[a], kl[a], qh[b], ql[b]);
+        }
+    }
+    // ---- dP = dO V^T (queries x keys), dP^T = V dO^T --------------------------------------------------------
+    f32x4 dp[2][2], dpT[2][2];
+    {
+      bf16x8 oh[2], ol[2], vh[2], vl[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        frag8(dO_s, DH, b * 16 + l15, 0, 1.0f, oh[b], ol[b]);
+        frag8(image, NF_IMG_LD, b * 16 + l15, 2 * DH, 1.0f, vh[b], vl[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          dp[a][b] = z4; dpT[a][b] = z4;
+          mm3(dp[a][b], oh[a], ol[a], vh[b], vl[b]);
+          mm3(dpT[a][b], vh[a], vl[a], oh[b], ol[b]);
+        }
+    }
+    // ---- P^T, delta (per query = per column of the transposed orientation), dS^T ---------------------------
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const float lse2 = vec[ib * 16 + l15] * LOG2E;
+      float dl = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = jb * 16 + 4 * g + r;
+          const float p = key < L ? __builtin_amdgcn_exp2f(fmaf(sT[jb][ib][r], LOG2E, -lse2)) : 0.f;
+          dl += p * dpT[jb][ib][r];
+          sT[jb][ib][r] = p;
+        }
+      dl += nf_xor16(dl, lane);
+      dl += nf_xor32(dl, lane);
+      if (g == 0) vec[32 + ib * 16 + l15] = dl;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sT[jb][ib][r] *= dpT[jb][ib][r] - dl;          // sT now holds dS^T
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- P, dS in the (queries x keys) orientation: rows 4g + r need lse / delta of THEIR query ------------
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const float4 lse_r = *reinterpret_cast<const float4*>(vec + ib * 16 + 4 * g);
+      const float4 dl_r = *reinterpret_cast<const float4*>(vec + 32 + ib * 16 + 4 * g);
+      const float ls4[4] = {lse_r.x * LOG2E, lse_r.y * LOG2E, lse_r.z * LOG2E, lse_r.w * LOG2E};
+      const float dl4[4] = {dl_r.x, dl_r.y, dl_r.z, dl_r.w};
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const bool kok = jb * 16 + l15 < L;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = kok ? __builtin_amdgcn_exp2f(fmaf(s[ib][jb][r], LOG2E, -ls4[r])) : 0.f;
+          s[ib][jb][r] = p;                                                          // s now holds P
+          dp[ib][jb][r] = p * (dp[ib][jb][r] - dl4[r]);                              // dp now holds dS
+        }
+      }
+    }
+    // ---- dV = P^T dO: A = P with the query slots kappa-permuted (exactly what a key-column lane holds) --------
+    f32x4 dv_[2][2], dk_[2][2], dq_[2][2];
+    {
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) kfrag(dO_s, DH, 0, db, 1.0f, bh[db], bl[db]);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        bf16x8 a_hi, a_lo;
+        rp_split8(make_float4(s[0][jb][0], s[0][jb][1], s[0][jb][2], s[0][jb][3]),
+                  make_float4(s[1][jb][0], s[1][jb][1], s[1][jb][2], s[1][jb][3]), a_hi, a_lo);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv_[jb][db] = z4;
+          mm3(dv_[jb][db], a_hi, a_lo, bh[db], bl[db]);
+        }
+      }
+    }
+    // ---- dK = dS^T (scale Q): A = dS in the same key-column form; dQ = scale dS K: A = dS^T (query-column form) ---
+    {
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) kfrag(image, NF_IMG_LD, 0, db, P.scale, bh[db], bl[db]);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        bf16x8 a_hi, a_lo;
+        rp_split8(make_float4(dp[0][jb][0], dp[0][jb][1], dp[0][jb][2], dp[0][jb][3]),
+                  make_float4(dp[1][jb][0], dp[1][jb][1], dp[1][jb][2], dp[1][jb][3]), a_hi, a_lo);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dk_[jb][db] = z4;
+          mm3(dk_[jb][db], a_hi, a_lo, bh[db], bl[db]);
+        }
+      }
+    }
+    {
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) kfrag(image, NF_IMG_LD, DH, db, 1.0f, bh[db], bl[db]);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        bf16x8 a_hi, a_lo;
+        rp_split8(make_float4(sT[0][ib][0], sT[0][ib][1], sT[0][ib][2], sT[0][ib][3]),
+                  make_float4(sT[1][ib][0], sT[1][ib][1], sT[1][ib][2], sT[1][ib][3]), a_hi, a_lo);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dq_[ib][db] = z4;
+          mm3(dq_[ib][db], a_hi, a_lo, bh[db], bl[db]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // every strided read of Q, K, V is done: dQ (x scale) -> Q columns, dK -> K columns, dV -> V columns
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (db * 16 + l15 < DH) {
+            image[(b * 16 + 4 * g + r) * NF_IMG_LD + db * 16 + l15] = dq_[b][db][r] * P.scale;
+            image[(b * 16 + 4 * g + r) * NF_IMG_LD + DH + db * 16 + l15] = dk_[b][db][r];
+            image[(b * 16 + 4 * g + r) * NF_IMG_LD + 2 * DH + db * 16 + l15] = dv_[b][db][r];
+          }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- image [token][dq | dk | dv | 0] -> registers -> this head's plane of dqkv -------------------------------
+    // The next head's inputs are parked in the image BETWEEN the LDS reads and the global stores of this head's
+    // result: waiting for their loads (vmcnt) then never waits on this head's stores, which get the whole next
+    // head to retire.
+    float4 stv[8];
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int slot_i = pass * 64 + ln;
+        stv[pass] = *reinterpret_cast<const float4*>(image + (slot_i >> 4) * NF_IMG_LD + 4 * (slot_i & 15));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    put_head_inputs(nx_qv, nx_dv, nx_ls);
+    if constexpr (!(ABL & 1)) {
+      float* out = P.dqkv + ((int64_t)h * P.n_news * L + row0) * 64;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int slot_i = pass * 64 + ln;
+        if ((slot_i >> 4) < L) {
+          store4(out + 4 * slot_i, stv[pass], !(ABL & 8));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass)
+        asm volatile("" ::"v"(stv[pass].x), "v"(stv[pass].y), "v"(stv[pass].z), "v"(stv[pass].w));
+    }
+  }
+}
+
+template <int OCC = 2, int ABL = 0>
+static inline int launch_news_attn_bwd(const NewsAttnBwdArgs& a_in, hipStream_t st) {
+  if (a_in.n_news <= 0) return NRL_OK;
+  NewsAttnBwdArgs a = a_in;
+  a.hpw = a.heads % 5 == 0 ? 5 : (a.heads % 3 == 0 ? 3 : 1);   // ~7 rounds of workgroups at B = 128 instead of 2.3
+  const int64_t units = a.n_news * (a.heads / a.hpw);
+  const int64_t blocks = ceil_div(units, NAB_WAVES);
+  NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
+  hipLaunchKernelGGL((news_attn_bwd_kernel<20, OCC, ABL>), dim3((unsigned)blocks), dim3(NAB_WAVES * 64), 0, st, a);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

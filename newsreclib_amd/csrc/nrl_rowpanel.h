@@ -42,6 +42,9 @@ struct RpImageJob {
   // conv_w > 0: the tap-reversed conv weight of the CNN dgrad (nrl_conv.h): element (n = d, k = t' * F + f) is
   // src[(f * W + (W - 1 - t')) * N + d], src = Wc (F, W * N)
   int conv_f, conv_w;
+  // kheads > 0: the reduction index of the image is a head-plane index (KCSlab, nrl_gemm.h): image k' = head * 64 + c
+  // is logical k = part * (kheads * kdh) + head * kdh + d (c = part * kdh + d < 3 kdh), zero for the pad c
+  int kheads, kdh;
 };
 constexpr int RP_MAX_JOBS = 8;
 struct RpImageJobs {
@@ -78,9 +81,16 @@ __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs 
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int k = k0 + e;
+    int k = k0 + e;
     float x = 0.f;
-    if (row >= 0) {
+    bool live = row >= 0;
+    if (J.kheads > 0) {
+      const int head = k >> 6, c = k & 63;
+      live = live && head < J.kheads && c < 3 * J.kdh;
+      const int part = c / J.kdh, d = c - part * J.kdh;
+      k = part * (J.kheads * J.kdh) + head * J.kdh + d;
+    }
+    if (live) {
       if (k < J.K) {
         if (J.conv_w > 0) {
           const int tr = k / J.conv_f, f = k - tr * J.conv_f;
@@ -107,7 +117,7 @@ static inline RpImageJob* rp_jobs_add(RpImageJobs* js, const float* src, int64_t
                                       const float* bias, uint16_t* img, int nblk) {
   RpImageJob& J = js->job[js->count];
   J.src = src; J.bias = bias; J.img = img; J.sn = sn; J.sk = sk; J.N = N; J.K = K; J.nblk = nblk;
-  J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0; J.conv_f = 0; J.conv_w = 0;
+  J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0; J.conv_f = 0; J.conv_w = 0; J.kheads = 0; J.kdh = 0;
   js->first_thread[js->count + 1] = js->first_thread[js->count] + (int64_t)J.kblocks * nblk * 64;
   js->count += 1;
   return &J;
@@ -119,6 +129,17 @@ static inline RpImageJob* rp_jobs_add_qkv_heads(RpImageJobs* js, const float* w_
   RpImageJob* J = rp_jobs_add(js, w_in, D, 1, heads * 64, D, b_in, img, heads * 4);
   J->heads = heads;
   J->dh = dh;
+  return J;
+}
+// image whose reduction index runs over head planes (the in-projection dgrad of the fused news path: dx = dqkv W_in
+// with dqkv in the KCSlab layout): K' = heads * 64 image rows, logical K = 3 * heads * dh
+static inline RpImageJob* rp_jobs_add_kheads(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int heads,
+                                             int dh, uint16_t* img, int nblk) {
+  RpImageJob* J = rp_jobs_add(js, src, sn, sk, N, 3 * heads * dh, nullptr, img, nblk);
+  J->kheads = heads;
+  J->kdh = dh;
+  J->kblocks = heads * 2;
+  js->first_thread[js->count] = js->first_thread[js->count - 1] + (int64_t)J->kblocks * nblk * 64;
   return J;
 }
 static inline int rp_jobs_launch(const RpImageJobs& js, hipStream_t st) {

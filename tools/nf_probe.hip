@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&b, (size_t)3 * D * 4));
   CK(hipMalloc(&o, (size_t)N * L * D * 4));
   CK(hipMalloc(&x, (size_t)N * L * D * 4));
-  CK(hipMalloc(&qkv, (size_t)N * L * 3 * D * 4));
+  CK(hipMalloc(&qkv, (size_t)N * L * 15 * 64 * 4));
   CK(hipMalloc(&lse, (size_t)N * H * L * 4));
   CK(hipMalloc(&ids, (size_t)N * L * 8));
   CK(hipMalloc(&img, rp_image_elems(H * 4, NF_KB) * 2));
@@ -83,12 +83,15 @@ int main(int argc, char** argv) {
   a.table = table; a.ids = ids; a.img = img; a.n_news = N; a.L = L; a.D = D; a.heads = H; a.dh = 20;
   a.scale = 1.0f / sqrtf(20.f); a.drop1 = make_dropout(0.2, 5, 0); a.o = o;
   NewsFusedArgs as = a;
-  as.x_save = x; as.qkv_save = qkv; as.lse = lse;
-  a.x_save = nullptr; a.qkv_save = nullptr; a.lse = nullptr;
+  as.x_save = x; as.qkv_save = qkv; as.lse = lse; as.qkv_head_major = 1;
+  a.x_save = nullptr; a.qkv_save = nullptr; a.lse = nullptr; a.qkv_head_major = 0;
   const double gf = 2.0 * N * L * 3.0 * D * D * 1e-9;
   auto report = [&](const char* name, float ms) { printf("%-46s %.3f ms  (%.0f TF fp32-equiv in-projection)\n", name, ms, gf / ms); fflush(stdout); };
   report("eval  (no saves)", time_ms([&] { launch_news_fused_fwd<0>(a, st); }, st));
   report("train (x, q|k|v, lse saved)", time_ms([&] { launch_news_fused_fwd<0>(as, st); }, st));
+  report("train streaming saves", time_ms([&] { launch_news_fused_fwd<16>(as, st); }, st));
+  report("eval  streaming o stores", time_ms([&] { launch_news_fused_fwd<32>(a, st); }, st));
+  report("train streaming o stores", time_ms([&] { launch_news_fused_fwd<32>(as, st); }, st));
   report("eval  no attention phase", time_ms([&] { launch_news_fused_fwd<1>(a, st); }, st));
   report("eval  no in-projection MFMAs", time_ms([&] { launch_news_fused_fwd<2>(a, st); }, st));
   report("eval  no attention, no MFMAs", time_ms([&] { launch_news_fused_fwd<3>(a, st); }, st));
@@ -96,5 +99,27 @@ int main(int argc, char** argv) {
   report("eval  no stores", time_ms([&] { launch_news_fused_fwd<8>(a, st); }, st));
   report("train no stores in the head loop", time_ms([&] { launch_news_fused_fwd<8>(as, st); }, st));
   report("eval  no attention, no MFMAs, no DMA", time_ms([&] { launch_news_fused_fwd<7>(a, st); }, st));
+  report("eval  (no saves), again", time_ms([&] { launch_news_fused_fwd<0>(a, st); }, st));
+  report("train (x, q|k|v, lse saved), again", time_ms([&] { launch_news_fused_fwd<0>(as, st); }, st));
+  report("train streaming saves, again", time_ms([&] { launch_news_fused_fwd<16>(as, st); }, st));
+  // ---- token-attention backward from the head-major slabs the training forward just wrote ----
+  float *d_o, *dqkv;
+  CK(hipMalloc(&d_o, (size_t)N * L * D * 4));
+  CK(hipMalloc(&dqkv, (size_t)N * L * 15 * 64 * 4));
+  CK(hipMemcpy(d_o, o, (size_t)N * L * D * 4, hipMemcpyDeviceToDevice));
+  NewsAttnBwdArgs ab;
+  ab.qkv_hm = qkv; ab.d_o = d_o; ab.lse = lse; ab.dqkv = dqkv; ab.n_news = N; ab.L = L; ab.D = D; ab.heads = H;
+  ab.scale = a.scale; ab.hpw = 1;
+  auto rep2 = [&](const char* name, float ms) { printf("%-46s %.3f ms\n", name, ms); fflush(stdout); };
+  rep2("attn bwd  2 waves/SIMD", time_ms([&] { launch_news_attn_bwd<2, 0>(ab, st); }, st));
+  rep2("attn bwd  3 waves/SIMD", time_ms([&] { launch_news_attn_bwd<3, 0>(ab, st); }, st));
+  rep2("attn bwd  plain (write-allocate) stores", time_ms([&] { launch_news_attn_bwd<2, 8>(ab, st); }, st));
+  rep2("attn bwd  no arithmetic, plain stores", time_ms([&] { launch_news_attn_bwd<2, 10>(ab, st); }, st));
+  rep2("attn bwd  no dqkv stores", time_ms([&] { launch_news_attn_bwd<2, 1>(ab, st); }, st));
+  rep2("attn bwd  no arithmetic", time_ms([&] { launch_news_attn_bwd<2, 2>(ab, st); }, st));
+  rep2("attn bwd  no arithmetic, no stores", time_ms([&] { launch_news_attn_bwd<2, 3>(ab, st); }, st));
+  rep2("attn bwd  no loads", time_ms([&] { launch_news_attn_bwd<2, 4>(ab, st); }, st));
+  rep2("attn bwd  no loads, no stores", time_ms([&] { launch_news_attn_bwd<2, 5>(ab, st); }, st));
+  rep2("attn bwd  nothing but LDS traffic", time_ms([&] { launch_news_attn_bwd<2, 7>(ab, st); }, st));
   return 0;
 }
