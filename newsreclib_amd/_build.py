@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnewsreclib_amd.so")
 SOURCES = ["nrl_api.hip", "nrl_kernels.hip", "nrl_attn_mfma.hip", "nrl_sort.hip"]
-HEADERS = ["nrl_common.h", "nrl_gemm.h", "nrl_gemm_bf16x3.h", "nrl_gemm_bf16x3_dma.h", "nrl_rowpanel.h", "nrl_gemm_ws.h", "nrl_news_fused.h", "nrl_kernels.h", "nrl_conv.h", "nrl_gru_fused.h", "nrl_api_lstur.inc", "nrl_api_blocks.inc", os.path.join("..", "..", "include", "newsreclib_amd.h")]
+HEADERS = ["nrl_common.h", "nrl_gemm.h", "nrl_gemm_bf16x3.h", "nrl_gemm_bf16x3_dma.h", "nrl_rowpanel.h", "nrl_gemm_ws.h", "nrl_wgrad_planes.h", "nrl_news_fused.h", "nrl_kernels.h", "nrl_conv.h", "nrl_gru_fused.h", "nrl_api_lstur.inc", "nrl_api_blocks.inc", os.path.join("..", "..", "include", "newsreclib_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -18,6 +18,7 @@
 #include "nrl_rowpanel.h"
 #include "nrl_gemm_ws.h"
 #include "nrl_news_fused.h"
+#include "nrl_wgrad_planes.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
 #include "nrl_gru_fused.h"
@@ -141,6 +142,14 @@ static bool g_news_attn_mfma = [] {
   return !(e != nullptr && e[0] == '0');
 }();
 
+// NRL_NEWS_PLANES=0: x and dqkv of the fused news path stay fp32 (head planes) and the in-projection weight gradient
+// runs on the wave-specialised kernel.  Default: both are written ONCE as (hi, lo) bf16 fragment-block planes by their
+// producers and consumed by wgrad_planes_kernel / the row-panel dgrad without any split (nrl_wgrad_planes.h).
+static bool g_news_planes = [] {
+  const char* e = getenv("NRL_NEWS_PLANES");
+  return !(e != nullptr && e[0] == '0');
+}();
+
 // NRL_WGRAD_WS=0: the large (I > 512) weight gradient back on the register-staged kernel (default: the
 // wave-specialised one, nrl_gemm_ws.h, 32 k-splits = one workgroup per CU: 4.81 -> 4.72 ms/step at B = 128)
 static bool g_wgrad_ws = [] {
@@ -162,6 +171,7 @@ struct BlockShape {
   int64_t pool_groups;  // output rows
   int pool_len;         // rows per output row
   AttnGeom geom;
+  int64_t pad_rows = 0; // news encoder: token rows padded to 32 per news (fragment-block planes), else 0
 };
 
 struct BlockWs {
@@ -192,17 +202,23 @@ static size_t plane_elems(int D, int Q) {
   return split_weight_elems(3 * D, D) + split_weight_elems(D, D) + split_weight_elems(Q, D);
 }
 
-// q|k|v: packed rows (M, 3D), or -- dh = 20, the fused news path -- head-major slabs of 64 floats per (token, head)
-static size_t qkv_elems(int64_t M, int D, int heads) {
-  const size_t packed = (size_t)M * 3 * D, slabs = (size_t)M * heads * 64;
+// q|k|v / dqkv: packed rows (M, 3D), or -- dh = 20, the fused news path -- 64 floats per (token, head): fp32 head-major
+// slabs / head planes over the real rows, or (hi, lo) bf16 fragment-block planes over the padded rows
+static size_t qkv_elems(int64_t M, int D, int heads, int64_t pad_rows) {
+  const size_t packed = (size_t)M * 3 * D, slabs = (size_t)(pad_rows > M ? pad_rows : M) * heads * 64;
   return (D == heads * 20 && slabs > packed) ? slabs : packed;
 }
+// x: post-dropout rows (M, D), or their fragment-block planes: 20 column blocks x (hi, lo) x 2 bytes = 320 floats per padded row
+static size_t x_elems(int64_t M, int D, int64_t pad_rows) {
+  const size_t rows = (size_t)M * D, planes = (size_t)pad_rows * 320;
+  return planes > rows ? planes : rows;
+}
 
-static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
+static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x, int64_t pad_rows = 0) {
   auto al = [](size_t n) { return align_up(n, 64); };
   size_t n = 0;
-  if (with_x) n += al((size_t)M * D);
-  n += al(qkv_elems(M, D, heads)) * 2;  // qkv, dqkv
+  if (with_x) n += al(x_elems(M, D, pad_rows));
+  n += al(qkv_elems(M, D, heads, pad_rows)) * 2;  // qkv, dqkv
   n += al((size_t)M * D) * 4;      // o, y, dy, d_o (later dx)
   n += al((size_t)M * Q);          // t / d_pre
   n += al((size_t)M);              // w
@@ -214,16 +230,16 @@ static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x) {
 
 static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x, BlockWs* out) {
   NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
-  if (ws_bytes < block_ws_floats(s.M, s.D, s.Q, s.heads, with_x) * sizeof(float)) {
+  if (ws_bytes < block_ws_floats(s.M, s.D, s.Q, s.heads, with_x, s.pad_rows) * sizeof(float)) {
     set_error("workspace too small: %zu < %zu bytes", ws_bytes,
-              block_ws_floats(s.M, s.D, s.Q, s.heads, with_x) * sizeof(float));
+              block_ws_floats(s.M, s.D, s.Q, s.heads, with_x, s.pad_rows) * sizeof(float));
     return NRL_E_WORKSPACE;
   }
   float* p = (float*)ws;
   auto take = [&](size_t n) { float* r = p; p += align_up(n, 64); return r; };
-  out->x = with_x ? take((size_t)s.M * s.D) : nullptr;
-  out->qkv = take(qkv_elems(s.M, s.D, s.heads));
-  out->dqkv = take(qkv_elems(s.M, s.D, s.heads));
+  out->x = with_x ? take(x_elems(s.M, s.D, s.pad_rows)) : nullptr;
+  out->qkv = take(qkv_elems(s.M, s.D, s.heads, s.pad_rows));
+  out->dqkv = take(qkv_elems(s.M, s.D, s.heads, s.pad_rows));
   out->o = take((size_t)s.M * s.D);
   out->y = take((size_t)s.M * s.D);
   out->dy = take((size_t)s.M * s.D);
@@ -469,13 +485,19 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
 }
 
 static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const BlockShape& s, const BlockWs& w,
-                            hipStream_t st, bool dqkv_head_planes = false) {
+                            hipStream_t st, bool dqkv_head_planes = false, bool bf16_planes = false) {
   const int D = s.D, Q = s.Q;
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
   NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
   // dW_o += dy^T o ; db_o += colsum(dy)
   NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
+  if (bf16_planes) {
+    // both operands pre-split by their producers: pure DMA + transpose-read + MFMA kernel (nrl_wgrad_planes.h)
+    static const int wp_splits = [] { const char* e = getenv("NRL_WGRAD_PLANES_SPLITS"); return e ? atoi(e) : 32; }();
+    return launch_wgrad_planes(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1,
+                               EpiAtomicWBHeads{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh}, wp_splits, st);
+  }
   if (dqkv_head_planes) {
     // dqkv in head planes (news_attn_bwd_kernel): 64 output rows per head, remapped to [Wq; Wk; Wv] rows on the way out
     static const int ws_splits = [] { const char* e = getenv("NRL_WGRAD_WS_SPLITS"); return e ? atoi(e) : 32; }();
@@ -507,6 +529,7 @@ static BlockShape news_shape(const NrlBlockParams* p, int64_t n_news, int L) {
   BlockShape s;
   s.D = p->embed_dim; s.Q = p->query_dim; s.heads = p->num_heads; s.dh = s.D / s.heads;
   s.M = n_news * L;
+  s.pad_rows = L <= 32 ? n_news * 32 : 0;
   s.pool_groups = n_news; s.pool_len = L;
   s.geom.q_outer = (int64_t)L * 3 * s.D; s.geom.q_seq = 3 * s.D;
   s.geom.o_outer = (int64_t)L * s.D; s.geom.o_seq = s.D;
@@ -574,11 +597,12 @@ int nrl_set_option(const char* name, int32_t value) {
   bool* flag = !strcmp(name, "news_fused") ? &g_news_fused
                : !strcmp(name, "news_fused_bwd") ? &g_news_fused_bwd
                : !strcmp(name, "news_attn_mfma") ? &g_news_attn_mfma
+               : !strcmp(name, "news_planes") ? &g_news_planes
                : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma
                                            : nullptr;
-  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, wgrad_ws, rowpanel, x3_dma)", name);
+  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, wgrad_ws, rowpanel, x3_dma)", name);
   *flag = value != 0;
   return NRL_OK;
 }
@@ -593,7 +617,7 @@ int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, ui
 
 size_t nrl_news_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t embed_dim,
                                         int32_t num_heads, int32_t query_dim) {
-  return block_ws_floats(n_news * seq_len, embed_dim, query_dim, num_heads, true) * sizeof(float);
+  return block_ws_floats(n_news * seq_len, embed_dim, query_dim, num_heads, true, seq_len <= 32 ? n_news * 32 : 0) * sizeof(float);
 }
 
 int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_t vocab,
@@ -619,7 +643,9 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     NewsFusedArgs a;
     a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
     a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.o = w.o;
-    a.x_save = save_for_backward ? w.x : nullptr;
+    const bool planes = !g_news_fused_bwd && g_news_attn_mfma && g_news_planes;
+    a.x_save = (save_for_backward && !planes) ? w.x : nullptr;
+    a.x_planes = (save_for_backward && planes) ? reinterpret_cast<unsigned char*>(w.x) : nullptr;
     a.qkv_save = (save_for_backward && !g_news_fused_bwd) ? w.qkv : nullptr;   // else recomputed in the backward
     a.qkv_head_major = g_news_attn_mfma ? 1 : 0;
     a.lse = save_for_backward ? w.lse : nullptr;
@@ -651,6 +677,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   BlockPlanes bp;
   const bool fused = news_fused_on(s, seq_len) && g_news_fused_bwd;
   const bool slabs = news_fused_on(s, seq_len) && !g_news_fused_bwd && g_news_attn_mfma;   // what the forward saved
+  const bool planes = slabs && g_news_planes;
   NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
   if (phase != 2) {
     NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st, fused || slabs));
@@ -658,7 +685,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       // token attention backward on the matrix cores from the head-major q|k|v slabs (nrl_news_fused.h)
       NewsAttnBwdArgs a;
       a.qkv_hm = w.qkv; a.d_o = w.d_o; a.lse = w.lse; a.dqkv = w.dqkv; a.n_news = n_news; a.L = seq_len; a.D = s.D;
-      a.heads = s.heads; a.scale = s.geom.scale; a.hpw = 1;
+      a.heads = s.heads; a.scale = s.geom.scale; a.hpw = 1; a.planes = planes ? 1 : 0;
       NRL_TRY(launch_news_attn_bwd(a, st));
     }
     if (fused) {
@@ -673,20 +700,23 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
     }
     // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
     const KCSlab dq_hp{w.dqkv, s.M};
+    const KCPlanes dq_pl{reinterpret_cast<const unsigned char*>(w.dqkv), s.pad_rows};
     if (sorted_positions != nullptr) {
       // dx is materialised (in the now dead d_o buffer) and reduced in id-sorted order: no hot-row contention
       float* dx = w.d_o;
       const EpiLinear epi{dx, s.D, nullptr, 0, d1, s.D};
-      if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
+      if (planes) NRL_TRY(rp_dispatch(dq_pl, bp.rp.in_d_hp, EpiNewsRows<EpiLinear>{epi, seq_len}, s.pad_rows, s.D, s.heads * 64, st));
+      else if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
       else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
       NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));
     } else {
       const EpiScatter epi{d_emb_table, ids, s.D, d1};
-      if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
+      if (planes) NRL_TRY(rp_dispatch(dq_pl, bp.rp.in_d_hp, EpiNewsRows<EpiScatter>{epi, seq_len}, s.pad_rows, s.D, s.heads * 64, st));
+      else if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
       else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
     }
   }
-  if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, s, w, st, slabs));
+  if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, s, w, st, slabs, planes));
   return NRL_OK;
 }
 

@@ -110,6 +110,34 @@ struct KCSlab {
   }
 };
 
+// dqkv of the fused news path as PRE-SPLIT fragment-block planes (nrl_wgrad_planes.h): token rows padded to 32 per
+// news, block (head, mb = row / 16, cb) = [p][16 rows][16 features] bf16.  A row-panel lane's fragment (row, 8
+// consecutive features) is 16 contiguous bytes of the hi plane and 16 of the lo plane: `load` returns the raw bits
+// (k % 8 == 0: hi, k % 8 == 4: lo) and the kernel skips its split (kPreSplit).  Logical k = head * 64 + c.
+struct KCPlanes {
+  static constexpr int kLayout = SRC_KC;
+  static constexpr bool kPreSplit = true;
+  const unsigned char* p;
+  int64_t rows;            // padded rows (n_news * 32)
+  struct State {
+    const unsigned char* ptr;
+    bool ok;
+  };
+  __device__ __forceinline__ State init(int64_t r) const {
+    const bool ok = r < rows;
+    const int64_t rr = ok ? r : 0;
+    return State{p + (rr >> 4) * 4096 + (rr & 15) * 32, ok};     // + per-k terms in `load`
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int) const {
+    // k = head * 64 + cb * 16 + half * 8 (+ 4: the lo plane)
+    const int64_t off = (int64_t)(k >> 6) * (rows >> 4) * 4096 + ((k >> 4) & 3) * 1024 + ((k >> 3) & 1) * 16 + ((k & 4) ? 512 : 0);
+    return *reinterpret_cast<const float4*>(s.ptr + off);
+  }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int, int, bool) const {
+    if (!s.ok) v = f4zero();
+  }
+};
+
 // rows gathered from an embedding table through int64 ids (nn.Embedding, text.py:224), times the
 // dropout multiplier of text.py:225; the tile column 0 workgroup also saves the post-dropout row
 // (needed by the in-projection weight gradient).  ids == nullptr means identity rows: a dense
@@ -402,6 +430,39 @@ template <class Epi, class = void>
 struct EpiHasVec4 : std::false_type {};
 template <class Epi>
 struct EpiHasVec4<Epi, std::enable_if_t<Epi::kVec4>> : std::true_type {};
+
+// Output rows of a GEMM over PADDED token rows (32 per news, KCPlanes) mapped back to the real rows news * L + t;
+// the pad rows t >= L produce nothing.
+template <class Epi>
+struct EpiNewsRows {
+  Epi inner;
+  int L;
+  struct Row {
+    typename Epi::Row in;
+    int64_t m;
+    bool ok;
+  };
+  __device__ __forceinline__ Row row(int64_t mp) const {
+    const int t = (int)(mp & 31);
+    const bool ok = t < L;
+    const int64_t m = (mp >> 5) * L + (ok ? t : 0);
+    return Row{inner.row(m), m, ok};
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    if (r.ok) inner(r.in, r.m, n, v);
+  }
+  static constexpr bool kVec4 = EpiHasVec4<Epi>::value;
+  __device__ __forceinline__ bool vec_ok() const {
+    if constexpr (EpiHasVec4<Epi>::value) return inner.vec_ok();
+    else return false;
+  }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    if constexpr (EpiHasVec4<Epi>::value) {
+      if (r.ok) inner.vec4(r.in, r.m, n, v);
+    }
+  }
+};
+
 
 // 4 x 4 transpose across the four lanes of a quad (DPP quad_perm): lane t of the quad holds column t of
 // rows 0..3 in a[0..3] on entry and row t, columns 0..3 on exit.

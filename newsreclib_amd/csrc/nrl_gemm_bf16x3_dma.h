@@ -40,6 +40,17 @@ __device__ __forceinline__ void glds16_asm(const void* src, uint32_t lds_byte_ad
       : "memory");
 }
 
+// the same with a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit VALU add per DMA
+__device__ __forceinline__ void glds16_saddr(const void* base_uniform, uint32_t lane_byte_off, uint32_t lds_byte_addr_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :
+      : "s"(lds_byte_addr_uniform), "v"(lane_byte_off), "s"(base_uniform)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

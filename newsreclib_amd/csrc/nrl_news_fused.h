@@ -42,6 +42,9 @@ struct NewsFusedArgs {
   Dropout drop1;
   float* o;                 // (n_news * L, D)
   float* x_save;            // (n_news * L, D) post-dropout rows, or null
+  unsigned char* x_planes;  // or (instead of x_save): the rows' (hi, lo) bf16 fragments as fragment-block planes
+                            // [news * 2 + rb][cb 0 .. 19][p][16 x 16] (nrl_wgrad_planes.h) -- exactly the registers
+                            // this kernel holds, so the in-projection weight gradient never splits or transposes x
   float* qkv_save;          // q|k|v (unscaled q) for the backward, or null (news_fused_bwd_kernel recomputes them):
                             //   qkv_head_major == 0: (n_news * L, 3D) packed rows (attn_bwd_small's layout)
                             //   qkv_head_major == 1: (n_news, heads, L, 64) = the private image rows [q | k | v | 0 4],
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
         v1.x *= m1 * P.drop1.mult(idx + 4); v1.y *= m1 * P.drop1.mult(idx + 5);
         v1.z *= m1 * P.drop1.mult(idx + 6); v1.w *= m1 * P.drop1.mult(idx + 7);
         if constexpr (SAVE) {
-          if (okr[rb]) {
+          if (P.x_planes == nullptr && okr[rb]) {
             if (in0) store4(P.x_save + growr[rb] * D + k, v0, NT);
             if (in1) store4(P.x_save + growr[rb] * D + k + 4, v1, NT);
           }
@@ -203,6 +206,14 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
           if (k + 4 == D) v1.x = 1.0f;
         }
         rp_split8(v0, v1, ah[rb][kb], al[rb][kb]);
+        if constexpr (SAVE) {
+          if (P.x_planes != nullptr && news_ok) {
+            // block (mb = 2 news + rb, cb = 2 kb + (g >> 1)): row l15, columns 8 (g & 1) .. + 7 (pad rows: zeros + the ones column)
+            unsigned char* dst = P.x_planes + (((news * 2 + rb) * 20 + 2 * kb + (g >> 1)) * 2) * 512 + l15 * 32 + (g & 1) * 16;
+            *reinterpret_cast<bf16x8*>(dst) = ah[rb][kb];
+            *reinterpret_cast<bf16x8*>(dst + 512) = al[rb][kb];
+          }
+        }
       }
     }
   }
@@ -441,10 +452,11 @@ static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t s
     a.full_wgs = (int)blocks;
   }
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
-  if (a.x_save != nullptr && a.lse != nullptr) {       // training: x + lse (+ q|k|v unless the backward recomputes them)
+  NRL_REQUIRE(a.x_planes == nullptr || NF_KB == 10, "x planes assume 20 column blocks");
+  if ((a.x_save != nullptr || a.x_planes != nullptr) && a.lse != nullptr) {   // training: x + lse (+ q|k|v unless recomputed)
     hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
   } else {
-    NRL_REQUIRE(a.x_save == nullptr && a.qkv_save == nullptr && a.lse == nullptr,
+    NRL_REQUIRE(a.x_save == nullptr && a.x_planes == nullptr && a.qkv_save == nullptr && a.lse == nullptr,
                 "fused news encoder: save x and lse (and optionally q|k|v), or nothing");
     hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
   }
@@ -476,6 +488,8 @@ struct NewsAttnBwdArgs {
   int L, D, heads;
   float scale;
   int hpw;              // heads per wave (divides heads)
+  int planes;           // 1: dqkv as (hi, lo) bf16 fragment-block planes [head][news * 2 + mb][cb 0 .. 3][p][16 x 16]
+                        // (nrl_wgrad_planes.h; token rows padded to 32 per news) instead of fp32 head planes
 };
 
 constexpr int NAB_WAVES = 4;
@@ -730,7 +744,22 @@ __global__ void __launch_bounds__(NAB_WAVES * 64, OCC) news_attn_bwd_kernel(cons
     // result: waiting for their loads (vmcnt) then never waits on this head's stores, which get the whole next
     // head to retire.
     float4 stv[8];
-    {
+    if (P.planes) {
+      // 16-byte chunks of 8 features, split once here: chunk ch = (block blk = ch >> 5, row r16, half) -> the block's hi
+      // plane at (ch & 31) * 16, lo plane 512 bytes on: every 512-byte block plane is written by 32 consecutive lanes
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int ch = pass * 64 + ln;
+        const int blk = ch >> 5, r16 = (ch >> 1) & 15, half = ch & 1;
+        const float* src = image + ((blk >> 2) * 16 + r16) * NF_IMG_LD + ((blk & 3) * 2 + half) * 8;
+        bf16x8 hi, lo;
+        rp_split8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), hi, lo);
+        stv[2 * pass] = __builtin_bit_cast(float4, hi);
+        stv[2 * pass + 1] = __builtin_bit_cast(float4, lo);
+      }
+    } else {
       int ln = lane;
       asm volatile("" : "+v"(ln));
 #pragma unroll
@@ -742,14 +771,23 @@ __global__ void __launch_bounds__(NAB_WAVES * 64, OCC) news_attn_bwd_kernel(cons
     __builtin_amdgcn_wave_barrier();
     put_head_inputs(nx_qv, nx_dv, nx_ls);
     if constexpr (!(ABL & 1)) {
-      float* out = P.dqkv + ((int64_t)h * P.n_news * L + row0) * 64;
       int ln = lane;
       asm volatile("" : "+v"(ln));
+      if (P.planes) {
+        float* out = P.dqkv + (((int64_t)h * P.n_news + news) * 2) * 4 * 256;   // 8 KiB per (head, news)
 #pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {
-        const int slot_i = pass * 64 + ln;
-        if ((slot_i >> 4) < L) {
-          store4(out + 4 * slot_i, stv[pass], !(ABL & 8));
+        for (int pass = 0; pass < 4; ++pass) {
+          const int ch = pass * 64 + ln;
+          float* dst = out + (ch >> 5) * 256 + (ch & 31) * 4;
+          store4(dst, stv[2 * pass], !(ABL & 8));
+          store4(dst + 128, stv[2 * pass + 1], !(ABL & 8));
+        }
+      } else {
+        float* out = P.dqkv + ((int64_t)h * P.n_news * L + row0) * 64;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+          const int slot_i = pass * 64 + ln;
+          if ((slot_i >> 4) < L) store4(out + 4 * slot_i, stv[pass], !(ABL & 8));
         }
       }
     } else {

@@ -167,6 +167,12 @@ __device__ __forceinline__ void rp_split8(const float4& v0, const float4& v1, bf
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
 
+// A operands that deliver their fragments already split (KCPlanes, nrl_gemm.h)
+template <class T, class = void>
+struct RpPreSplit : std::false_type {};
+template <class T>
+struct RpPreSplit<T, std::enable_if_t<T::kPreSplit>> : std::true_type {};
+
 // ---- kernel ------------------------------------------------------------------------------------------
 // WAVES wavefronts x 32 rows each; NBLK = ceil(N / 16) column blocks per wave; LDS ring of 2 k-block chunks.
 template <int NBLK, int WAVES, class AOp, class Epi, int DEEP = 0>
@@ -218,7 +224,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     for (int i = 0; i < 2; ++i) {
       A.finish(r[i][0], st[i], rowi[i], k, K, true);
       A.finish(r[i][1], st[i], rowi[i], k + 4, K, true);
-      rp_split8(r[i][0], r[i][1], ah[i], al[i]);
+      if constexpr (RpPreSplit<AOp>::value) {
+        ah[i] = __builtin_bit_cast(bf16x8, r[i][0]);       // the producer split once (hi | lo planes)
+        al[i] = __builtin_bit_cast(bf16x8, r[i][1]);
+      } else {
+        rp_split8(r[i][0], r[i][1], ah[i], al[i]);
+      }
     }
   };
 

@@ -1,0 +1,216 @@
+// Weight gradient of the news encoder's in-projection from PRE-SPLIT operands (gfx950):
+//
+//     dW'[i'][j] += sum over token rows m of  dqkv[m][i'] * x[m][j]        (embedding_dim 300: 960 x 301 outputs)
+//
+// The register-staged / wave-specialised kernels (nrl_gemm_bf16x3.h, nrl_gemm_ws.h) fetch both operands as fp32,
+// split every element to (hi, lo) bf16 in VALU once per tile that uses it, transpose through registers into LDS
+// and reach 25 % matrix-core occupancy (0.62 ms at B = 128: 4 x the MFMA time).  Here the PRODUCERS of the two
+// operands -- the token-attention backward (dqkv) and the fused forward (x, which holds exactly these fragments in
+// registers) -- write the split once, as "fragment-block planes":
+//
+//   block (mb = m / 16, cb = feature / 16), plane p (0 = hi, 1 = lo): 16 x 16 bf16, [m % 16][feature % 16] row-major,
+//   512 bytes; a token-row block of x is [cb 0 .. ncb - 1][p][512], of dqkv (per head) [cb 0 .. 3][p][512]
+//   (rows m are padded to 32 per news: two blocks per news, pad rows zero in dqkv).
+//
+// and this kernel is nothing but LDS-DMA (global_load_lds_dwordx4: a block pair is 1 KiB of contiguous global and
+// LDS memory), `ds_read_b64_tr_b16` fragment reads (the 16 x 16 block is [k = token][i = feature]: the transpose
+// read hands lane (i, g) its four tokens 4g .. 4g + 3, two blocks = the 8 k of a 16 x 16 x 32 MFMA operand -- the
+// SAME token set on the A and the B side, which is all a reduction needs) and MFMAs.  No VALU in the loop.
+//
+// Workgroup = 4 wavefronts (2 x 2), tile 256 (4 heads x 64) x 160, k-tile = 32 token rows = one news; three 52 KiB
+// LDS stages; split-K over news with atomic accumulation (EpiAtomicWBHeads remaps the 64-row head groups to the
+// [Wq; Wk; Wv] rows).  Arithmetic: hi * lo + lo * hi + hi * hi into fp32, as everywhere else.
+#pragma once
+#include "nrl_gemm_bf16x3_dma.h"
+
+namespace nrl {
+
+// tile = 256 rows (4 heads x 64) x 32 * WP_TN columns (WP_TN = column blocks per wave; 10 = the whole width would fetch
+// every dqkv byte once per launch, but its 320 accumulator registers per lane make hipcc shuttle them through
+// v_accvgpr moves: 0.68 ms against 0.47)
+constexpr int WP_TN = 5;
+constexpr int WP_A_STAGE = 32 * 1024, WP_B_STAGE = 2 * (2 * WP_TN) * 1024, WP_STAGE = WP_A_STAGE + WP_B_STAGE, WP_STAGES = 3;
+constexpr int WP_PIECES = WP_STAGE / 1024;                 // 72 one-KiB pieces per k-tile, 18 per wave
+static_assert(WP_PIECES % 4 == 0, "pieces are dealt to four waves");
+
+typedef short wp_v4i16 __attribute__((ext_vector_type(4)));
+
+struct WgradPlanesArgs {
+  const unsigned char* a;   // dqkv planes: ((head * n_mb + mb) * 4 + cb) * 1024 + p * 512
+  const unsigned char* b;   // x planes:    (mb * ncb_b + cb) * 1024 + p * 512
+  int64_t n_mb;             // token-row blocks (even: 2 per news)
+  int heads, ncb_b;         // ncb_b = 20: 320 feature columns (300 + the ones column + pad)
+  int tiles_m, tiles_n;     // ceil(heads / 4), ncb_b / (2 * WP_TN)
+  int nsplit;
+  int64_t kt_per_split;     // k-tiles (news) per split
+  int64_t M;                // heads * 64 logical output rows
+  int N;                    // valid output columns (D + 1)
+};
+
+// ABL (tools/wp_probe.hip only): 1 = no DMA inside the loop, 2 = no MFMAs
+template <class Epi, int ABL = 0>
+__global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesArgs P, const Epi epi) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char wp_smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wp_smem;
+
+  // workgroup -> (tile, split): all tiles of a split on ONE XCD (its operand slices are re-read from that L2)
+  const int tiles_total = P.tiles_m * P.tiles_n;
+  const int64_t bid = blockIdx.x;
+  const int64_t xcd = bid % 8, local = bid / 8;
+  const int t = (int)(local % tiles_total);
+  const int64_t split = (local / tiles_total) * 8 + xcd;
+  if (split >= P.nsplit) return;
+  const int tm = t / P.tiles_n, tn = t % P.tiles_n;
+  const int64_t kt_all = P.n_mb / 2;
+  const int64_t kt0 = split * P.kt_per_split;
+  const int64_t kt1 = kt0 + P.kt_per_split < kt_all ? kt0 + P.kt_per_split : kt_all;
+  if (kt0 >= kt1) return;
+  const int nkt = (int)(kt1 - kt0);
+
+  // ---- DMA: one-KiB pieces (a 16 x 16 block, both planes): 8 A + 5 B pieces per wave and k-tile ------------------
+  //   A piece (q, wave) = (hh = q >> 1, mbi = q & 1, cb = wave): LDS [hh][mbi][cb][p][512]
+  //   B piece pb = 4 q + wave = (mbi = pb / 10, cb = pb % 10):    LDS [mbi][cb][p][512]
+  // Wave-uniform base pointers of the split's first k-tile live in SGPRs; a k-tile advances them by a constant.
+  static_assert(WP_TN == 5, "piece dealing below assumes 32 A + 20 B pieces");
+  const unsigned char* base_a[8];
+  const unsigned char* base_b[5];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    int head = 4 * tm + (q >> 1);
+    head = head < P.heads ? head : P.heads - 1;           // empty head slots of the last tile: rows dropped by the epilogue
+    base_a[q] = P.a + (((int64_t)head * P.n_mb + 2 * kt0 + (q & 1)) * 4 + wave) * 1024;
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int pb = 4 * q + wave, mbi = pb / 10, cb = pb - mbi * 10;
+    base_b[q] = P.b + ((2 * kt0 + mbi) * P.ncb_b + 10 * tn + cb) * 1024;
+  }
+  const int64_t step_a = 2 * 4 * 1024, step_b = 2 * (int64_t)P.ncb_b * 1024;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  // pieces [c0, c1) of this wave's 13 (0..7: A, 8..12: B) of k-tile `rel` (relative to kt0) into `stage`
+  auto issue = [&](int rel, int stage, int c0, int c1) {
+    const uint32_t sbase = smem_base + (uint32_t)stage * WP_STAGE + (uint32_t)wave * 1024u;
+#pragma unroll
+    for (int c = c0; c < c1; ++c) {
+      if (c < 8) glds16_saddr(base_a[c] + rel * step_a, lane16, sbase + (uint32_t)c * 4096u);
+      else glds16_saddr(base_b[c - 8] + rel * step_b, lane16, sbase + (uint32_t)WP_A_STAGE + (uint32_t)(c - 8) * 4096u);
+    }
+  };
+
+  f32x4 acc[8][WP_TN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < WP_TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transpose-read address of this lane inside a 16 x 16 block: row 4g + (l15 >> 2), 4 bf16 at column 4 (l15 & 3)
+  const uint32_t lane_off = (uint32_t)((4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8);
+  auto frag = [&](uint32_t blk0, uint32_t blk1) -> bf16x8 {
+    typedef __attribute__((address_space(3))) wp_v4i16* lds_v4;
+    const wp_v4i16 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(blk0 + lane_off));
+    const wp_v4i16 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(blk1 + lane_off));
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    const v8i16 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  issue(0, 0, 0, 13);
+  issue(nkt > 1 ? 1 : 0, 1, 0, 13);
+  int stage = 0;
+  for (int it = 0; it < nkt; ++it) {
+    // tile `it` (issued two iterations ago) has landed for this wave: at most the pieces of tile it + 1 are in flight
+    if constexpr (ABL & 1) wait_vmcnt<0>(); else wait_vmcnt<WP_PIECES / 4>();
+    __builtin_amdgcn_s_barrier();                          // ... and for every wave; stage (it + 2) % 3 is free
+    const int nx = it + 2 < nkt ? it + 2 : nkt - 1;        // uniform control flow: the tail re-fetches the last tile
+    const int st2 = stage == 0 ? 2 : stage - 1;            // (it + 2) % 3
+    // (the 13 DMA issues of tile it + 2 are spread over the eight row steps below: as one block in front of the
+    //  MFMAs their scalar address arithmetic was ~1000 cycles per k-tile that nothing overlapped)
+    auto issue_part = [&](int step) {
+      if constexpr (!(ABL & 1)) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue(nx, st2, step < 5 ? 2 * step : 5 + step, step < 5 ? 2 * step + 2 : 6 + step);   // 2 2 2 2 2 1 1 1
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    const uint32_t sa = smem_base + (uint32_t)stage * WP_STAGE;
+    const uint32_t sb = sa + WP_A_STAGE;
+    // B fragments of this wave's column blocks
+    bf16x8 bh[WP_TN], bl[WP_TN];
+#pragma unroll
+    for (int j = 0; j < WP_TN; ++j) {
+      const uint32_t c0 = sb + (uint32_t)(WP_TN * wn + j) * 1024u, c1 = c0 + (uint32_t)(2 * WP_TN) * 1024u;   // mbi = 0, 1
+      bh[j] = frag(c0, c1);
+      bl[j] = frag(c0 + 512u, c1 + 512u);
+    }
+    // A fragments of row block i + 1 are fetched while the MFMAs of row block i run (two named sets; on its own hipcc
+    // reads each fragment right before its first MFMA and waits for the LDS there)
+    auto read_a = [&](int i, bf16x8& ah, bf16x8& al) {
+      const int hh = 2 * wm + (i >> 2), cb = i & 3;
+      const uint32_t a0 = sa + (uint32_t)((hh * 2 + 0) * 4 + cb) * 1024u, a1 = sa + (uint32_t)((hh * 2 + 1) * 4 + cb) * 1024u;
+      ah = frag(a0, a1);
+      al = frag(a0 + 512u, a1 + 512u);
+    };
+    auto mfma_row = [&](int i, const bf16x8& ah, const bf16x8& al) {
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+        for (int j = 0; j < WP_TN; ++j) {
+          if constexpr (ABL & 2) asm volatile("" ::"v"(ah), "v"(al), "v"(bh[j]), "v"(bl[j]));
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al : ah, pass == 0 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    bf16x8 ah0, al0, ah1, al1;
+    read_a(0, ah0, al0);
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      read_a(i + 1, ah1, al1);
+      mfma_row(i, ah0, al0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * WP_TN, 0);
+      issue_part(i);
+      if (i + 2 < 8) read_a(i + 2, ah0, al0);
+      mfma_row(i + 1, ah1, al1);
+      if (i + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * WP_TN, 0);
+      issue_part(i + 1);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  wait_vmcnt<0>();                                          // the re-fetched tail tile must not outlive the LDS allocation
+
+  store_accumulators<8, WP_TN>(epi, acc, (int64_t)tm * 256, tn * 32 * WP_TN, wm, wn, l15, g, P.M, P.N);
+}
+
+template <int ABL = 0, class Epi>
+static inline int launch_wgrad_planes(const void* a_planes, const void* b_planes, int64_t n_news, int heads, int ncb_b,
+                                      int n_valid, const Epi& epi, int nsplit, hipStream_t st) {
+  if (n_news <= 0) return NRL_OK;
+  NRL_REQUIRE(a_planes && b_planes && heads > 0 && ncb_b > 0 && ncb_b % (2 * WP_TN) == 0, "wgrad_planes: bad arguments");
+  WgradPlanesArgs P;
+  P.a = (const unsigned char*)a_planes; P.b = (const unsigned char*)b_planes;
+  P.n_mb = 2 * n_news; P.heads = heads; P.ncb_b = ncb_b;
+  P.tiles_m = (heads + 3) / 4; P.tiles_n = ncb_b / (2 * WP_TN);
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > n_news) nsplit = (int)n_news;
+  P.kt_per_split = ceil_div(n_news, nsplit);
+  P.nsplit = (int)ceil_div(n_news, P.kt_per_split);
+  P.M = (int64_t)heads * 64; P.N = n_valid;
+  const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * ceil_div(P.nsplit, 8) * 8;
+  NRL_REQUIRE(blocks < (1LL << 31), "wgrad_planes: grid too large");
+  static bool attr_done = false;                            // 156 KiB of dynamic LDS: opt in once per kernel instance
+  if (!attr_done) {
+    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<Epi, ABL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, WP_STAGES * WP_STAGE));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_planes_kernel<Epi, ABL>), dim3((unsigned)blocks), dim3(256), WP_STAGES * WP_STAGE, st, P, epi);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+}  // namespace nrl

@@ -83,8 +83,8 @@ int main(int argc, char** argv) {
   a.table = table; a.ids = ids; a.img = img; a.n_news = N; a.L = L; a.D = D; a.heads = H; a.dh = 20;
   a.scale = 1.0f / sqrtf(20.f); a.drop1 = make_dropout(0.2, 5, 0); a.o = o;
   NewsFusedArgs as = a;
-  as.x_save = x; as.qkv_save = qkv; as.lse = lse; as.qkv_head_major = 1;
-  a.x_save = nullptr; a.qkv_save = nullptr; a.lse = nullptr; a.qkv_head_major = 0;
+  as.x_save = x; as.x_planes = nullptr; as.qkv_save = qkv; as.lse = lse; as.qkv_head_major = 1;
+  a.x_save = nullptr; a.x_planes = nullptr; a.qkv_save = nullptr; a.lse = nullptr; a.qkv_head_major = 0;
   const double gf = 2.0 * N * L * 3.0 * D * D * 1e-9;
   auto report = [&](const char* name, float ms) { printf("%-46s %.3f ms  (%.0f TF fp32-equiv in-projection)\n", name, ms, gf / ms); fflush(stdout); };
   report("eval  (no saves)", time_ms([&] { launch_news_fused_fwd<0>(a, st); }, st));
@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(d_o, o, (size_t)N * L * D * 4, hipMemcpyDeviceToDevice));
   NewsAttnBwdArgs ab;
   ab.qkv_hm = qkv; ab.d_o = d_o; ab.lse = lse; ab.dqkv = dqkv; ab.n_news = N; ab.L = L; ab.D = D; ab.heads = H;
-  ab.scale = a.scale; ab.hpw = 1;
+  ab.scale = a.scale; ab.hpw = 1; ab.planes = 0;
   auto rep2 = [&](const char* name, float ms) { printf("%-46s %.3f ms\n", name, ms); fflush(stdout); };
   rep2("attn bwd  2 waves/SIMD", time_ms([&] { launch_news_attn_bwd<2, 0>(ab, st); }, st));
   rep2("attn bwd  3 waves/SIMD", time_ms([&] { launch_news_attn_bwd<3, 0>(ab, st); }, st));
