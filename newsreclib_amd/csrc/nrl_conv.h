@@ -50,16 +50,39 @@ struct KCWindow {
 
 // k-major windowed source for the conv weight gradient: element (k = m, r = t*inner + j) is
 // x[m + t - pad][j] (0 outside the news); `ones` appends the bias column as in RCPlain.
+// n / d for n < 2^31 as one v_mul_hi_u32 + shift (round-up magic, 31-bit dividend): the windowed accessor below
+// divides per 16-byte load, and hipcc's generic 32-bit division is ~40 VALU instructions -- in the loader waves of
+// the weight-gradient kernels that was the whole k-tile budget
+struct FastDiv {
+  uint32_t magic, shift, d;   // q = umulhi(n, magic) >> shift   (d == 1: magic = 0, q = n)
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return magic == 0 ? n : (__umulhi(n, magic) >> shift); }
+  __device__ __forceinline__ uint32_t mod(uint32_t n) const { return n - div(n) * d; }
+};
+static inline FastDiv make_fast_div(uint32_t d) {
+  FastDiv f{0u, 0u, d};
+  if (d <= 1) return f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;                           // l = ceil(log2 d)
+  f.magic = (uint32_t)(((1ull << (31 + l)) / d) + 1);   // in [2^31, 2^32)
+  f.shift = l - 1;                                      // (n * magic) >> (31 + l) = umulhi >> (l - 1)
+  return f;
+}
+
 struct RCWindow {
   static constexpr int kLayout = SRC_RC;
   const float* x;  // (M, inner) with slack
   int inner, L, pad, ones;
   int64_t rows;    // = W * inner
+  FastDiv divL, divI;   // by L and by inner (rc_window() fills them)
   struct State {};
   __device__ __forceinline__ float4 load(int64_t k, int64_t r, int64_t K) const {
     const int64_t kk = k < K ? k : K - 1;
     const int64_t rr = r < rows ? r : rows - 4;
     return *reinterpret_cast<const float4*>(x + (kk - pad) * inner + rr);
+  }
+  // token position of window element (k, r): (k mod L) + tap(r) - pad      (k < 2^31, r < rows)
+  __device__ __forceinline__ int token(int64_t k, int64_t r) const {
+    return (int)divL.mod((uint32_t)k) + (int)divI.div((uint32_t)r) - pad;
   }
   __device__ __forceinline__ void finish(float4& v, int64_t k, int64_t r, int64_t kend) const {
     if (k >= kend) {
@@ -70,16 +93,19 @@ struct RCWindow {
       v = (ones && r == rows) ? make_float4(1.f, 0.f, 0.f, 0.f) : f4zero();
       return;
     }
-    const int l = (int)((uint32_t)k % (uint32_t)L) + (int)((uint32_t)r / (uint32_t)inner) - pad;  // k, r < 2^32
+    const int l = token(k, r);
     if (l < 0 || l >= L) v = f4zero();
   }
   __device__ __forceinline__ const float* src(int64_t k, int64_t r, int64_t kend) const {
     if (k >= kend) return nrl_dma_zero16;
     if (r >= rows) return (ones && r == rows) ? nrl_dma_ones16 : nrl_dma_zero16;
-    const int l = (int)((uint32_t)k % (uint32_t)L) + (int)((uint32_t)r / (uint32_t)inner) - pad;
+    const int l = token(k, r);
     return (l < 0 || l >= L) ? nrl_dma_zero16 : x + (k - pad) * inner + r;
   }
 };
+static inline RCWindow rc_window(const float* x, int inner, int L, int pad, int ones, int64_t rows) {
+  return RCWindow{x, inner, L, pad, ones, rows, make_fast_div((uint32_t)L), make_fast_div((uint32_t)inner)};
+}
 
 // conv weight Wc (F, W*D) as the (K = W*F, N = D) operand of the dgrad with reversed taps:
 // element (k = t'*F + f, r = d) = Wc[f][(W-1-t')*D + d]
