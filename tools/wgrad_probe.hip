@@ -102,13 +102,24 @@ int main() {
     const RCPlain a{g_dy, I, I, 0}, b{g_x, J, J, 1};
     auto old_big = [&](float* dw, float* db) { launch_gemm_bf16x3<4, 2, 4, 5, 0>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits_for(I, 256, 160), st); };
     auto old_tn = [&](float* dw, float* db) { launch_gemm_bf16x3_dma_tn<2, 2, 2, 5, 2>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits_for(I, 64, 160), st); };
-    for (int splits : {64, 127, 256}) {
-      char nm[64];
-      snprintf(nm, sizeof nm, "ws<4,2,2,8,5> 256x160 splits=%d", splits);
-      if (I > 512) compare(nm, I, J, old_big, [&](float* dw, float* db) { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
-      snprintf(nm, sizeof nm, "ws<4,2,2,5,5> 160x160 splits=%d", splits);
-      if (I > 512) compare(nm, I, J, old_big, [&](float* dw, float* db) { launch_gemm_bf16x3_ws<4, 2, 2, 5, 5>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
-      else compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_ws<4, 2, 2, 5, 5>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
+    if (I > 512) {
+      for (int splits : {32, 64}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "ws<4,2,2,8,5> 256x160 splits=%d", splits);
+        compare(nm, I, J, old_big, [&](float* dw, float* db) { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
+      }
+    } else {
+      // larger wave tiles for the transposing LDS-DMA kernel: a fragment is split by every wave that reads it, so
+      // MFMAs per fragment (TM * TN / (TM + TN)) is what the VALU budget follows
+      for (int splits : {32, 64, 128}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "tn<2,2,5,5> 160x160 splits=%d", splits);
+        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_dma_tn<2, 2, 5, 5, 2>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
+        snprintf(nm, sizeof nm, "tn<2,2,4,5> 128x160 splits=%d", splits);
+        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_dma_tn<2, 2, 4, 5, 2>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
+        snprintf(nm, sizeof nm, "tn<2,2,7,5> 224x160 splits=%d", splits);
+        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_dma_tn<2, 2, 7, 5, 2>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
+      }
     }
   }
   return 0;
