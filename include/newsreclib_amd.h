@@ -92,7 +92,10 @@ int nrl_get_gemm_engine(void);
  * compute the same function; a forward and its backward must run under the same setting.
  *   "news_fused": gather + in-projection + token attention of the news encoder in one kernel (bf16x3 engine,
  *                 L <= 32, D = 20 * heads in [288, 316]);  "rowpanel": row-panel kernel for the N <= 320 projections;
- *   "x3_dma": LDS-DMA staged tiled GEMMs. */
+ *   "x3_dma": LDS-DMA staged tiled GEMMs;  "news_attn_mfma": token-attention backward of the fused news path on the
+ *   matrix cores from head-major q|k|v slabs;  "news_planes": x / dqkv of that path as pre-split bf16 fragment-block
+ *   planes (DMA-only in-projection weight gradient);  "wgrad_ws": wave-specialised kernel for the 900-row weight
+ *   gradient.  A backward must run under the options of its forward (they select workspace formats). */
 int nrl_set_option(const char* name, int32_t value);
 
 /* ---- measurement hook (bench.py "roofline"): HIP-event timing of the dominant kernel, the
