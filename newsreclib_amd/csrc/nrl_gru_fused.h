@@ -11,23 +11,44 @@
 //     r | z | n and W_hn h + b_hn the backward needs (same buffers and meanings as gru_gate_fwd).
 // What it does NOT fix: the step still costs ~1.6 us per k-tile of a wave's share (14.5 us at Hd = 700, 5 us at
 // Hd = 52) -- W_hh is re-fetched every step (L2 does not survive the kernel boundary on this multi-XCD part) and a
-// CU's outstanding-miss capacity, not bandwidth, paces the fetch.  Keeping W_hh in LDS across steps needs a
-// persistent kernel with a grid-wide barrier per step; not built.
+// CU's outstanding-miss capacity, not bandwidth, paces the fetch.  The persistent form (PERSIST = 1 below: W_hh
+// fragments resident in registers, one cooperative launch, a grid-wide barrier per step) is built and correct but
+// slower -- see gru_persistent_fwd.
 // Grid = ceil(B / (16 TR)) x ceil(Hd / 16) workgroups, flattened and XCD-ordered.  hidden_dim <= 768; beyond that,
 // and under the exact-fp32 engine, nrl_gru_fwd keeps the two-launch path.
 #pragma once
+#include <hip/hip_cooperative_groups.h>
+
 #include "nrl_gemm_bf16x3.h"
 
 namespace nrl {
 
 constexpr int GRU_FUSED_MAXK = 6;
 
-template <int TR>   // 16-row tiles per workgroup: W_hh is streamed once per workgroup ROW, so B / (16 TR) times per step
+// Grid-wide barrier of a co-resident (cooperative) launch on one device counter: release the workgroup's h_t stores,
+// count in, spin until all `target` arrivals are in, acquire.  (cooperative_groups::grid_group::sync() measured
+// ~30 us per call here -- twice the whole fused step it was meant to save.)
+__device__ __forceinline__ void gru_grid_barrier(unsigned* ctr, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// PERSIST = 1: the whole recurrence in ONE cooperative launch -- the workgroup's 48 columns of W_hh^T stay in registers
+// (144 VGPRs of (hi, lo) fragments, loaded once), every time step reloads only its h_{t-1} rows and ends in a grid-wide
+// barrier; `t` is then the number of steps and h_prev / gi_gates / ghn / h_new point at step 0 (step strides B*Hd /
+// 3*B*Hd floats, h_new = h_prev + B*Hd as nrl_gru_fwd lays the saved states out).
+template <int TR, int PERSIST = 0>   // 16-row tiles per workgroup: W_hh is streamed once per workgroup ROW
 __global__ void __launch_bounds__(256)
-    gru_step_fused_kernel(const float* __restrict__ h_prev, const uint16_t* __restrict__ w_hi, const int64_t ld,
+    gru_step_fused_kernel(const float* h_prev, const uint16_t* __restrict__ w_hi, const int64_t ld,
                           float* gi_gates, const float* __restrict__ b_hh, const int64_t* __restrict__ len,
-                          const int t, const int B, const int Hd, const int save, float* __restrict__ ghn,
-                          float* __restrict__ h_new) {
+                          int t, const int B, const int Hd, const int save, float* ghn,
+                          float* h_new, unsigned* barrier_ctr) {
   __shared__ float red[4][TR][3][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
@@ -47,8 +68,24 @@ __global__ void __launch_bounds__(256)
   const int unit = u0 + l15 < Hd ? u0 + l15 : Hd - 1;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float4 a0[GRU_FUSED_MAXK][TR], a1[GRU_FUSED_MAXK][TR];
   uint4 bh[GRU_FUSED_MAXK][3], bl[GRU_FUSED_MAXK][3];
+#pragma unroll
+  for (int s = 0; s < GRU_FUSED_MAXK; ++s) {
+    const int kt = wave + 4 * s;
+    if (kt < nk) {
+#pragma unroll
+      for (int gate = 0; gate < 3; ++gate) {
+        // interleaved planes: the k-tile of a row is [32 hi | 32 lo]; this lane's 8 k's are 16 bytes of each
+        const uint16_t* p = w_hi + ((int64_t)gate * Hd + unit) * ld + 64 * kt + 8 * g;
+        bh[s][gate] = *reinterpret_cast<const uint4*>(p);
+        bl[s][gate] = *reinterpret_cast<const uint4*>(p + 32);
+      }
+    }
+  }
+  const int steps = PERSIST ? t : 1;
+  for (int step = 0; step < steps; ++step) {
+  if constexpr (PERSIST) t = step;
+  float4 a0[GRU_FUSED_MAXK][TR], a1[GRU_FUSED_MAXK][TR];
 #pragma unroll
   for (int s = 0; s < GRU_FUSED_MAXK; ++s) {
     const int kt = wave + 4 * s;
@@ -60,13 +97,6 @@ __global__ void __launch_bounds__(256)
         const float* arow = h_prev + (int64_t)row * Hd;
         a0[s][i] = k + 3 < Hd ? *reinterpret_cast<const float4*>(arow + k) : zero4;       // Hd % 4 == 0
         a1[s][i] = k + 7 < Hd ? *reinterpret_cast<const float4*>(arow + k + 4) : zero4;
-      }
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate) {
-        // interleaved planes: the k-tile of a row is [32 hi | 32 lo]; this lane's 8 k's are 16 bytes of each
-        const uint16_t* p = w_hi + ((int64_t)gate * Hd + unit) * ld + 64 * kt + 8 * g;
-        bh[s][gate] = *reinterpret_cast<const uint4*>(p);
-        bl[s][gate] = *reinterpret_cast<const uint4*>(p + 32);
       }
     }
   }
@@ -135,6 +165,14 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
+  if constexpr (PERSIST) {
+    h_prev += (int64_t)B * Hd;
+    h_new += (int64_t)B * Hd;
+    ghn += (int64_t)B * Hd;
+    gi_gates += (int64_t)B * 3 * Hd;
+    gru_grid_barrier(barrier_ctr, (unsigned)(step + 1) * gridDim.x);   // every workgroup's h_t visible before anyone reads it
+  }
+  }
 }
 
 inline bool gru_step_fused_ok(int Hd) {
@@ -156,15 +194,59 @@ inline int gru_step_fused(const float* h_prev, const uint16_t* w_hi, int64_t ld,
   const dim3 block(256);
   if (tr >= 4) {
     hipLaunchKernelGGL(gru_step_fused_kernel<4>, dim3((unsigned)(ceil_div(B, 64) * ceil_div(Hd, 16))), block, 0,
-                       stream, h_prev, w_hi, ld, gi_gates, b_hh, len, t, (int)B, Hd, save ? 1 : 0, ghn, h_new);
+                       stream, h_prev, w_hi, ld, gi_gates, b_hh, len, t, (int)B, Hd, save ? 1 : 0, ghn, h_new, (unsigned*)nullptr);
   } else if (tr == 2) {
     hipLaunchKernelGGL(gru_step_fused_kernel<2>, dim3((unsigned)(ceil_div(B, 32) * ceil_div(Hd, 16))), block, 0,
-                       stream, h_prev, w_hi, ld, gi_gates, b_hh, len, t, (int)B, Hd, save ? 1 : 0, ghn, h_new);
+                       stream, h_prev, w_hi, ld, gi_gates, b_hh, len, t, (int)B, Hd, save ? 1 : 0, ghn, h_new, (unsigned*)nullptr);
   } else {
     hipLaunchKernelGGL(gru_step_fused_kernel<1>, dim3((unsigned)(ceil_div(B, 16) * ceil_div(Hd, 16))), block, 0,
-                       stream, h_prev, w_hi, ld, gi_gates, b_hh, len, t, (int)B, Hd, save ? 1 : 0, ghn, h_new);
+                       stream, h_prev, w_hi, ld, gi_gates, b_hh, len, t, (int)B, Hd, save ? 1 : 0, ghn, h_new, (unsigned*)nullptr);
   }
   NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// The whole forward recurrence in one cooperative launch (see PERSIST above).  Returns NRL_E_INVALID-free "not
+// applicable" as *done = false when the grid cannot be co-resident (the caller then launches step by step).
+inline int gru_persistent_fwd(const float* hs0, const uint16_t* w_hi, int64_t ld, float* g0, const float* b_hh,
+                              const int64_t* len, int64_t T, int64_t B, int Hd, float* ghn0, unsigned* barrier_ctr,
+                              hipStream_t stream, bool* done) {
+  *done = false;
+  // OFF by default (NRL_GRU_PERSISTENT=1 enables): measured SLOWER than one launch per step -- LSTUR step 10.97 vs 9.92 ms
+  // at B = 128, Hd = 700, T = 50, i.e. ~36 us per step against 14.5 us.  The device-scope release / acquire a grid
+  // barrier needs on this 8-XCD part writes back and invalidates the XCD's whole L2 every step (buffer_wbl2 /
+  // buffer_inv sc1), which a kernel boundary does once and in hardware; cooperative_groups' grid.sync() costs the same.
+  // What remains to try: exchanging h_t through sc1 (agent-coherent) loads / stores only, with no full fence.
+  static const bool on = [] { const char* e = getenv("NRL_GRU_PERSISTENT"); return e != nullptr && e[0] == '1'; }();
+  if (!on || B == 0 || T <= 1) return NRL_OK;
+  const int tr = Hd >= 512 ? 2 : 1;
+  const int64_t blocks = ceil_div(B, 16 * tr) * ceil_div(Hd, 16);
+  const void* fn = tr == 2 ? reinterpret_cast<const void*>(&gru_step_fused_kernel<2, 1>)
+                           : reinterpret_cast<const void*>(&gru_step_fused_kernel<1, 1>);
+  static int cus = 0, per_cu[3] = {0, -1, -1};
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    NRL_HIP(hipGetDevice(&dev));
+    NRL_HIP(hipGetDeviceProperties(&prop, dev));
+    if (!prop.cooperativeLaunch) { cus = -1; return NRL_OK; }
+    cus = prop.multiProcessorCount;
+  }
+  if (cus < 0) return NRL_OK;
+  if (per_cu[tr] < 0) {
+    int n = 0;
+    NRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0));
+    per_cu[tr] = n;
+  }
+  if (blocks > (int64_t)cus * per_cu[tr]) return NRL_OK;   // would not be co-resident: a grid barrier would hang
+  const float* h_prev = hs0;
+  float* h_new = const_cast<float*>(hs0) + B * Hd;
+  int steps = (int)T, Bi = (int)B, save = 1;
+  NRL_HIP(hipMemsetAsync(barrier_ctr, 0, sizeof(unsigned), stream));
+  void* args[] = {(void*)&h_prev, (void*)&w_hi, (void*)&ld, (void*)&g0, (void*)&b_hh, (void*)&len, (void*)&steps,
+                  (void*)&Bi, (void*)&Hd, (void*)&save, (void*)&ghn0, (void*)&h_new, (void*)&barrier_ctr};
+  NRL_HIP(hipLaunchCooperativeKernel(fn, dim3((unsigned)blocks), dim3(256), args, 0, stream));
+  *done = true;
   return NRL_OK;
 }
 

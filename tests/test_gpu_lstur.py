@@ -171,3 +171,35 @@ def test_lstur_config5_shapes_train_step():
     assert preds.shape == targets.shape and int(cand_news_size.sum()) == preds.shape[0]
     for k, gr in module_grads(mod).items():
         assert torch.isfinite(gr).all() and float(gr.abs().max()) > 0.0, k
+
+
+_PERSISTENT_GRU_SCRIPT = r"""
+import numpy as np, torch
+from newsreclib_amd import _lib
+from newsreclib_amd.ops_lstur import GruFn
+from oracle.lstur_oracle import gru_last_hidden
+_lib.set_gemm_engine("bf16x3")
+for (B, T, Din, Hd) in [(16, 50, 700, 700), (128, 20, 64, 400), (5, 7, 24, 24)]:
+    rng = np.random.default_rng(B + T)
+    t = lambda *s, scale=1.0: torch.from_numpy((rng.standard_normal(s) * scale).astype(np.float32))
+    hist, h0 = t(B, T, Din, scale=0.5), t(B, Hd, scale=0.5)
+    lengths = torch.from_numpy(rng.integers(1, T + 1, B)); lengths[0] = T
+    params = [t(3 * Hd, Din, scale=Din ** -0.5), t(3 * Hd, Hd, scale=Hd ** -0.5), t(3 * Hd, scale=0.05), t(3 * Hd, scale=0.05)]
+    ref = gru_last_hidden(hist, lengths, h0, *params)
+    out = GruFn.apply(hist.cuda(), lengths.cuda(), h0.cuda(), *[x.cuda() for x in params], None)
+    err = float((out.cpu() - ref).abs().max())
+    assert err <= 5e-4, (B, T, Din, Hd, err)
+print("PERSISTENT_GRU_OK")
+"""
+
+
+def test_gru_persistent_cooperative_launch_matches_oracle():
+    # the one-launch recurrence (W_hh resident in registers, grid barrier per step) is an opt-in measurement variant
+    # (NRL_GRU_PERSISTENT=1, read once per process): run it in a child process, under a timeout -- a grid barrier
+    # that is not co-resident would hang, which the launcher's occupancy check is there to exclude
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NRL_GRU_PERSISTENT="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", _PERSISTENT_GRU_SCRIPT], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "PERSISTENT_GRU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
