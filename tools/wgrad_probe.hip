@@ -8,6 +8,7 @@
 
 #include "nrl_gemm_bf16x3_dma.h"
 #include "nrl_gemm_ws.h"
+#include "../tools/experimental/nrl_wgrad_tn2.h"
 
 namespace nrl {
 void set_error(const char* fmt, ...) {
@@ -111,14 +112,12 @@ int main() {
     } else {
       // larger wave tiles for the transposing LDS-DMA kernel: a fragment is split by every wave that reads it, so
       // MFMAs per fragment (TM * TN / (TM + TN)) is what the VALU budget follows
-      for (int splits : {32, 64, 128}) {
+      for (int splits : {32, 43, 64, 128}) {
         char nm[64];
-        snprintf(nm, sizeof nm, "tn<2,2,5,5> 160x160 splits=%d", splits);
-        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_dma_tn<2, 2, 5, 5, 2>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
-        snprintf(nm, sizeof nm, "tn<2,2,4,5> 128x160 splits=%d", splits);
-        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_dma_tn<2, 2, 4, 5, 2>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
-        snprintf(nm, sizeof nm, "tn<2,2,7,5> 224x160 splits=%d", splits);
-        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_dma_tn<2, 2, 7, 5, 2>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
+        snprintf(nm, sizeof nm, "tn2<4,5> 128x160 splits=%d", splits);
+        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_tn2<4, 5>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
+        snprintf(nm, sizeof nm, "tn2<3,5> 96x160 splits=%d", splits);
+        compare(nm, I, J, old_tn, [&](float* dw, float* db) { launch_gemm_bf16x3_tn2<3, 5>(a, b, EpiAtomicWB{dw, J, db, J}, I, J + 1, M, splits, st); }, st);
       }
     }
   }
