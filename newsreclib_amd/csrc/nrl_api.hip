@@ -150,6 +150,13 @@ static bool g_news_planes = [] {
   return !(e != nullptr && e[0] == '0');
 }();
 
+// NRL_NEWS_OD_PLANES=0: `o` and `dy` of the fused news path stay fp32 rows (out-projection weight gradient on the
+// transposing fp32-fed kernel).  Default (with news_planes): both as planes, nrl_wgrad_planes.h's generic kernel.
+static bool g_news_od_planes = [] {
+  const char* e = getenv("NRL_NEWS_OD_PLANES");
+  return !(e != nullptr && e[0] == '0');
+}();
+
 // NRL_WGRAD_WS=0: the large (I > 512) weight gradient back on the register-staged kernel (default: the
 // wave-specialised one, nrl_gemm_ws.h, 32 k-splits = one workgroup per CU: 4.81 -> 4.72 ms/step at B = 128)
 static bool g_wgrad_ws = [] {
@@ -172,6 +179,8 @@ struct BlockShape {
   int pool_len;         // rows per output row
   AttnGeom geom;
   int64_t pad_rows = 0; // news encoder: token rows padded to 32 per news (fragment-block planes), else 0
+  bool od_planes = false;  // fused news path: `o` and `dy` are (hi, lo) bf16 fragment-block planes over the real rows (19
+                           // block columns at D = 300; `o` in the head-permuted feature order), not fp32 rows
 };
 
 struct BlockWs {
@@ -183,7 +192,7 @@ struct BlockWs {
 // the five narrow projections of the block that run on the row-panel kernel: forward out-projection and
 // additive-attention linear, and the three activation-gradient GEMMs
 struct BlockRp {
-  RpImage out_f, att_f, att_d, out_d, in_d, in_heads, in_d_hp;
+  RpImage out_f, att_f, att_d, out_d, in_d, in_heads, in_d_hp, out_f_perm;
   bool on = false;
 };
 static bool block_rp_ok(int D, int Q) { return g_rowpanel && rp_nblk_supported(D) && rp_nblk_supported(Q); }
@@ -195,7 +204,8 @@ static size_t block_rp_elems(int D, int Q) {
          + rp_image_elems(nd, rp_kblocks(Q, false))         // att dgrad (N = D, K = Q)
          + rp_image_elems(nd, rp_kblocks(3 * D, false))     // in dgrad (N = D, K = 3D)
          + rp_image_elems((D / 20) * 4, NF_KB)              // per-head q|k|v image of the fused news encoder
-         + rp_image_elems(nd, (D / 20) * 2);                // its in-projection dgrad over head planes (K' = heads * 64)
+         + rp_image_elems(nd, (D / 20) * 2)                 // its in-projection dgrad over head planes (K' = heads * 64)
+         + rp_image_elems(nd, rp_kblocks(D + 32, false));   // its out-projection forward over the head-permuted `o` planes
 }
 
 static size_t plane_elems(int D, int Q) {
@@ -214,12 +224,20 @@ static size_t x_elems(int64_t M, int D, int64_t pad_rows) {
   return planes > rows ? planes : rows;
 }
 
+// o / dy: fp32 rows (M, D), or (news path) planes over the real rows rounded up to 32: 16 floats per (row, block column)
+static size_t od_elems(int64_t M, int D, int heads, int64_t pad_rows) {
+  const size_t rows = (size_t)M * D;
+  if (pad_rows <= 0 || D != heads * 20) return rows;
+  const size_t planes = (size_t)((M + 31) / 32 * 32) * (size_t)(heads + (heads + 3) / 4) * 16;
+  return planes > rows ? planes : rows;
+}
+
 static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x, int64_t pad_rows = 0) {
   auto al = [](size_t n) { return align_up(n, 64); };
   size_t n = 0;
   if (with_x) n += al(x_elems(M, D, pad_rows));
   n += al(qkv_elems(M, D, heads, pad_rows)) * 2;  // qkv, dqkv
-  n += al((size_t)M * D) * 4;      // o, y, dy, d_o (later dx)
+  n += al(od_elems(M, D, heads, pad_rows)) * 2 + al((size_t)M * D) * 2;      // o, dy | y, d_o (later dx)
   n += al((size_t)M * Q);          // t / d_pre
   n += al((size_t)M);              // w
   n += al((size_t)M * heads);      // lse
@@ -240,9 +258,9 @@ static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x,
   out->x = with_x ? take(x_elems(s.M, s.D, s.pad_rows)) : nullptr;
   out->qkv = take(qkv_elems(s.M, s.D, s.heads, s.pad_rows));
   out->dqkv = take(qkv_elems(s.M, s.D, s.heads, s.pad_rows));
-  out->o = take((size_t)s.M * s.D);
+  out->o = take(od_elems(s.M, s.D, s.heads, s.pad_rows));
   out->y = take((size_t)s.M * s.D);
-  out->dy = take((size_t)s.M * s.D);
+  out->dy = take(od_elems(s.M, s.D, s.heads, s.pad_rows));
   out->d_o = take((size_t)s.M * s.D);
   out->t = take((size_t)s.M * s.Q);
   out->w = take((size_t)s.M);
@@ -316,6 +334,11 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
       bp->rp.in_d_hp.img = q; bp->rp.in_d_hp.nblk = nd; bp->rp.in_d_hp.kblocks = fused_heads * 2;
       if (fill) rp_jobs_add_kheads(&jobs, P->in_proj_weight, 1, D, D, fused_heads, D / fused_heads, q, nd);
       q += rp_image_elems(nd, fused_heads * 2);
+      // y = o W_o^T with `o` in head-permuted planes (KCPlanesG): reduction index = plane slot
+      bp->rp.out_f_perm.img = q; bp->rp.out_f_perm.nblk = nd;
+      bp->rp.out_f_perm.kblocks = (16 * (fused_heads + (fused_heads + 3) / 4) + 31) / 32;
+      if (fill) rp_jobs_add_kperm(&jobs, P->out_proj_weight, D, 1, D, fused_heads, q, nd);
+      q += rp_image_elems(nd, rp_kblocks(D + 32, false));
     }
     if (fill) NRL_TRY(rp_jobs_launch(jobs, st));
   }
@@ -451,9 +474,16 @@ static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const Bl
   const int D = s.D, Q = s.Q;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
   // y = dropout(o W_o^T + b_o)        (out-projection, text.py:229-230)
-  NRL_TRY(gemm_fwd(KCPlain{w.o, D, s.M}, P->out_proj_weight, bp.out,
-                   EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, false, st,
-                   bp.rp.on ? &bp.rp.out_f : nullptr));
+  if (s.od_planes) {
+    // `o` arrives as head-permuted (hi, lo) planes from the fused forward: no split, reduction over plane slots
+    const int ncb = s.heads + (s.heads + 3) / 4;
+    NRL_TRY(rp_dispatch(KCPlanesG{reinterpret_cast<const unsigned char*>(w.o), s.M, ncb}, bp.rp.out_f_perm,
+                        EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, 16 * ncb, st));
+  } else {
+    NRL_TRY(gemm_fwd(KCPlain{w.o, D, s.M}, P->out_proj_weight, bp.out,
+                     EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, false, st,
+                     bp.rp.on ? &bp.rp.out_f : nullptr));
+  }
   // t = tanh(y W_a^T + b_a)           (attention.py:34)
   NRL_TRY(gemm_fwd(KCPlain{w.y, D, s.M}, P->att_weight, bp.att, EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q},
                    s.M, Q, D, true, st, bp.rp.on ? &bp.rp.att_f : nullptr));
@@ -473,12 +503,24 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
   const int D = s.D, Q = s.Q;
   // additive attention backward: t -> d_pre in place, dq_a
   NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st));
-  // dy = (d_pre W_a + w * d_out) * dropout2
-  NRL_TRY(gemm_dgrad(w.t, P->att_weight, bp.att, EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, Q, D, st,
-                     bp.rp.on ? &bp.rp.att_d : nullptr));
-  // d_o = dy W_o
-  NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{w.d_o, D}, s.M, D, D, st,
-                     bp.rp.on ? &bp.rp.out_d : nullptr));
+  if (s.od_planes) {
+    // dy = (d_pre W_a + w * d_out) * dropout2, written ONCE as (hi, lo) planes: its only readers are the two GEMMs below
+    const int ncb = (D + 15) / 16;
+    unsigned char* dyp = reinterpret_cast<unsigned char*>(w.dy);
+    if (s.M % 32 != 0)   // the weight gradient reads whole 32-row k-tiles: rows past M in the last one must be zero
+      NRL_HIP(hipMemsetAsync(dyp + (s.M / 32) * 2 * ncb * 1024, 0, (size_t)2 * ncb * 1024, st));
+    NRL_TRY(rp_dispatch(KCPlain{w.t, Q, s.M}, bp.rp.att_d,
+                        EpiPoolBwdPlanes{EpiPoolBwd{nullptr, D, w.w, d_out, s.pool_len, drop2}, dyp, ncb}, s.M, D, Q, st));
+    // d_o = dy W_o
+    NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
+  } else {
+    // dy = (d_pre W_a + w * d_out) * dropout2
+    NRL_TRY(gemm_dgrad(w.t, P->att_weight, bp.att, EpiPoolBwd{w.dy, D, w.w, d_out, s.pool_len, drop2}, s.M, Q, D, st,
+                       bp.rp.on ? &bp.rp.att_d : nullptr));
+    // d_o = dy W_o
+    NRL_TRY(gemm_dgrad(w.dy, P->out_proj_weight, bp.out, EpiStore{w.d_o, D}, s.M, D, D, st,
+                       bp.rp.on ? &bp.rp.out_d : nullptr));
+  }
   // attention backward -> dqkv
   if (!attention_elsewhere) NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
   return NRL_OK;
@@ -490,7 +532,15 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
   NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
   // dW_o += dy^T o ; db_o += colsum(dy)
-  NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
+  if (s.od_planes) {
+    // both operands are planes over the same (real) rows: DMA + transpose-read + MFMA only (wgrad_planes_g_kernel)
+    static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_G_SPLITS"); return e ? atoi(e) : 64; }();
+    const int ncb_o = s.heads + (s.heads + 3) / 4, ncb_dy = (D + 15) / 16;
+    NRL_TRY((launch_wgrad_planes_g<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
+                                         EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st)));
+  } else {
+    NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
+  }
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
   if (bf16_planes) {
     // both operands pre-split by their producers: pure DMA + transpose-read + MFMA kernel (nrl_wgrad_planes.h)
@@ -598,11 +648,12 @@ int nrl_set_option(const char* name, int32_t value) {
                : !strcmp(name, "news_fused_bwd") ? &g_news_fused_bwd
                : !strcmp(name, "news_attn_mfma") ? &g_news_attn_mfma
                : !strcmp(name, "news_planes") ? &g_news_planes
+               : !strcmp(name, "news_od_planes") ? &g_news_od_planes
                : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma
                                            : nullptr;
-  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, wgrad_ws, rowpanel, x3_dma)", name);
+  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, wgrad_ws, rowpanel, x3_dma)", name);
   *flag = value != 0;
   return NRL_OK;
 }
@@ -644,6 +695,15 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
     a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.o = w.o;
     const bool planes = !g_news_fused_bwd && g_news_attn_mfma && g_news_planes;
+    BlockShape sf = s;
+    sf.od_planes = planes && g_news_od_planes;
+    a.o_planes = nullptr;
+    if (sf.od_planes) {
+      a.o_planes = reinterpret_cast<unsigned char*>(w.o);
+      const int ncb = s.heads + (s.heads + 3) / 4;
+      if (s.M % 32 != 0)   // rows past M in the last 32-row k-tile of the weight gradient
+        NRL_HIP(hipMemsetAsync(a.o_planes + (s.M / 32) * 2 * ncb * 1024, 0, (size_t)2 * ncb * 1024, st));
+    }
     a.x_save = (save_for_backward && !planes) ? w.x : nullptr;
     a.x_planes = (save_for_backward && planes) ? reinterpret_cast<unsigned char*>(w.x) : nullptr;
     a.qkv_save = (save_for_backward && !g_news_fused_bwd) ? w.qkv : nullptr;   // else recomputed in the backward
@@ -653,7 +713,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
       ProfScope prof(st, 2.0 * (double)s.M * 3.0 * s.D * s.D + 4.0 * (double)s.M * seq_len * s.D);
       NRL_TRY(launch_news_fused_fwd(a, st));
     }
-    return block_fwd_tail(p, s, w, bp, d2, out, st);
+    return block_fwd_tail(p, sf, w, bp, d2, out, st);
   }
   KCGather a_in{emb_table, ids, s.M, s.D, d1, save_for_backward ? w.x : nullptr};
   return block_fwd(p, a_in, s, w, d2, save_for_backward != 0, true, out, (hipStream_t)stream);
@@ -678,9 +738,11 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   const bool fused = news_fused_on(s, seq_len) && g_news_fused_bwd;
   const bool slabs = news_fused_on(s, seq_len) && !g_news_fused_bwd && g_news_attn_mfma;   // what the forward saved
   const bool planes = slabs && g_news_planes;
+  BlockShape sb_ = s;
+  sb_.od_planes = planes && g_news_od_planes;
   NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
   if (phase != 2) {
-    NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st, fused || slabs));
+    NRL_TRY(block_bwd_phase1(p, g, sb_, w, bp, d2, d_out, st, fused || slabs));
     if (slabs) {
       // token attention backward on the matrix cores from the head-major q|k|v slabs (nrl_news_fused.h)
       NewsAttnBwdArgs a;
@@ -716,7 +778,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
     }
   }
-  if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, s, w, st, slabs, planes));
+  if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, sb_, w, st, slabs, planes));
   return NRL_OK;
 }
 

@@ -138,6 +138,37 @@ struct KCPlanes {
   }
 };
 
+// plain fragment-block planes over real rows: block (mb = row / 16, cb = k / 16) at ((mb * ncb + cb) * 2 + p) * 512
+// (the fused news path's `o` and `dy`, written by the fused forward / the row-panel epilogue EpiPoolBwdPlanes)
+struct KCPlanesG {
+  static constexpr int kLayout = SRC_KC;
+  static constexpr bool kPreSplit = true;
+  const unsigned char* p;
+  int64_t rows;
+  int ncb;
+  struct State {
+    const unsigned char* ptr;
+    bool ok;
+  };
+  __device__ __forceinline__ State init(int64_t r) const {
+    const bool ok = r < rows;
+    const int64_t rr = ok ? r : 0;
+    return State{p + (rr >> 4) * ncb * 1024 + (rr & 15) * 32, ok};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int) const {
+    int cb = k >> 4;
+    cb = cb < ncb ? cb : ncb - 1;                  // k-block tail past the last block column: the image rows there are zero
+    return *reinterpret_cast<const float4*>(s.ptr + cb * 1024 + ((k >> 3) & 1) * 16 + ((k & 4) ? 512 : 0));
+  }
+  // (the block columns may carry unwritten bytes past the last feature: dy has 300 of 304 -- anything there must not
+  //  reach the matrix cores, a NaN bit pattern times a zero weight is still NaN)
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
+    const int k0 = k & ~7;                           // the chunk holds features k0 .. k0 + 7 (kend % 4 == 0)
+    if (!s.ok || k0 >= kend) v = f4zero();
+    else if (k0 + 4 >= kend) { v.z = 0.f; v.w = 0.f; }
+  }
+};
+
 // rows gathered from an embedding table through int64 ids (nn.Embedding, text.py:224), times the
 // dropout multiplier of text.py:225; the tile column 0 workgroup also saves the post-dropout row
 // (needed by the in-projection weight gradient).  ids == nullptr means identity rows: a dense
@@ -327,7 +358,7 @@ struct EpiPoolBwd {
   __device__ __forceinline__ bool vec_ok() const {
     return (ldc & 3) == 0 && (((uintptr_t)c | (uintptr_t)d_out | (uintptr_t)relu_src) & 15) == 0;
   }
-  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+  __device__ __forceinline__ float4 apply4(const Row& r, int n, float4 v) const {
     const float4 gv = *reinterpret_cast<const float4*>(r.g + n);
     v.x = fmaf(r.wm, gv.x, v.x); v.y = fmaf(r.wm, gv.y, v.y); v.z = fmaf(r.wm, gv.z, v.z); v.w = fmaf(r.wm, gv.w, v.w);
     if (drop.thresh != 0u) {
@@ -339,8 +370,9 @@ struct EpiPoolBwd {
       v.x = sv.x > 0.f ? v.x : 0.f; v.y = sv.y > 0.f ? v.y : 0.f;
       v.z = sv.z > 0.f ? v.z : 0.f; v.w = sv.w > 0.f ? v.w : 0.f;
     }
-    store4(r.out + n, v, stream);
+    return v;
   }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const { store4(r.out + n, apply4(r, n, v), stream); }
 };
 
 // out += v with atomics: split-K partial sums of the small per-step GRU GEMMs (the k-loop of a 128-row
@@ -370,6 +402,30 @@ struct EpiAtomicWB {
       atomicAdd(r.out + n, v);
     else if (n == n_w && db != nullptr)
       atomicAdd(db + m, v);
+  }
+};
+
+// EpiAtomicWB whose output COLUMN runs over the head-permuted slots of the `o` planes (NewsFusedArgs::o_planes): slot
+// n = 16 cb + c is feature head * 20 + d, the first free slot after the last head is the ones column (bias gradient)
+struct EpiAtomicWBPerm {
+  float* dw;
+  int64_t ldc;
+  float* db;  // may be null
+  int heads;
+  struct Row {
+    float* out;
+    int64_t m;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{dw + m * ldc, m}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    const int cb = n >> 4, c = n & 15;
+    int head, d;
+    if (cb < heads) { head = cb; d = c; }
+    else { head = 4 * (cb - heads) + (c >> 2); d = 16 + (c & 3); }
+    if (head < heads)
+      atomicAdd(r.out + head * 20 + d, v);
+    else if (head == heads && d == 16 && db != nullptr)
+      atomicAdd(db + r.m, v);
   }
 };
 

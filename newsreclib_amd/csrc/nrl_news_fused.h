@@ -41,6 +41,11 @@ struct NewsFusedArgs {
   float scale;              // 1 / sqrt(dh)
   Dropout drop1;
   float* o;                 // (n_news * L, D)
+  unsigned char* o_planes;  // or (instead of o): (hi, lo) bf16 fragment-block planes over the REAL rows m = news * L + t,
+                            // [m / 16][cb 0 .. 18][p][16 x 16], feature order permuted so that a head writes whole block
+                            // rows: block cb < heads = features 0 .. 15 of head cb, block heads + s = features 16 .. 19 of
+                            // heads 4s .. 4s + 3 (4 columns each); the first free column (block 18, column 12 at 15 heads)
+                            // carries the ones of the bias gradient (KCPlanesG / rp_jobs_add_kperm / EpiAtomicWBPerm)
   float* x_save;            // (n_news * L, D) post-dropout rows, or null
   unsigned char* x_planes;  // or (instead of x_save): the rows' (hi, lo) bf16 fragments as fragment-block planes
                             // [news * 2 + rb][cb 0 .. 19][p][16 x 16] (nrl_wgrad_planes.h) -- exactly the registers
@@ -221,17 +226,59 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
   // image (q columns = O, column 60 = log-sum-exp of the query) of head `hp` -> global, 16-byte row stores
   auto flush_o = [&](int hp) {
     if (!news_ok || (ABL & 8)) return;
-    float* o_out = P.o + row0 * (int64_t)D;             // wave-uniform base + 32-bit lane offsets
     // (the lane id is made opaque here: hipcc otherwise hoists every pass's address arithmetic out of the head
     //  loop and spills it -- the MFMA phase has no registers to spare)
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    if (P.o_planes != nullptr) {
+      // main block of the head: 32 rows x 2 halves of 8 features = 64 lanes, one 16-byte chunk per plane each
+      {
+        const int row = ln >> 1, half = ln & 1;
+        const int64_t m = row0 + row;
+        bf16x8 hi, lo;
+        rp_split8(*reinterpret_cast<const float4*>(image + row * NF_IMG_LD + half * 8),
+                  *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + half * 8 + 4), hi, lo);
+        unsigned char* dst = P.o_planes + (((m >> 4) * 19 + hp) * 2) * 512 + (m & 15) * 32 + half * 16;
+        if (row < L) {
+          *reinterpret_cast<bf16x8*>(dst) = hi;
+          *reinterpret_cast<bf16x8*>(dst + 512) = lo;
+        }
+      }
+      // features 16 .. 19 -> 4 columns of the block shared by four heads (+ the ones column after the last head)
+      {
+        const int row = ln & 31;
+        const int64_t m = row0 + row;
+        const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 16);
+        uint32_t h0, l0, h1, l1;
+        split_pair(v.x, v.y, h0, l0);
+        split_pair(v.z, v.w, h1, l1);
+        unsigned char* blk = P.o_planes + (((m >> 4) * 19 + heads + (hp >> 2)) * 2) * 512 + (m & 15) * 32;
+        if (row < L) {
+          if (ln < 32) {
+            *reinterpret_cast<uint2*>(blk + (hp & 3) * 8) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(blk + 512 + (hp & 3) * 8) = make_uint2(l0, l1);
+          } else if (hp == heads - 1 && (heads & 3) != 0) {
+            // free columns of the last shared block: 1.0 (bf16 0x3F80) in the first, zeros after it
 #pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {               // 32 rows x 5 float4 = 160 slots
-      const int slot_i = pass * 64 + ln;
-      const int row = slot_i / 5, c4 = slot_i - row * 5;
-      if (slot_i < 160 && row < L)
-        store4(o_out + (row * D + hp * DH + 4 * c4), *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4), NT_O);
+            for (int q = 0; q < 3; ++q) {
+              const int slot = (heads & 3) + q;
+              if (slot < 4) {
+                *reinterpret_cast<uint2*>(blk + slot * 8) = make_uint2(q == 0 ? 0x3F80u : 0u, 0u);
+                *reinterpret_cast<uint2*>(blk + 512 + slot * 8) = make_uint2(0u, 0u);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      float* o_out = P.o + row0 * (int64_t)D;             // wave-uniform base + 32-bit lane offsets
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {               // 32 rows x 5 float4 = 160 slots
+        const int slot_i = pass * 64 + ln;
+        const int row = slot_i / 5, c4 = slot_i - row * 5;
+        if (slot_i < 160 && row < L)
+          store4(o_out + (row * D + hp * DH + 4 * c4), *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4), NT_O);
+      }
     }
     if (SAVE && ln < L) P.lse[(news * heads + hp) * L + ln] = image[ln * NF_IMG_LD + 60];
   };

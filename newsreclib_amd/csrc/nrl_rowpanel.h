@@ -45,6 +45,10 @@ struct RpImageJob {
   // kheads > 0: the reduction index of the image is a head-plane index (KCSlab, nrl_gemm.h): image k' = head * 64 + c
   // is logical k = part * (kheads * kdh) + head * kdh + d (c = part * kdh + d < 3 kdh), zero for the pad c
   int kheads, kdh;
+  // kperm_heads > 0 (dh = 20): the reduction index follows the feature order of the fused forward's `o` planes -- block
+  // cb < heads = features 0 .. 15 of head cb, block heads + s = features 16 .. 19 of heads 4s .. 4s + 3; every other slot
+  // (the ones column, the tail) is a zero row
+  int kperm_heads;
 };
 constexpr int RP_MAX_JOBS = 8;
 struct RpImageJobs {
@@ -84,6 +88,14 @@ __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs 
     int k = k0 + e;
     float x = 0.f;
     bool live = row >= 0;
+    if (J.kperm_heads > 0) {
+      const int cb = k >> 4, c = k & 15;
+      int head, d;
+      if (cb < J.kperm_heads) { head = cb; d = c; }
+      else { head = 4 * (cb - J.kperm_heads) + (c >> 2); d = 16 + (c & 3); }
+      live = live && head < J.kperm_heads;
+      k = head * 20 + d;
+    }
     if (J.kheads > 0) {
       const int head = k >> 6, c = k & 63;
       live = live && head < J.kheads && c < 3 * J.kdh;
@@ -117,7 +129,7 @@ static inline RpImageJob* rp_jobs_add(RpImageJobs* js, const float* src, int64_t
                                       const float* bias, uint16_t* img, int nblk) {
   RpImageJob& J = js->job[js->count];
   J.src = src; J.bias = bias; J.img = img; J.sn = sn; J.sk = sk; J.N = N; J.K = K; J.nblk = nblk;
-  J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0; J.conv_f = 0; J.conv_w = 0; J.kheads = 0; J.kdh = 0;
+  J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0; J.conv_f = 0; J.conv_w = 0; J.kheads = 0; J.kdh = 0; J.kperm_heads = 0;
   js->first_thread[js->count + 1] = js->first_thread[js->count] + (int64_t)J.kblocks * nblk * 64;
   js->count += 1;
   return &J;
@@ -139,6 +151,16 @@ static inline RpImageJob* rp_jobs_add_kheads(RpImageJobs* js, const float* src, 
   J->kheads = heads;
   J->kdh = dh;
   J->kblocks = heads * 2;
+  js->first_thread[js->count] = js->first_thread[js->count - 1] + (int64_t)J->kblocks * nblk * 64;
+  return J;
+}
+// image whose reduction index is the head-permuted feature order of the `o` planes (out-projection forward of the fused
+// news path): K' = 16 * (heads + ceil(heads / 4)) slots
+static inline RpImageJob* rp_jobs_add_kperm(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int heads,
+                                            uint16_t* img, int nblk) {
+  RpImageJob* J = rp_jobs_add(js, src, sn, sk, N, heads * 20, nullptr, img, nblk);
+  J->kperm_heads = heads;
+  J->kblocks = (16 * (heads + (heads + 3) / 4) + 31) / 32;
   js->first_thread[js->count] = js->first_thread[js->count - 1] + (int64_t)J->kblocks * nblk * 64;
   return J;
 }
@@ -166,6 +188,44 @@ __device__ __forceinline__ void rp_split8(const float4& v0, const float4& v1, bf
   hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
+
+// EpiPoolBwd writing dy as (hi, lo) bf16 fragment-block planes over the real rows (KCPlanesG) instead of fp32: dy is read
+// only by the out-projection's dgrad and wgrad GEMMs, so the split is done once, here.  A lane of the 16-byte output stage
+// holds 4 consecutive columns of one row = 8 bytes of each plane; the wave's stores of one accumulator block fill one
+// 512-byte block plane.
+struct EpiPoolBwdPlanes {
+  EpiPoolBwd inner;          // `c` unused; ldc = row length of d_out / relu_src (= N)
+  unsigned char* planes;
+  int ncb;
+  struct Row {
+    EpiPoolBwd::Row in;
+    unsigned char* blk;      // block row of this output row in block column 0, hi plane
+  };
+  __device__ __forceinline__ Row row(int64_t m) const {
+    return Row{inner.row(m), planes + (m >> 4) * ncb * 1024 + (m & 15) * 32};
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    float x = v + r.in.wm * r.in.g[n];
+    if (inner.drop.thresh != 0u) x *= inner.drop.mult(r.in.idx0 + (uint32_t)n);
+    if (r.in.src != nullptr && !(r.in.src[n] > 0.0f)) x = 0.0f;
+    uint32_t h, l;
+    split_pair(x, 0.0f, h, l);                       // low halves = this element
+    unsigned char* dst = r.blk + (n >> 4) * 1024 + (n & 15) * 2;
+    *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(h & 0xFFFFu);
+    *reinterpret_cast<uint16_t*>(dst + 512) = (uint16_t)(l & 0xFFFFu);
+  }
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const { return inner.vec_ok(); }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    v = inner.apply4(r.in, n, v);
+    uint32_t h0, l0, h1, l1;
+    split_pair(v.x, v.y, h0, l0);
+    split_pair(v.z, v.w, h1, l1);
+    unsigned char* dst = r.blk + (n >> 4) * 1024 + (n & 15) * 2;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l0, l1);
+  }
+};
 
 // A operands that deliver their fragments already split (KCPlanes, nrl_gemm.h)
 template <class T, class = void>

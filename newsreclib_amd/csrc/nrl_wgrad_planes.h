@@ -213,4 +213,170 @@ static inline int launch_wgrad_planes(const void* a_planes, const void* b_planes
   return NRL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Generic form: both operands plain fragment-block planes over the SAME row blocks,
+//   A: (mb * ncb_a + cb) * 1024 + p * 512,  B: (mb * ncb_b + cb) * 1024 + p * 512        (mb = row / 16)
+// C[i][j] += sum over rows A[m][i] B[m][j]; tile (2 TM x 16) x (2 TN x 16), 4 waves (2 x 2), three LDS stages.  Used for the
+// out-projection weight gradient of the fused news path (dy planes from the row-panel epilogue, o planes from the fused
+// forward): 160 x 160 tiles (TM = TN = 5) cover its 19 x 19 blocks with two tiles a side.
+struct WgradPlanesGArgs {
+  const unsigned char* a;
+  const unsigned char* b;
+  int64_t n_mb;             // row blocks (even)
+  int ncb_a, ncb_b;
+  int tiles_m, tiles_n;
+  int nsplit;
+  int64_t kt_per_split;     // k-tiles (32 rows) per split
+  int64_t M;                // valid output rows
+  int N;                    // valid output columns
+};
+
+template <int TM, int TN, class Epi>
+__global__ void __launch_bounds__(256, 1) wgrad_planes_g_kernel(const WgradPlanesGArgs P, const Epi epi) {
+  constexpr int A_ST = 4 * TM * 1024, B_ST = 4 * TN * 1024, STAGE = A_ST + B_ST;
+  constexpr int NP = TM + TN;                              // pieces per wave and k-tile
+  constexpr int PER_STEP = (NP + TM - 1) / TM;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char wp_smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wp_smem;
+
+  const int tiles_total = P.tiles_m * P.tiles_n;
+  const int64_t bid = blockIdx.x;
+  const int64_t xcd = bid % 8, local = bid / 8;
+  const int t = (int)(local % tiles_total);
+  const int64_t split = (local / tiles_total) * 8 + xcd;
+  if (split >= P.nsplit) return;
+  const int tm = t / P.tiles_n, tn = t % P.tiles_n;
+  const int64_t kt_all = P.n_mb / 2;
+  const int64_t kt0 = split * P.kt_per_split;
+  const int64_t kt1 = kt0 + P.kt_per_split < kt_all ? kt0 + P.kt_per_split : kt_all;
+  if (kt0 >= kt1) return;
+  const int nkt = (int)(kt1 - kt0);
+
+  // piece (q, wave) of an operand = (block column cbi = (4 q + wave) >> 1, row block mbi = (4 q + wave) & 1): LDS [cbi][mbi][p][512]
+  const unsigned char* base_a[TM];
+  const unsigned char* base_b[TN];
+#pragma unroll
+  for (int q = 0; q < TM; ++q) {
+    const int pa = 4 * q + wave;
+    int cb = 2 * TM * tm + (pa >> 1);
+    cb = cb < P.ncb_a ? cb : P.ncb_a - 1;                  // block columns past the matrix: rows dropped by the epilogue
+    base_a[q] = P.a + ((2 * kt0 + (pa & 1)) * P.ncb_a + cb) * 1024;
+  }
+#pragma unroll
+  for (int q = 0; q < TN; ++q) {
+    const int pb = 4 * q + wave;
+    int cb = 2 * TN * tn + (pb >> 1);
+    cb = cb < P.ncb_b ? cb : P.ncb_b - 1;
+    base_b[q] = P.b + ((2 * kt0 + (pb & 1)) * P.ncb_b + cb) * 1024;
+  }
+  const int64_t step_a = 2 * (int64_t)P.ncb_a * 1024, step_b = 2 * (int64_t)P.ncb_b * 1024;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto issue = [&](int rel, int stage, int c0, int c1) {
+    const uint32_t sbase = smem_base + (uint32_t)stage * STAGE + (uint32_t)wave * 1024u;
+#pragma unroll
+    for (int c = c0; c < c1; ++c) {
+      if (c < TM) glds16_saddr(base_a[c] + rel * step_a, lane16, sbase + (uint32_t)c * 4096u);
+      else if (c < NP) glds16_saddr(base_b[c - TM] + rel * step_b, lane16, sbase + (uint32_t)A_ST + (uint32_t)(c - TM) * 4096u);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lane_off = (uint32_t)((4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8);
+  auto frag = [&](uint32_t blk0) -> bf16x8 {               // row blocks mbi = 0, 1 of one block column are 1 KiB apart
+    typedef __attribute__((address_space(3))) wp_v4i16* lds_v4;
+    const wp_v4i16 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(blk0 + lane_off));
+    const wp_v4i16 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(blk0 + 1024u + lane_off));
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, (v8i16)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  issue(0, 0, 0, NP);
+  issue(nkt > 1 ? 1 : 0, 1, 0, NP);
+  int stage = 0;
+  for (int it = 0; it < nkt; ++it) {
+    wait_vmcnt<NP>();                                      // tile `it` landed for this wave (tile it + 1 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    const int nx = it + 2 < nkt ? it + 2 : nkt - 1;
+    const int st2 = stage == 0 ? 2 : stage - 1;
+    const uint32_t sa = smem_base + (uint32_t)stage * STAGE;
+    const uint32_t sb = sa + A_ST;
+    bf16x8 bh[TN], bl[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const uint32_t c0 = sb + (uint32_t)(wn * TN + j) * 2048u;
+      bh[j] = frag(c0);
+      bl[j] = frag(c0 + 512u);
+    }
+    bf16x8 ah[2], al[2];
+    {
+      const uint32_t a0 = sa + (uint32_t)(wm * TM) * 2048u;
+      ah[0] = frag(a0);
+      al[0] = frag(a0 + 512u);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i + 1 < TM) {
+        const uint32_t a0 = sa + (uint32_t)(wm * TM + i + 1) * 2048u;
+        ah[(i + 1) & 1] = frag(a0);
+        al[(i + 1) & 1] = frag(a0 + 512u);
+      }
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i & 1] : ah[i & 1], pass == 0 ? bl[j] : bh[j],
+                                                             acc[i][j], 0, 0, 0);
+      if (i + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * TN, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(nx, st2, i * PER_STEP, (i + 1) * PER_STEP);    // this k-tile's DMA issues spread over the row steps
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  wait_vmcnt<0>();
+
+  store_accumulators<TM, TN>(epi, acc, (int64_t)tm * (32 * TM), tn * (32 * TN), wm, wn, l15, g, P.M, P.N);
+}
+
+template <int TM, int TN, class Epi>
+static inline int launch_wgrad_planes_g(const void* a_planes, int ncb_a, const void* b_planes, int ncb_b, int64_t rows,
+                                        int64_t m_valid, int n_valid, const Epi& epi, int nsplit, hipStream_t st) {
+  if (rows <= 0) return NRL_OK;
+  NRL_REQUIRE(a_planes && b_planes && ncb_a > 0 && ncb_b > 0 && rows % 32 == 0, "wgrad_planes_g: bad arguments (rows % 32 == 0)");
+  constexpr int LDS = 3 * 4 * (TM + TN) * 1024;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  WgradPlanesGArgs P;
+  P.a = (const unsigned char*)a_planes; P.b = (const unsigned char*)b_planes;
+  P.n_mb = rows / 16; P.ncb_a = ncb_a; P.ncb_b = ncb_b;
+  P.tiles_m = (ncb_a + 2 * TM - 1) / (2 * TM); P.tiles_n = (ncb_b + 2 * TN - 1) / (2 * TN);
+  const int64_t kt = rows / 32;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > kt) nsplit = (int)kt;
+  P.kt_per_split = ceil_div(kt, nsplit);
+  P.nsplit = (int)ceil_div(kt, P.kt_per_split);
+  P.M = m_valid; P.N = n_valid;
+  const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * ceil_div(P.nsplit, 8) * 8;
+  NRL_REQUIRE(blocks < (1LL << 31), "wgrad_planes_g: grid too large");
+  static bool attr_done = false;
+  if (!attr_done) {
+    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_g_kernel<TM, TN, Epi>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_planes_g_kernel<TM, TN, Epi>), dim3((unsigned)blocks), dim3(256), LDS, st, P, epi);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
 }  // namespace nrl

@@ -181,7 +181,9 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
     assert e_sep <= 5e-5 and e_ref <= 1e-4
     if p_drop == 0:
         assert _maxerr(res[True][2], res[True][0]) <= 1e-6      # eval (no-save) variant == train variant at p = 0
-    assert torch.equal(res["full"][0], res[True][0])            # same forward kernel, with / without the q|k|v save
+    # same forward kernel with / without the q|k|v save; the out-projection behind it sums over the features in the
+    # head-permuted order of the `o` planes in one case and in natural order in the other: equal to rounding, not bitwise
+    assert _maxerr(res["full"][0], res[True][0]) <= 2e-6
     worst = 0.0
     for k, gf in res[True][1].items():
         rg = op[O.NEWS_PREFIX + k].grad.clone()

@@ -83,8 +83,8 @@ int main(int argc, char** argv) {
   a.table = table; a.ids = ids; a.img = img; a.n_news = N; a.L = L; a.D = D; a.heads = H; a.dh = 20;
   a.scale = 1.0f / sqrtf(20.f); a.drop1 = make_dropout(0.2, 5, 0); a.o = o;
   NewsFusedArgs as = a;
-  as.x_save = x; as.x_planes = nullptr; as.qkv_save = qkv; as.lse = lse; as.qkv_head_major = 1;
-  a.x_save = nullptr; a.x_planes = nullptr; a.qkv_save = nullptr; a.lse = nullptr; a.qkv_head_major = 0;
+  as.x_save = x; as.x_planes = nullptr; as.o_planes = nullptr; as.qkv_save = qkv; as.lse = lse; as.qkv_head_major = 1;
+  a.x_save = nullptr; a.x_planes = nullptr; a.o_planes = nullptr; a.qkv_save = nullptr; a.lse = nullptr; a.qkv_head_major = 0;
   const double gf = 2.0 * N * L * 3.0 * D * D * 1e-9;
   auto report = [&](const char* name, float ms) { printf("%-46s %.3f ms  (%.0f TF fp32-equiv in-projection)\n", name, ms, gf / ms); fflush(stdout); };
   report("eval  (no saves)", time_ms([&] { launch_news_fused_fwd<0>(a, st); }, st));

@@ -161,5 +161,72 @@ int main() {
              fl / ms * 1e-9, ((double)heads * n_mb * 4 * 1024 * 2 + (double)n_mb * ncb_b * 1024 * 4) / ms * 1e-9);
     }
   }
+  {
+    // ---- generic form (out-projection shape): A (rows x 300) and B (rows x 301 incl. a ones column) as 19 block columns each
+    const int ncb = 19, I = 300, J = 300;
+    {
+      const int64_t rows = 32 * 41, n_mb = rows / 16;
+      std::vector<float> A((size_t)rows * 304, 0.f), B((size_t)rows * 304, 0.f);
+      uint32_t s = 99;
+      auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+      for (int64_t m = 0; m < rows; ++m) {
+        for (int c = 0; c < I; ++c) A[m * 304 + c] = rnd();
+        for (int c = 0; c < J; ++c) B[m * 304 + c] = rnd();
+        B[m * 304 + J] = 1.0f;
+      }
+      auto planes = [&](const std::vector<float>& X) {
+        std::vector<uint16_t> p((size_t)n_mb * ncb * 512);
+        for (int64_t m = 0; m < rows; ++m)
+          for (int c = 0; c < 304; ++c) {
+            const float x = X[m * 304 + c];
+            const uint16_t hi = bf16_rne(x), lo = bf16_rne(x - bf16_f(hi));
+            const size_t blk = ((size_t)(m / 16) * ncb + c / 16) * 512;
+            p[blk + (m % 16) * 16 + c % 16] = hi;
+            p[blk + 256 + (m % 16) * 16 + c % 16] = lo;
+          }
+        return p;
+      };
+      const auto pa = planes(A), pb = planes(B);
+      uint16_t *da, *db_;
+      float *dw, *dbias;
+      CK(hipMalloc(&da, pa.size() * 2)); CK(hipMalloc(&db_, pb.size() * 2));
+      CK(hipMalloc(&dw, (size_t)I * J * 4)); CK(hipMalloc(&dbias, I * 4));
+      CK(hipMemcpy(da, pa.data(), pa.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMemcpy(db_, pb.data(), pb.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMemset(dw, 0, (size_t)I * J * 4)); CK(hipMemset(dbias, 0, I * 4));
+      if (launch_wgrad_planes_g<5, 5>(da, ncb, db_, ncb, rows, I, J + 1, EpiAtomicWB{dw, J, dbias, J}, 7, st) != NRL_OK) return 1;
+      CK(hipStreamSynchronize(st));
+      std::vector<float> hw((size_t)I * J), hb(I);
+      CK(hipMemcpy(hw.data(), dw, hw.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hb.data(), dbias, hb.size() * 4, hipMemcpyDeviceToHost));
+      double worst = 0; size_t bad = 0;
+      for (int i = 0; i < I; ++i)
+        for (int j = 0; j <= J; ++j) {
+          double ref = 0, mag = 0;
+          for (int64_t m = 0; m < rows; ++m) { const double a = A[m * 304 + i], b = B[m * 304 + j]; ref += a * b; mag += fabs(a * b); }
+          const double got = j < J ? hw[(size_t)i * J + j] : hb[i];
+          const double err = fabs(got - ref) / (mag + 1e-30);
+          worst = std::max(worst, err); bad += err > 3e-5;
+        }
+      printf("generic 300 x 301 (1312 rows, 7 splits): worst |err| / sum|a b| = %.3e, outside 3e-5: %zu\n", worst, bad);
+    }
+    {
+      const int64_t rows = 211200, n_mb = rows / 16;
+      uint16_t *da, *db_; float *dw, *dbias;
+      CK(hipMalloc(&da, (size_t)n_mb * ncb * 1024)); CK(hipMalloc(&db_, (size_t)n_mb * ncb * 1024));
+      CK(hipMalloc(&dw, (size_t)I * J * 4)); CK(hipMalloc(&dbias, I * 4));
+      CK(hipMemset(da, 0x3c, (size_t)n_mb * ncb * 1024)); CK(hipMemset(db_, 0x3c, (size_t)n_mb * ncb * 1024));
+      for (int nsplit : {32, 64, 128}) {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        auto fn = [&] { launch_wgrad_planes_g<5, 5>(da, ncb, db_, ncb, rows, I, J + 1, EpiAtomicWB{dw, J, dbias, J}, nsplit, st); };
+        for (int i = 0; i < 5; ++i) fn();
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 20; ++i) fn();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("generic 300 x 301 over 211200 rows, 160 x 160 tiles, %3d splits: %.3f ms\n", nsplit, ms / 20);
+      }
+    }
+  }
   return 0;
 }
