@@ -27,7 +27,9 @@ namespace nrl {
 
 // tile = 256 rows (4 heads x 64) x 32 * WP_TN columns (WP_TN = column blocks per wave; 10 = the whole width would fetch
 // every dqkv byte once per launch, but its 320 accumulator registers per lane make hipcc shuttle them through
-// v_accvgpr moves: 0.68 ms against 0.47)
+// v_accvgpr moves: 0.68 ms against 0.47; the same 256 x 320 tile on EIGHT waves (2 x 4, two waves per SIMD, 160
+// accumulator registers each) fits registers but only two 72 KiB LDS stages: 0.40 ms against 0.36 -- the kernel lives
+// on bytes in flight (~7-8 TB/s of L2 -> LDS traffic at two k-tiles ahead), and one k-tile ahead is not enough)
 constexpr int WP_TN = 5;
 constexpr int WP_A_STAGE = 32 * 1024, WP_B_STAGE = 2 * (2 * WP_TN) * 1024, WP_STAGE = WP_A_STAGE + WP_B_STAGE, WP_STAGES = 3;
 constexpr int WP_PIECES = WP_STAGE / 1024;                 // 72 one-KiB pieces per k-tile, 18 per wave
