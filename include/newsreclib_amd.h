@@ -94,7 +94,8 @@ int nrl_get_gemm_engine(void);
  *                 L <= 32, D = 20 * heads in [288, 316]);  "rowpanel": row-panel kernel for the N <= 320 projections;
  *   "x3_dma": LDS-DMA staged tiled GEMMs;  "news_attn_mfma": token-attention backward of the fused news path on the
  *   matrix cores from head-major q|k|v slabs;  "news_planes": x / dqkv of that path as pre-split bf16 fragment-block
- *   planes (DMA-only in-projection weight gradient);  "wgrad_ws": wave-specialised kernel for the 900-row weight
+ *   planes (DMA-only in-projection weight gradient);  "news_od_planes": o / dy of that path as planes too
+ *   (out-projection forward / dgrad / weight gradient without splits);  "wgrad_ws": wave-specialised kernel for the 900-row weight
  *   gradient.  A backward must run under the options of its forward (they select workspace formats). */
 int nrl_set_option(const char* name, int32_t value);
 
