@@ -95,7 +95,8 @@ int nrl_get_gemm_engine(void);
  *   "x3_dma": LDS-DMA staged tiled GEMMs;  "news_attn_mfma": token-attention backward of the fused news path on the
  *   matrix cores from head-major q|k|v slabs;  "news_planes": x / dqkv of that path as pre-split bf16 fragment-block
  *   planes (DMA-only in-projection weight gradient);  "news_od_planes": o / dy of that path as planes too
- *   (out-projection forward / dgrad / weight gradient without splits);  "wgrad_ws": wave-specialised kernel for the 900-row weight
+ *   (out-projection forward / dgrad / weight gradient without splits);  "news_aa_planes": y (second copy) and d_pre as
+ *   planes for the additive-attention GEMMs;  "wgrad_ws": wave-specialised kernel for the 900-row weight
  *   gradient.  A backward must run under the options of its forward (they select workspace formats). */
 int nrl_set_option(const char* name, int32_t value);
 

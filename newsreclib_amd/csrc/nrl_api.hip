@@ -157,6 +157,13 @@ static bool g_news_od_planes = [] {
   return !(e != nullptr && e[0] == '0');
 }();
 
+// NRL_NEWS_AA_PLANES=0: the additive-attention GEMMs of the fused news path read fp32 y / d_pre.  Default (with
+// news_od_planes): the out-projection epilogue writes y ALSO as planes, pool_bwd_pre writes d_pre ONLY as planes.
+static bool g_news_aa_planes = [] {
+  const char* e = getenv("NRL_NEWS_AA_PLANES");
+  return !(e != nullptr && e[0] == '0');
+}();
+
 // NRL_WGRAD_WS=0: the large (I > 512) weight gradient back on the register-staged kernel (default: the
 // wave-specialised one, nrl_gemm_ws.h, 32 k-splits = one workgroup per CU: 4.81 -> 4.72 ms/step at B = 128)
 static bool g_wgrad_ws = [] {
@@ -179,12 +186,14 @@ struct BlockShape {
   int pool_len;         // rows per output row
   AttnGeom geom;
   int64_t pad_rows = 0; // news encoder: token rows padded to 32 per news (fragment-block planes), else 0
+  bool aa_planes = false;  // fused news path: y also / d_pre only as planes (BlockWs::yp, tp) for the additive-attention GEMMs
   bool od_planes = false;  // fused news path: `o` and `dy` are (hi, lo) bf16 fragment-block planes over the real rows (19
                            // block columns at D = 300; `o` in the head-permuted feature order), not fp32 rows
 };
 
 struct BlockWs {
   float *x, *qkv, *o, *y, *t, *w, *lse, *dy, *dqkv, *d_o;
+  float *yp, *tp;    // news path only: bf16 planes of y (19 block columns at D = 300) and of d_pre (13 at Q = 200), else null
   uint16_t* planes;  // bf16 hi/lo planes of the three weights (bf16x3 engine)
   uint16_t* rp;      // fragment-ordered weight images of the row-panel GEMMs (nrl_rowpanel.h)
 };
@@ -238,6 +247,8 @@ static size_t block_ws_floats(int64_t M, int D, int Q, int heads, bool with_x, i
   if (with_x) n += al(x_elems(M, D, pad_rows));
   n += al(qkv_elems(M, D, heads, pad_rows)) * 2;  // qkv, dqkv
   n += al(od_elems(M, D, heads, pad_rows)) * 2 + al((size_t)M * D) * 2;      // o, dy | y, d_o (later dx)
+  if (pad_rows > 0 && D == heads * 20)                                       // y planes, d_pre planes
+    n += al((size_t)((M + 31) / 32 * 32) * ((D + 16) / 16) * 16) + al((size_t)((M + 31) / 32 * 32) * ((Q + 15) / 16) * 16);
   n += al((size_t)M * Q);          // t / d_pre
   n += al((size_t)M);              // w
   n += al((size_t)M * heads);      // lse
@@ -261,6 +272,11 @@ static int carve_ws(void* ws, size_t ws_bytes, const BlockShape& s, bool with_x,
   out->o = take(od_elems(s.M, s.D, s.heads, s.pad_rows));
   out->y = take((size_t)s.M * s.D);
   out->dy = take(od_elems(s.M, s.D, s.heads, s.pad_rows));
+  out->yp = out->tp = nullptr;
+  if (s.pad_rows > 0 && s.D == s.heads * 20) {
+    out->yp = take((size_t)((s.M + 31) / 32 * 32) * ((s.D + 16) / 16) * 16);
+    out->tp = take((size_t)((s.M + 31) / 32 * 32) * ((s.Q + 15) / 16) * 16);
+  }
   out->d_o = take((size_t)s.M * s.D);
   out->t = take((size_t)s.M * s.Q);
   out->w = take((size_t)s.M);
@@ -474,19 +490,32 @@ static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const Bl
   const int D = s.D, Q = s.Q;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
   // y = dropout(o W_o^T + b_o)        (out-projection, text.py:229-230)
+  const int ncb_y = (D + 16) / 16;                       // y planes: D features + the ones column
+  unsigned char* const ypl = reinterpret_cast<unsigned char*>(w.yp);
   if (s.od_planes) {
     // `o` arrives as head-permuted (hi, lo) planes from the fused forward: no split, reduction over plane slots
     const int ncb = s.heads + (s.heads + 3) / 4;
-    NRL_TRY(rp_dispatch(KCPlanesG{reinterpret_cast<const unsigned char*>(w.o), s.M, ncb}, bp.rp.out_f_perm,
-                        EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, 16 * ncb, st));
+    const KCPlanesG a_o{reinterpret_cast<const unsigned char*>(w.o), s.M, ncb};
+    const EpiLinear epi{w.y, D, P->out_proj_bias, 0, drop2, D};
+    if (s.aa_planes) {
+      if (s.M % 32 != 0)   // rows past M in the last 32-row k-tile of the weight gradient
+        NRL_HIP(hipMemsetAsync(ypl + (s.M / 32) * 2 * ncb_y * 1024, 0, (size_t)2 * ncb_y * 1024, st));
+      NRL_TRY(rp_dispatch(a_o, bp.rp.out_f_perm, EpiLinearPlanes{epi, ypl, ncb_y}, s.M, D, 16 * ncb, st));
+    } else {
+      NRL_TRY(rp_dispatch(a_o, bp.rp.out_f_perm, epi, s.M, D, 16 * ncb, st));
+    }
   } else {
     NRL_TRY(gemm_fwd(KCPlain{w.o, D, s.M}, P->out_proj_weight, bp.out,
                      EpiLinear{w.y, D, P->out_proj_bias, 0, drop2, D}, s.M, D, D, false, st,
                      bp.rp.on ? &bp.rp.out_f : nullptr));
   }
   // t = tanh(y W_a^T + b_a)           (attention.py:34)
-  NRL_TRY(gemm_fwd(KCPlain{w.y, D, s.M}, P->att_weight, bp.att, EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q},
-                   s.M, Q, D, true, st, bp.rp.on ? &bp.rp.att_f : nullptr));
+  if (s.aa_planes) {
+    NRL_TRY(rp_dispatch(KCPlanesG{ypl, s.M, ncb_y}, bp.rp.att_f, EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q}, s.M, Q, D, st));
+  } else {
+    NRL_TRY(gemm_fwd(KCPlain{w.y, D, s.M}, P->att_weight, bp.att, EpiLinear{w.t, Q, P->att_bias, 1, nodrop, Q},
+                     s.M, Q, D, true, st, bp.rp.on ? &bp.rp.att_f : nullptr));
+  }
   // w = softmax(t . q_a); out = sum w y   (attention.py:37-40)
   NRL_TRY(pool_fwd(w.t, P->att_query, w.y, s.pool_groups, s.pool_len, Q, D, w.w, out, st));
   return NRL_OK;
@@ -502,15 +531,21 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
                             bool attention_elsewhere = false) {
   const int D = s.D, Q = s.Q;
   // additive attention backward: t -> d_pre in place, dq_a
-  NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st));
+  const int ncb_q = (Q + 15) / 16;
+  unsigned char* const tpl = reinterpret_cast<unsigned char*>(w.tp);
+  if (s.aa_planes && s.M % 32 != 0)
+    NRL_HIP(hipMemsetAsync(tpl + (s.M / 32) * 2 * ncb_q * 1024, 0, (size_t)2 * ncb_q * 1024, st));
+  NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st,
+                       s.aa_planes ? tpl : nullptr));
   if (s.od_planes) {
     // dy = (d_pre W_a + w * d_out) * dropout2, written ONCE as (hi, lo) planes: its only readers are the two GEMMs below
     const int ncb = (D + 15) / 16;
     unsigned char* dyp = reinterpret_cast<unsigned char*>(w.dy);
     if (s.M % 32 != 0)   // the weight gradient reads whole 32-row k-tiles: rows past M in the last one must be zero
       NRL_HIP(hipMemsetAsync(dyp + (s.M / 32) * 2 * ncb * 1024, 0, (size_t)2 * ncb * 1024, st));
-    NRL_TRY(rp_dispatch(KCPlain{w.t, Q, s.M}, bp.rp.att_d,
-                        EpiPoolBwdPlanes{EpiPoolBwd{nullptr, D, w.w, d_out, s.pool_len, drop2}, dyp, ncb}, s.M, D, Q, st));
+    const EpiPoolBwdPlanes epi_dy{EpiPoolBwd{nullptr, D, w.w, d_out, s.pool_len, drop2}, dyp, ncb};
+    if (s.aa_planes) NRL_TRY(rp_dispatch(KCPlanesG{tpl, s.M, ncb_q}, bp.rp.att_d, epi_dy, s.M, D, Q, st));
+    else NRL_TRY(rp_dispatch(KCPlain{w.t, Q, s.M}, bp.rp.att_d, epi_dy, s.M, D, Q, st));
     // d_o = dy W_o
     NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
   } else {
@@ -530,7 +565,14 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
                             hipStream_t st, bool dqkv_head_planes = false, bool bf16_planes = false) {
   const int D = s.D, Q = s.Q;
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
-  NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
+  if (s.aa_planes) {
+    // d_pre (pool_bwd_pre) and y (out-projection epilogue, with its ones column) as planes over the same rows
+    static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
+    NRL_TRY((launch_wgrad_planes_g<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
+                                         EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st)));
+  } else {
+    NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
+  }
   // dW_o += dy^T o ; db_o += colsum(dy)
   if (s.od_planes) {
     // both operands are planes over the same (real) rows: DMA + transpose-read + MFMA only (wgrad_planes_g_kernel)
@@ -649,11 +691,12 @@ int nrl_set_option(const char* name, int32_t value) {
                : !strcmp(name, "news_attn_mfma") ? &g_news_attn_mfma
                : !strcmp(name, "news_planes") ? &g_news_planes
                : !strcmp(name, "news_od_planes") ? &g_news_od_planes
+               : !strcmp(name, "news_aa_planes") ? &g_news_aa_planes
                : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma
                                            : nullptr;
-  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, wgrad_ws, rowpanel, x3_dma)", name);
+  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, news_aa_planes, wgrad_ws, rowpanel, x3_dma)", name);
   *flag = value != 0;
   return NRL_OK;
 }
@@ -697,6 +740,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     const bool planes = !g_news_fused_bwd && g_news_attn_mfma && g_news_planes;
     BlockShape sf = s;
     sf.od_planes = planes && g_news_od_planes;
+    sf.aa_planes = sf.od_planes && g_news_aa_planes && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
     a.o_planes = nullptr;
     if (sf.od_planes) {
       a.o_planes = reinterpret_cast<unsigned char*>(w.o);
@@ -740,6 +784,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   const bool planes = slabs && g_news_planes;
   BlockShape sb_ = s;
   sb_.od_planes = planes && g_news_od_planes;
+  sb_.aa_planes = sb_.od_planes && g_news_aa_planes && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
   NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
   if (phase != 2) {
     NRL_TRY(block_bwd_phase1(p, g, sb_, w, bp, d2, d_out, st, fused || slabs));

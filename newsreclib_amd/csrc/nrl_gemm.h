@@ -290,7 +290,8 @@ struct EpiLinear {
   __device__ __forceinline__ bool vec_ok() const {
     return (ldc & 3) == 0 && (((uintptr_t)c | (uintptr_t)bias | (uintptr_t)gate_src) & 15) == 0;
   }
-  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const { store4(r.out + n, apply4(r, n, v), stream); }
+  __device__ __forceinline__ float4 apply4(const Row& r, int n, float4 v) const {
     if (bias != nullptr) {
       const float4 b = *reinterpret_cast<const float4*>(bias + n);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
@@ -306,7 +307,7 @@ struct EpiLinear {
       v.x = sv.x > 0.f ? v.x : 0.f; v.y = sv.y > 0.f ? v.y : 0.f;
       v.z = sv.z > 0.f ? v.z : 0.f; v.w = sv.w > 0.f ? v.w : 0.f;
     }
-    store4(r.out + n, v, stream);
+    return v;
   }
 };
 

@@ -499,11 +499,25 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// (a, b) -> packed bf16 (hi_a | hi_b << 16), (lo_a | lo_b << 16): the bf16x3 split of nrl_gemm_bf16x3.h (same builtins,
+// same round-to-nearest-even values; repeated here because this translation unit does not see the GEMM headers)
+typedef __bf16 pool_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pool_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const pool_bf16x2 h = __builtin_convertvector(pool_f32x2{a, b}, pool_bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  const pool_bf16x2 l = __builtin_convertvector(pool_f32x2{a - ha, b - hb}, pool_bf16x2);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 __global__ void __launch_bounds__(256)
     pool_bwd_pre_kernel(const float* __restrict__ d_out, const float* __restrict__ y,
                         const float* __restrict__ w, float* __restrict__ t_dpre,
                         const float* __restrict__ q_a, float* __restrict__ dq_a, int64_t groups, int S, int Q,
-                        int D) {
+                        int D, unsigned char* __restrict__ dpre_planes, int ncb_q) {
+  // dpre_planes != nullptr: d_pre goes out as (hi, lo) bf16 fragment-block planes over the rows (KCPlanesG; its readers
+  // are the additive-attention dgrad and weight-gradient GEMMs only) and t is left as it is
   extern __shared__ float sm[];  // c[S] -> da[S]
   __shared__ float4 part[256];
   float* c_s = sm;
@@ -548,8 +562,19 @@ __global__ void __launch_bounds__(256)
           const float4 tv = t4[(int64_t)l * Q4 + c4];
           acc.x = fmaf(da, tv.x, acc.x); acc.y = fmaf(da, tv.y, acc.y);
           acc.z = fmaf(da, tv.z, acc.z); acc.w = fmaf(da, tv.w, acc.w);
-          t4[(int64_t)l * Q4 + c4] = make_float4(da * qn.x * (1.0f - tv.x * tv.x), da * qn.y * (1.0f - tv.y * tv.y),
-                                                 da * qn.z * (1.0f - tv.z * tv.z), da * qn.w * (1.0f - tv.w * tv.w));
+          const float4 dp = make_float4(da * qn.x * (1.0f - tv.x * tv.x), da * qn.y * (1.0f - tv.y * tv.y),
+                                        da * qn.z * (1.0f - tv.z * tv.z), da * qn.w * (1.0f - tv.w * tv.w));
+          if (dpre_planes != nullptr) {
+            const int64_t m = row0 + l;
+            uint32_t h0, l0, h1, l1;
+            split_pair(dp.x, dp.y, h0, l0);
+            split_pair(dp.z, dp.w, h1, l1);
+            unsigned char* dst = dpre_planes + ((m >> 4) * ncb_q + (c4 >> 2)) * 1024 + (m & 15) * 32 + (c4 & 3) * 8;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l0, l1);
+          } else {
+            t4[(int64_t)l * Q4 + c4] = dp;
+          }
         }
         accq[it & 3] = acc;
       }
@@ -595,14 +620,14 @@ int pool_fwd(const float* t, const float* q_a, const float* y, int64_t groups, i
 }
 
 int pool_bwd_pre(const float* d_out, const float* y, const float* w, float* t_dpre, const float* q_a,
-                 float* dq_a, int64_t groups, int S, int Q, int D, hipStream_t stream) {
+                 float* dq_a, int64_t groups, int S, int Q, int D, hipStream_t stream, void* dpre_planes) {
   if (groups == 0) return NRL_OK;
   NRL_REQUIRE(S > 0 && S <= 8192 && groups < (1LL << 31), "pool_bwd_pre: bad shape");
   NRL_REQUIRE(Q % 4 == 0 && D % 4 == 0, "pool_bwd_pre: Q and D must be multiples of 4");
   NRL_REQUIRE(Q <= 4096, "pool_bwd_pre: query_dim > 4096 unsupported");
   const unsigned grid = (unsigned)(groups < 2048 ? groups : 2048);  // 8 workgroups per CU, persistent over groups
   hipLaunchKernelGGL(pool_bwd_pre_kernel, dim3(grid), dim3(256), S * sizeof(float), stream, d_out, y, w, t_dpre,
-                     q_a, dq_a, groups, S, Q, D);
+                     q_a, dq_a, groups, S, Q, D, (unsigned char*)dpre_planes, (Q + 15) / 16);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -227,6 +227,40 @@ struct EpiPoolBwdPlanes {
   }
 };
 
+// EpiLinear that ALSO writes its output as (hi, lo) bf16 fragment-block planes over the real rows (KCPlanesG): y of the fused
+// news path is read as fp32 by the pooling kernels and as a GEMM operand by the additive-attention forward and weight
+// gradient.  The lane that owns the last four columns appends the ones column of the bias gradient (column n_cols) and
+// zeros to the end of the block (n_cols % 16 == 12: the reference width 300).
+struct EpiLinearPlanes {
+  EpiLinear inner;
+  unsigned char* planes;
+  int ncb;
+  struct Row {
+    EpiLinear::Row in;
+    unsigned char* blk;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const {
+    return Row{inner.row(m), planes + (m >> 4) * ncb * 1024 + (m & 15) * 32};
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t m, int n, float v) const { inner(r.in, m, n, v); }   // (not used: vec_ok)
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const { return inner.vec_ok(); }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    v = inner.apply4(r.in, n, v);
+    store4(r.in.out + n, v, inner.stream);
+    uint32_t h0, l0, h1, l1;
+    split_pair(v.x, v.y, h0, l0);
+    split_pair(v.z, v.w, h1, l1);
+    unsigned char* dst = r.blk + (n >> 4) * 1024 + (n & 15) * 2;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l0, l1);
+    if (n + 4 == inner.n_cols && (inner.n_cols & 15) == 12) {
+      *reinterpret_cast<uint2*>(dst + 8) = make_uint2(0x3F80u, 0u);      // 1.0, 0, 0, 0
+      *reinterpret_cast<uint2*>(dst + 512 + 8) = make_uint2(0u, 0u);
+    }
+  }
+};
+
 // A operands that deliver their fragments already split (KCPlanes, nrl_gemm.h)
 template <class T, class = void>
 struct RpPreSplit : std::false_type {};
