@@ -740,7 +740,8 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     const bool planes = !g_news_fused_bwd && g_news_attn_mfma && g_news_planes;
     BlockShape sf = s;
     sf.od_planes = planes && g_news_od_planes;
-    sf.aa_planes = sf.od_planes && g_news_aa_planes && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
+    // (training only: in an evaluation forward the second copy of y costs more than the additive-attention GEMM saves)
+    sf.aa_planes = sf.od_planes && g_news_aa_planes && save_for_backward && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
     a.o_planes = nullptr;
     if (sf.od_planes) {
       a.o_planes = reinterpret_cast<unsigned char*>(w.o);
