@@ -16,7 +16,7 @@ from .abstract_recommender import AbstractRecommender
 from .click_predictor import DotProduct
 from .dense_batch import dense_rows
 from .news_encoder import CNNMHSAAddAtt, NewsEncoder, _draw_seed
-from .nrms_module import prepare_batch
+from .nrms_module import prepare_batch, text_vocab
 from .user_encoder_cen_news_rec import UserEncoder
 
 
@@ -82,12 +82,11 @@ class CenNewsRecModule(AbstractRecommender):
         self.click_predictor = DotProduct()
         self._init_step_outputs(outputs)
 
-    @staticmethod
-    def _prepare(batch: Dict) -> Dict:
-        return prepare_batch(batch)
+    def _prepare(self, batch: Dict) -> Dict:
+        return prepare_batch(batch, text_vocab(self))
 
     def forward(self, batch: Dict, seed: Optional[int] = None) -> torch.Tensor:
-        batch = prepare_batch(batch)
+        batch = prepare_batch(batch, text_vocab(self))
         if self.training and seed is None:
             seed = _draw_seed()
         hist_vec, cand_vec = self._encode_news(batch, seed)

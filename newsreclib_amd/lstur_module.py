@@ -18,7 +18,7 @@ from .abstract_recommender import AbstractRecommender
 from .click_predictor import DotProduct
 from .dense_batch import dense_rows
 from .news_encoder import CNNAddAtt, LinearEncoder, NewsEncoder, _draw_seed
-from .nrms_module import prepare_batch
+from .nrms_module import prepare_batch, text_vocab
 from .user_encoder_lstur import UserEncoder
 
 
@@ -96,13 +96,12 @@ class LSTURModule(AbstractRecommender):
         self.click_predictor = DotProduct()
         self._init_step_outputs(outputs)
 
-    @staticmethod
-    def _prepare(batch: Dict) -> Dict:
-        return prepare_batch(batch)
+    def _prepare(self, batch: Dict) -> Dict:
+        return prepare_batch(batch, text_vocab(self))
 
     # -- reference: lstur_module.py:278-303 -----------------------------------------------------------
     def forward(self, batch: Dict, seed: Optional[int] = None) -> torch.Tensor:
-        batch = prepare_batch(batch)
+        batch = prepare_batch(batch, text_vocab(self))
         B = batch["batch_size"]
         if self.training and seed is None:
             seed = _draw_seed()                       # one draw per step; streams separate the dropouts

@@ -16,7 +16,7 @@ from .abstract_recommender import AbstractRecommender
 from .click_predictor import DotProduct
 from .dense_batch import dense_rows
 from .news_encoder import LinearEncoder, MHSAAddAtt, NewsEncoder, _draw_seed
-from .nrms_module import prepare_batch
+from .nrms_module import prepare_batch, text_vocab
 from .user_encoder_mins import UserEncoder
 
 
@@ -83,13 +83,12 @@ class MINSModule(AbstractRecommender):
         self.click_predictor = DotProduct()
         self._init_step_outputs(outputs)
 
-    @staticmethod
-    def _prepare(batch: Dict) -> Dict:
-        return prepare_batch(batch)
+    def _prepare(self, batch: Dict) -> Dict:
+        return prepare_batch(batch, text_vocab(self))
 
     # -- reference: mins_module.py:250-279 -------------------------------------------------------------
     def forward(self, batch: Dict, seed: Optional[int] = None) -> torch.Tensor:
-        batch = prepare_batch(batch)
+        batch = prepare_batch(batch, text_vocab(self))
         if self.training and seed is None:
             seed = _draw_seed()
         hist_vec, cand_vec = self._encode_news(batch, seed)

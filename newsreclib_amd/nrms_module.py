@@ -52,6 +52,17 @@ def attach_layout(batch: Dict) -> Dict:
     return out
 
 
+def text_vocab(module) -> Optional[int]:
+    """Rows of the word-embedding table the module's text encoders share (None: no embedding table, e.g. a PLM): the
+    exclusive upper bound of the token ids, which lets ``prepare_batch`` group them with the counting sort."""
+    enc = getattr(module, "news_encoder", None)
+    for te in getattr(enc, "text_encoders", {}).values() if enc is not None else ():
+        emb = getattr(te, "embedding_layer", None)
+        if emb is not None:
+            return int(emb.weight.shape[0])
+    return None
+
+
 def prepare_batch(batch: Dict, vocab: Optional[int] = None) -> Dict:
     """``attach_layout`` + the per-step device work on the token ids: history and candidate ids as the single
     encoder call sees them, and their id-sorted visiting order for the embedding gradient (the sort the reference

@@ -11,6 +11,7 @@ import torch
 from . import _lib
 from ._lib import NrlCnnGrads, NrlCnnParams, NrlGruGrads, NrlGruParams
 from .ops import _chk, _grad_targets, _stream
+from .ops import sort_positions as _sort_positions
 
 
 def _cnn_params(tensors: Sequence[torch.Tensor], embed_dim: int) -> NrlCnnParams:
@@ -49,7 +50,7 @@ class CnnEncoderFn(torch.autograd.Function):
                                            ws.numel(), _stream()), "nrl_cnn_encoder_fwd")
         if save:
             if order is None:
-                order = torch.argsort(ids.reshape(-1))
+                order = _sort_positions(ids, V)     # counting sort over the vocabulary (ops.sort_positions)
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (float(p_drop), int(seed), int(stream0)), grad_bufs
@@ -193,7 +194,7 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
                                                 ws.data_ptr(), ws.numel(), _stream()), "nrl_cnn_mhsa_encoder_fwd")
         if save:
             if order is None:
-                order = torch.argsort(ids.reshape(-1))
+                order = _sort_positions(ids, V)     # counting sort over the vocabulary (ops.sort_positions)
             ctx.save_for_backward(ids, _chk(order, torch.int64, "order"), *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
             ctx.engine = engine

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import ops, ops_blocks
 from .dense_batch import dense_rows
-from .nrms_module import NRMSModule, prepare_batch
+from .nrms_module import NRMSModule, prepare_batch, text_vocab
 
 
 class SentiRecModule(NRMSModule):
@@ -70,7 +70,7 @@ class SentiRecModule(NRMSModule):
 
     # -- reference: sentirec_module.py:236-273 ---------------------------------------------------------
     def forward(self, batch: Dict):
-        batch = prepare_batch(batch)
+        batch = prepare_batch(batch, text_vocab(self))
         if self.hparams.use_plm:
             hist_vec = self.news_encoder(batch["x_hist"])
             cand_vec = self.news_encoder(batch["x_cand"])

@@ -18,7 +18,7 @@ from .abstract_recommender import AbstractRecommender
 from .click_predictor import CrossEntropyLoss, DotProduct
 from .dense_batch import dense_rows
 from .news_encoder import CNNAddAtt, NewsEncoder, _draw_seed
-from .nrms_module import prepare_batch
+from .nrms_module import prepare_batch, text_vocab
 from .user_encoder_naml import UserEncoder
 
 
@@ -83,13 +83,12 @@ class TANRModule(AbstractRecommender):
         self.click_predictor = DotProduct()
         self._init_step_outputs(outputs)
 
-    @staticmethod
-    def _prepare(batch: Dict) -> Dict:
-        return prepare_batch(batch)
+    def _prepare(self, batch: Dict) -> Dict:
+        return prepare_batch(batch, text_vocab(self))
 
     # -- reference: tanr_module.py:258-286 -------------------------------------------------------------
     def forward(self, batch: Dict, seed: Optional[int] = None):
-        batch = prepare_batch(batch)
+        batch = prepare_batch(batch, text_vocab(self))
         if self.training and seed is None:
             seed = _draw_seed()
         hist_vec, cand_vec = self._encode_news(batch, seed)
