@@ -198,6 +198,38 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
     print(f"   recomputing backward: worst gradient error vs oracle {worst:.3e} (relative to the largest gradient)")
 
 
+@pytest.mark.parametrize("option", ["news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes"])
+@pytest.mark.parametrize("N,L", [(9, 17), (70, 30)])
+def test_news_path_format_switches_agree(N, L, option):
+    """The measurement switches of the fused news path select private workspace formats (head-major q|k|v slabs, bf16
+    fragment-block planes for x / dqkv, o / dy, y / d_pre): every fallback must give the same encoder output and the same
+    gradients as the default, to rounding."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.news_encoder import MHSAAddAtt
+    _lib.set_gemm_engine("bf16x3")
+    params = _news_params(vocab=97, seed=N + 1)
+    gen = torch.Generator().manual_seed(N * 7 + L)
+    ids = torch.randint(0, 97, (N, L), generator=gen)
+    d_out = torch.randn(N, 300, generator=gen)
+    res = []
+    for on in (True, False):
+        _lib.set_option(option, on)
+        try:
+            enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
+            enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+            enc = enc.to(DEV)
+            enc.train()
+            out = enc(ids.to(DEV), seed=7)
+            out.backward(d_out.to(DEV))
+            res.append((out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in enc.named_parameters()}))
+        finally:
+            _lib.set_option(option, True)
+    assert _maxerr(res[0][0], res[1][0]) <= 5e-6
+    for k, g0 in res[0][1].items():
+        scale = max(1.0, float(g0.abs().max()))
+        assert _maxerr(g0, res[1][1][k]) <= 1e-4 * scale, (option, k)
+
+
 @pytest.mark.parametrize("B,H", [(3, 4), (5, 50), (40, 7), (130, 3)])
 def test_user_encoder_fwd_and_bwd_vs_oracle(B, H):
     from newsreclib_amd.user_encoder import UserEncoder
