@@ -164,6 +164,13 @@ static bool g_news_aa_planes = [] {
   return !(e != nullptr && e[0] == '0');
 }();
 
+// NRL_WGRAD_2STEP=0: the planes weight gradients add their split-K partial tiles with atomics instead of storing them and
+// reducing in a second small kernel (nrl_wgrad_planes.h: ~60 us of L2 atomics per launch become ~25 us)
+static bool g_wgrad_2step = [] {
+  const char* e = getenv("NRL_WGRAD_2STEP");
+  return !(e != nullptr && e[0] == '0');
+}();
+
 // NRL_WGRAD_WS=0: the large (I > 512) weight gradient back on the register-staged kernel (default: the
 // wave-specialised one, nrl_gemm_ws.h, 32 k-splits = one workgroup per CU: 4.81 -> 4.72 ms/step at B = 128)
 static bool g_wgrad_ws = [] {
@@ -564,12 +571,16 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
 static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const BlockShape& s, const BlockWs& w,
                             hipStream_t st, bool dqkv_head_planes = false, bool bf16_planes = false) {
   const int D = s.D, Q = s.Q;
+  // partial tiles of the planes weight gradients: the q|k|v slabs are dead once the attention backward has run
+  const size_t scratch_avail = (bf16_planes && g_wgrad_2step) ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
+  auto scratch_for = [&](size_t need) -> float* { return need <= scratch_avail ? w.qkv : nullptr; };
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
   if (s.aa_planes) {
     // d_pre (pool_bwd_pre) and y (out-projection epilogue, with its ones column) as planes over the same rows
     static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
     NRL_TRY((launch_wgrad_planes_g<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
-                                         EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st)));
+                                         EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st,
+                                         scratch_for(wgrad_planes_g_scratch_floats(7, 5, (Q + 15) / 16, (D + 16) / 16, sp)))));
   } else {
     NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
   }
@@ -579,7 +590,8 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
     static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_G_SPLITS"); return e ? atoi(e) : 64; }();
     const int ncb_o = s.heads + (s.heads + 3) / 4, ncb_dy = (D + 15) / 16;
     NRL_TRY((launch_wgrad_planes_g<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
-                                         EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st)));
+                                         EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st,
+                                         scratch_for(wgrad_planes_g_scratch_floats(5, 5, ncb_dy, ncb_o, sp)))));
   } else {
     NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
   }
@@ -588,7 +600,8 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
     // both operands pre-split by their producers: pure DMA + transpose-read + MFMA kernel (nrl_wgrad_planes.h)
     static const int wp_splits = [] { const char* e = getenv("NRL_WGRAD_PLANES_SPLITS"); return e ? atoi(e) : 32; }();
     return launch_wgrad_planes(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1,
-                               EpiAtomicWBHeads{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh}, wp_splits, st);
+                               EpiAtomicWBHeads{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh}, wp_splits, st,
+                               scratch_for(wgrad_planes_scratch_floats(s.heads, 20, wp_splits)));
   }
   if (dqkv_head_planes) {
     // dqkv in head planes (news_attn_bwd_kernel): 64 output rows per head, remapped to [Wq; Wk; Wv] rows on the way out
@@ -692,6 +705,7 @@ int nrl_set_option(const char* name, int32_t value) {
                : !strcmp(name, "news_planes") ? &g_news_planes
                : !strcmp(name, "news_od_planes") ? &g_news_od_planes
                : !strcmp(name, "news_aa_planes") ? &g_news_aa_planes
+               : !strcmp(name, "wgrad_2step") ? &g_wgrad_2step
                : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma

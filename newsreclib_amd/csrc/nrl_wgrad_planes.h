@@ -47,7 +47,47 @@ struct WgradPlanesArgs {
   int64_t kt_per_split;     // k-tiles (news) per split
   int64_t M;                // heads * 64 logical output rows
   int N;                    // valid output columns (D + 1)
+  float* scratch;           // (nsplit, tiles, BM x BN) partial tiles, or null: atomics straight into the gradient
 };
+
+// Split-K reduction in two steps.  With one atomic per (split, output element) a launch issues 6 - 10 M fp32 atomics on
+// 0.2 - 0.3 M addresses: ~60 us at the L2's atomic rate, whatever the batch (a third of the kernel at B = 32).  Instead every
+// workgroup stores its partial tile (16-byte coalesced stores, 26 - 42 MB per launch) and wgrad_reduce_kernel sums the
+// splits of each element in a fixed order and hands ONE value per element to the epilogue.
+template <int BM, int BN, class Epi>
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ scratch, int nsplit, int tiles_n, int tiles_total,
+                                                           int64_t M, int N, const Epi epi) {
+  constexpr int Q = BM * BN / 4;                             // float4 per tile
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)tiles_total * Q) return;
+  const int t = (int)(i / Q), q = (int)(i - (int64_t)t * Q);
+  const int r = q / (BN / 4), c = 4 * (q - r * (BN / 4));
+  const float4* src = reinterpret_cast<const float4*>(scratch) + (int64_t)t * Q + q;
+  // eight partial tiles in flight per lane, summed in split order (a fixed order: the result does not depend on timing)
+  const int64_t stride = (int64_t)tiles_total * Q;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 8 <= nsplit; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(s + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  }
+  for (; s < nsplit; ++s) {
+    const float4 v = src[s * stride];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int64_t m = (int64_t)(t / tiles_n) * BM + r;
+  const int n = (t % tiles_n) * BN + c;
+  if (m < M) {
+    const typename Epi::Row row = epi.row(m);
+    if (n < N) epi(row, m, n, a.x);
+    if (n + 1 < N) epi(row, m, n + 1, a.y);
+    if (n + 2 < N) epi(row, m, n + 2, a.z);
+    if (n + 3 < N) epi(row, m, n + 3, a.w);
+  }
+}
 
 // ABL (tools/wp_probe.hip only): 1 = no DMA inside the loop, 2 = no MFMAs
 template <class Epi, int ABL = 0>
@@ -185,12 +225,20 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesA
   }
   wait_vmcnt<0>();                                          // the re-fetched tail tile must not outlive the LDS allocation
 
-  store_accumulators<8, WP_TN>(epi, acc, (int64_t)tm * 256, tn * 32 * WP_TN, wm, wn, l15, g, P.M, P.N);
+  if (P.scratch != nullptr) {
+    const EpiStore part{P.scratch + ((int64_t)split * tiles_total + t) * (256 * 32 * WP_TN), 32 * WP_TN};
+    store_accumulators<8, WP_TN>(part, acc, 0, 0, wm, wn, l15, g, 256, 32 * WP_TN);
+  } else {
+    store_accumulators<8, WP_TN>(epi, acc, (int64_t)tm * 256, tn * 32 * WP_TN, wm, wn, l15, g, P.M, P.N);
+  }
 }
 
+static inline size_t wgrad_planes_scratch_floats(int heads, int ncb_b, int nsplit) {
+  return (size_t)nsplit * ((heads + 3) / 4) * (ncb_b / (2 * WP_TN)) * 256 * 32 * WP_TN;
+}
 template <int ABL = 0, class Epi>
 static inline int launch_wgrad_planes(const void* a_planes, const void* b_planes, int64_t n_news, int heads, int ncb_b,
-                                      int n_valid, const Epi& epi, int nsplit, hipStream_t st) {
+                                      int n_valid, const Epi& epi, int nsplit, hipStream_t st, float* scratch = nullptr) {
   if (n_news <= 0) return NRL_OK;
   NRL_REQUIRE(a_planes && b_planes && heads > 0 && ncb_b > 0 && ncb_b % (2 * WP_TN) == 0, "wgrad_planes: bad arguments");
   WgradPlanesArgs P;
@@ -210,8 +258,16 @@ static inline int launch_wgrad_planes(const void* a_planes, const void* b_planes
                                 hipFuncAttributeMaxDynamicSharedMemorySize, WP_STAGES * WP_STAGE));
     attr_done = true;
   }
+  P.scratch = P.nsplit > 1 ? scratch : nullptr;
   hipLaunchKernelGGL((wgrad_planes_kernel<Epi, ABL>), dim3((unsigned)blocks), dim3(256), WP_STAGES * WP_STAGE, st, P, epi);
   NRL_LAUNCH_CHECK();
+  if (P.scratch != nullptr) {
+    const int tiles = P.tiles_m * P.tiles_n;
+    const int64_t threads = (int64_t)tiles * 256 * 32 * WP_TN / 4;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<256, 32 * WP_TN, Epi>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st,
+                       P.scratch, P.nsplit, P.tiles_n, tiles, P.M, P.N, epi);
+    NRL_LAUNCH_CHECK();
+  }
   return NRL_OK;
 }
 
@@ -231,6 +287,7 @@ struct WgradPlanesGArgs {
   int64_t kt_per_split;     // k-tiles (32 rows) per split
   int64_t M;                // valid output rows
   int N;                    // valid output columns
+  float* scratch;           // (nsplit, tiles, BM x BN) partial tiles, or null
 };
 
 template <int TM, int TN, class Epi>
@@ -348,12 +405,21 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_g_kernel(const WgradPlane
   }
   wait_vmcnt<0>();
 
-  store_accumulators<TM, TN>(epi, acc, (int64_t)tm * (32 * TM), tn * (32 * TN), wm, wn, l15, g, P.M, P.N);
+  if (P.scratch != nullptr) {
+    const EpiStore part{P.scratch + ((int64_t)split * tiles_total + t) * (32 * TM * 32 * TN), 32 * TN};
+    store_accumulators<TM, TN>(part, acc, 0, 0, wm, wn, l15, g, 32 * TM, 32 * TN);
+  } else {
+    store_accumulators<TM, TN>(epi, acc, (int64_t)tm * (32 * TM), tn * (32 * TN), wm, wn, l15, g, P.M, P.N);
+  }
 }
 
+static inline size_t wgrad_planes_g_scratch_floats(int TM, int TN, int ncb_a, int ncb_b, int nsplit) {
+  return (size_t)nsplit * ((ncb_a + 2 * TM - 1) / (2 * TM)) * ((ncb_b + 2 * TN - 1) / (2 * TN)) * (32 * TM) * (32 * TN);
+}
 template <int TM, int TN, class Epi>
 static inline int launch_wgrad_planes_g(const void* a_planes, int ncb_a, const void* b_planes, int ncb_b, int64_t rows,
-                                        int64_t m_valid, int n_valid, const Epi& epi, int nsplit, hipStream_t st) {
+                                        int64_t m_valid, int n_valid, const Epi& epi, int nsplit, hipStream_t st,
+                                        float* scratch = nullptr) {
   if (rows <= 0) return NRL_OK;
   NRL_REQUIRE(a_planes && b_planes && ncb_a > 0 && ncb_b > 0 && rows % 32 == 0, "wgrad_planes_g: bad arguments (rows % 32 == 0)");
   constexpr int LDS = 3 * 4 * (TM + TN) * 1024;
@@ -376,8 +442,16 @@ static inline int launch_wgrad_planes_g(const void* a_planes, int ncb_a, const v
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
+  P.scratch = P.nsplit > 1 ? scratch : nullptr;
   hipLaunchKernelGGL((wgrad_planes_g_kernel<TM, TN, Epi>), dim3((unsigned)blocks), dim3(256), LDS, st, P, epi);
   NRL_LAUNCH_CHECK();
+  if (P.scratch != nullptr) {
+    const int tiles = P.tiles_m * P.tiles_n;
+    const int64_t threads = (int64_t)tiles * (32 * TM) * (32 * TN) / 4;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<32 * TM, 32 * TN, Epi>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st,
+                       P.scratch, P.nsplit, P.tiles_n, tiles, P.M, P.N, epi);
+    NRL_LAUNCH_CHECK();
+  }
   return NRL_OK;
 }
 

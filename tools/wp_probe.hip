@@ -117,7 +117,7 @@ int main() {
   }
   {
     // ---- speed at B = 128 -----------------------------------------------------------------------------
-    const int64_t n_news = 7040, n_mb = 2 * n_news;
+    const int64_t n_news = getenv("WP_NEWS") ? atoll(getenv("WP_NEWS")) : 7040, n_mb = 2 * n_news;
     uint16_t *da, *db_;
     float *dw, *dbias;
     CK(hipMalloc(&da, (size_t)heads * n_mb * 4 * 1024));
