@@ -1011,32 +1011,54 @@ __global__ void __launch_bounds__(256)
     embedding_grad_sorted_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
                                  const int64_t* __restrict__ order, int64_t n_rows, int D,
                                  float* __restrict__ d_table) {
+  // The segment's (position, id) pairs are fetched by 64 lanes at once and parked in LDS; the row loads of eight
+  // positions are then in flight together.  (One position at a time, each iteration was a chain of three dependent
+  // global loads -- order -> id -> row: ~50 us per launch however small the batch.)  Rows are still ADDED in sorted order.
+  __shared__ int64_t s_pos[EMB_SEG_ROWS], s_id[EMB_SEG_ROWS];
   const int64_t beg = (int64_t)blockIdx.x * EMB_SEG_ROWS;
   const int64_t end = beg + EMB_SEG_ROWS < n_rows ? beg + EMB_SEG_ROWS : n_rows;
-  if (ids[order[end - 1]] == 0) return;  // sorted ascending: the whole segment is padding
+  const int n = (int)(end - beg);
   const int tid = threadIdx.x;
+  if (tid < EMB_SEG_ROWS) {
+    const int64_t pos = tid < n ? order[beg + tid] : 0;
+    s_pos[tid] = pos;
+    s_id[tid] = tid < n ? ids[pos] : 0;                 // slots past the end behave like padding rows
+  }
+  __syncthreads();
+  if (s_id[n - 1] == 0) return;  // sorted ascending: the whole segment is padding
+  const bool d0 = tid < D, d1 = tid + 256 < D;
   float acc0 = 0.f, acc1 = 0.f;  // dims tid and tid + 256 (D <= 512)
   int64_t cur = -1;
-  for (int64_t j = beg; j < end; ++j) {
-    const int64_t pos = order[j];
-    const int64_t id = ids[pos];
-    if (id != cur) {
-      if (cur > 0) {
-        if (tid < D) atomicAdd(d_table + cur * D + tid, acc0);
-        if (tid + 256 < D) atomicAdd(d_table + cur * D + tid + 256, acc1);
-      }
-      cur = id;
-      acc0 = acc1 = 0.f;
+  for (int j0 = 0; j0 < n; j0 += 8) {
+    float r0[8], r1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u < EMB_SEG_ROWS ? j0 + u : EMB_SEG_ROWS - 1;
+      const bool live = j0 + u < n && s_id[j] != 0;
+      const float* row = dx + s_pos[j] * D;
+      r0[u] = (live && d0) ? row[tid] : 0.f;
+      r1[u] = (live && d1) ? row[tid + 256] : 0.f;
     }
-    if (id != 0) {
-      const float* row = dx + pos * D;
-      if (tid < D) acc0 += row[tid];
-      if (tid + 256 < D) acc1 += row[tid + 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (j0 + u < n) {
+        const int64_t id = s_id[j0 + u];
+        if (id != cur) {
+          if (cur > 0) {
+            if (d0) atomicAdd(d_table + cur * D + tid, acc0);
+            if (d1) atomicAdd(d_table + cur * D + tid + 256, acc1);
+          }
+          cur = id;
+          acc0 = acc1 = 0.f;
+        }
+        acc0 += r0[u];
+        acc1 += r1[u];
+      }
     }
   }
   if (cur > 0) {
-    if (tid < D) atomicAdd(d_table + cur * D + tid, acc0);
-    if (tid + 256 < D) atomicAdd(d_table + cur * D + tid + 256, acc1);
+    if (d0) atomicAdd(d_table + cur * D + tid, acc0);
+    if (d1) atomicAdd(d_table + cur * D + tid + 256, acc1);
   }
 }
 
