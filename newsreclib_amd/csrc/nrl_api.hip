@@ -442,7 +442,7 @@ static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, co
 
 // dW (I, J) += dY^T X, db (I) += colsum(dY): dY (M, I), X (M, J); split-K over M
 static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, float* db, int64_t M,
-                      hipStream_t st) {
+                      hipStream_t st, float* scratch = nullptr, size_t scratch_floats = 0) {
   const RCPlain a{dy, I, I, 0}, b{x, J, J, 1};
   const EpiAtomicWB epi{dW, J, db, J};
   if (cur_engine() == ENGINE_BF16X3) {
@@ -457,12 +457,13 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
     };
     if (I > 512 && g_wgrad_ws) {
       static const int ws_splits = [] { const char* e = getenv("NRL_WGRAD_WS_SPLITS"); return e ? atoi(e) : 32; }();
-      return launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, M >= (int64_t)ws_splits * 512 ? ws_splits : splits(256), st);
+      return launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, M >= (int64_t)ws_splits * 512 ? ws_splits : splits(256), st,
+                                                  scratch, scratch_floats);
     }
     if (I > 512) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, I, J + 1, M, splits(256), st);
     // small outputs: LDS-DMA staged, transposition at the fragment read (0.35 -> 0.30 ms at 300 x 300;
     // the 900-row gradient is faster register-staged, profiles/r01_gemm_x3_dma_probe.txt)
-    if (g_x3_dma) return launch_gemm_bf16x3_dma_tn<2, 2, 2, 5, 2>(a, b, epi, I, J + 1, M, splits(64), st);
+    if (g_x3_dma) return launch_gemm_bf16x3_dma_tn<2, 2, 2, 5, 2>(a, b, epi, I, J + 1, M, splits(64), st, scratch, scratch_floats);
     return launch_gemm_bf16x3<X3_TILE_W>(a, b, epi, I, J + 1, M, splits(64), st);
   }
   if (I > 512) return launch_gemm<NRL_TILE>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 128, 160), st);
@@ -574,6 +575,10 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
   // partial tiles of the planes weight gradients: the q|k|v slabs are dead once the attention backward has run
   const size_t scratch_avail = (bf16_planes && g_wgrad_2step) ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
   auto scratch_for = [&](size_t need) -> float* { return need <= scratch_avail ? w.qkv : nullptr; };
+  // the fp32-fed weight gradients (user encoder; the fallbacks of the news path) reduce their splits the same way, the packed
+  // q|k|v rows being dead by now as well (attention backward and in-projection dgrad have run)
+  float* const sc = g_wgrad_2step && !dqkv_head_planes && !bf16_planes ? w.qkv : nullptr;
+  const size_t sc_n = sc != nullptr ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
   if (s.aa_planes) {
     // d_pre (pool_bwd_pre) and y (out-projection epilogue, with its ones column) as planes over the same rows
@@ -582,7 +587,7 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
                                          EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st,
                                          scratch_for(wgrad_planes_g_scratch_floats(7, 5, (Q + 15) / 16, (D + 16) / 16, sp)))));
   } else {
-    NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st));
+    NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st, sc, sc_n));
   }
   // dW_o += dy^T o ; db_o += colsum(dy)
   if (s.od_planes) {
@@ -593,7 +598,7 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
                                          EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st,
                                          scratch_for(wgrad_planes_g_scratch_floats(5, 5, ncb_dy, ncb_o, sp)))));
   } else {
-    NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st));
+    NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st, sc, sc_n));
   }
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
   if (bf16_planes) {
@@ -613,7 +618,7 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
                                                 EpiAtomicWBHeads{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh},
                                                 Ip, D + 1, s.M, (int)sp, st);
   }
-  NRL_TRY(gemm_wgrad(w.dqkv, 3 * D, x_rows, D, G->in_proj_weight, G->in_proj_bias, s.M, st));
+  NRL_TRY(gemm_wgrad(w.dqkv, 3 * D, x_rows, D, G->in_proj_weight, G->in_proj_bias, s.M, st, sc, sc_n));
   return NRL_OK;
 }
 

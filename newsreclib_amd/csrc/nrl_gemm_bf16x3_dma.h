@@ -338,7 +338,7 @@ template <int WM, int WN, int TM, int TN, int S, class AOp, class BOp, class Epi
 __global__ void __launch_bounds__(WM* WN * 64)
     gemm_bf16x3_dma_tn_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N,
                               const int64_t K, const int tiles_n, const int64_t tiles_total,
-                              const int64_t k_per_split, const int nsplit) {
+                              const int64_t k_per_split, const int nsplit, float* scratch) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
   constexpr int A_BYTES = BK * BM * 4, B_BYTES = BK * BN * 4;
@@ -488,12 +488,17 @@ __global__ void __launch_bounds__(WM* WN * 64)
   else
     k_loop(std::false_type{});
 
-  store_accumulators<TM, TN>(epi, acc, m0, n0, wm, wn, l15, g, M, N);
+  if (scratch != nullptr) {   // split-K in two steps (wgrad_reduce_kernel, nrl_gemm.h)
+    const EpiStore part{scratch + (split * tiles_total + t) * (BM * BN), BN};
+    store_accumulators<TM, TN>(part, acc, 0, 0, wm, wn, l15, g, BM, BN);
+  } else {
+    store_accumulators<TM, TN>(epi, acc, m0, n0, wm, wn, l15, g, M, N);
+  }
 }
 
 template <int WM, int WN, int TM, int TN, int S, class AOp, class BOp, class Epi>
 int launch_gemm_bf16x3_dma_tn(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, int64_t K, int splits,
-                              hipStream_t stream) {
+                              hipStream_t stream, float* scratch = nullptr, size_t scratch_floats = 0) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
   const int64_t tiles_m = ceil_div(M, BM);
@@ -504,9 +509,11 @@ int launch_gemm_bf16x3_dma_tn(const AOp& A, const BOp& B, const Epi& epi, int64_
   splits = (int)ceil_div(K, kps);
   const int64_t nblocks = splits > 1 ? ceil_div(splits, 8) * 8 * tiles_total : tiles_total;
   NRL_REQUIRE(nblocks < (1LL << 31), "gemm grid too large");
+  if (splits < 2 || (size_t)splits * tiles_total * BM * BN > scratch_floats) scratch = nullptr;
   hipLaunchKernelGGL((gemm_bf16x3_dma_tn_kernel<WM, WN, TM, TN, S, AOp, BOp, Epi>), dim3((unsigned)nblocks),
-                     dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits);
+                     dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits, scratch);
   NRL_LAUNCH_CHECK();
+  if (scratch != nullptr) return launch_wgrad_reduce<BM, BN>(scratch, splits, tiles_n, tiles_total, M, N, epi, stream);
   return NRL_OK;
 }
 

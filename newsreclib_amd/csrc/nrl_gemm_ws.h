@@ -24,7 +24,8 @@ namespace nrl {
 template <int NL, int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
 __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
     gemm_bf16x3_ws_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N, const int64_t K,
-                          const int tiles_n, const int64_t tiles_total, const int64_t k_per_split, const int nsplit) {
+                          const int tiles_n, const int64_t tiles_total, const int64_t k_per_split, const int nsplit,
+                          float* scratch) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, BK = 32;
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
   constexpr int BUF = 2 * (PLANE_A + PLANE_B);
@@ -196,12 +197,17 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
     compute(tt & 1);
     __builtin_amdgcn_s_barrier();                       // barrier tt + 1
   }
-  store_accumulators<TM, TN>(epi, acc, m0, n0, wm, wn, l15, g, M, N);
+  if (scratch != nullptr) {   // split-K in two steps (wgrad_reduce_kernel, nrl_gemm.h): partial tile -> scratch[split][tile]
+    const EpiStore part{scratch + (split * tiles_total + t) * (BM * BN), BN};
+    store_accumulators<TM, TN>(part, acc, 0, 0, wm, wn, l15, g, BM, BN);
+  } else {
+    store_accumulators<TM, TN>(epi, acc, m0, n0, wm, wn, l15, g, M, N);
+  }
 }
 
 template <int NL, int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi>
 int launch_gemm_bf16x3_ws(const AOp& A, const BOp& B, const Epi& epi, int64_t M, int N, int64_t K, int splits,
-                          hipStream_t stream) {
+                          hipStream_t stream, float* scratch = nullptr, size_t scratch_floats = 0) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
   const int64_t tiles_m = ceil_div(M, BM);
@@ -210,11 +216,13 @@ int launch_gemm_bf16x3_ws(const AOp& A, const BOp& B, const Epi& epi, int64_t M,
   if (splits < 1) splits = 1;
   int64_t kps = ceil_div(ceil_div(K, splits), 32) * 32;
   splits = (int)ceil_div(K, kps);
+  if (splits < 2 || (size_t)splits * tiles_total * BM * BN > scratch_floats) scratch = nullptr;
   const int64_t nblocks = splits > 1 ? ceil_div(splits, 8) * 8 * tiles_total : tiles_total;
   NRL_REQUIRE(nblocks < (1LL << 31), "gemm grid too large");
   hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<NL, WM, WN, TM, TN, AOp, BOp, Epi>), dim3((unsigned)nblocks),
-                     dim3((NL + WM * WN) * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits);
+                     dim3((NL + WM * WN) * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits, scratch);
   NRL_LAUNCH_CHECK();
+  if (scratch != nullptr) return launch_wgrad_reduce<BM, BN>(scratch, splits, tiles_n, tiles_total, M, N, epi, stream);
   return NRL_OK;
 }
 

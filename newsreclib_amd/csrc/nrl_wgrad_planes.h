@@ -50,45 +50,7 @@ struct WgradPlanesArgs {
   float* scratch;           // (nsplit, tiles, BM x BN) partial tiles, or null: atomics straight into the gradient
 };
 
-// Split-K reduction in two steps.  With one atomic per (split, output element) a launch issues 6 - 10 M fp32 atomics on
-// 0.2 - 0.3 M addresses: ~60 us at the L2's atomic rate, whatever the batch (a third of the kernel at B = 32).  Instead every
-// workgroup stores its partial tile (16-byte coalesced stores, 26 - 42 MB per launch) and wgrad_reduce_kernel sums the
-// splits of each element in a fixed order and hands ONE value per element to the epilogue.
-template <int BM, int BN, class Epi>
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ scratch, int nsplit, int tiles_n, int tiles_total,
-                                                           int64_t M, int N, const Epi epi) {
-  constexpr int Q = BM * BN / 4;                             // float4 per tile
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)tiles_total * Q) return;
-  const int t = (int)(i / Q), q = (int)(i - (int64_t)t * Q);
-  const int r = q / (BN / 4), c = 4 * (q - r * (BN / 4));
-  const float4* src = reinterpret_cast<const float4*>(scratch) + (int64_t)t * Q + q;
-  // eight partial tiles in flight per lane, summed in split order (a fixed order: the result does not depend on timing)
-  const int64_t stride = (int64_t)tiles_total * Q;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  int s = 0;
-  for (; s + 8 <= nsplit; s += 8) {
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[(s + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-  }
-  for (; s < nsplit; ++s) {
-    const float4 v = src[s * stride];
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-  }
-  const int64_t m = (int64_t)(t / tiles_n) * BM + r;
-  const int n = (t % tiles_n) * BN + c;
-  if (m < M) {
-    const typename Epi::Row row = epi.row(m);
-    if (n < N) epi(row, m, n, a.x);
-    if (n + 1 < N) epi(row, m, n + 1, a.y);
-    if (n + 2 < N) epi(row, m, n + 2, a.z);
-    if (n + 3 < N) epi(row, m, n + 3, a.w);
-  }
-}
-
+// (split-K reduction in two steps: wgrad_reduce_kernel, nrl_gemm.h)
 // ABL (tools/wp_probe.hip only): 1 = no DMA inside the loop, 2 = no MFMAs
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesArgs P, const Epi epi) {
