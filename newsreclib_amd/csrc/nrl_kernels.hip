@@ -535,12 +535,20 @@ __global__ void __launch_bounds__(256)
   for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const int64_t row0 = g * S;
     const float4* dr = reinterpret_cast<const float4*>(d_out + g * D);
-    for (int l = wave; l < S; l += 4) {
-      const float4* yr = reinterpret_cast<const float4*>(y + (row0 + l) * D);
-      float acc = 0.f;
-      for (int d = lane; d < D4; d += 64) acc = dot4(dr[d], yr[d], acc);
-      acc = wave_sum(acc);
-      if (lane == 0) c_s[l] = acc;
+    // c_l = d_out . y_l: sixteen lanes per row, sixteen rows of the group at a time (one wave per row left every row a
+    // serial load -> reduce chain: the kernel sat at ~45 us per group however few groups there were)
+    {
+      const int gi = tid >> 4, li = tid & 15;
+      for (int l = gi; l < S; l += 16) {
+        const float4* yr = reinterpret_cast<const float4*>(y + (row0 + l) * D);
+        float acc = 0.f;
+        for (int d = li; d < D4; d += 16) acc = dot4(dr[d], yr[d], acc);
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 8, 64);
+        if (li == 0) c_s[l] = acc;
+      }
     }
     __syncthreads();
     if (wave == 0) {
