@@ -507,9 +507,17 @@ int launch_gemm_bf16x3_dma_tn(const AOp& A, const BOp& B, const Epi& epi, int64_
   if (splits < 1) splits = 1;
   int64_t kps = ceil_div(ceil_div(K, splits), 32) * 32;
   splits = (int)ceil_div(K, kps);
+  if (scratch != nullptr && splits > 1 && (size_t)splits * tiles_total * BM * BN > scratch_floats) {
+    // fewer, longer splits if that is what fits the scratch (the two-step reduction no longer pays per split in atomics)
+    const int fit = (int)(scratch_floats / ((size_t)tiles_total * BM * BN));
+    if (fit >= 2 && fit * 2 >= splits) {
+      kps = ceil_div(ceil_div(K, fit), 32) * 32;
+      splits = (int)ceil_div(K, kps);
+    }
+  }
+  if (splits < 2 || (size_t)splits * tiles_total * BM * BN > scratch_floats) scratch = nullptr;
   const int64_t nblocks = splits > 1 ? ceil_div(splits, 8) * 8 * tiles_total : tiles_total;
   NRL_REQUIRE(nblocks < (1LL << 31), "gemm grid too large");
-  if (splits < 2 || (size_t)splits * tiles_total * BM * BN > scratch_floats) scratch = nullptr;
   hipLaunchKernelGGL((gemm_bf16x3_dma_tn_kernel<WM, WN, TM, TN, S, AOp, BOp, Epi>), dim3((unsigned)nblocks),
                      dim3(WM * WN * 64), 0, stream, A, B, epi, M, N, K, tiles_n, tiles_total, kps, splits, scratch);
   NRL_LAUNCH_CHECK();
