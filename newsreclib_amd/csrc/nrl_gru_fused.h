@@ -25,18 +25,20 @@ namespace nrl {
 
 constexpr int GRU_FUSED_MAXK = 6;
 
-// Grid-wide barrier of a co-resident (cooperative) launch on one device counter: release the workgroup's h_t stores,
-// count in, spin until all `target` arrivals are in, acquire.  (cooperative_groups::grid_group::sync() measured
-// ~30 us per call here -- twice the whole fused step it was meant to save.)
+// Grid-wide barrier of a co-resident (cooperative) launch on one device counter.  The hidden state is exchanged through
+// agent-coherent (sc1, write-through) stores, so the arriving side only has to wait for ITS stores to complete
+// (vmcnt(0)) -- no `buffer_wbl2` of the XCD's whole L2, which is what made a fence-based barrier (and
+// cooperative_groups::grid_group::sync()) cost ~30 us per step; the leaving side invalidates its L2 (`buffer_inv sc1`,
+// cheap) so that the h_t lines written by the other XCDs are fetched from memory.
 __device__ __forceinline__ void gru_grid_barrier(unsigned* ctr, unsigned target) {
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's sc1 stores of h_t have reached memory
+  __syncthreads();                                         // ... and every wave's of this workgroup
   if (threadIdx.x == 0) {
-    __threadfence();
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    __threadfence();
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
   }
   __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // PERSIST = 1: the whole recurrence in ONE cooperative launch -- the workgroup's 48 columns of W_hh^T stay in registers
@@ -156,7 +158,9 @@ __global__ void __launch_bounds__(256)
       const float z = 1.0f / (1.0f + expf(-(gi_gates[o + Hd] + gh[1] + b_hh[u + Hd])));
       const float n = tanhf(gi_gates[o + 2 * Hd] + rg * hn);
       const float hp = h_prev[idx];
-      h_new[idx] = (int64_t)t < len[m] ? (1.0f - z) * n + z * hp : hp;
+      const float hv = (int64_t)t < len[m] ? (1.0f - z) * n + z * hp : hp;
+      if constexpr (PERSIST) __hip_atomic_store(h_new + idx, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+      else h_new[idx] = hv;
       if (save) {
         gi_gates[o] = rg;
         gi_gates[o + Hd] = z;
@@ -212,11 +216,12 @@ inline int gru_persistent_fwd(const float* hs0, const uint16_t* w_hi, int64_t ld
                               const int64_t* len, int64_t T, int64_t B, int Hd, float* ghn0, unsigned* barrier_ctr,
                               hipStream_t stream, bool* done) {
   *done = false;
-  // OFF by default (NRL_GRU_PERSISTENT=1 enables): measured SLOWER than one launch per step -- LSTUR step 10.97 vs 9.92 ms
-  // at B = 128, Hd = 700, T = 50, i.e. ~36 us per step against 14.5 us.  The device-scope release / acquire a grid
-  // barrier needs on this 8-XCD part writes back and invalidates the XCD's whole L2 every step (buffer_wbl2 /
-  // buffer_inv sc1), which a kernel boundary does once and in hardware; cooperative_groups' grid.sync() costs the same.
-  // What remains to try: exchanging h_t through sc1 (agent-coherent) loads / stores only, with no full fence.
+  // OFF by default (NRL_GRU_PERSISTENT=1 enables): measured SLOWER than one launch per step -- LSTUR step 10.15 vs 9.55 ms at
+  // B = 128, Hd = 700, T = 50, i.e. ~27 us per time step against 15.4 us.  History: with a fence-based barrier (and with
+  // cooperative_groups' grid.sync()) a step cost ~36 us -- the device-scope release writes back the XCD's whole L2; exchanging
+  // h_t through sc1 stores + an acquire-only barrier (gru_grid_barrier) brought it to ~27 us.  What is left is the round trip
+  // of 176 workgroups on 8 XCDs through one memory-side counter plus a cold L2 after the invalidate, against the ~5 us a
+  // kernel boundary costs in a back-to-back stream.
   static const bool on = [] { const char* e = getenv("NRL_GRU_PERSISTENT"); return e != nullptr && e[0] == '1'; }();
   if (!on || B == 0 || T <= 1) return NRL_OK;
   const int tr = Hd >= 512 ? 2 : 1;
