@@ -389,6 +389,18 @@ static Epi with_stream(Epi e, int64_t M, int N) {
 template <class AOp, class Epi>
 static int rp_dispatch(const AOp& a, const RpImage& b, const Epi& epi_in, int64_t M, int N, int K, hipStream_t st) {
   const Epi epi = with_stream(epi_in, M, N);
+  // Few rows (the user encoder: M = B * H = 50 workgroups of 128 rows at B = 128): 16-row panels -- twice the workgroups, half
+  // the MFMA work per wave and k-block; the kernel's time there is one panel's k-loop latency (NRL_RP_HALF_ROWS=0 disables)
+  static const int64_t half_rows = [] { const char* e = getenv("NRL_RP_HALF_ROWS"); return e ? atoll(e) : (int64_t)16384; }();
+  if constexpr (std::is_same<AOp, KCPlain>::value) {
+    if (M <= half_rows) {
+      switch (b.nblk) {
+        case 13: return launch_rp_gemm<13, 4, 0, 1>(a, b, epi, M, N, K, st);
+        case 19: return launch_rp_gemm<19, 4, 0, 1>(a, b, epi, M, N, K, st);
+        case 20: return launch_rp_gemm<20, 4, 0, 1>(a, b, epi, M, N, K, st);
+      }
+    }
+  }
   switch (b.nblk) {
     case 13: return launch_rp_gemm<13>(a, b, epi, M, N, K, st);
     case 19: return launch_rp_gemm<19>(a, b, epi, M, N, K, st);

@@ -268,8 +268,10 @@ template <class T>
 struct RpPreSplit<T, std::enable_if_t<T::kPreSplit>> : std::true_type {};
 
 // ---- kernel ------------------------------------------------------------------------------------------
-// WAVES wavefronts x 32 rows each; NBLK = ceil(N / 16) column blocks per wave; LDS ring of 2 k-block chunks.
-template <int NBLK, int WAVES, class AOp, class Epi, int DEEP = 0>
+// WAVES wavefronts x 16 RB rows each (RB = 2 row blocks; RB = 1 halves the MFMA work of a k-block per wave and doubles the
+// workgroup count: for the few-row launches of the user encoder, where a panel's k-loop latency is the whole kernel);
+// NBLK = ceil(N / 16) column blocks per wave; LDS ring of 2 k-block chunks.
+template <int NBLK, int WAVES, class AOp, class Epi, int DEEP = 0, int RB = 2>
 __global__ void __launch_bounds__(WAVES * 64, 2)
     rp_gemm_kernel(const AOp A, const uint16_t* __restrict__ img, const Epi epi, const int64_t M, const int N,
                    const int K, const int kblocks) {
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.x * (WAVES * 32);
+  const int64_t m0 = (int64_t)blockIdx.x * (WAVES * 16 * RB);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
   // this wave's share of a chunk: pieces wave, wave + WAVES, ... (clamped: a duplicate rewrites the same bytes)
@@ -297,25 +299,25 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     }
   };
 
-  typename AOp::State st[2];
-  int64_t rowi[2];
+  typename AOp::State st[RB];
+  int64_t rowi[RB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    rowi[i] = m0 + wave * 32 + i * 16 + l15;
+  for (int i = 0; i < RB; ++i) {
+    rowi[i] = m0 + wave * (16 * RB) + i * 16 + l15;
     st[i] = A.init(rowi[i]);
   }
-  auto load_raw = [&](int kb, float4 (&r)[2][2]) {
+  auto load_raw = [&](int kb, float4 (&r)[RB][2]) {
     const int k = kb * 32 + 8 * g;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
       r[i][0] = A.load(st[i], k, K);
       r[i][1] = A.load(st[i], k + 4, K);
     }
   };
-  auto convert = [&](int kb, float4 (&r)[2][2], bf16x8 (&ah)[2], bf16x8 (&al)[2]) {
+  auto convert = [&](int kb, float4 (&r)[RB][2], bf16x8 (&ah)[RB], bf16x8 (&al)[RB]) {
     const int k = kb * 32 + 8 * g;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
       A.finish(r[i][0], st[i], rowi[i], k, K, true);
       A.finish(r[i][1], st[i], rowi[i], k + 4, K, true);
       if constexpr (RpPreSplit<AOp>::value) {
@@ -327,9 +329,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     }
   };
 
-  f32x4 acc[2][NBLK];
+  f32x4 acc[RB][NBLK];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -346,7 +348,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
       bl[jj] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + 1024);
     }
   };
-  auto mfma_pair = [&](int p, const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const bf16x8 (&bh)[2],
+  auto mfma_pair = [&](int p, const bf16x8 (&ah)[RB], const bf16x8 (&al)[RB], const bf16x8 (&bh)[2],
                        const bf16x8 (&bl)[2]) {
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass)
@@ -354,11 +356,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
       for (int jj = 0; jj < 2; ++jj)
         if (2 * p + jj < NBLK)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < RB; ++i)
             acc[i][2 * p + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i] : ah[i],
                                                                         pass == 0 ? bl[jj] : bh[jj], acc[i][2 * p + jj], 0, 0, 0);
   };
-  auto mfma_chunk = [&](int slot, const bf16x8 (&ah)[2], const bf16x8 (&al)[2]) {
+  auto mfma_chunk = [&](int slot, const bf16x8 (&ah)[RB], const bf16x8 (&al)[RB]) {
     const unsigned char* base = smem + slot * CHUNK + lane * 16;
     bf16x8 bh0[2], bl0[2], bh1[2], bl1[2];
     read_pair(base, 0, bh0, bl0);
@@ -377,9 +379,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     for (int p = 0; p < NPAIR; ++p) {
       if (p + 1 < NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       if (2 * p + 1 < NBLK) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * RB, 0);
       } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * RB, 0);
       }
     }
   };
@@ -387,21 +389,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
   // k-loop.  The (hi, lo) fragments of k-block kb are loop-carried; the raw loads of k-block kb + 1 are issued at
   // the top of iteration kb and converted at its END, behind ~1800 cycles of MFMAs -- hipcc's own wait for them
   // (a vmcnt(0): it cannot see the asm DMA) then finds both the loads and the chunk DMA long landed.
-  bf16x8 ah[2], al[2];
+  bf16x8 ah[RB], al[RB];
   if constexpr (DEEP) {
     // two k-blocks of raw A loads in flight (two NAMED register sets, loop unrolled by two): the rows of k-block
     // kb + 2 are requested at the top of iteration kb and converted at the end of iteration kb + 1.  The chunk DMA
     // of an iteration is issued BEFORE its four row loads, so `vmcnt(4)` at the top of the next iteration covers it.
-    float4 ra[2][2], rb[2][2];
+    float4 ra[RB][2], rb[RB][2];
     auto clampk = [&](int k) { return k < kblocks ? k : kblocks - 1; };
     {
-      float4 r0[2][2];
+      float4 r0[RB][2];
       issue(0, 0);
       load_raw(0, r0);
       load_raw(clampk(1), ra);
       convert(0, r0, ah, al);
     }
-    auto step = [&](int kb, float4 (&cur)[2][2], float4 (&nxt)[2][2]) {
+    auto step = [&](int kb, float4 (&cur)[RB][2], float4 (&nxt)[RB][2]) {
       wait_vmcnt<4>();
       __builtin_amdgcn_s_barrier();
       issue(clampk(kb + 1), (kb + 1) & 1);
@@ -417,7 +419,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     }
   } else {
     {
-      float4 r0[2][2];
+      float4 r0[RB][2];
       issue(0, 0);
       load_raw(0, r0);
       convert(0, r0, ah, al);
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
       // the last iteration re-issues its own chunk into the idle slot and re-loads its own rows: uniform control
       // flow instead of a branch (one redundant chunk per workgroup)
       const int kn = kb + 1 < kblocks ? kb + 1 : kb;
-      float4 r[2][2];
+      float4 r[RB][2];
       issue(kn, (kb + 1) & 1);
       load_raw(kn, r);
       __builtin_amdgcn_sched_barrier(0);
@@ -440,16 +442,16 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     }
   }
 
-  store_accumulators<2, NBLK>(epi, acc, m0, 0, wave, 0, l15, g, M, N);
+  store_accumulators<RB, NBLK>(epi, acc, m0, 0, wave, 0, l15, g, M, N);
 }
 
-template <int NBLK, int WAVES = 4, int DEEP = 0, class AOp, class Epi>
+template <int NBLK, int WAVES = 4, int DEEP = 0, int RB = 2, class AOp, class Epi>
 int launch_rp_gemm(const AOp& A, const RpImage& B, const Epi& epi, int64_t M, int N, int K, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
   NRL_REQUIRE(B.img != nullptr && B.nblk == NBLK && N <= NBLK * 16 && B.kblocks * 32 >= K, "row-panel GEMM: image / shape mismatch");
-  const int64_t blocks = ceil_div(M, WAVES * 32);
+  const int64_t blocks = ceil_div(M, WAVES * 16 * RB);
   NRL_REQUIRE(blocks < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, stream, A,
+  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP, RB>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, stream, A,
                      B.img, epi, M, N, K, B.kblocks);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
