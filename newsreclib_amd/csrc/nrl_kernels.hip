@@ -565,23 +565,37 @@ __global__ void __launch_bounds__(256)
       for (int c4 = cc; c4 < Q4; c4 += cpp, ++it) {
         const float4 qn = q4[c4];
         float4 acc = accq[it & 3];
-        for (int l = rg; l < S; l += RG) {
-          const float da = c_s[l];
-          const float4 tv = t4[(int64_t)l * Q4 + c4];
-          acc.x = fmaf(da, tv.x, acc.x); acc.y = fmaf(da, tv.y, acc.y);
-          acc.z = fmaf(da, tv.z, acc.z); acc.w = fmaf(da, tv.w, acc.w);
-          const float4 dp = make_float4(da * qn.x * (1.0f - tv.x * tv.x), da * qn.y * (1.0f - tv.y * tv.y),
-                                        da * qn.z * (1.0f - tv.z * tv.z), da * qn.w * (1.0f - tv.w * tv.w));
-          if (dpre_planes != nullptr) {
-            const int64_t m = row0 + l;
-            uint32_t h0, l0, h1, l1;
-            split_pair(dp.x, dp.y, h0, l0);
-            split_pair(dp.z, dp.w, h1, l1);
-            unsigned char* dst = dpre_planes + ((m >> 4) * ncb_q + (c4 >> 2)) * 1024 + (m & 15) * 32 + (c4 & 3) * 8;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l0, l1);
-          } else {
-            t4[(int64_t)l * Q4 + c4] = dp;
+        // eight rows of t in flight per lane (one row at a time, the in-place store of row l ordered the load of row
+        // l + RG behind it: a serial chain of ~2 us memory round trips per row, ~40 us per group whatever the batch)
+        for (int l0 = rg; l0 < S; l0 += 8 * RG) {
+          float4 tv8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int l = l0 + u * RG;
+            tv8[u] = l < S ? t4[(int64_t)l * Q4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int l = l0 + u * RG;
+            if (l < S) {
+              const float da = c_s[l];
+              const float4 tv = tv8[u];
+              acc.x = fmaf(da, tv.x, acc.x); acc.y = fmaf(da, tv.y, acc.y);
+              acc.z = fmaf(da, tv.z, acc.z); acc.w = fmaf(da, tv.w, acc.w);
+              const float4 dp = make_float4(da * qn.x * (1.0f - tv.x * tv.x), da * qn.y * (1.0f - tv.y * tv.y),
+                                            da * qn.z * (1.0f - tv.z * tv.z), da * qn.w * (1.0f - tv.w * tv.w));
+              if (dpre_planes != nullptr) {
+                const int64_t m = row0 + l;
+                uint32_t h0, l0_, h1, l1;
+                split_pair(dp.x, dp.y, h0, l0_);
+                split_pair(dp.z, dp.w, h1, l1);
+                unsigned char* dst = dpre_planes + ((m >> 4) * ncb_q + (c4 >> 2)) * 1024 + (m & 15) * 32 + (c4 & 3) * 8;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l0_, l1);
+              } else {
+                t4[(int64_t)l * Q4 + c4] = dp;
+              }
+            }
           }
         }
         accq[it & 3] = acc;
