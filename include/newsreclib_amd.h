@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 8
+#define NRL_ABI_VERSION 9
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -99,6 +99,9 @@ int nrl_get_gemm_engine(void);
  *   planes for the additive-attention GEMMs;  "wgrad_ws": wave-specialised kernel for the 900-row weight
  *   gradient.  A backward must run under the options of its forward (they select workspace formats). */
 int nrl_set_option(const char* name, int32_t value);
+/* Bit mask of the current switch values (bit order = the list above).  The switches select private workspace formats, so
+ * a host that lets them change at run time compares the mask of a forward with the one at its backward. */
+int32_t nrl_get_options(void);
 
 /* ---- measurement hook (bench.py "roofline"): HIP-event timing of the dominant kernel, the
  * in-projection GEMM with the fused embedding gather, recorded on the launch stream.  The ProfScope

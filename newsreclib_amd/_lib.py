@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "nrl_set_gemm_engine": (c_int32, [c_int32]),
     "nrl_get_gemm_engine": (c_int32, []),
     "nrl_set_option": (c_int32, [c_char_p, c_int32]),
+    "nrl_get_options": (c_int32, []),
     "nrl_prof_enable": (c_int32, [c_int32]),
     "nrl_prof_read": (c_int32, [POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "nrl_dropout_key": (c_uint32, [c_uint64, c_uint32]),
@@ -205,6 +206,18 @@ def get_gemm_engine() -> str:
 def set_option(name: str, value: bool) -> None:
     """Kernel-selection switch ("news_fused", "rowpanel", "x3_dma") for A/B measurements and equivalence tests."""
     check(load().nrl_set_option(name.encode(), int(bool(value))), "nrl_set_option")
+
+
+def options_mask() -> int:
+    """Bit mask of the kernel-selection switches (they choose private workspace formats: an autograd forward records it
+    and its backward refuses to run under another one)."""
+    return int(load().nrl_get_options())
+
+
+def require_options(mask: int, what: str) -> None:
+    if options_mask() != mask:
+        raise RuntimeError(f"newsreclib_amd: a kernel-selection switch (nrl_set_option / NRL_* environment) changed between "
+                           f"the forward and the backward of {what}; the saved workspace is in the forward's format")
 
 
 def engine_code() -> int:

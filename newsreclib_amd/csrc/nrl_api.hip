@@ -732,6 +732,16 @@ int nrl_set_option(const char* name, int32_t value) {
   return NRL_OK;
 }
 
+// bit mask of the kernel-selection switches, in the order nrl_set_option lists them: a backward whose forward ran under
+// another mask would read a workspace in the wrong private format (ops.py compares the two and refuses)
+int32_t nrl_get_options(void) {
+  const bool flags[] = {g_news_fused,  g_news_fused_bwd, g_news_attn_mfma, g_news_planes, g_news_od_planes,
+                        g_news_aa_planes, g_wgrad_2step, g_wgrad_ws,       g_rowpanel,    g_x3_dma};
+  int32_t m = 0;
+  for (size_t i = 0; i < sizeof(flags) / sizeof(flags[0]); ++i) m |= flags[i] ? (1 << i) : 0;
+  return m;
+}
+
 uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream) { return dropout_key(seed, stream); }
 
 int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, uint32_t stream,

@@ -98,7 +98,7 @@ class NewsEncoderFn(torch.autograd.Function):
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
-            ctx.table_grad_hook, ctx.engine = table_grad_hook, engine
+            ctx.table_grad_hook, ctx.engine, ctx.options = table_grad_hook, engine, _lib.options_mask()
         return out
 
     @staticmethod
@@ -110,6 +110,7 @@ class NewsEncoderFn(torch.autograd.Function):
         N, L = ids.shape
         V, D = emb.shape
         d_out = _chk(d_out, torch.float32, "d_out")
+        _lib.require_options(ctx.options, "the news encoder")   # the workspace formats the forward wrote
         bp = _block_params(params[1:], heads, ctx.engine)      # the engine the forward ran under
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         bg = _block_grads(bufs[1:])

@@ -230,6 +230,25 @@ def test_news_path_format_switches_agree(N, L, option):
         assert _maxerr(g0, res[1][1][k]) <= 1e-4 * scale, (option, k)
 
 
+def test_backward_refuses_a_switch_changed_since_the_forward():
+    """The switches select private workspace formats: a backward under another setting than its forward must fail loudly
+    (it would read planes where packed rows were written), not return wrong gradients."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.news_encoder import MHSAAddAtt
+    _lib.set_gemm_engine("bf16x3")
+    params = _news_params(vocab=53, seed=3)
+    enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
+    enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+    enc = enc.to(DEV).train()
+    out = enc(torch.randint(0, 53, (5, 30)).to(DEV), seed=1)
+    _lib.set_option("news_planes", False)
+    try:
+        with pytest.raises(RuntimeError, match="changed between"):
+            out.sum().backward()
+    finally:
+        _lib.set_option("news_planes", True)
+
+
 @pytest.mark.parametrize("B,H", [(3, 4), (5, 50), (40, 7), (130, 3)])
 def test_user_encoder_fwd_and_bwd_vs_oracle(B, H):
     from newsreclib_amd.user_encoder import UserEncoder
