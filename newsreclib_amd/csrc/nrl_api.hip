@@ -18,6 +18,7 @@
 #include "nrl_rowpanel.h"
 #include "nrl_gemm_ws.h"
 #include "nrl_news_fused.h"
+#include "nrl_news_tail.h"
 #include "nrl_wgrad_planes.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
@@ -164,6 +165,22 @@ static bool g_news_aa_planes = [] {
   return !(e != nullptr && e[0] == '0');
 }();
 
+// NRL_NEWS_TAIL=0: the back half of the fused news path (out-projection, additive attention, pooling) stays on the
+// row-panel GEMMs + pool_fwd.  Default (with news_aa_planes): ONE kernel per forward, nrl_news_tail.h -- y exists only as
+// planes (training) or not at all (evaluation).
+static bool g_news_tail = [] {
+  const char* e = getenv("NRL_NEWS_TAIL");
+  return !(e != nullptr && e[0] == '0');
+}();
+
+// NRL_NEWS_TAIL_BWD=0: the additive-attention backward of the fused news path stays on pool_bwd_pre + the row-panel
+// activation-gradient GEMM (the forward tail then also saves the tanh output).  Default (with news_tail): ONE kernel that
+// recomputes tanh from the y planes (news_tail_bwd_kernel).
+static bool g_news_tail_bwd = [] {
+  const char* e = getenv("NRL_NEWS_TAIL_BWD");
+  return !(e != nullptr && e[0] == '0');
+}();
+
 // NRL_WGRAD_2STEP=0: the planes weight gradients add their split-K partial tiles with atomics instead of storing them and
 // reducing in a second small kernel (nrl_wgrad_planes.h: ~60 us of L2 atomics per launch become ~25 us)
 static bool g_wgrad_2step = [] {
@@ -194,6 +211,8 @@ struct BlockShape {
   AttnGeom geom;
   int64_t pad_rows = 0; // news encoder: token rows padded to 32 per news (fragment-block planes), else 0
   bool aa_planes = false;  // fused news path: y also / d_pre only as planes (BlockWs::yp, tp) for the additive-attention GEMMs
+  bool tail_bwd = false;   // ... and the additive-attention backward recomputes tanh in one kernel (no t buffer)
+  bool tail = false;       // fused news path: the forward's back half ran as ONE kernel (nrl_news_tail.h): y exists only as planes
   bool od_planes = false;  // fused news path: `o` and `dy` are (hi, lo) bf16 fragment-block planes over the real rows (19
                            // block columns at D = 300; `o` in the head-permuted feature order), not fp32 rows
 };
@@ -208,7 +227,7 @@ struct BlockWs {
 // the five narrow projections of the block that run on the row-panel kernel: forward out-projection and
 // additive-attention linear, and the three activation-gradient GEMMs
 struct BlockRp {
-  RpImage out_f, att_f, att_d, out_d, in_d, in_heads, in_d_hp, out_f_perm;
+  RpImage out_f, att_f, att_d, out_d, in_d, in_heads, in_d_hp, out_f_perm, tail_o, tail_a, tail_ad;
   bool on = false;
 };
 static bool block_rp_ok(int D, int Q) { return g_rowpanel && rp_nblk_supported(D) && rp_nblk_supported(Q); }
@@ -221,7 +240,9 @@ static size_t block_rp_elems(int D, int Q) {
          + rp_image_elems(nd, rp_kblocks(3 * D, false))     // in dgrad (N = D, K = 3D)
          + rp_image_elems((D / 20) * 4, NF_KB)              // per-head q|k|v image of the fused news encoder
          + rp_image_elems(nd, (D / 20) * 2)                 // its in-projection dgrad over head planes (K' = heads * 64)
-         + rp_image_elems(nd, rp_kblocks(D + 32, false));   // its out-projection forward over the head-permuted `o` planes
+         + rp_image_elems(nd, rp_kblocks(D + 32, false))    // its out-projection forward over the head-permuted `o` planes
+         + rp_image_elems(NT_FB, NT_KB) + rp_image_elems(NT_QB, NT_KS)    // the two images of the fused tail (nrl_news_tail.h)
+         + rp_image_elems(NT_FB, NT_QS);                                   // ... and W_a^T for its backward
 }
 
 static size_t plane_elems(int D, int Q) {
@@ -362,6 +383,19 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
       bp->rp.out_f_perm.kblocks = (16 * (fused_heads + (fused_heads + 3) / 4) + 31) / 32;
       if (fill) rp_jobs_add_kperm(&jobs, P->out_proj_weight, D, 1, D, fused_heads, q, nd);
       q += rp_image_elems(nd, rp_kblocks(D + 32, false));
+      // fused tail (nrl_news_tail.h): W_o over the plane slots with b_o at the ones slot; W_a in kappa order with b_a
+      if (g_news_tail && news_tail_ok(32, D, Q, fused_heads)) {
+        bp->rp.tail_o.img = q; bp->rp.tail_o.nblk = NT_FB; bp->rp.tail_o.kblocks = NT_KB;
+        if (fill) rp_jobs_add_kperm(&jobs, P->out_proj_weight, D, 1, D, fused_heads, q, NT_FB, P->out_proj_bias);
+        q += rp_image_elems(NT_FB, NT_KB);
+        bp->rp.tail_a.img = q; bp->rp.tail_a.nblk = NT_QB; bp->rp.tail_a.kblocks = NT_KS;
+        if (fill) rp_jobs_add_kappa(&jobs, P->att_weight, D, 1, Q, D, P->att_bias, q, NT_QB);
+        q += rp_image_elems(NT_QB, NT_KS);
+        // backward: dy^T = W_a^T d_pre^T, element (n = feature, k = query) = W_a[k][n], queries in kappa order
+        bp->rp.tail_ad.img = q; bp->rp.tail_ad.nblk = NT_FB; bp->rp.tail_ad.kblocks = NT_QS;
+        if (fill && news_tail_bwd_ok(32, D, Q, fused_heads)) rp_jobs_add_kappa(&jobs, P->att_weight, 1, D, D, Q, nullptr, q, NT_FB);
+        q += rp_image_elems(NT_FB, NT_QS);
+      }
     }
     if (fill) NRL_TRY(rp_jobs_launch(jobs, st));
   }
@@ -555,8 +589,24 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
   unsigned char* const tpl = reinterpret_cast<unsigned char*>(w.tp);
   if (s.aa_planes && s.M % 32 != 0)
     NRL_HIP(hipMemsetAsync(tpl + (s.M / 32) * 2 * ncb_q * 1024, 0, (size_t)2 * ncb_q * 1024, st));
-  NRL_TRY(pool_bwd_pre(d_out, w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st,
-                       s.aa_planes ? tpl : nullptr));
+  if (s.tail_bwd) {
+    // tanh recomputed from the y planes, d_pre / dq_a / dy in ONE kernel (nrl_news_tail.h)
+    const int ncb = (D + 15) / 16;
+    unsigned char* dyp = reinterpret_cast<unsigned char*>(w.dy);
+    if (s.M % 32 != 0)
+      NRL_HIP(hipMemsetAsync(dyp + (s.M / 32) * 2 * ncb * 1024, 0, (size_t)2 * ncb * 1024, st));
+    NewsTailBwdArgs b;
+    b.y_planes = reinterpret_cast<const unsigned char*>(w.yp); b.w = w.w; b.d_out = d_out; b.img_a = bp.rp.tail_a.img;
+    b.img_ad = bp.rp.tail_ad.img; b.q_a = P->att_query; b.n_news = s.pool_groups; b.L = s.pool_len; b.D = D; b.Q = Q;
+    b.drop2 = drop2; b.dpre_planes = tpl; b.dy_planes = dyp; b.dq_a = G->att_query;
+    NRL_TRY(launch_news_tail_bwd(b, st));
+    // d_o = dy W_o
+    NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
+    if (!attention_elsewhere) NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+    return NRL_OK;
+  }
+  NRL_TRY(pool_bwd_pre(d_out, s.tail ? nullptr : w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st,
+                       s.aa_planes ? tpl : nullptr, s.tail ? w.yp : nullptr));
   if (s.od_planes) {
     // dy = (d_pre W_a + w * d_out) * dropout2, written ONCE as (hi, lo) planes: its only readers are the two GEMMs below
     const int ncb = (D + 15) / 16;
@@ -647,6 +697,15 @@ static bool news_fused_on(const BlockShape& s, int L) {
          news_fused_ok(L, s.D, s.heads);
 }
 
+// ... and its back half as one kernel too, when `o` arrives as planes and the y / d_pre planes exist
+static bool news_tail_on(const BlockShape& s, int L, const BlockWs& w) {
+  return g_news_tail && s.od_planes && g_news_aa_planes && w.yp != nullptr && news_tail_ok(L, s.D, s.Q, s.heads);
+}
+
+static bool news_tail_bwd_on(const BlockShape& s, int L, const BlockWs& w) {
+  return news_tail_on(s, L, w) && g_news_tail_bwd && w.tp != nullptr && news_tail_bwd_ok(L, s.D, s.Q, s.heads);
+}
+
 static BlockShape news_shape(const NrlBlockParams* p, int64_t n_news, int L) {
   BlockShape s;
   s.D = p->embed_dim; s.Q = p->query_dim; s.heads = p->num_heads; s.dh = s.D / s.heads;
@@ -722,12 +781,14 @@ int nrl_set_option(const char* name, int32_t value) {
                : !strcmp(name, "news_planes") ? &g_news_planes
                : !strcmp(name, "news_od_planes") ? &g_news_od_planes
                : !strcmp(name, "news_aa_planes") ? &g_news_aa_planes
+               : !strcmp(name, "news_tail") ? &g_news_tail
+               : !strcmp(name, "news_tail_bwd") ? &g_news_tail_bwd
                : !strcmp(name, "wgrad_2step") ? &g_wgrad_2step
                : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
                : !strcmp(name, "rowpanel") ? &g_rowpanel
                : !strcmp(name, "x3_dma")   ? &g_x3_dma
                                            : nullptr;
-  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, news_aa_planes, wgrad_ws, rowpanel, x3_dma)", name);
+  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, news_aa_planes, news_tail, news_tail_bwd, wgrad_2step, wgrad_ws, rowpanel, x3_dma)", name);
   *flag = value != 0;
   return NRL_OK;
 }
@@ -736,7 +797,7 @@ int nrl_set_option(const char* name, int32_t value) {
 // another mask would read a workspace in the wrong private format (ops.py compares the two and refuses)
 int32_t nrl_get_options(void) {
   const bool flags[] = {g_news_fused,  g_news_fused_bwd, g_news_attn_mfma, g_news_planes, g_news_od_planes,
-                        g_news_aa_planes, g_wgrad_2step, g_wgrad_ws,       g_rowpanel,    g_x3_dma};
+                        g_news_aa_planes, g_wgrad_2step, g_wgrad_ws,       g_rowpanel,    g_x3_dma, g_news_tail, g_news_tail_bwd};
   int32_t m = 0;
   for (size_t i = 0; i < sizeof(flags) / sizeof(flags[0]); ++i) m |= flags[i] ? (1 << i) : 0;
   return m;
@@ -799,6 +860,21 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
       ProfScope prof(st, 2.0 * (double)s.M * 3.0 * s.D * s.D + 4.0 * (double)s.M * seq_len * s.D);
       NRL_TRY(launch_news_fused_fwd(a, st));
     }
+    if (news_tail_on(sf, seq_len, w)) {
+      // out-projection + dropout + additive attention + pooling in ONE kernel (nrl_news_tail.h)
+      NewsTailArgs t;
+      t.o_planes = a.o_planes; t.img_o = bp.rp.tail_o.img; t.img_a = bp.rp.tail_a.img; t.q_a = p->att_query;
+      t.n_news = n_news; t.L = seq_len; t.D = s.D; t.Q = s.Q; t.drop2 = d2; t.out = out;
+      t.y_planes = nullptr; t.t = nullptr; t.w = nullptr;
+      if (save_for_backward) {
+        t.y_planes = reinterpret_cast<unsigned char*>(w.yp); t.w = w.w;
+        t.t = news_tail_bwd_on(sf, seq_len, w) ? nullptr : w.t;     // the fused backward recomputes the tanh output
+        const int ncb_y = (s.D + 16) / 16;
+        if (s.M % 32 != 0)   // rows past M in the last 32-row k-tile of the weight gradient
+          NRL_HIP(hipMemsetAsync(t.y_planes + (s.M / 32) * 2 * ncb_y * 1024, 0, (size_t)2 * ncb_y * 1024, st));
+      }
+      return launch_news_tail_fwd(t, st);
+    }
     return block_fwd_tail(p, sf, w, bp, d2, out, st);
   }
   KCGather a_in{emb_table, ids, s.M, s.D, d1, save_for_backward ? w.x : nullptr};
@@ -827,6 +903,8 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   BlockShape sb_ = s;
   sb_.od_planes = planes && g_news_od_planes;
   sb_.aa_planes = sb_.od_planes && g_news_aa_planes && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
+  sb_.tail = news_tail_on(sb_, seq_len, w);
+  sb_.tail_bwd = sb_.tail && sb_.aa_planes && news_tail_bwd_on(sb_, seq_len, w);
   NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
   if (phase != 2) {
     NRL_TRY(block_bwd_phase1(p, g, sb_, w, bp, d2, d_out, st, fused || slabs));

@@ -34,10 +34,11 @@ int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* ls
 int pool_fwd(const float* t, const float* q_a, const float* y, int64_t groups, int S, int Q, int D,
              float* w, float* out, hipStream_t stream);
 // turns t (tanh outputs) IN PLACE into d_pre = da * q_a * (1 - t^2) and adds dq_a; with `dpre_planes` d_pre is written
-// there instead, as (hi, lo) bf16 fragment-block planes over the rows ((Q + 15) / 16 block columns), and t is not touched
+// there instead, as (hi, lo) bf16 fragment-block planes over the rows ((Q + 15) / 16 block columns), and t is not touched;
+// with `y_planes` (and y == nullptr) y is read from its planes ((D + 16) / 16 block columns: the fused news tail)
 int pool_bwd_pre(const float* d_out, const float* y, const float* w, float* t_dpre,
                  const float* q_a, float* dq_a, int64_t groups, int S, int Q, int D,
-                 hipStream_t stream, void* dpre_planes = nullptr);
+                 hipStream_t stream, void* dpre_planes = nullptr, const void* y_planes = nullptr);
 
 int to_dense_fwd(const float* x, const int64_t* offsets, int64_t B, int64_t max_len, int D,
                  float* dense, hipStream_t stream);

@@ -515,7 +515,10 @@ __global__ void __launch_bounds__(256)
     pool_bwd_pre_kernel(const float* __restrict__ d_out, const float* __restrict__ y,
                         const float* __restrict__ w, float* __restrict__ t_dpre,
                         const float* __restrict__ q_a, float* __restrict__ dq_a, int64_t groups, int S, int Q,
-                        int D, unsigned char* __restrict__ dpre_planes, int ncb_q) {
+                        int D, unsigned char* __restrict__ dpre_planes, int ncb_q,
+                        const unsigned char* __restrict__ y_planes, int ncb_y) {
+  // y_planes != nullptr (y == nullptr): y exists only as (hi, lo) bf16 fragment-block planes over the rows (the fused news
+  // tail, nrl_news_tail.h, never writes it as fp32) and enters the dot products as hi + lo
   // dpre_planes != nullptr: d_pre goes out as (hi, lo) bf16 fragment-block planes over the rows (KCPlanesG; its readers
   // are the additive-attention dgrad and weight-gradient GEMMs only) and t is left as it is
   extern __shared__ float sm[];  // c[S] -> da[S]
@@ -540,9 +543,23 @@ __global__ void __launch_bounds__(256)
     {
       const int gi = tid >> 4, li = tid & 15;
       for (int l = gi; l < S; l += 16) {
-        const float4* yr = reinterpret_cast<const float4*>(y + (row0 + l) * D);
         float acc = 0.f;
-        for (int d = li; d < D4; d += 16) acc = dot4(dr[d], yr[d], acc);
+        if (y_planes != nullptr) {
+          const int64_t m = row0 + l;
+          const unsigned char* blk = y_planes + (m >> 4) * ncb_y * 1024 + (m & 15) * 32;
+          for (int d = li; d < D4; d += 16) {
+            const unsigned char* src = blk + (d >> 2) * 1024 + (d & 3) * 8;
+            const uint2 h = *reinterpret_cast<const uint2*>(src), lo = *reinterpret_cast<const uint2*>(src + 512);
+            const float4 yv = make_float4(__builtin_bit_cast(float, h.x << 16) + __builtin_bit_cast(float, lo.x << 16),
+                                          __builtin_bit_cast(float, h.x & 0xffff0000u) + __builtin_bit_cast(float, lo.x & 0xffff0000u),
+                                          __builtin_bit_cast(float, h.y << 16) + __builtin_bit_cast(float, lo.y << 16),
+                                          __builtin_bit_cast(float, h.y & 0xffff0000u) + __builtin_bit_cast(float, lo.y & 0xffff0000u));
+            acc = dot4(dr[d], yv, acc);
+          }
+        } else {
+          const float4* yr = reinterpret_cast<const float4*>(y + (row0 + l) * D);
+          for (int d = li; d < D4; d += 16) acc = dot4(dr[d], yr[d], acc);
+        }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
@@ -642,14 +659,17 @@ int pool_fwd(const float* t, const float* q_a, const float* y, int64_t groups, i
 }
 
 int pool_bwd_pre(const float* d_out, const float* y, const float* w, float* t_dpre, const float* q_a,
-                 float* dq_a, int64_t groups, int S, int Q, int D, hipStream_t stream, void* dpre_planes) {
+                 float* dq_a, int64_t groups, int S, int Q, int D, hipStream_t stream, void* dpre_planes,
+                 const void* y_planes) {
   if (groups == 0) return NRL_OK;
+  NRL_REQUIRE((y != nullptr) != (y_planes != nullptr), "pool_bwd_pre: y as fp32 rows or as planes");
   NRL_REQUIRE(S > 0 && S <= 8192 && groups < (1LL << 31), "pool_bwd_pre: bad shape");
   NRL_REQUIRE(Q % 4 == 0 && D % 4 == 0, "pool_bwd_pre: Q and D must be multiples of 4");
   NRL_REQUIRE(Q <= 4096, "pool_bwd_pre: query_dim > 4096 unsupported");
   const unsigned grid = (unsigned)(groups < 2048 ? groups : 2048);  // 8 workgroups per CU, persistent over groups
   hipLaunchKernelGGL(pool_bwd_pre_kernel, dim3(grid), dim3(256), S * sizeof(float), stream, d_out, y, w, t_dpre,
-                     q_a, dq_a, groups, S, Q, D, (unsigned char*)dpre_planes, (Q + 15) / 16);
+                     q_a, dq_a, groups, S, Q, D, (unsigned char*)dpre_planes, (Q + 15) / 16, (const unsigned char*)y_planes,
+                     (D + 16) / 16);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -49,11 +49,15 @@ struct RpImageJob {
   // cb < heads = features 0 .. 15 of head cb, block heads + s = features 16 .. 19 of heads 4s .. 4s + 3; every other slot
   // (the ones column, the tail) is a zero row
   int kperm_heads;
+  // kappa != 0: inside every k-block of 32 the reduction index follows the accumulator-to-fragment permutation of the fused
+  // news tail (nrl_news_tail.h): slot 8g + e holds logical k = 32 kb + (e < 4 ? 4g + e : 16 + 4g + e - 4)
+  int kappa;
 };
-constexpr int RP_MAX_JOBS = 8;
+constexpr int RP_MAX_JOBS = 12;
 struct RpImageJobs {
   RpImageJob job[RP_MAX_JOBS];
   int count;
+  int overflow;                           // a job past RP_MAX_JOBS was added: rp_jobs_launch fails instead of overrunning
   int64_t first_thread[RP_MAX_JOBS + 1];  // prefix sums of kblocks * nblk * 64
 };
 
@@ -86,6 +90,10 @@ __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs 
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     int k = k0 + e;
+    if (J.kappa != 0) {
+      const int gg = lane >> 4;
+      k = kb * 32 + (e < 4 ? 4 * gg + e : 16 + 4 * gg + (e - 4));
+    }
     float x = 0.f;
     bool live = row >= 0;
     if (J.kperm_heads > 0) {
@@ -93,8 +101,9 @@ __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs 
       int head, d;
       if (cb < J.kperm_heads) { head = cb; d = c; }
       else { head = 4 * (cb - J.kperm_heads) + (c >> 2); d = 16 + (c & 3); }
-      live = live && head < J.kperm_heads;
-      k = head * 20 + d;
+      // (slot K = 20 heads is the ones column of the `o` planes when heads % 4 != 0: the bias row, if the job has one)
+      if (head < J.kperm_heads) k = head * 20 + d;
+      else if (k != J.K || J.bias == nullptr) live = false;
     }
     if (J.kheads > 0) {
       const int head = k >> 6, c = k & 63;
@@ -124,12 +133,17 @@ __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs 
   dst[64] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-static inline void rp_jobs_init(RpImageJobs* js) { js->count = 0; js->first_thread[0] = 0; }
+static inline void rp_jobs_init(RpImageJobs* js) { js->count = 0; js->overflow = 0; js->first_thread[0] = 0; }
 static inline RpImageJob* rp_jobs_add(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int K,
                                       const float* bias, uint16_t* img, int nblk) {
+  if (js->count >= RP_MAX_JOBS) {          // (reported by rp_jobs_launch; the last slot is overwritten, nothing overruns)
+    js->overflow = 1;
+    js->count = RP_MAX_JOBS - 1;
+  }
   RpImageJob& J = js->job[js->count];
   J.src = src; J.bias = bias; J.img = img; J.sn = sn; J.sk = sk; J.N = N; J.K = K; J.nblk = nblk;
   J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0; J.conv_f = 0; J.conv_w = 0; J.kheads = 0; J.kdh = 0; J.kperm_heads = 0;
+  J.kappa = 0;
   js->first_thread[js->count + 1] = js->first_thread[js->count] + (int64_t)J.kblocks * nblk * 64;
   js->count += 1;
   return &J;
@@ -157,14 +171,22 @@ static inline RpImageJob* rp_jobs_add_kheads(RpImageJobs* js, const float* src, 
 // image whose reduction index is the head-permuted feature order of the `o` planes (out-projection forward of the fused
 // news path): K' = 16 * (heads + ceil(heads / 4)) slots
 static inline RpImageJob* rp_jobs_add_kperm(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int heads,
-                                            uint16_t* img, int nblk) {
-  RpImageJob* J = rp_jobs_add(js, src, sn, sk, N, heads * 20, nullptr, img, nblk);
+                                            uint16_t* img, int nblk, const float* bias = nullptr) {
+  RpImageJob* J = rp_jobs_add(js, src, sn, sk, N, heads * 20, bias, img, nblk);
   J->kperm_heads = heads;
   J->kblocks = (16 * (heads + (heads + 3) / 4) + 31) / 32;
   js->first_thread[js->count] = js->first_thread[js->count - 1] + (int64_t)J->kblocks * nblk * 64;
   return J;
 }
+// image in kappa order (second projection of the fused news tail): bias at k = K against the ones feature of y
+static inline RpImageJob* rp_jobs_add_kappa(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int K,
+                                            const float* bias, uint16_t* img, int nblk) {
+  RpImageJob* J = rp_jobs_add(js, src, sn, sk, N, K, bias, img, nblk);
+  J->kappa = 1;
+  return J;
+}
 static inline int rp_jobs_launch(const RpImageJobs& js, hipStream_t st) {
+  NRL_REQUIRE(js.overflow == 0, "row-panel image jobs: more than %d images in one launch", RP_MAX_JOBS);
   if (js.count == 0) return NRL_OK;
   const int64_t total = js.first_thread[js.count];
   hipLaunchKernelGGL(rp_weight_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, js);

@@ -183,7 +183,9 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
         assert _maxerr(res[True][2], res[True][0]) <= 1e-6      # eval (no-save) variant == train variant at p = 0
     # same forward kernel with / without the q|k|v save; the out-projection behind it sums over the features in the
     # head-permuted order of the `o` planes in one case and in natural order in the other: equal to rounding, not bitwise
-    assert _maxerr(res["full"][0], res[True][0]) <= 2e-6
+    # ("full" also keeps o / y as fp32 rows, i.e. the row-panel back half with its fp32 pooling, where the default runs the
+    #  fused tail -- y pooled as hi + lo bf16, v_exp / v_rcp tanh: rounding-level differences, nrl_news_tail.h)
+    assert _maxerr(res["full"][0], res[True][0]) <= 5e-5
     worst = 0.0
     for k, gf in res[True][1].items():
         rg = op[O.NEWS_PREFIX + k].grad.clone()
@@ -198,7 +200,7 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
     print(f"   recomputing backward: worst gradient error vs oracle {worst:.3e} (relative to the largest gradient)")
 
 
-@pytest.mark.parametrize("option", ["news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes"])
+@pytest.mark.parametrize("option", ["news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes", "news_tail", "news_tail_bwd"])
 @pytest.mark.parametrize("N,L", [(9, 17), (70, 30)])
 def test_news_path_format_switches_agree(N, L, option):
     """The measurement switches of the fused news path select private workspace formats (head-major q|k|v slabs, bf16
@@ -224,7 +226,8 @@ def test_news_path_format_switches_agree(N, L, option):
             res.append((out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in enc.named_parameters()}))
         finally:
             _lib.set_option(option, True)
-    assert _maxerr(res[0][0], res[1][0]) <= 5e-6
+    # (the fused tail pools y as hi + lo bf16 -- 16 mantissa bits -- and uses the v_exp / v_rcp tanh: rounding-level, not bitwise)
+    assert _maxerr(res[0][0], res[1][0]) <= (5e-5 if option == "news_tail" else 5e-6)
     for k, g0 in res[0][1].items():
         scale = max(1.0, float(g0.abs().max()))
         assert _maxerr(g0, res[1][1][k]) <= 1e-4 * scale, (option, k)
