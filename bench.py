@@ -175,7 +175,26 @@ def self_launch(n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+WORKLOADS = {
+    # BASELINE.json configs[1] (the configuration `metric` is quoted on) and configs[2]'s per-rank shape
+    "mindsmall": {"batch": 128, "vocab": 70_000,
+                  "name": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDsmall-shaped train step: B=128/GPU, H=50, C=5, "
+                          "L=30, V=70000, dropout 0.2, Adam lr 1e-4 (BASELINE.json configs[1])"},
+    "mindlarge": {"batch": 64, "vocab": 150_000,
+                  "name": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDlarge-shaped train step: B=64/GPU (512 global on "
+                          "8 GPUs), H=50, C=5, L=30, V=150000, dropout 0.2, Adam lr 1e-4 (BASELINE.json configs[2])"},
+}
+
+
 def main():
+    global B_PER_GPU, VOCAB, M_ROWS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -185,7 +204,13 @@ def main():
                     help="only the timed region (profiling runs): skip forward_only / f32_engine / cpu_baseline")
     ap.add_argument("--engine", choices=["f32", "bf16x3"], default="bf16x3",
                     help="projection-GEMM engine: exact fp32 MFMA, or fp32 via 3 bf16 MFMAs per product")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mindsmall",
+                    help="mindsmall = BASELINE.json configs[1] (headline); mindlarge = configs[2]'s per-rank shape (V=150k, B=64/GPU)")
+    ap.add_argument("--grad-exchange", choices=["dense", "rows"], default="dense",
+                    help="N > 1: all-reduce of the whole flat gradient, or all-gather of the touched table rows + dense rest")
     args = ap.parse_args()
+    B_PER_GPU, VOCAB = WORKLOADS[args.workload]["batch"], WORKLOADS[args.workload]["vocab"]
+    M_ROWS = B_PER_GPU * (H + C) * L
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
@@ -211,7 +236,7 @@ def main():
     _lib.set_gemm_engine(args.engine)
 
     mod = build_module(device)
-    trainer = NRMSTrainer(mod, lr=LR)
+    trainer = NRMSTrainer(mod, lr=LR, grad_exchange=args.grad_exchange)
     # impressions shard on the user axis: rank r owns its own B_PER_GPU impressions (seed by rank)
     # what a collate function hands over: the RecommendationBatch tensors in HBM plus the row-length metadata it
     # has on the host anyway (offsets, max sizes).  The per-step device work on the ids -- concatenating history
@@ -225,36 +250,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed region: EXACTLY `steps` steps, no instrumentation inside (no profiling hook, no event records) ----
     for i in range(args.warmup):
         trainer.step(batches[i % N_BATCHES])
     barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(batches[i % N_BATCHES])
+    barrier()
+    dt = time.perf_counter() - t0
+
+    # ---- second, instrumented pass (NOT the headline): per-step boundaries for the median, HIP events around the dominant
+    # kernel (nrl_prof, recorded on the launch stream) for the roofline line ----
     lib.nrl_prof_enable(1)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         trainer.step(batches[i % N_BATCHES])
-        marks[i + 1].record()                    # per-step boundary on the step's own stream (for the median)
+        marks[i + 1].record()
     barrier()
-    dt = time.perf_counter() - t0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    lib.nrl_prof_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(flops))
+    lib.nrl_prof_enable(0)
     # what the id bookkeeping inside the step costs (measured after the timed region)
     t1 = time.perf_counter()
     for i in range(20):
         prepare_batch(batches[i % N_BATCHES], VOCAB)
     torch.cuda.synchronize()
     prepare_ms = (time.perf_counter() - t1) / 20 * 1e3
-    tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    lib.nrl_prof_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(flops))
-    lib.nrl_prof_enable(0)
 
+    median_ms = statistics.median(step_ms)
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt, median_ms], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+        dt, median_ms = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
-        value = world * B_PER_GPU * args.steps / dt
+        # the metric is B / median step time over >= 50 steps; with fewer steps the mean of the
+        # timed region stands in (both are printed either way)
+        mean_value = world * B_PER_GPU * args.steps / dt
+        median_value = world * B_PER_GPU / (median_ms * 1e-3)
+        value = median_value if args.steps >= 50 else mean_value
         avg_s = tot_ms.value * 1e-3 / max(1, launches.value)
         tflops = (flops.value / max(1, launches.value)) / avg_s / 1e12 if avg_s > 0 else None
         # The dominant kernel of the step and its ALGORITHMIC work (no materialised
@@ -263,11 +300,19 @@ def main():
         algo_bytes = M_ROWS * 8 + M_ROWS * D * 4
         fused = args.engine == "bf16x3" and os.environ.get("NRL_NEWS_FUSED", "1") != "0"
         pmc_name = "pmc_news_fused_fwd_bf16x3.json" if fused else f"pmc_in_proj_fwd_{args.engine}.json"
-        traffic, step_bytes = None, None
+        traffic, step_bytes, prof_meta = None, None, None
         pmc = os.path.join(ROOT, "profiles", pmc_name)
-        if os.path.exists(pmc):
+        build_id = lib.nrl_build_id().decode()
+        if os.path.exists(pmc) and args.workload == "mindsmall":
             j = json.load(open(pmc))
             traffic, step_bytes = j.get("hbm_bytes_per_launch"), j.get("hbm_bytes_per_step")
+            # the counters are a committed profile (rocprofv3 PMC passes cannot run inside the timed process): say which
+            # build of the kernels they were taken on, and whether that is the build running now
+            prof_meta = {"file": "profiles/" + pmc_name, "git_head": j.get("git_head"), "build_id": j.get("build_id"),
+                         "matches_running_build": j.get("build_id") == build_id}
+            if not prof_meta["matches_running_build"]:
+                print(f"bench.py: WARNING: {pmc_name} was taken on build {j.get('build_id')}, the library running now is "
+                      f"{build_id}: `traffic` / `counter_bytes` may be stale (tools/profile_round.sh regenerates them)", file=sys.stderr)
         if args.engine == "f32":
             # exact fp32 MFMA: intensity (114 GFLOP / 0.255 GB) >> ridge 25 FLOP/B -> MFMA-bound
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<4,2,2,5,16,KCGather,KCPlain,EpiLinear> (in-projection "
@@ -288,29 +333,32 @@ def main():
                                  "frac": round(algo_bytes / avg_s / 1e9 / HBM_PEAK_GBPS, 4)}}
         roof["algorithmic_bytes_per_launch"] = algo_bytes
         # whole step against the survey's algorithmic model: 4.49 GFLOP and 11.7 MB per impression (fp32-equivalent)
-        step_s = dt / args.steps
+        step_s = median_ms * 1e-3
         step_flops = 4.49e9 * B_PER_GPU
         roof["step"] = {"algorithmic_flops": step_flops, "algorithmic_bytes": 11.7e6 * B_PER_GPU,
                         "counter_bytes": step_bytes,
-                        "frac_of_fp32_mfma_peak": round(step_flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                         "frac_of_bf16x3_peak": round(3 * step_flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                         "frac_of_hbm_peak_algorithmic": round(11.7e6 * B_PER_GPU / step_s / 1e9 / HBM_PEAK_GBPS, 4)}
-        roof.update({"traffic": traffic, "launches": launches.value, "avg_launch_ms": round(avg_s * 1e3, 4)})
+        roof.update({"traffic": traffic, "traffic_profile": prof_meta, "launches": launches.value,
+                     "avg_launch_ms": round(avg_s * 1e3, 4), "measured": "HIP events on the launch stream, instrumented second pass"})
         out = {
-            "metric": "impressions/sec (train step) NRMS MINDsmall-shape", "value": round(value, 1),
+            "metric": "impressions/sec (train step) NRMS MINDsmall-shape" if args.workload == "mindsmall"
+                      else "impressions/sec (train step) NRMS MINDlarge-shape", "value": round(value, 1),
             "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "median_ms_per_step": round(statistics.median(step_ms), 4), "prepare_ms": round(prepare_ms, 4),
+            "median_ms_per_step": round(median_ms, 4), "value_basis": "median step" if args.steps >= 50 else "mean of the timed region",
+            "mean_value": round(mean_value, 1), "prepare_ms": round(prepare_ms, 4),
             "rccl_ranks": dist.get_world_size() if distributed else 1,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.engine == "f32" else "f32 (projections: 3xbf16 split MFMA)",
             "data": "synthetic",
-            "config": {"workload": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDsmall-shaped train step: "
-                                   "B=128/GPU, H=50, C=5, L=30, V=70000, dropout 0.2, Adam lr 1e-4 "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": WORKLOADS[args.workload]["name"],
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "gemm_engine": args.engine},
+            "build_id": build_id, "git_head": git_head(),
             "roofline": roof,
         }
+        if distributed:
+            out["grad_exchange"] = trainer.exchange_info()
         if world == 1 and not args.no_extras:
             # the forward-only (evaluation-mode) rate of the same workload, outside the timed region
             mod.eval()
@@ -326,7 +374,8 @@ def main():
             mod.train()
             out["forward_only"] = {"value": round(B_PER_GPU / fdt, 1), "unit": "impressions/s", "ms": round(fdt * 1e3, 4)}
         if world == 1 and args.engine != "f32" and not args.no_extras:
-            # the exact-fp32 projection engine on the same workload (extra key, outside the timed region)
+            # the exact-fp32 projection engine on the same workload (extra key, outside the timed region), with its own
+            # roofline: the in-projection GEMM with the fused gather, against the fp32 MFMA peak
             _lib.set_gemm_engine("f32")
             for i in range(3):
                 trainer.step(batches[i % N_BATCHES])
@@ -337,9 +386,25 @@ def main():
                 trainer.step(batches[i % N_BATCHES])
             torch.cuda.synchronize()
             d32 = (time.perf_counter() - t1) / n32
+            lib.nrl_prof_enable(1)
+            for i in range(5):
+                trainer.step(batches[i % N_BATCHES])
+            torch.cuda.synchronize()
+            t32, l32, f32 = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            lib.nrl_prof_read(ctypes.byref(t32), ctypes.byref(l32), ctypes.byref(f32))
+            lib.nrl_prof_enable(0)
             _lib.set_gemm_engine(args.engine)
             out["f32_engine"] = {"value": round(B_PER_GPU / d32, 1), "unit": "impressions/s",
                                  "ms_per_step": round(d32 * 1e3, 4), "dtype": "f32 (v_mfma_f32_16x16x4_f32 projections)"}
+            dl, dms, dfl = l32.value, t32.value, f32.value          # (nrl_prof_enable(1) restarted the counters)
+            if dl > 0 and dms > 0:
+                tf32 = dfl / dl / (dms * 1e-3 / dl) / 1e12
+                out["f32_engine"]["roofline"] = {
+                    "bound": "mfma", "kernel": "gemm_f32_kernel<4,2,2,5,16,KCGather,KCPlain,EpiLinear> (in-projection forward "
+                                               "with fused embedding gather + dropout)",
+                    "achieved": round(tf32, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf32 / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(dms / dl, 4), "launches": dl,
+                    "step_frac_of_fp32_mfma_peak": round(step_flops / d32 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
         if world == 1 and not args.no_extras:
             # the other single-GPU configurations of BASELINE.json, driver-timed (outside the timed region)
             del trainer, mod, batches

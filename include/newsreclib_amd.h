@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 9
+#define NRL_ABI_VERSION 10
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -60,7 +60,12 @@ typedef struct NrlBlockParams {
   int32_t gemm_engine; /* projection engine of THIS call: 0 = process default (nrl_set_gemm_engine),
                         * 1 = exact fp32, 2 = bf16x3.  A backward must be given the value its forward ran under
                         * (the bf16 weight planes in the workspace exist only under bf16x3). */
+  int32_t options;     /* kernel-selection switches of THIS call: 0 = the process defaults (nrl_set_option / NRL_*
+                        * environment), otherwise NRL_OPTIONS_EXPLICIT | mask with the bit order of nrl_get_options().  The
+                        * switches choose the private formats of the workspace: a backward must be given the word its
+                        * forward ran under (a host stores NRL_OPTIONS_EXPLICIT | nrl_get_options() at the forward). */
 } NrlBlockParams;
+#define NRL_OPTIONS_EXPLICIT 0x40000000
 
 /* Gradient accumulators, same shapes as NrlBlockParams; kernels ADD into them (callers zero
  * them, or pass the persistent .grad / flat DP gradient buffer to accumulate in place). */
@@ -75,6 +80,9 @@ typedef struct NrlBlockGrads {
 } NrlBlockGrads;
 
 int nrl_abi_version(void);
+/* 32 hex digits: hash of the sources the library was built from (newsreclib_amd/_build.py source_hash()); a host that has
+ * the sources beside the library compares the two instead of trusting file times. */
+const char* nrl_build_id(void);
 const char* nrl_last_error(void);
 
 /* ---- projection GEMM engine: the process DEFAULT, used by calls whose params carry gemm_engine == 0 and by the
@@ -87,25 +95,34 @@ const char* nrl_last_error(void);
 int nrl_set_gemm_engine(int32_t engine);
 int nrl_get_gemm_engine(void);
 
-/* ---- kernel-selection switches for A/B measurements and the equivalence tests (process-wide, diagnostic; the
- * environment variables NRL_NEWS_FUSED / NRL_ROWPANEL / NRL_X3_DMA = 0 set the same flags at load time).  All paths
- * compute the same function; a forward and its backward must run under the same setting.
- *   "news_fused": gather + in-projection + token attention of the news encoder in one kernel (bf16x3 engine,
- *                 L <= 32, D = 20 * heads in [288, 316]);  "rowpanel": row-panel kernel for the N <= 320 projections;
- *   "x3_dma": LDS-DMA staged tiled GEMMs;  "news_attn_mfma": token-attention backward of the fused news path on the
- *   matrix cores from head-major q|k|v slabs;  "news_planes": x / dqkv of that path as pre-split bf16 fragment-block
- *   planes (DMA-only in-projection weight gradient);  "news_od_planes": o / dy of that path as planes too
- *   (out-projection forward / dgrad / weight gradient without splits);  "news_aa_planes": y (second copy) and d_pre as
- *   planes for the additive-attention GEMMs;  "wgrad_ws": wave-specialised kernel for the 900-row weight
- *   gradient.  A backward must run under the options of its forward (they select workspace formats). */
+/* ---- kernel-selection switches for A/B measurements and the equivalence tests.  All paths compute the same function;
+ * they differ in the kernels used and in the PRIVATE formats of the workspace.  The switches of a call are
+ * NrlBlockParams.options (per call, thread-safe); nrl_set_option changes the process DEFAULTS that options == 0 refers
+ * to (the environment variables NRL_<NAME>=0/1 set the same defaults at load time).  Bit order of the mask:
+ *   0 "news_fused"      gather + in-projection + token attention of the news encoder in one kernel (bf16x3 engine,
+ *                       L <= 32, D = 20 * heads in [288, 316])
+ *   1 "news_fused_bwd"  (default OFF) q|k|v recomputed inside the attention backward instead of saved
+ *   2 "news_attn_mfma"  token-attention backward of the fused news path on the matrix cores from head-major q|k|v slabs
+ *   3 "news_planes"     x / dqkv of that path as pre-split bf16 fragment-block planes (DMA-only weight gradient)
+ *   4 "news_od_planes"  o / dy of that path as planes too
+ *   5 "news_aa_planes"  y and d_pre as planes for the additive-attention GEMMs
+ *   6 "wgrad_2step"     split-K partial tiles stored and reduced in a second kernel instead of atomics
+ *   7 "wgrad_ws"        wave-specialised kernel for the 900-row weight gradient
+ *   8 "rowpanel"        row-panel kernel for the N <= 320 projections
+ *   9 "x3_dma"          LDS-DMA staged tiled GEMMs
+ *  10 "news_tail"       out-projection + dropout + additive attention + pooling of the fused news path in ONE kernel
+ *  11 "news_tail_bwd"   additive-attention backward of that path in ONE kernel that recomputes tanh from the y planes
+ * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
+ * must see the same defaults (newsreclib_amd/ops*.py compare nrl_get_options() at both). */
 int nrl_set_option(const char* name, int32_t value);
-/* Bit mask of the current switch values (bit order = the list above).  The switches select private workspace formats, so
- * a host that lets them change at run time compares the mask of a forward with the one at its backward. */
+/* Bit mask of the process-default switch values (bit order above). */
 int32_t nrl_get_options(void);
 
-/* ---- measurement hook (bench.py "roofline"): HIP-event timing of the dominant kernel, the
- * in-projection GEMM with the fused embedding gather, recorded on the launch stream.  The ProfScope
- * only wraps news-encoder forward launches; total_flops sums 2*M*3D*D per launch. */
+/* ---- measurement hook (bench.py "roofline"): HIP-event timing of the dominant kernel of the step, recorded on the launch
+ * stream.  The ProfScope wraps the news-encoder forward's first launch only: under the default bf16x3 engine the fused
+ * kernel (embedding gather + dropout + in-projection + per-head token attention, nrl_news_fused.h), counted as
+ * 2*M*3D*D + 4*M*L*D FLOPs per launch; under the exact-fp32 engine the in-projection GEMM with the fused gather,
+ * 2*M*3D*D.  Diagnostic state, process-wide: enable it around a measurement pass, not in a timed region. */
 int nrl_prof_enable(int32_t on);
 int nrl_prof_read(double* total_ms, int64_t* launches, double* total_flops);
 

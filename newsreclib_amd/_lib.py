@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -20,7 +20,11 @@ class NrlBlockParams(ctypes.Structure):
         ("out_proj_weight", c_void_p), ("out_proj_bias", c_void_p),
         ("att_weight", c_void_p), ("att_bias", c_void_p), ("att_query", c_void_p),
         ("embed_dim", c_int32), ("num_heads", c_int32), ("query_dim", c_int32), ("gemm_engine", c_int32),
+        ("options", c_int32),
     ]
+
+
+OPTIONS_EXPLICIT = 0x40000000
 
 
 class NrlBlockGrads(ctypes.Structure):
@@ -76,6 +80,7 @@ class NrlMhaGrads(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/newsreclib_amd.h one to one
 SIGNATURES = {
     "nrl_abi_version": (c_int32, []),
+    "nrl_build_id": (c_char_p, []),
     "nrl_last_error": (c_char_p, []),
     "nrl_set_gemm_engine": (c_int32, [c_int32]),
     "nrl_get_gemm_engine": (c_int32, []),
@@ -181,6 +186,13 @@ def load() -> ctypes.CDLL:
     got = lib.nrl_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"ABI version mismatch: library {got}, binding {ABI_VERSION} (rebuild)")
+    # the library must have been built from the sources lying beside it (content hash, not file times)
+    from . import _build
+    if os.path.isdir(_build.CSRC):
+        want, have = _build.source_hash(), lib.nrl_build_id().decode()
+        if want != have:
+            raise RuntimeError(f"{LIB_PATH} was built from other sources (build id {have}, sources {want}): run "
+                               "`python -m newsreclib_amd._build` or `__graft_entry__.build()`")
     _lib = lib
     eng = os.environ.get("NRL_GEMM_ENGINE")
     if eng:
@@ -212,6 +224,13 @@ def options_mask() -> int:
     """Bit mask of the kernel-selection switches (they choose private workspace formats: an autograd forward records it
     and its backward refuses to run under another one)."""
     return int(load().nrl_get_options())
+
+
+def options_word() -> int:
+    """The per-call switch word of the current process defaults (``NrlBlockParams.options``): captured by an autograd
+    forward and handed to its backward, so the backward reads the workspace in the format the forward wrote even if the
+    defaults changed in between (and two modules may run under different switches)."""
+    return OPTIONS_EXPLICIT | options_mask()
 
 
 def require_options(mask: int, what: str) -> None:

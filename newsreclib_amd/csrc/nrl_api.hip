@@ -18,7 +18,7 @@
 #include "nrl_rowpanel.h"
 #include "nrl_gemm_ws.h"
 #include "nrl_news_fused.h"
-#include "nrl_news_tail.h"
+#include "nrl_news_tail_api.h"
 #include "nrl_wgrad_planes.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
@@ -108,92 +108,64 @@ struct EngineScope {
   ~EngineScope() { t_engine = prev; }
 };
 static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
-// A/B switch for measurements: NRL_X3_DMA=0 keeps every bf16x3 GEMM on the register-staged kernel
-static bool g_x3_dma = [] {
-  const char* e = getenv("NRL_X3_DMA");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// A/B switch: NRL_ROWPANEL=0 keeps the narrow (N <= 320) forward / dgrad projections on the tiled kernels
-static bool g_rowpanel = [] {
-  const char* e = getenv("NRL_ROWPANEL");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// A/B switch: NRL_NEWS_FUSED=0 keeps the news encoder's gather + in-projection + attention as separate kernels
-static bool g_news_fused = [] {
-  const char* e = getenv("NRL_NEWS_FUSED");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_NEWS_FUSED_BWD=1 (or nrl_set_option("news_fused_bwd", 1)): the forward does not save q|k|v; the backward
-// recomputes them per head inside the matrix-core attention backward (news_fused_bwd_kernel).  OFF by default:
-// measured at B = 128 it removes 1.9 GB of HBM traffic per step but costs time (the kernel holds the 160-VGPR
-// embedding fragments through the attention backward and spills: 1.69 ms against 0.60 ms for attn_bwd_small plus
-// 0.22 ms of q|k|v stores in the forward; step 5.56 vs 4.76 ms, profiles/r02_fused_bwd_ab.txt).
-static bool g_news_fused_bwd = [] {
-  const char* e = getenv("NRL_NEWS_FUSED_BWD");
-  return e != nullptr && e[0] == '1';
-}();
-
-// NRL_NEWS_ATTN_MFMA=0: the fused forward saves q|k|v as packed rows and the backward runs attn_bwd_small (fp32 VALU).
-// Default: head-major slabs + news_attn_bwd_kernel (matrix cores), nrl_news_fused.h.
-static bool g_news_attn_mfma = [] {
-  const char* e = getenv("NRL_NEWS_ATTN_MFMA");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_NEWS_PLANES=0: x and dqkv of the fused news path stay fp32 (head planes) and the in-projection weight gradient
-// runs on the wave-specialised kernel.  Default: both are written ONCE as (hi, lo) bf16 fragment-block planes by their
-// producers and consumed by wgrad_planes_kernel / the row-panel dgrad without any split (nrl_wgrad_planes.h).
-static bool g_news_planes = [] {
-  const char* e = getenv("NRL_NEWS_PLANES");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_NEWS_OD_PLANES=0: `o` and `dy` of the fused news path stay fp32 rows (out-projection weight gradient on the
-// transposing fp32-fed kernel).  Default (with news_planes): both as planes, nrl_wgrad_planes.h's generic kernel.
-static bool g_news_od_planes = [] {
-  const char* e = getenv("NRL_NEWS_OD_PLANES");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_NEWS_AA_PLANES=0: the additive-attention GEMMs of the fused news path read fp32 y / d_pre.  Default (with
-// news_od_planes): the out-projection epilogue writes y ALSO as planes, pool_bwd_pre writes d_pre ONLY as planes.
-static bool g_news_aa_planes = [] {
-  const char* e = getenv("NRL_NEWS_AA_PLANES");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_NEWS_TAIL=0: the back half of the fused news path (out-projection, additive attention, pooling) stays on the
-// row-panel GEMMs + pool_fwd.  Default (with news_aa_planes): ONE kernel per forward, nrl_news_tail.h -- y exists only as
-// planes (training) or not at all (evaluation).
-static bool g_news_tail = [] {
-  const char* e = getenv("NRL_NEWS_TAIL");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_NEWS_TAIL_BWD=0: the additive-attention backward of the fused news path stays on pool_bwd_pre + the row-panel
-// activation-gradient GEMM (the forward tail then also saves the tanh output).  Default (with news_tail): ONE kernel that
-// recomputes tanh from the y planes (news_tail_bwd_kernel).
-static bool g_news_tail_bwd = [] {
-  const char* e = getenv("NRL_NEWS_TAIL_BWD");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_WGRAD_2STEP=0: the planes weight gradients add their split-K partial tiles with atomics instead of storing them and
-// reducing in a second small kernel (nrl_wgrad_planes.h: ~60 us of L2 atomics per launch become ~25 us)
-static bool g_wgrad_2step = [] {
-  const char* e = getenv("NRL_WGRAD_2STEP");
-  return !(e != nullptr && e[0] == '0');
-}();
-
-// NRL_WGRAD_WS=0: the large (I > 512) weight gradient back on the register-staged kernel (default: the
-// wave-specialised one, nrl_gemm_ws.h, 32 k-splits = one workgroup per CU: 4.81 -> 4.72 ms/step at B = 128)
-static bool g_wgrad_ws = [] {
-  const char* e = getenv("NRL_WGRAD_WS");
-  return !(e != nullptr && e[0] == '0');
-}();
+// ---- kernel-selection switches ------------------------------------------------------------------------------------
+// They choose between kernels that compute the same thing (A/B measurements, equivalence tests) and with it the PRIVATE
+// formats of a call's workspace, so a backward must run under the switches of its forward.  The value a call runs under
+// is fixed at its entry (OptScope) and thread-local: NrlBlockParams.options carries it per call (forward and backward of
+// one module get the same word, two modules in one process may differ); options == 0 means "the process defaults", which
+// start from the NRL_* environment and change through nrl_set_option.
+//   news_fused      NRL_NEWS_FUSED=0       gather + in-projection + token attention as separate kernels (nrl_news_fused.h)
+//   news_fused_bwd  NRL_NEWS_FUSED_BWD=1   q|k|v not saved, recomputed inside the matrix-core attention backward (slower:
+//                                          160 VGPRs of fragments held through it, 78 spills; profiles/r02_fused_bwd_ab.txt)
+//   news_attn_mfma  NRL_NEWS_ATTN_MFMA=0   q|k|v saved as packed rows, attn_bwd_small (fp32 VALU) instead of the slabs +
+//                                          news_attn_bwd_kernel
+//   news_planes     NRL_NEWS_PLANES=0      x / dqkv stay fp32 (no fragment-block planes, nrl_wgrad_planes.h)
+//   news_od_planes  NRL_NEWS_OD_PLANES=0   o / dy stay fp32 rows
+//   news_aa_planes  NRL_NEWS_AA_PLANES=0   the additive-attention GEMMs read fp32 y / d_pre
+//   wgrad_2step     NRL_WGRAD_2STEP=0      split-K partial tiles added with atomics instead of stored + reduced
+//   wgrad_ws        NRL_WGRAD_WS=0         the large weight gradient on the register-staged kernel (nrl_gemm_ws.h otherwise)
+//   rowpanel        NRL_ROWPANEL=0         the narrow (N <= 320) projections on the tiled kernels
+//   x3_dma          NRL_X3_DMA=0           every bf16x3 GEMM on the register-staged kernel
+//   news_tail       NRL_NEWS_TAIL=0        out-projection / additive attention / pooling of the fused news path on the
+//                                          row-panel GEMMs + pool_fwd instead of ONE kernel (nrl_news_tail.h)
+//   news_tail_bwd   NRL_NEWS_TAIL_BWD=0    additive-attention backward on pool_bwd_pre + the row-panel GEMM (the forward tail
+//                                          then also saves the tanh output) instead of ONE kernel that recomputes tanh
+enum {
+  O_NEWS_FUSED = 0, O_NEWS_FUSED_BWD, O_NEWS_ATTN_MFMA, O_NEWS_PLANES, O_NEWS_OD_PLANES, O_NEWS_AA_PLANES, O_WGRAD_2STEP,
+  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_COUNT
+};
+static const char* const kOptName[O_COUNT] = {"news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes",
+                                              "news_aa_planes", "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail",
+                                              "news_tail_bwd"};
+static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_BWD", "NRL_NEWS_ATTN_MFMA", "NRL_NEWS_PLANES",
+                                             "NRL_NEWS_OD_PLANES", "NRL_NEWS_AA_PLANES", "NRL_WGRAD_2STEP", "NRL_WGRAD_WS",
+                                             "NRL_ROWPANEL", "NRL_X3_DMA", "NRL_NEWS_TAIL", "NRL_NEWS_TAIL_BWD"};
+static std::atomic<uint32_t> g_opt_default{[] {
+  uint32_t m = 0;
+  for (int i = 0; i < O_COUNT; ++i) {
+    const bool dflt = i != O_NEWS_FUSED_BWD;                 // everything on but the recomputing backward
+    const char* e = getenv(kOptEnv[i]);
+    const bool v = e == nullptr ? dflt : (dflt ? e[0] != '0' : e[0] == '1');
+    m |= v ? (1u << i) : 0u;
+  }
+  return m;
+}()};
+static thread_local int64_t t_opts = -1;
+static inline bool opt(int bit) {
+  const uint32_t m = t_opts >= 0 ? (uint32_t)t_opts : g_opt_default.load(std::memory_order_relaxed);
+  return (m >> bit) & 1u;
+}
+struct OptScope {
+  int64_t prev;
+  explicit OptScope(int32_t per_call) : prev(t_opts) {
+    t_opts = (per_call & NRL_OPTIONS_EXPLICIT) ? (int64_t)(per_call & ((1 << O_COUNT) - 1))
+                                               : (int64_t)g_opt_default.load(std::memory_order_relaxed);
+  }
+  ~OptScope() { t_opts = prev; }
+};
+static inline bool options_field_ok(int32_t v) {
+  return v == 0 || ((v & NRL_OPTIONS_EXPLICIT) && (v & ~(NRL_OPTIONS_EXPLICIT | ((1 << O_COUNT) - 1))) == 0);
+}
 
 static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {
   const int64_t tiles = ceil_div(rows_out, bm) * ceil_div(cols_out, bn);
@@ -230,7 +202,7 @@ struct BlockRp {
   RpImage out_f, att_f, att_d, out_d, in_d, in_heads, in_d_hp, out_f_perm, tail_o, tail_a, tail_ad;
   bool on = false;
 };
-static bool block_rp_ok(int D, int Q) { return g_rowpanel && rp_nblk_supported(D) && rp_nblk_supported(Q); }
+static bool block_rp_ok(int D, int Q) { return opt(O_ROWPANEL) && rp_nblk_supported(D) && rp_nblk_supported(Q); }
 static size_t block_rp_elems(int D, int Q) {
   if (!block_rp_ok(D, Q)) return 0;
   const int nd = rp_nblk_for(D), nq = rp_nblk_for(Q);
@@ -319,6 +291,7 @@ static int check_params(const NrlBlockParams* p) {
   NRL_REQUIRE(p->in_proj_weight && p->in_proj_bias && p->out_proj_weight && p->out_proj_bias &&
                   p->att_weight && p->att_bias && p->att_query, "null parameter pointer");
   NRL_REQUIRE(engine_field_ok(p->gemm_engine), "gemm_engine must be 0 (default), 1 (f32) or 2 (bf16x3)");
+  NRL_REQUIRE(options_field_ok(p->options), "options must be 0 (process defaults) or NRL_OPTIONS_EXPLICIT | switch mask");
   NRL_REQUIRE(p->embed_dim > 0 && p->embed_dim % 4 == 0, "embed_dim must be a positive multiple of 4");
   NRL_REQUIRE(p->query_dim > 0 && p->query_dim % 4 == 0, "query_dim must be a positive multiple of 4");
   NRL_REQUIRE(p->num_heads > 0 && p->embed_dim % p->num_heads == 0, "embed_dim must be divisible by num_heads");
@@ -384,7 +357,7 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
       if (fill) rp_jobs_add_kperm(&jobs, P->out_proj_weight, D, 1, D, fused_heads, q, nd);
       q += rp_image_elems(nd, rp_kblocks(D + 32, false));
       // fused tail (nrl_news_tail.h): W_o over the plane slots with b_o at the ones slot; W_a in kappa order with b_a
-      if (g_news_tail && news_tail_ok(32, D, Q, fused_heads)) {
+      if (opt(O_NEWS_TAIL) && news_tail_geometry_ok(32, D, Q, fused_heads)) {
         bp->rp.tail_o.img = q; bp->rp.tail_o.nblk = NT_FB; bp->rp.tail_o.kblocks = NT_KB;
         if (fill) rp_jobs_add_kperm(&jobs, P->out_proj_weight, D, 1, D, fused_heads, q, NT_FB, P->out_proj_bias);
         q += rp_image_elems(NT_FB, NT_KB);
@@ -393,7 +366,7 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
         q += rp_image_elems(NT_QB, NT_KS);
         // backward: dy^T = W_a^T d_pre^T, element (n = feature, k = query) = W_a[k][n], queries in kappa order
         bp->rp.tail_ad.img = q; bp->rp.tail_ad.nblk = NT_FB; bp->rp.tail_ad.kblocks = NT_QS;
-        if (fill && news_tail_bwd_ok(32, D, Q, fused_heads)) rp_jobs_add_kappa(&jobs, P->att_weight, 1, D, D, Q, nullptr, q, NT_FB);
+        if (fill && news_tail_bwd_geometry_ok(32, D, Q, fused_heads)) rp_jobs_add_kappa(&jobs, P->att_weight, 1, D, D, Q, nullptr, q, NT_FB);
         q += rp_image_elems(NT_FB, NT_QS);
       }
     }
@@ -455,7 +428,7 @@ static int gemm_fwd(const AOp& a, const float* W, const SplitWeight& sw, const E
     if constexpr (std::is_same<AOp, KCPlain>::value)
       if (rp != nullptr && rp->img != nullptr) return rp_dispatch(a, *rp, epi, M, N, K, st);
     const KCSplit b{sw.hi, sw.lo, sw.ld, N};
-    if constexpr (!std::is_same<AOp, KCGather>::value) if (g_x3_dma) {
+    if constexpr (!std::is_same<AOp, KCGather>::value) if (opt(O_X3_DMA)) {
       // (the gathered operand keeps the register-staged kernel: its dropout hash would be re-evaluated by
       // every wave column at fragment-read time)
       if (q_tile && N <= 224) return launch_gemm_bf16x3_dma<X3_DMA_TILE_Q>(a, b, epi, M, N, K, st);
@@ -479,7 +452,7 @@ static int gemm_dgrad(const float* dy, const float* W, const SplitWeight& sw, co
   if (cur_engine() == ENGINE_BF16X3) {
     if (rp != nullptr && rp->img != nullptr) return rp_dispatch(a, *rp, epi, M, Kw, Nw, st);
     const KCSplit b{sw.hi_t, sw.lo_t, sw.ld_t, Kw};
-    if (g_x3_dma) return launch_gemm_bf16x3_dma<X3_DMA_TILE>(a, b, epi, M, Kw, Nw, st);
+    if (opt(O_X3_DMA)) return launch_gemm_bf16x3_dma<X3_DMA_TILE>(a, b, epi, M, Kw, Nw, st);
     if (big_tiles(M, Kw)) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, M, Kw, Nw, 1, st);
     return launch_gemm_bf16x3<X3_TILE>(a, b, epi, M, Kw, Nw, 1, st);
   }
@@ -501,7 +474,7 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
       const int64_t max_s = ceil_div(M, 256);
       return (int)(sp > max_s ? max_s : (sp < 1 ? 1 : sp));
     };
-    if (I > 512 && g_wgrad_ws) {
+    if (I > 512 && opt(O_WGRAD_WS)) {
       static const int ws_splits = [] { const char* e = getenv("NRL_WGRAD_WS_SPLITS"); return e ? atoi(e) : 32; }();
       return launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, M >= (int64_t)ws_splits * 512 ? ws_splits : splits(256), st,
                                                   scratch, scratch_floats);
@@ -509,7 +482,7 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
     if (I > 512) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, I, J + 1, M, splits(256), st);
     // small outputs: LDS-DMA staged, transposition at the fragment read (0.35 -> 0.30 ms at 300 x 300;
     // the 900-row gradient is faster register-staged, profiles/r01_gemm_x3_dma_probe.txt)
-    if (g_x3_dma) return launch_gemm_bf16x3_dma_tn<2, 2, 2, 5, 2>(a, b, epi, I, J + 1, M, splits(64), st, scratch, scratch_floats);
+    if (opt(O_X3_DMA)) return launch_gemm_bf16x3_dma_tn<2, 2, 2, 5, 2>(a, b, epi, I, J + 1, M, splits(64), st, scratch, scratch_floats);
     return launch_gemm_bf16x3<X3_TILE_W>(a, b, epi, I, J + 1, M, splits(64), st);
   }
   if (I > 512) return launch_gemm<NRL_TILE>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 128, 160), st);
@@ -599,7 +572,7 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
     b.y_planes = reinterpret_cast<const unsigned char*>(w.yp); b.w = w.w; b.d_out = d_out; b.img_a = bp.rp.tail_a.img;
     b.img_ad = bp.rp.tail_ad.img; b.q_a = P->att_query; b.n_news = s.pool_groups; b.L = s.pool_len; b.D = D; b.Q = Q;
     b.drop2 = drop2; b.dpre_planes = tpl; b.dy_planes = dyp; b.dq_a = G->att_query;
-    NRL_TRY(launch_news_tail_bwd(b, st));
+    NRL_TRY(news_tail_bwd(b, st));
     // d_o = dy W_o
     NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
     if (!attention_elsewhere) NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
@@ -635,11 +608,11 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
                             hipStream_t st, bool dqkv_head_planes = false, bool bf16_planes = false) {
   const int D = s.D, Q = s.Q;
   // partial tiles of the planes weight gradients: the q|k|v slabs are dead once the attention backward has run
-  const size_t scratch_avail = (bf16_planes && g_wgrad_2step) ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
+  const size_t scratch_avail = (bf16_planes && opt(O_WGRAD_2STEP)) ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
   auto scratch_for = [&](size_t need) -> float* { return need <= scratch_avail ? w.qkv : nullptr; };
   // the fp32-fed weight gradients (user encoder; the fallbacks of the news path) reduce their splits the same way, the packed
   // q|k|v rows being dead by now as well (attention backward and in-projection dgrad have run)
-  float* const sc = g_wgrad_2step && !dqkv_head_planes && !bf16_planes ? w.qkv : nullptr;
+  float* const sc = opt(O_WGRAD_2STEP) && !dqkv_head_planes && !bf16_planes ? w.qkv : nullptr;
   const size_t sc_n = sc != nullptr ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
   // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
   if (s.aa_planes) {
@@ -693,24 +666,30 @@ static int check_grads(const NrlBlockGrads* g) {
 
 // the fused front half applies to the reference's news-encoder geometry under the bf16x3 engine
 static bool news_fused_on(const BlockShape& s, int L) {
-  return g_news_fused && cur_engine() == ENGINE_BF16X3 && block_rp_ok(s.D, s.Q) && s.dh == 20 &&
+  return opt(O_NEWS_FUSED) && cur_engine() == ENGINE_BF16X3 && block_rp_ok(s.D, s.Q) && s.dh == 20 &&
          news_fused_ok(L, s.D, s.heads);
 }
 
 // ... and its back half as one kernel too, when `o` arrives as planes and the y / d_pre planes exist
 static bool news_tail_on(const BlockShape& s, int L, const BlockWs& w) {
-  return g_news_tail && s.od_planes && g_news_aa_planes && w.yp != nullptr && news_tail_ok(L, s.D, s.Q, s.heads);
+  return opt(O_NEWS_TAIL) && s.od_planes && opt(O_NEWS_AA_PLANES) && w.yp != nullptr && news_fused_ok(L, s.D, s.heads) && news_tail_geometry_ok(L, s.D, s.Q, s.heads);
 }
 
 static bool news_tail_bwd_on(const BlockShape& s, int L, const BlockWs& w) {
-  return news_tail_on(s, L, w) && g_news_tail_bwd && w.tp != nullptr && news_tail_bwd_ok(L, s.D, s.Q, s.heads);
+  return news_tail_on(s, L, w) && opt(O_NEWS_TAIL_BWD) && w.tp != nullptr && news_tail_bwd_geometry_ok(L, s.D, s.Q, s.heads);
+}
+
+// token rows padded to 32 per news: only where the fragment-block planes of the fused news path exist (D = 20 heads within
+// NF_KB k-blocks); any other geometry keeps plain (M, D) rows and pays nothing for the padding
+static int64_t news_pad_rows(int64_t n_news, int L, int D, int heads) {
+  return (heads > 0 && news_fused_ok(L, D, heads)) ? n_news * 32 : 0;
 }
 
 static BlockShape news_shape(const NrlBlockParams* p, int64_t n_news, int L) {
   BlockShape s;
   s.D = p->embed_dim; s.Q = p->query_dim; s.heads = p->num_heads; s.dh = s.D / s.heads;
   s.M = n_news * L;
-  s.pad_rows = L <= 32 ? n_news * 32 : 0;
+  s.pad_rows = news_pad_rows(n_news, L, s.D, s.heads);
   s.pool_groups = n_news; s.pool_len = L;
   s.geom.q_outer = (int64_t)L * 3 * s.D; s.geom.q_seq = 3 * s.D;
   s.geom.o_outer = (int64_t)L * s.D; s.geom.o_seq = s.D;
@@ -739,6 +718,7 @@ using namespace nrl;
 extern "C" {
 
 int nrl_abi_version(void) { return NRL_ABI_VERSION; }
+// (nrl_build_id: nrl_build_id.hip)
 const char* nrl_last_error(void) { return g_err; }
 
 int nrl_prof_enable(int32_t on) {
@@ -775,33 +755,20 @@ int nrl_get_gemm_engine(void) { return g_default_engine.load(); }
 
 int nrl_set_option(const char* name, int32_t value) {
   NRL_REQUIRE(name != nullptr, "set_option: null name");
-  bool* flag = !strcmp(name, "news_fused") ? &g_news_fused
-               : !strcmp(name, "news_fused_bwd") ? &g_news_fused_bwd
-               : !strcmp(name, "news_attn_mfma") ? &g_news_attn_mfma
-               : !strcmp(name, "news_planes") ? &g_news_planes
-               : !strcmp(name, "news_od_planes") ? &g_news_od_planes
-               : !strcmp(name, "news_aa_planes") ? &g_news_aa_planes
-               : !strcmp(name, "news_tail") ? &g_news_tail
-               : !strcmp(name, "news_tail_bwd") ? &g_news_tail_bwd
-               : !strcmp(name, "wgrad_2step") ? &g_wgrad_2step
-               : !strcmp(name, "wgrad_ws") ? &g_wgrad_ws
-               : !strcmp(name, "rowpanel") ? &g_rowpanel
-               : !strcmp(name, "x3_dma")   ? &g_x3_dma
-                                           : nullptr;
-  NRL_REQUIRE(flag != nullptr, "set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, news_aa_planes, news_tail, news_tail_bwd, wgrad_2step, wgrad_ws, rowpanel, x3_dma)", name);
-  *flag = value != 0;
-  return NRL_OK;
+  for (int i = 0; i < O_COUNT; ++i)
+    if (!strcmp(name, kOptName[i])) {
+      if (value != 0) g_opt_default.fetch_or(1u << i);
+      else g_opt_default.fetch_and(~(1u << i));
+      return NRL_OK;
+    }
+  set_error("set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, "
+            "news_aa_planes, wgrad_2step, wgrad_ws, rowpanel, x3_dma, news_tail, news_tail_bwd)", name);
+  return NRL_E_INVALID;
 }
 
-// bit mask of the kernel-selection switches, in the order nrl_set_option lists them: a backward whose forward ran under
-// another mask would read a workspace in the wrong private format (ops.py compares the two and refuses)
-int32_t nrl_get_options(void) {
-  const bool flags[] = {g_news_fused,  g_news_fused_bwd, g_news_attn_mfma, g_news_planes, g_news_od_planes,
-                        g_news_aa_planes, g_wgrad_2step, g_wgrad_ws,       g_rowpanel,    g_x3_dma, g_news_tail, g_news_tail_bwd};
-  int32_t m = 0;
-  for (size_t i = 0; i < sizeof(flags) / sizeof(flags[0]); ++i) m |= flags[i] ? (1 << i) : 0;
-  return m;
-}
+// bit mask of the process-default switch values, in the order nrl_set_option lists them; NRL_OPTIONS_EXPLICIT | mask is
+// what a host stores at a forward and hands to the matching backward in NrlBlockParams.options
+int32_t nrl_get_options(void) { return (int32_t)g_opt_default.load(); }
 
 uint32_t nrl_dropout_key(uint64_t seed, uint32_t stream) { return dropout_key(seed, stream); }
 
@@ -813,7 +780,8 @@ int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, ui
 
 size_t nrl_news_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t embed_dim,
                                         int32_t num_heads, int32_t query_dim) {
-  return block_ws_floats(n_news * seq_len, embed_dim, query_dim, num_heads, true, seq_len <= 32 ? n_news * 32 : 0) * sizeof(float);
+  return block_ws_floats(n_news * seq_len, embed_dim, query_dim, num_heads, true, news_pad_rows(n_news, seq_len, embed_dim, num_heads)) *
+         sizeof(float);
 }
 
 int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_t vocab,
@@ -822,6 +790,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
                          void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   const EngineScope engine_scope(p->gemm_engine);
+  const OptScope opt_scope(p->options);
   NRL_REQUIRE(emb_table && ids && out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_fwd: bad arguments");
   NRL_REQUIRE(((uintptr_t)emb_table & 15) == 0, "embedding table must be 16-byte aligned");
   NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
@@ -839,11 +808,11 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     NewsFusedArgs a;
     a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
     a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.o = w.o;
-    const bool planes = !g_news_fused_bwd && g_news_attn_mfma && g_news_planes;
+    const bool planes = !opt(O_NEWS_FUSED_BWD) && opt(O_NEWS_ATTN_MFMA) && opt(O_NEWS_PLANES);
     BlockShape sf = s;
-    sf.od_planes = planes && g_news_od_planes;
+    sf.od_planes = planes && opt(O_NEWS_OD_PLANES);
     // (training only: in an evaluation forward the second copy of y costs more than the additive-attention GEMM saves)
-    sf.aa_planes = sf.od_planes && g_news_aa_planes && save_for_backward && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
+    sf.aa_planes = sf.od_planes && opt(O_NEWS_AA_PLANES) && save_for_backward && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
     a.o_planes = nullptr;
     if (sf.od_planes) {
       a.o_planes = reinterpret_cast<unsigned char*>(w.o);
@@ -853,8 +822,8 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     }
     a.x_save = (save_for_backward && !planes) ? w.x : nullptr;
     a.x_planes = (save_for_backward && planes) ? reinterpret_cast<unsigned char*>(w.x) : nullptr;
-    a.qkv_save = (save_for_backward && !g_news_fused_bwd) ? w.qkv : nullptr;   // else recomputed in the backward
-    a.qkv_head_major = g_news_attn_mfma ? 1 : 0;
+    a.qkv_save = (save_for_backward && !opt(O_NEWS_FUSED_BWD)) ? w.qkv : nullptr;   // else recomputed in the backward
+    a.qkv_head_major = opt(O_NEWS_ATTN_MFMA) ? 1 : 0;
     a.lse = save_for_backward ? w.lse : nullptr;
     {
       ProfScope prof(st, 2.0 * (double)s.M * 3.0 * s.D * s.D + 4.0 * (double)s.M * seq_len * s.D);
@@ -873,7 +842,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
         if (s.M % 32 != 0)   // rows past M in the last 32-row k-tile of the weight gradient
           NRL_HIP(hipMemsetAsync(t.y_planes + (s.M / 32) * 2 * ncb_y * 1024, 0, (size_t)2 * ncb_y * 1024, st));
       }
-      return launch_news_tail_fwd(t, st);
+      return news_tail_fwd(t, st);
     }
     return block_fwd_tail(p, sf, w, bp, d2, out, st);
   }
@@ -887,6 +856,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
                          const float* d_out, int32_t phase, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   const EngineScope engine_scope(p->gemm_engine);
+  const OptScope opt_scope(p->options);
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(d_emb_table && ids && d_out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_bwd: bad arguments");
   NRL_REQUIRE(phase >= 0 && phase <= 2, "news_encoder_bwd: phase must be 0 (all), 1 or 2");
@@ -897,12 +867,12 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
-  const bool fused = news_fused_on(s, seq_len) && g_news_fused_bwd;
-  const bool slabs = news_fused_on(s, seq_len) && !g_news_fused_bwd && g_news_attn_mfma;   // what the forward saved
-  const bool planes = slabs && g_news_planes;
+  const bool fused = news_fused_on(s, seq_len) && opt(O_NEWS_FUSED_BWD);
+  const bool slabs = news_fused_on(s, seq_len) && !opt(O_NEWS_FUSED_BWD) && opt(O_NEWS_ATTN_MFMA);   // what the forward saved
+  const bool planes = slabs && opt(O_NEWS_PLANES);
   BlockShape sb_ = s;
-  sb_.od_planes = planes && g_news_od_planes;
-  sb_.aa_planes = sb_.od_planes && g_news_aa_planes && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
+  sb_.od_planes = planes && opt(O_NEWS_OD_PLANES);
+  sb_.aa_planes = sb_.od_planes && opt(O_NEWS_AA_PLANES) && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
   sb_.tail = news_tail_on(sb_, seq_len, w);
   sb_.tail_bwd = sb_.tail && sb_.aa_planes && news_tail_bwd_on(sb_, seq_len, w);
   NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
@@ -957,6 +927,7 @@ int nrl_user_encoder_fwd(const NrlBlockParams* p, const float* hist, int64_t bat
                          int32_t save_for_backward, float* out, void* ws, size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   const EngineScope engine_scope(p->gemm_engine);
+  const OptScope opt_scope(p->options);
   NRL_REQUIRE(hist && out && batch > 0 && hist_len > 0, "user_encoder_fwd: bad arguments");
   NRL_REQUIRE(((uintptr_t)hist & 15) == 0, "hist must be 16-byte aligned");
   NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
@@ -982,6 +953,7 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
                          void* stream) {
   NRL_TRY(check_params(p));
   const EngineScope engine_scope(p->gemm_engine);
+  const OptScope opt_scope(p->options);
   NRL_TRY(check_grads(g));
   NRL_REQUIRE(hist && d_out && d_hist && batch > 0 && hist_len > 0, "user_encoder_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;

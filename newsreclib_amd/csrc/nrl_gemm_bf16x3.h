@@ -396,7 +396,7 @@ int launch_gemm_bf16x3(const AOp& A, const BOp& B, const Epi& epi, int64_t M, in
 __device__ __forceinline__ int64_t split_pos(int64_t row, int k, int ld) {  // hi position; lo is + 32
   return row * ld + 2 * (k & ~31) + (k & 31);
 }
-__global__ void split_weight_kernel(const float* __restrict__ w, int N, int K, int Kp, int Np,
+static __global__ void split_weight_kernel(const float* __restrict__ w, int N, int K, int Kp, int Np,
                                     uint16_t* __restrict__ hi, uint16_t* __restrict__ hi_t) {
   const int64_t total = (int64_t)N * Kp, total_t = (int64_t)K * Np;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + total_t;

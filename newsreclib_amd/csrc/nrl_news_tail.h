@@ -24,37 +24,51 @@
 //   pooling   softmax over the 32 token lanes (DPP row reductions), out[f] = sum_t w_t (hi + lo)[f][t].
 // y enters the pooling sum as hi + lo (16 mantissa bits, the precision it has as a bf16x3 operand everywhere else).
 //
-// Workgroup = 8 wavefronts, two per SIMD (<= 256 VGPRs); LDS = 3 x 40 KB weight ring (one k-block of the W_o image, or
-// five k-steps of a query group of the W_a image, per slot) + q_a.  Sync: one barrier + one vmcnt(0) per chunk; chunk
-// c + 2 is issued when chunk c starts, training stores go out right after that barrier so the next wait finds them done.
+// Two workgroup shapes (template parameter WAVES, NtCfg below), both two wavefronts per SIMD (<= 256 VGPRs):
+//   8 waves, one workgroup per CU: 3 x 40 KB weight ring, chunk c + 2 issued when chunk c starts; every weight byte is
+//     fetched once per 8 news, but the two waves of a SIMD run in lock step (same barriers), so their VALU epilogues
+//     (dropout hash, split, tanh, pooling) coincide and the matrix pipe idles meanwhile;
+//   4 waves, two workgroups per CU: 2 x 38 KB ring each, chunk c + 1 issued when chunk c starts; twice the L2 -> LDS
+//     weight traffic, but the two waves of a SIMD belong to free-running workgroups and one's epilogue hides under the
+//     other's MFMAs.
+// Sync: one barrier + one vmcnt(0) per chunk; training stores go out right after that barrier so the next wait finds them done.
 #pragma once
+#include <utility>
+
 #include "nrl_news_fused.h"
+#include "nrl_news_tail_api.h"
 
 namespace nrl {
 
-constexpr int NT_WAVES = 8;          // news per workgroup
-constexpr int NT_FB = 19;            // feature blocks of y (D = 300 + the ones column)
-constexpr int NT_KB = 10;            // k-blocks of 32 plane slots of `o` (19 block columns)
-constexpr int NT_QB = 13;            // query blocks (Q <= 208)
-constexpr int NT_KS = 10;            // k-steps of phase 2 (pairs of feature blocks)
-constexpr int NT_SLOT = 40 * 1024;   // ring slot: 38 pieces (phase 1) / <= 40 pieces (phase 2) of 1 KiB
-constexpr int NT_SLOTS = 3;
-constexpr int NT_NCHUNK = NT_KB + 8;  // phase 2: 4 query groups x 2 halves of the reduction
-
-struct NewsTailArgs {
-  const unsigned char* o_planes;  // (hi, lo) planes of `o` over the real rows, 19 block columns (head-permuted + ones at slot D)
-  const uint16_t* img_o;          // W_o image, reduction in plane-slot order, b_o at slot D (rp_jobs_add_kperm with bias)
-  const uint16_t* img_a;          // W_a image, reduction in kappa order, b_a at feature D (rp_jobs_add_kappa)
-  const float* q_a;               // (Q)
-  int64_t n_news;
-  int L, D, Q;
-  Dropout drop2;
-  float* out;                     // (n_news, D)
-  unsigned char* y_planes;        // training: post-dropout y as planes over the real rows (19 block columns, ones at D), or null
-  float* t;                       // training, optional: tanh output (n_news * L, Q) for pool_bwd_pre; null when the backward
-                                  // recomputes it (news_tail_bwd_kernel)
-  float* w;                       // training: pooling weights (n_news * L), or null
+template <int WAVES>
+struct NtCfg;
+template <>
+struct NtCfg<8> {                      // one workgroup per CU
+  static constexpr int SLOT = 40 * 1024, SLOTS = 3, LOOK = 2;
+  static constexpr int KPARTS = 2;     // forward phase 2: k-steps {0-4, 5-9} per query group (<= 40 pieces of 1 KiB)
+  static constexpr int KPC = 2;        // backward phase C: k-steps per chunk
+  static constexpr int BSLOT = 40 * 1024;
 };
+template <>
+struct NtCfg<4> {                      // two workgroups per CU
+  static constexpr int SLOT = 38 * 1024, SLOTS = 2, LOOK = 1;
+  static constexpr int KPARTS = 3;     // k-steps {0-3, 4-6, 7-9} (<= 32 pieces)
+  static constexpr int KPC = 1;
+  static constexpr int BSLOT = 26 * 1024;
+};
+// compile-time loop: f(integral_constant<int, 0>{}), f(<1>), ...  (hipcc gives up `#pragma unroll` on the largest bodies and then
+// indexes the register arrays dynamically -- they land in scratch)
+template <class F, int... I>
+__device__ __forceinline__ void nt_static_for(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void nt_static_for(F&& f) {
+  nt_static_for(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+__host__ __device__ constexpr int nt_kp0(int kparts, int p) {   // first k-step of part p of the phase-2 reduction
+  return kparts == 2 ? 5 * p : (p == 0 ? 0 : p == 1 ? 4 : p == 2 ? 7 : 10);
+}
 
 __device__ __forceinline__ float nt_dpp(float v, int ctrl_sel) {
   const int i = __builtin_bit_cast(int, v);
@@ -82,6 +96,13 @@ __device__ __forceinline__ float nt_row_max(float v) {
   v = fmaxf(v, nt_dpp(v, 3));
   return v;
 }
+// 8-byte plane store; NT = 1: streaming (write-once activations far larger than the L2 gain nothing from write-allocate)
+template <int NT>
+__device__ __forceinline__ void nt_store8(unsigned char* dst, uint32_t a, uint32_t b) {
+  typedef uint32_t nt_u32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (NT) __builtin_nontemporal_store(nt_u32x2{a, b}, reinterpret_cast<nt_u32x2*>(dst));
+  else *reinterpret_cast<uint2*>(dst) = make_uint2(a, b);
+}
 // tanh(x) = 1 - 2 / (exp(2x) + 1): v_exp_f32 + v_rcp_f32 (1 ulp each; absolute error ~1e-7, saturates cleanly at +-1)
 __device__ __forceinline__ float nt_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
@@ -92,48 +113,56 @@ __device__ __forceinline__ float nt_tanh(float x) {
 // 8 = no phase-1 MFMAs, 16 = no phase-2 MFMAs, 32 = no pooling reduction
 // SAVE: 0 = evaluation (nothing but `out`), 1 = training (y planes + w; the fused backward recomputes tanh), 2 = training with
 // the tanh output t as well (backward through pool_bwd_pre)
-template <int SAVE, int ABL = 0>
-__global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_fwd_kernel(const NewsTailArgs P) {
+template <int SAVE, int WAVES, int ABL = 0>
+__global__ void __launch_bounds__(WAVES * 64, 2) news_tail_fwd_kernel(const NewsTailArgs P) {
+  using Cfg = NtCfg<WAVES>;
+  constexpr int NT_SLOT = Cfg::SLOT, NT_SLOTS = Cfg::SLOTS, LOOK = Cfg::LOOK, KPARTS = Cfg::KPARTS;
+  constexpr int NT_NCHUNK = NT_KB + 4 * KPARTS;       // phase 2: 4 query groups x KPARTS parts of the reduction
+  constexpr int PPW = (40 + WAVES - 1) / WAVES;       // DMA pieces per wave and chunk (<= 40 pieces per chunk)
+  constexpr int STREAM = (ABL & 64) ? 0 : 1;          // y planes: streaming stores (probe: ABL 64 = plain)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NT_SLOTS * NT_SLOT + 1024];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   float* const qa_s = reinterpret_cast<float*>(smem + NT_SLOTS * NT_SLOT);
   if (tid < 256) qa_s[tid] = tid < P.Q ? P.q_a[tid] : 0.f;
   __syncthreads();
 
   const int L = P.L, D = P.D, Q = P.Q;
-  const int64_t news_raw = (int64_t)blockIdx.x * NT_WAVES + wave;
+  const int64_t news_raw = (int64_t)blockIdx.x * WAVES + wave;
   const bool news_ok = news_raw < P.n_news;
   const int64_t news = news_ok ? news_raw : 0;      // idle waves of the last workgroup recompute news 0 and store nothing
   const int64_t row0 = news * L;
 
-  // ---- weight DMA: chunk c < NT_KB = k-block c of the W_o image (38 pieces of 1 KiB); chunk NT_KB + 2 grp + half =
-  // k-steps 5 half .. 5 half + 4 x query blocks of group grp x (hi, lo) of the W_a image.  Pieces wave, wave + 8, ...
+  // ---- weight DMA: chunk c < NT_KB = k-block c of the W_o image (38 pieces of 1 KiB); chunk NT_KB + KPARTS grp + part =
+  // k-steps of part `part` x query blocks of group grp x (hi, lo) of the W_a image.  Pieces wave, wave + WAVES, ...
   auto issue_chunk = [&](int c) {
     if constexpr (ABL & 4) return;
     const uint32_t dst = smem_base + (uint32_t)(c % NT_SLOTS) * (uint32_t)NT_SLOT;
     if (c < NT_KB) {
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_o) + (size_t)c * (NT_FB * 2048) + lane * 16;
+      // (wave-uniform SGPR base + one shared lane offset: per-piece VGPR address pairs cost 2 x PPW registers)
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_o) + (size_t)c * (NT_FB * 2048);
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        int piece = wave + q * NT_WAVES;
+      for (int q = 0; q < PPW; ++q) {
+        int piece = wave + q * WAVES;
         piece = piece < 2 * NT_FB ? piece : 2 * NT_FB - 1;
-        glds16_asm(src + piece * 1024, dst + (uint32_t)piece * 1024u);
+        glds16_saddr(src + piece * 1024, lane_off, dst + (uint32_t)piece * 1024u);
       }
     } else if (c < NT_NCHUNK) {
-      const int j = c - NT_KB, grp = j >> 1, half = j & 1;
+      const int j = c - NT_KB, grp = j / KPARTS, part = j - grp * KPARTS;
       const int nb0 = grp == 0 ? 0 : 1 + 3 * grp, nbs = grp == 0 ? 4 : 3;
-      const int pieces = 10 * nbs;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_a) + lane * 16;
+      const int ks0 = nt_kp0(KPARTS, part), nks = nt_kp0(KPARTS, part + 1) - ks0;
+      const int pieces = 2 * nks * nbs;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_a);
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        int piece = wave + q * NT_WAVES;
+      for (int q = 0; q < PPW; ++q) {
+        int piece = wave + q * WAVES;
         piece = piece < pieces ? piece : pieces - 1;
         const int ks = piece / (2 * nbs), rem = piece - ks * 2 * nbs;     // rem = nb * 2 + plane
-        glds16_asm(src + ((size_t)((5 * half + ks) * NT_QB + nb0) * 2 + rem) * 1024, dst + (uint32_t)piece * 1024u);
+        glds16_saddr(src + ((size_t)((ks0 + ks) * NT_QB + nb0) * 2 + rem) * 1024, lane_off, dst + (uint32_t)piece * 1024u);
       }
     }
   };
@@ -222,15 +251,15 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_fwd_kernel(const N
     }
   };
 
-  issue_chunk(0);
-  issue_chunk(1);
+#pragma unroll
+  for (int c = 0; c < LOOK; ++c) issue_chunk(c);
   {
     bf16x8 oha[2], ola[2], ohb[2], olb[2];
     load_o(0, oha, ola);
     auto step = [&](int kb, const bf16x8 (&ch)[2], const bf16x8 (&cl)[2], bf16x8 (&nh)[2], bf16x8 (&nl)[2]) {
-      wait_vmcnt<0>();                     // chunk kb has landed for this wave (issued two chunks ago) ...
-      __builtin_amdgcn_s_barrier();        // ... and for all; everyone is done with the slot chunk kb + 2 goes to
-      issue_chunk(kb + 2);
+      wait_vmcnt<0>();                     // chunk kb has landed for this wave (issued LOOK chunks ago) ...
+      __builtin_amdgcn_s_barrier();        // ... and for all; everyone is done with the slot chunk kb + LOOK goes to
+      issue_chunk(kb + LOOK);
       load_o(kb + 1 < NT_KB ? kb + 1 : kb, nh, nl);
       __builtin_amdgcn_sched_barrier(0);
       p1_chunk(kb % NT_SLOTS, ch, cl);
@@ -279,38 +308,43 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_fwd_kernel(const N
       asm volatile("" : "+v"(m));
       unsigned char* dst = P.y_planes + ((m >> 4) * NT_FB + 2 * s) * 1024 + (m & 15) * 32 + 8 * g;
       const uint4 h = __builtin_bit_cast(uint4, yh[s][tb]), l = __builtin_bit_cast(uint4, yl[s][tb]);
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h.x, h.y);
-      *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l.x, l.y);
+      nt_store8<STREAM>(dst, h.x, h.y);
+      nt_store8<STREAM>(dst + 512, l.x, l.y);
       if (2 * s + 1 < NT_FB) {
-        *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(h.z, h.w);
-        *reinterpret_cast<uint2*>(dst + 1536) = make_uint2(l.z, l.w);
+        nt_store8<STREAM>(dst + 1024, h.z, h.w);
+        nt_store8<STREAM>(dst + 1536, l.z, l.w);
       }
     }
   };
 
   // =============================== phase 2: pre^T = W_a y^T, tanh, . q_a =================================
   float apart[2] = {0.f, 0.f};
-#pragma unroll
-  for (int grp = 0; grp < 4; ++grp) {
-    const int nb0 = grp == 0 ? 0 : 1 + 3 * grp, nbs = grp == 0 ? 4 : 3;
+  nt_static_for<4>([&](auto grp_c) {
+    constexpr int grp = decltype(grp_c)::value;
+    constexpr int nb0 = grp == 0 ? 0 : 1 + 3 * grp, nbs = grp == 0 ? 4 : 3;
     f32x4 pacc[4][2];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) pacc[nb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int c = NT_KB + 2 * grp + half;
+    nt_static_for<KPARTS>([&](auto part_c) {
+      constexpr int part = decltype(part_c)::value;
+      constexpr int c = NT_KB + KPARTS * grp + part;
+      constexpr int ks0 = nt_kp0(KPARTS, part), nks = nt_kp0(KPARTS, part + 1) - ks0;
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      issue_chunk(c + 2);
-      // training stores under this chunk's MFMAs: k-steps j (and 8 + j for the first two chunks) of the y planes
-      store_y(c - NT_KB);
-      if (c - NT_KB < 2) store_y(8 + c - NT_KB);
+      issue_chunk(c + LOOK);
+      // training stores under this chunk's MFMAs: k-step j of the y planes in the j-th chunk of phase 2 (the first chunks
+      // take the k-steps that are left over when there are fewer chunks than k-steps)
+      {
+        constexpr int j = c - NT_KB, nch = 4 * KPARTS;
+        if constexpr (j < NT_KS) store_y(j);
+        if constexpr (nch + j < NT_KS) store_y(nch + j);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* base = smem + (c % NT_SLOTS) * NT_SLOT + lane * 16;
-      const int nsteps = 5 * nbs;                    // step i = (k-step 5 half + i / nbs, query block nb0 + i % nbs)
-      const int npairs = (nsteps + 1) / 2;
+      constexpr int nsteps = nks * nbs;              // step i = (k-step ks0 + i / nbs, query block nb0 + i % nbs)
+      constexpr int npairs = (nsteps + 1) / 2;
       auto p2_read = [&](int p, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -331,7 +365,7 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_fwd_kernel(const N
           for (int jj = 0; jj < 2; ++jj) {
             const int i = 2 * p + jj;
             if (i < nsteps) {
-              const int s = 5 * half + i / nbs, nb = i % nbs;
+              const int s = ks0 + i / nbs, nb = i % nbs;
 #pragma unroll
               for (int tb = 0; tb < 2; ++tb)
                 pacc[nb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj],
@@ -363,7 +397,7 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_fwd_kernel(const N
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     // group epilogue: t = tanh(pre) (b_a came in through the ones feature), a += t . q_a over this lane's 4 queries
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -388,7 +422,7 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_fwd_kernel(const N
       //  result is only read after the last group -- down to the pooling, keeping every tanh value and q_a alive: spills)
       asm volatile("" : "+v"(apart[0]), "+v"(apart[1]));
     }
-  }
+  });
 
   // =============================== softmax over the tokens, pooled sum ====================================
   float wt[2];
@@ -444,26 +478,23 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_fwd_kernel(const N
     if (news_ok && l15 == 0 && f0 < D) *reinterpret_cast<float4*>(outp + f0) = make_float4(pr[0], pr[1], pr[2], pr[3]);
   }
   // (every DMA issued has been waited for: the last chunk's wait covers chunks up to NT_NCHUNK - 1, none is issued later)
+  static_assert(2 * 5 * 4 <= NT_SLOT / 1024 || KPARTS == 3, "phase-2 chunk must fit a ring slot");
 }
 
-static inline bool news_tail_ok(int L, int D, int Q, int heads) {
-  return news_fused_ok(L, D, heads) && D == 300 && Q % 4 == 0 && Q > 0 && Q <= 16 * NT_QB;
-}
-
-template <int ABL = 0>
+template <int WAVES = 4, int ABL = 0>
 static inline int launch_news_tail_fwd(const NewsTailArgs& a, hipStream_t st) {
   if (a.n_news <= 0) return NRL_OK;
-  const int64_t blocks = ceil_div(a.n_news, NT_WAVES);
+  const int64_t blocks = ceil_div(a.n_news, WAVES);
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   NRL_REQUIRE(a.D == 300 && a.Q <= 16 * NT_QB && a.L >= 1 && a.L <= 32, "fused news tail: unsupported geometry");
   NRL_REQUIRE((((uintptr_t)a.out | (uintptr_t)a.t | (uintptr_t)a.q_a) & 15) == 0, "fused news tail: 16-byte alignment");
   if (a.y_planes != nullptr) {
     NRL_REQUIRE(a.w != nullptr, "fused news tail: save y planes and w (and optionally t), or nothing");
-    if (a.t != nullptr) hipLaunchKernelGGL((news_tail_fwd_kernel<2, ABL>), dim3((unsigned)blocks), dim3(NT_WAVES * 64), 0, st, a);
-    else hipLaunchKernelGGL((news_tail_fwd_kernel<1, ABL>), dim3((unsigned)blocks), dim3(NT_WAVES * 64), 0, st, a);
+    if (a.t != nullptr) hipLaunchKernelGGL((news_tail_fwd_kernel<2, WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
+    else hipLaunchKernelGGL((news_tail_fwd_kernel<1, WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
   } else {
     NRL_REQUIRE(a.t == nullptr && a.w == nullptr, "fused news tail: save y planes and w (and optionally t), or nothing");
-    hipLaunchKernelGGL((news_tail_fwd_kernel<0, ABL>), dim3((unsigned)blocks), dim3(NT_WAVES * 64), 0, st, a);
+    hipLaunchKernelGGL((news_tail_fwd_kernel<0, WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
   }
   NRL_LAUNCH_CHECK();
   return NRL_OK;
@@ -480,38 +511,29 @@ static inline int launch_news_tail_fwd(const NewsTailArgs& a, hipStream_t st) {
 //                                                  order) * d_pre^T (B: the accumulators of phase A, split once), two halves
 // Outputs: d_pre and dy as (hi, lo) planes over the real rows (operands of the two weight gradients and of the
 // out-projection's activation gradient), dq_a through LDS + one atomic per query and workgroup.
-struct NewsTailBwdArgs {
-  const unsigned char* y_planes;  // the forward's y planes (19 block columns, ones at feature D)
-  const float* w;                 // (n_news * L) pooling weights
-  const float* d_out;             // (n_news, D)
-  const uint16_t* img_a;          // the forward's W_a image (kappa order, b_a at feature D)
-  const uint16_t* img_ad;         // W_a^T image: 19 feature blocks, reduction = queries in kappa order (7 k-blocks)
-  const float* q_a;               // (Q)
-  int64_t n_news;
-  int L, D, Q;
-  Dropout drop2;
-  unsigned char* dpre_planes;     // out: 13 block columns
-  unsigned char* dy_planes;       // out: 19 block columns
-  float* dq_a;                    // (Q), accumulated
-};
-
-constexpr int NT_QS = 7;           // k-steps of phase C (pairs of query blocks)
-constexpr int NT_DROW = 320;       // floats per news of the staged d_out (zero-padded past D)
-
-template <int ABL = 0>
-__global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const NewsTailBwdArgs P) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NT_SLOTS * NT_SLOT + 2048 + NT_WAVES * NT_DROW * 4];
+template <int WAVES, int ABL = 0>
+__global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const NewsTailBwdArgs P) {
+  using Cfg = NtCfg<WAVES>;
+  constexpr int NT_SLOT = Cfg::BSLOT, NT_SLOTS = Cfg::SLOTS, LOOK = Cfg::LOOK, KPC = Cfg::KPC;
+  constexpr int NPC = (NT_QS + KPC - 1) / KPC;         // phase-C chunks per half of the features
+  constexpr int NT_NCHUNK = NT_KS + 2 * NPC;
+  constexpr int PPW = (2 * KPC * 10 + WAVES - 1) / WAVES > (2 * NT_QB + WAVES - 1) / WAVES ? (2 * KPC * 10 + WAVES - 1) / WAVES
+                                                                                             : (2 * NT_QB + WAVES - 1) / WAVES;
+  static_assert(2 * NT_QB * 1024 <= NT_SLOT && 2 * KPC * 10 * 1024 <= NT_SLOT, "chunk must fit a ring slot");
+  constexpr int STREAM = (ABL & 64) ? 0 : 1;          // d_pre / dy planes: streaming stores (probe: ABL 64 = plain)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NT_SLOTS * NT_SLOT + 2048 + WAVES * NT_DROW * 4];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   float* const qa_s = reinterpret_cast<float*>(smem + NT_SLOTS * NT_SLOT);          // 256 floats
   float* const dq_s = qa_s + 256;                                                   // 256 floats
   float* const d_s = dq_s + 256 + wave * NT_DROW;                                   // this wave's d_out row
 
   const int L = P.L, D = P.D, Q = P.Q;
-  const int64_t news_raw = (int64_t)blockIdx.x * NT_WAVES + wave;
+  const int64_t news_raw = (int64_t)blockIdx.x * WAVES + wave;
   const bool news_ok = news_raw < P.n_news;
   const int64_t news = news_ok ? news_raw : 0;
   const int64_t row0 = news * L;
@@ -524,31 +546,31 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const N
   for (int i = lane; i < NT_DROW; i += 64) d_s[i] = i < D ? P.d_out[news * D + i] : 0.f;
   __syncthreads();
 
-  // chunk c < NT_KS: k-step c of the W_a image (26 pieces); chunk NT_KS + 4 half + p: k-steps 2p, 2p + 1 of the W_a^T image
+  // chunk c < NT_KS: k-step c of the W_a image (26 pieces); chunk NT_KS + NPC half + p: k-steps KPC p .. of the W_a^T image
   // x feature blocks of the half (10 or 9) x (hi, lo)
   auto issue_chunk = [&](int c) {
     if constexpr (ABL & 4) return;
     const uint32_t dst = smem_base + (uint32_t)(c % NT_SLOTS) * (uint32_t)NT_SLOT;
     if (c < NT_KS) {
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_a) + (size_t)c * (NT_QB * 2048) + lane * 16;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_a) + (size_t)c * (NT_QB * 2048);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int piece = wave + q * NT_WAVES;
+      for (int q = 0; q < PPW; ++q) {
+        int piece = wave + q * WAVES;
         piece = piece < 2 * NT_QB ? piece : 2 * NT_QB - 1;
-        glds16_asm(src + piece * 1024, dst + (uint32_t)piece * 1024u);
+        glds16_saddr(src + piece * 1024, lane_off, dst + (uint32_t)piece * 1024u);
       }
     } else if (c < NT_NCHUNK) {
-      const int j = c - NT_KS, half = j >> 2, p = j & 3;
+      const int j = c - NT_KS, half = j / NPC, p = j - half * NPC;
       const int fb0 = half ? 10 : 0, nfb = half ? 9 : 10;
-      const int nks = p < 3 ? 2 : 1;
+      const int nks = (p + 1) * KPC <= NT_QS ? KPC : NT_QS - p * KPC;
       const int pieces = nks * nfb * 2;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_ad) + lane * 16;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_ad);
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        int piece = wave + q * NT_WAVES;
+      for (int q = 0; q < PPW; ++q) {
+        int piece = wave + q * WAVES;
         piece = piece < pieces ? piece : pieces - 1;
         const int ks = piece / (2 * nfb), rem = piece - ks * 2 * nfb;      // rem = fb * 2 + plane
-        glds16_asm(src + ((size_t)((2 * p + ks) * NT_FB + fb0) * 2 + rem) * 1024, dst + (uint32_t)piece * 1024u);
+        glds16_saddr(src + ((size_t)((KPC * p + ks) * NT_FB + fb0) * 2 + rem) * 1024, lane_off, dst + (uint32_t)piece * 1024u);
       }
     }
   };
@@ -586,15 +608,15 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const N
     for (int tb = 0; tb < 2; ++tb) pacc[nb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int PA_PAIRS = (NT_QB + 1) / 2;
-  issue_chunk(0);
-  issue_chunk(1);
+#pragma unroll
+  for (int c = 0; c < LOOK; ++c) issue_chunk(c);
   {
     bf16x8 yha[2], yla[2], yhb[2], ylb[2];
     load_y(0, yha, yla);
     auto step = [&](int s, const bf16x8 (&ch)[2], const bf16x8 (&cl)[2], bf16x8 (&nh)[2], bf16x8 (&nl)[2]) {
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      issue_chunk(s + 2);
+      issue_chunk(s + LOOK);
       load_y(s + 1 < NT_KS ? s + 1 : s, nh, nl);
       // this k-step's slice of d_out in kappa order, split: the A fragment of row qc_row in block qc_blk
       bf16x8 dh, dl;
@@ -717,11 +739,11 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const N
       asm volatile("" : "+v"(m));
       unsigned char* dst = P.dpre_planes + ((m >> 4) * NT_QB + 2 * s) * 1024 + (m & 15) * 32 + 8 * g;
       const uint4 h = __builtin_bit_cast(uint4, ph[s][tb]), l = __builtin_bit_cast(uint4, pl[s][tb]);
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h.x, h.y);
-      *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l.x, l.y);
+      nt_store8<STREAM>(dst, h.x, h.y);
+      nt_store8<STREAM>(dst + 512, l.x, l.y);
       if (2 * s + 1 < NT_QB) {
-        *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(h.z, h.w);
-        *reinterpret_cast<uint2*>(dst + 1536) = make_uint2(l.z, l.w);
+        nt_store8<STREAM>(dst + 1024, h.z, h.w);
+        nt_store8<STREAM>(dst + 1536, l.z, l.w);
       }
     }
   };
@@ -736,19 +758,20 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const N
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) acc[fb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int c = NT_KS + 4 * half + p;
+    for (int p = 0; p < NPC; ++p) {
+      const int c = NT_KS + NPC * half + p;
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      issue_chunk(c + 2);
+      issue_chunk(c + LOOK);
+      const int nks = (p + 1) * KPC <= NT_QS ? KPC : NT_QS - p * KPC;
       if (half == 0) {                         // the d_pre planes go out under the first half's MFMAs
-        store_dpre(2 * p);
-        if (2 * p + 1 < NT_QS) store_dpre(2 * p + 1);
+#pragma unroll
+        for (int ks = 0; ks < KPC; ++ks)
+          if (ks < nks) store_dpre(KPC * p + ks);
       }
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* base = smem + (c % NT_SLOTS) * NT_SLOT + lane * 16;
-      const int nks = p < 3 ? 2 : 1;
-      const int nsteps = nks * nfb;              // step i = (k-step 2p + i / nfb, feature block fb0 + i % nfb)
+      const int nsteps = nks * nfb;              // step i = (k-step KPC p + i / nfb, feature block fb0 + i % nfb)
       const int npairs = (nsteps + 1) / 2;
       auto rd = [&](int pp, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
 #pragma unroll
@@ -770,7 +793,7 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const N
           for (int jj = 0; jj < 2; ++jj) {
             const int i = 2 * pp + jj;
             if (i < nsteps) {
-              const int s = 2 * p + i / nfb, fb = i % nfb;
+              const int s = KPC * p + i / nfb, fb = i % nfb;
 #pragma unroll
               for (int tb = 0; tb < 2; ++tb)
                 acc[fb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj], pass == 0 ? pl[s][tb] : ph[s][tb],
@@ -814,8 +837,8 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const N
         split_pair(v[2], v[3], h1, l1);
         if (!(ABL & 2) && news_ok && tok_ok[tb]) {
           unsigned char* dst = P.dy_planes + ((m >> 4) * NT_FB + fb0 + fb) * 1024 + (m & 15) * 32 + 8 * g;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-          *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l0, l1);
+          nt_store8<STREAM>(dst, h0, h1);
+          nt_store8<STREAM>(dst + 512, l0, l1);
         }
       }
     }
@@ -827,18 +850,14 @@ __global__ void __launch_bounds__(NT_WAVES * 64, 2) news_tail_bwd_kernel(const N
   if (tid < Q) atomicAdd(P.dq_a + tid, dq_s[tid]);
 }
 
-static inline bool news_tail_bwd_ok(int L, int D, int Q, int heads) {
-  return news_tail_ok(L, D, Q, heads) && Q < 16 * NT_QB && Q <= 256;   // (a free query row for d_out)
-}
-
-template <int ABL = 0>
+template <int WAVES = 4, int ABL = 0>
 static inline int launch_news_tail_bwd(const NewsTailBwdArgs& a, hipStream_t st) {
   if (a.n_news <= 0) return NRL_OK;
-  const int64_t blocks = ceil_div(a.n_news, NT_WAVES);
+  const int64_t blocks = ceil_div(a.n_news, WAVES);
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   NRL_REQUIRE(a.D == 300 && a.Q < 16 * NT_QB && a.Q % 4 == 0 && a.L >= 1 && a.L <= 32, "fused news tail backward: unsupported geometry");
   NRL_REQUIRE((((uintptr_t)a.d_out | (uintptr_t)a.q_a) & 15) == 0, "fused news tail backward: 16-byte alignment");
-  hipLaunchKernelGGL((news_tail_bwd_kernel<ABL>), dim3((unsigned)blocks), dim3(NT_WAVES * 64), 0, st, a);
+  hipLaunchKernelGGL((news_tail_bwd_kernel<WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ int rp_image_row(const RpImageJob& J, int n) {
   return part * (J.heads * J.dh) + head * J.dh + d;   // rows [Wq; Wk; Wv] of in_proj_weight
 }
 
-__global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs jobs) {
+static __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpImageJobs jobs) {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (tid >= jobs.first_thread[jobs.count]) return;
   int j = 0;

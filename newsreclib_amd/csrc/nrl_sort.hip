@@ -20,8 +20,16 @@ namespace nrl {
 // (256 positions per workgroup: 825 workgroups, 82 us at B = 128; 2048: 104 workgroups)
 constexpr int CS_THREADS = 256, CS_ITEMS = 8, CS_BLOCK = CS_THREADS * CS_ITEMS, CS_SLOTS = 2 * CS_BLOCK;
 
-__global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __restrict__ ids, int64_t n, int* __restrict__ hist,
-                                                            int* __restrict__ rank) {
+// ids outside [0, vocab) cannot index the histogram (and -1 is the hash table's empty-slot sentinel): they are grouped
+// with the nearest valid id, consistently in both passes, so the result stays a permutation of the positions and every
+// write stays in bounds.  (The embedding gather of such an id is the caller's error; the sort must not add memory
+// corruption to it.)
+__device__ __forceinline__ int cs_clamp_id(int64_t id, int vocab) {
+  return id < 0 ? 0 : (id >= vocab ? vocab - 1 : (int)id);
+}
+
+__global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __restrict__ ids, int64_t n, int vocab,
+                                                            int* __restrict__ hist, int* __restrict__ rank) {
   __shared__ int keys[CS_SLOTS], cnt[CS_SLOTS], base[CS_SLOTS];
   const int tid = threadIdx.x;
   for (int s = tid; s < CS_SLOTS; s += CS_THREADS) {
@@ -37,7 +45,7 @@ __global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __re
     slot[q] = 0;
     lrank[q] = 0;
     if (p < n) {
-      const int id = (int)ids[p];
+      const int id = cs_clamp_id(ids[p], vocab);
       int s = (int)(((uint32_t)id * 0x9E3779B1u) >> 20) & (CS_SLOTS - 1);
       while (true) {                                      // <= CS_BLOCK distinct ids per workgroup in 2 x CS_BLOCK slots
         const int prev = atomicCAS(&keys[s], -1, id);
@@ -83,9 +91,9 @@ __global__ void __launch_bounds__(1024) cs_scan_kernel(int* __restrict__ hist, i
 // order[block prefix + start-in-block[id] + rank] = position; the prefix of the <= 1024 block totals is rebuilt per
 // workgroup in LDS (a few hundred cached loads)
 __global__ void __launch_bounds__(256) cs_scatter_kernel(const int64_t* __restrict__ ids, int64_t n,
-                                                         const int* __restrict__ start, const int* __restrict__ totals,
-                                                         int nblocks, const int* __restrict__ rank,
-                                                         int64_t* __restrict__ order) {
+                                                         int vocab, const int* __restrict__ start,
+                                                         const int* __restrict__ totals, int nblocks,
+                                                         const int* __restrict__ rank, int64_t* __restrict__ order) {
   __shared__ int pre[1024];
   const int tid = threadIdx.x;
   for (int b = tid; b < 1024; b += 256) pre[b] = b < nblocks ? totals[b] : 0;
@@ -110,7 +118,7 @@ __global__ void __launch_bounds__(256) cs_scatter_kernel(const int64_t* __restri
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * 256 + tid;
   if (p < n) {
-    const int id = (int)ids[p];
+    const int id = cs_clamp_id(ids[p], vocab);
     order[pre[id >> 10] + start[id] + rank[p]] = p;
   }
 }
@@ -143,12 +151,12 @@ int nrl_sort_positions(const int64_t* ids, int64_t n, int64_t vocab, int64_t* or
   const int sblocks = (int)ceil_div(vocab, 1024);
   NRL_HIP(hipMemsetAsync(hist, 0, (size_t)vocab * sizeof(int), st));
   const unsigned blocks = (unsigned)ceil_div(n, CS_BLOCK);
-  hipLaunchKernelGGL(cs_rank_kernel, dim3(blocks), dim3(CS_THREADS), 0, st, ids, n, hist, rank);
+  hipLaunchKernelGGL(cs_rank_kernel, dim3(blocks), dim3(CS_THREADS), 0, st, ids, n, (int)vocab, hist, rank);
   NRL_LAUNCH_CHECK();
   hipLaunchKernelGGL(cs_scan_kernel, dim3((unsigned)sblocks), dim3(1024), 0, st, hist, (int)vocab, totals);
   NRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cs_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, ids, n, hist, totals, sblocks,
-                     rank, order);
+  hipLaunchKernelGGL(cs_scatter_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, ids, n, (int)vocab, hist, totals,
+                     sblocks, rank, order);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -21,6 +21,7 @@
 // LDS stages; split-K over news with atomic accumulation (EpiAtomicWBHeads remaps the 64-row head groups to the
 // [Wq; Wk; Wv] rows).  Arithmetic: hi * lo + lo * hi + hi * hi into fp32, as everywhere else.
 #pragma once
+#include <atomic>
 #include "nrl_gemm_bf16x3_dma.h"
 
 namespace nrl {
@@ -214,11 +215,13 @@ static inline int launch_wgrad_planes(const void* a_planes, const void* b_planes
   P.M = (int64_t)heads * 64; P.N = n_valid;
   const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * ceil_div(P.nsplit, 8) * 8;
   NRL_REQUIRE(blocks < (1LL << 31), "wgrad_planes: grid too large");
-  static bool attr_done = false;                            // 156 KiB of dynamic LDS: opt in once per kernel instance
-  if (!attr_done) {
+  static std::atomic<uint64_t> attr_done{0};                // 156 KiB of dynamic LDS: opt in once per kernel instance AND device
+  int dev = 0;
+  NRL_HIP(hipGetDevice(&dev));
+  if (!((attr_done.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
     NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<Epi, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, WP_STAGES * WP_STAGE));
-    attr_done = true;
+    attr_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
   }
   P.scratch = P.nsplit > 1 ? scratch : nullptr;
   hipLaunchKernelGGL((wgrad_planes_kernel<Epi, ABL>), dim3((unsigned)blocks), dim3(256), WP_STAGES * WP_STAGE, st, P, epi);
@@ -398,11 +401,13 @@ static inline int launch_wgrad_planes_g(const void* a_planes, int ncb_a, const v
   P.M = m_valid; P.N = n_valid;
   const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * ceil_div(P.nsplit, 8) * 8;
   NRL_REQUIRE(blocks < (1LL << 31), "wgrad_planes_g: grid too large");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::atomic<uint64_t> attr_done{0};                // (per kernel instance and device; a racing second call is harmless)
+  int dev = 0;
+  NRL_HIP(hipGetDevice(&dev));
+  if (!((attr_done.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
     NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_g_kernel<TM, TN, Epi>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
   }
   P.scratch = P.nsplit > 1 ? scratch : nullptr;
   hipLaunchKernelGGL((wgrad_planes_g_kernel<TM, TN, Epi>), dim3((unsigned)blocks), dim3(256), LDS, st, P, epi);

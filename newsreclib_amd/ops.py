@@ -32,14 +32,14 @@ def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _block_params(tensors: Sequence[torch.Tensor], heads: int, engine: int = 0) -> NrlBlockParams:
+def _block_params(tensors: Sequence[torch.Tensor], heads: int, engine: int = 0, options: int = 0) -> NrlBlockParams:
     w_in, b_in, w_o, b_o, w_a, b_a, q_a = tensors
     D, Q = w_o.shape[0], w_a.shape[0]
     if w_in.shape != (3 * D, D) or b_in.shape != (3 * D,) or b_o.shape != (D,) or \
             w_a.shape != (Q, D) or b_a.shape != (Q,) or q_a.shape != (Q,):
         raise ValueError("newsreclib_amd: inconsistent MHSA/additive-attention parameter shapes")
     return NrlBlockParams(w_in.data_ptr(), b_in.data_ptr(), w_o.data_ptr(), b_o.data_ptr(),
-                          w_a.data_ptr(), b_a.data_ptr(), q_a.data_ptr(), D, heads, Q, int(engine))
+                          w_a.data_ptr(), b_a.data_ptr(), q_a.data_ptr(), D, heads, Q, int(engine), int(options))
 
 
 def _block_grads(bufs: Sequence[torch.Tensor]) -> NrlBlockGrads:
@@ -80,8 +80,8 @@ class NewsEncoderFn(torch.autograd.Function):
             raise ValueError("newsreclib_amd: token ids must be (num_news, num_tokens)")
         N, L = ids.shape
         V, D = emb.shape
-        engine = _lib.engine_code()
-        bp = _block_params(params[1:], heads, engine)
+        engine, options = _lib.engine_code(), _lib.options_word()
+        bp = _block_params(params[1:], heads, engine, options)
         save = any(ctx.needs_input_grad)
         ws_bytes = lib.nrl_news_encoder_workspace_bytes(N, L, D, heads, bp.query_dim)
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=ids.device)
@@ -98,7 +98,7 @@ class NewsEncoderFn(torch.autograd.Function):
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
-            ctx.table_grad_hook, ctx.engine, ctx.options = table_grad_hook, engine, _lib.options_mask()
+            ctx.table_grad_hook, ctx.engine, ctx.options = table_grad_hook, engine, options
         return out
 
     @staticmethod
@@ -110,8 +110,9 @@ class NewsEncoderFn(torch.autograd.Function):
         N, L = ids.shape
         V, D = emb.shape
         d_out = _chk(d_out, torch.float32, "d_out")
-        _lib.require_options(ctx.options, "the news encoder")   # the workspace formats the forward wrote
-        bp = _block_params(params[1:], heads, ctx.engine)      # the engine the forward ran under
+        # the engine and the kernel-selection switches the forward ran under travel with the call: the backward reads the
+        # workspace in the format the forward wrote, whatever the process defaults are by now
+        bp = _block_params(params[1:], heads, ctx.engine, ctx.options)
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         bg = _block_grads(bufs[1:])
         ws = ctx.ws
@@ -128,7 +129,7 @@ class NewsEncoderFn(torch.autograd.Function):
             # the embedding-table gradient (>96 % of all gradient bytes) is complete after phase 1: let the
             # data-parallel trainer start its all-reduce now, under the weight-gradient GEMMs of phase 2
             run(1)
-            hook(bufs[0])
+            hook(bufs[0], ids)
             run(2)
         ctx.ws = None
         return (None, *rets, None, None, None, None, None, None, None)
@@ -147,7 +148,8 @@ class UserEncoderFn(torch.autograd.Function):
             raise ValueError("newsreclib_amd: hist_news_vector must be (batch, history, dim)")
         B, H, D = hist.shape
         engine = _lib.engine_code()
-        bp = _block_params(params, heads, engine)
+        options = _lib.options_word()
+        bp = _block_params(params, heads, engine, options)
         if bp.embed_dim != D:
             raise ValueError("newsreclib_amd: hist feature dim does not match the encoder")
         save = any(ctx.needs_input_grad)
@@ -160,6 +162,7 @@ class UserEncoderFn(torch.autograd.Function):
         if save:
             ctx.save_for_backward(hist, *params)
             ctx.ws, ctx.heads, ctx.grad_bufs, ctx.engine = ws, heads, grad_bufs, engine
+            ctx.options = options
             ctx.drop = (float(p_drop), int(seed), int(stream0), int(bool(input_dropout)))
         return out
 
@@ -169,7 +172,7 @@ class UserEncoderFn(torch.autograd.Function):
         hist, *params = ctx.saved_tensors
         B, H, D = hist.shape
         d_out = _chk(d_out, torch.float32, "d_out")
-        bp = _block_params(params, ctx.heads, ctx.engine)
+        bp = _block_params(params, ctx.heads, ctx.engine, ctx.options)   # (engine and switches of the forward)
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         bg = _block_grads(bufs)
         d_hist = torch.empty_like(hist)

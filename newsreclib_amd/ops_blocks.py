@@ -36,13 +36,14 @@ class AdditiveAttentionFn(torch.autograd.Function):
                                                   ws.data_ptr(), ws.numel(), _stream()), "nrl_additive_attention_fwd")
         if save:
             ctx.save_for_backward(y, *params)
-            ctx.ws, ctx.grad_bufs, ctx.engine = ws, grad_bufs, _lib.engine_code()
+            ctx.ws, ctx.grad_bufs, ctx.engine, ctx.options = ws, grad_bufs, _lib.engine_code(), _lib.options_mask()
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
         _lib.require_engine(ctx.engine, "additive attention")
+        _lib.require_options(ctx.options, "additive attention")
         y, *params = ctx.saved_tensors
         G, S, D = y.shape
         Q = params[0].shape[0]
@@ -77,12 +78,14 @@ class LinearActFn(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(a, w, bias, c)
             ctx.ws, ctx.code, ctx.grad_bufs, ctx.engine = ws, code, grad_bufs, _lib.engine_code()
+            ctx.options = _lib.options_mask()
         return c
 
     @staticmethod
     def backward(ctx, d_c):
         lib = _lib.load()
         _lib.require_engine(ctx.engine, "linear + activation")
+        _lib.require_options(ctx.options, "linear + activation")
         a, w, bias, c = ctx.saved_tensors
         M, K = a.shape
         N = w.shape[0]
@@ -124,6 +127,7 @@ class MhaFn(torch.autograd.Function):
         if save:
             ctx.save_for_backward(x, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs, ctx.engine = ws, (int(heads), float(scale or 0.0)), grad_bufs, engine
+            ctx.options = _lib.options_mask()
         return out
 
     @staticmethod
@@ -134,6 +138,7 @@ class MhaFn(torch.autograd.Function):
         S, Bt, D = x.shape
         heads, scale = ctx.cfg
         d_out = _chk(d_out, torch.float32, "d_out")
+        _lib.require_options(ctx.options, "multi-head attention")
         mp = NrlMhaParams(*[p.data_ptr() for p in params], D, heads, scale, ctx.engine)
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         mg = NrlMhaGrads(*[b.data_ptr() for b in bufs])

@@ -54,13 +54,14 @@ class CnnEncoderFn(torch.autograd.Function):
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (float(p_drop), int(seed), int(stream0)), grad_bufs
-            ctx.engine = _lib.engine_code()
+            ctx.engine, ctx.options = _lib.engine_code(), _lib.options_mask()
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
         _lib.require_engine(ctx.engine, "the CNN text encoder")
+        _lib.require_options(ctx.options, "the CNN text encoder")
         ids, order, *params = ctx.saved_tensors
         emb = params[0]
         p_drop, seed, stream0 = ctx.cfg
@@ -142,13 +143,14 @@ class GruFn(torch.autograd.Function):
         if save:
             ctx.save_for_backward(hist, lengths, *params)
             ctx.has_h0 = h0 is not None
-            ctx.ws, ctx.grad_bufs, ctx.engine = ws, grad_bufs, _lib.engine_code()
+            ctx.ws, ctx.grad_bufs, ctx.engine, ctx.options = ws, grad_bufs, _lib.engine_code(), _lib.options_mask()
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
         _lib.require_engine(ctx.engine, "the GRU")
+        _lib.require_options(ctx.options, "the GRU")
         hist, lengths, *params = ctx.saved_tensors
         B, T, Din = hist.shape
         Hd = params[1].shape[1]
@@ -183,7 +185,8 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
         V, D = emb.shape
         F_, _, W, _ = w_c.shape
         engine = _lib.engine_code()
-        bp = _block_params(params[3:], heads, engine)
+        options = _lib.options_word()
+        bp = _block_params(params[3:], heads, engine, options)
         cp = NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), None, None, None, D, F_, W, bp.query_dim)
         save = any(ctx.needs_input_grad)
         ws = torch.empty(max(lib.nrl_cnn_mhsa_encoder_workspace_bytes(N, L, D, F_, W, heads, bp.query_dim), 256),
@@ -197,7 +200,7 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
                 order = _sort_positions(ids, V)     # counting sort over the vocabulary (ops.sort_positions)
             ctx.save_for_backward(ids, _chk(order, torch.int64, "order"), *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
-            ctx.engine = engine
+            ctx.engine, ctx.options = engine, options
         return out
 
     @staticmethod
@@ -211,7 +214,7 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
         V, D = emb.shape
         F_, _, W, _ = w_c.shape
         d_out = _chk(d_out, torch.float32, "d_out")
-        bp = _block_params(params[3:], heads, ctx.engine)
+        bp = _block_params(params[3:], heads, ctx.engine, ctx.options)   # (engine and switches of the forward)
         cp = NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), None, None, None, D, F_, W, bp.query_dim)
         bufs, rets = _grad_targets(params, ctx.grad_bufs)
         cg = NrlCnnGrads(bufs[1].data_ptr(), bufs[2].data_ptr(), None, None, None)

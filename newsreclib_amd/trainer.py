@@ -96,7 +96,7 @@ class OverlappedGradReduce:
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
-    def start_head(self, _grad=None) -> None:
+    def start_head(self, _grad=None, _ids=None) -> None:
         if self._active() and self.head > 0:
             self._work = dist.all_reduce(self.flat.grad[: self.head], op=dist.ReduceOp.SUM, group=self.group,
                                          async_op=True)
@@ -113,15 +113,98 @@ class OverlappedGradReduce:
             self._work = None
         return 1.0 / dist.get_world_size(self.group)
 
+    def info(self) -> Dict:
+        return {"mode": "dense", "payload_bytes_per_rank": 4 * self.flat.numel,
+                "note": "sum all-reduce of the whole flat fp32 gradient (table head async under the weight gradients)"}
+
+
+class TouchedRowsExchange:
+    """Gradient exchange that ships only the embedding-table rows a rank TOUCHED this step (SURVEY.md section 8e,
+    "optional later"): the (V, D) table gradient is > 96 % of the flat gradient and a rank's batch touches at most
+    B * (H + C) * L of its V rows.
+
+    After phase 1 of the news-encoder backward (``start_head``, called from inside the backward with the token ids):
+    each rank gathers its unique sorted ids and their gradient rows, all ranks all-gather (counts, ids, rows) -- async,
+    under the weight-gradient GEMMs.  ``finish`` all-reduces the small dense rest, zeroes the rank's own touched rows and
+    adds EVERY rank's rows (its own included, from the gathered buffer) in ascending rank order: each replica performs the
+    same additions in the same order, so the replicas stay bit-identical, and with two ranks the result is bit-identical to
+    the dense all-reduce (a + b == b + a).  Dense Adam is unchanged (rows nobody touched carry a zero gradient).
+    Costs one host sync per step (the unique counts size the gather buffers); the dense path has none."""
+
+    def __init__(self, flat: "FlatParams", head_numel: int, table: torch.Tensor, group=None):
+        self.flat, self.head, self.group = flat, int(head_numel), group
+        self.rows, self.dim = int(table.shape[0]), int(table.shape[1])
+        self._pending = None
+        self._payload = 0
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _table_grad(self) -> torch.Tensor:
+        return self.flat.grad[: self.rows * self.dim].view(self.rows, self.dim)
+
+    def start_head(self, _grad=None, ids=None) -> None:
+        if not self._active() or self.head <= 0 or ids is None:
+            return
+        world = dist.get_world_size(self.group)
+        g = self._table_grad()
+        uniq = torch.unique(ids.reshape(-1))                                  # sorted unique ids of this rank
+        count = torch.tensor([uniq.numel()], dtype=torch.int64, device=g.device)
+        counts = [torch.zeros_like(count) for _ in range(world)]
+        dist.all_gather(counts, count, group=self.group)
+        counts = [int(c) for c in torch.cat(counts).tolist()]                 # (host sync: sizes of the gather buffers)
+        cap = max(max(counts), 1)
+        ids_pad = torch.zeros(cap, dtype=torch.int64, device=g.device)
+        ids_pad[: uniq.numel()] = uniq
+        rows_pad = torch.zeros(cap, self.dim, dtype=g.dtype, device=g.device)
+        rows_pad[: uniq.numel()] = g.index_select(0, uniq)
+        ids_all = [torch.empty_like(ids_pad) for _ in range(world)]
+        rows_all = [torch.empty_like(rows_pad) for _ in range(world)]
+        w1 = dist.all_gather(ids_all, ids_pad, group=self.group, async_op=True)
+        w2 = dist.all_gather(rows_all, rows_pad, group=self.group, async_op=True)
+        self._pending = (uniq, counts, ids_all, rows_all, w1, w2)
+        self._payload = cap * (8 + 4 * self.dim) + 8 + 4 * (self.flat.numel - self.head)
+
+    def finish(self) -> float:
+        if not self._active():
+            return 1.0
+        world = dist.get_world_size(self.group)
+        if self._pending is None:                   # the hook did not fire (or carried no ids): dense fallback
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._payload = 4 * self.flat.numel
+            return 1.0 / world
+        if self.head < self.flat.numel:
+            dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
+        uniq, counts, ids_all, rows_all, w1, w2 = self._pending
+        self._pending = None
+        w1.wait()
+        w2.wait()
+        g = self._table_grad()
+        g.index_fill_(0, uniq, 0.0)                 # own rows out, then every rank's rows in, in rank order
+        for r in range(world):
+            n = counts[r]
+            if n > 0:
+                g.index_add_(0, ids_all[r][:n], rows_all[r][:n])    # unique indices: no contention, deterministic
+        return 1.0 / world
+
+    def info(self) -> Dict:
+        return {"mode": "rows", "payload_bytes_per_rank": int(self._payload), "dense_payload_bytes_per_rank": 4 * self.flat.numel,
+                "note": "all-gather of (unique ids, their table-gradient rows) padded to the largest rank + dense all-reduce of "
+                        "the non-table gradient; last step's sizes"}
+
 
 class NRMSTrainer:
     """forward -> CE loss -> backward (table-gradient all-reduce overlapped) -> fused Adam."""
 
-    def __init__(self, module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, group=None):
+    def __init__(self, module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, group=None,
+                 grad_exchange: str = "dense"):
+        if grad_exchange not in ("dense", "rows"):
+            raise ValueError("grad_exchange must be 'dense' (all-reduce of the flat gradient) or 'rows' (touched table rows)")
         self.module = module
         self.flat = FlatParams(module.parameters())
         self.opt = FusedAdam(self.flat, lr, betas, eps)
         self.group = group
+        self._losses: List[torch.Tensor] = []
         # leading segment = first parameter = the embedding table when the news encoder is MHSAAddAtt
         head = 0
         te = None
@@ -133,15 +216,37 @@ class NRMSTrainer:
         if te is not None and hasattr(te, "table_grad_hook") and len(enc.text_encoders) == 1 \
                 and self.flat.params[0] is te.embedding_layer.weight:
             head = self.flat.offsets[1] if len(self.flat.offsets) > 1 else self.flat.numel
-        self.reduce = OverlappedGradReduce(self.flat, head, group)
+        if grad_exchange == "rows" and head > 0:
+            self.reduce = TouchedRowsExchange(self.flat, head, te.embedding_layer.weight, group)
+        else:
+            self.reduce = OverlappedGradReduce(self.flat, head, group)
         if head > 0:
             te.table_grad_hook = self.reduce.start_head
+
+    def epoch_end(self) -> Dict[str, float]:
+        """Mean train loss over the steps since the last call (all ranks' steps under data parallelism), then reset --
+        what ``on_train_epoch_end`` logs as train/loss when Lightning drives the module (nrms_module.py:380-396)."""
+        if not self._losses:
+            return {}
+        tot = torch.stack(self._losses).sum().reshape(1).double()
+        cnt = torch.tensor([float(len(self._losses))], dtype=torch.float64, device=tot.device)
+        self._losses = []
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            both = torch.cat([tot, cnt])
+            dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group)
+            tot, cnt = both[:1], both[1:]
+        return {"train/loss": float(tot / cnt)}
+
+    def exchange_info(self) -> Dict:
+        """What the data-parallel gradient exchange ships per rank and step (bench.py prints it for N > 1)."""
+        return self.reduce.info()
 
     def step(self, batch: Dict) -> torch.Tensor:
         self.module.train()
         # model_step directly: training_step would append preds / targets to training_step_outputs every step, and
-        # nothing here runs the epoch-end hook that clears them (use `epoch_end()` for the epoch metrics instead)
+        # nothing here runs the epoch-end hook that clears them; the loss is still tracked for `epoch_end()`
         loss = self.module.model_step(batch)[0]
+        self._losses.append(loss.detach())
         loss.backward()
         # parameters whose gradient came through ordinary autograd (``.grad``: a transformer body, a small
         # head fed through torch ops) rather than through a kernel writing ``main_grad``: fold them in

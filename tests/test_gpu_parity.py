@@ -233,23 +233,44 @@ def test_news_path_format_switches_agree(N, L, option):
         assert _maxerr(g0, res[1][1][k]) <= 1e-4 * scale, (option, k)
 
 
-def test_backward_refuses_a_switch_changed_since_the_forward():
-    """The switches select private workspace formats: a backward under another setting than its forward must fail loudly
-    (it would read planes where packed rows were written), not return wrong gradients."""
+def test_switches_travel_with_the_call():
+    """The kernel-selection switches select private workspace formats.  They are per call (NrlBlockParams.options): the
+    autograd forward captures the word and hands it to its backward, so (a) a backward still reads the workspace in the
+    format its forward wrote when the process defaults changed in between, and (b) two modules of one process can run
+    under different switches; entry points without the field (CNN encoder ...) refuse a backward under other defaults."""
     from newsreclib_amd import _lib
     from newsreclib_amd.news_encoder import MHSAAddAtt
     _lib.set_gemm_engine("bf16x3")
     params = _news_params(vocab=53, seed=3)
-    enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
-    enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
-    enc = enc.to(DEV).train()
-    out = enc(torch.randint(0, 53, (5, 30)).to(DEV), seed=1)
+    ids = torch.randint(0, 53, (5, 30)).to(DEV)
+
+    def make():
+        enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
+        enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+        return enc.to(DEV).train()
+
+    ref = make()
+    ref(ids, seed=1).sum().backward()
+    ref_g = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    # (a) defaults changed between forward and backward
+    enc = make()
+    out = enc(ids, seed=1)
     _lib.set_option("news_planes", False)
     try:
-        with pytest.raises(RuntimeError, match="changed between"):
-            out.sum().backward()
+        out.sum().backward()
+        # (b) a second module, forward AND backward under the changed defaults, next to the first one's tape
+        other = make()
+        out2 = other(ids, seed=1)
     finally:
         _lib.set_option("news_planes", True)
+    out2.sum().backward()                      # its own switches (news_planes off), defaults back to on
+    for k, g in ref_g.items():
+        scale = max(1.0, float(g.abs().max()))
+        assert torch.equal(dict(enc.named_parameters())[k].grad, g) or _maxerr(dict(enc.named_parameters())[k].grad, g) <= 1e-6 * scale, k
+        assert _maxerr(dict(other.named_parameters())[k].grad, g) <= 1e-4 * scale, k
+    assert _lib.options_word() & _lib.OPTIONS_EXPLICIT
+    with pytest.raises(RuntimeError, match="changed between"):
+        _lib.require_options(_lib.options_mask() ^ 1, "a test call")
 
 
 @pytest.mark.parametrize("B,H", [(3, 4), (5, 50), (40, 7), (130, 3)])
@@ -423,9 +444,16 @@ def test_full_size_properties_b128():
         v_all = te(ids)
         v_part = te(ids[37:101])
     assert torch.equal(v_all[37:101], v_part)
-    # a user's scores change with the batch composition (seq-first MHA), sub-batch of 64 users:
-    sub = prepare_batch(make_batch(64, 70_000, "fixed", seed=1234, device=DEV))
-    assert sub["x_hist"]["title"].shape[0] == 64 * 50
+    # a user's scores change with the batch composition (seq-first MHA, user/nrms.py:27-36): the SAME first 64 users, their
+    # clicks and candidates, scored without the other 64 users of the batch
+    raw = make_batch(128, 70_000, "fixed", seed=1234, device=DEV)
+    sub = {"batch_hist": raw["batch_hist"][: 64 * 50], "batch_cand": raw["batch_cand"][: 64 * 5],
+           "x_hist": {"title": raw["x_hist"]["title"][: 64 * 50]}, "x_cand": {"title": raw["x_cand"]["title"][: 64 * 5]},
+           "labels": raw["labels"][: 64 * 5], "user_ids": raw["user_ids"][:64], "user_idx": raw["user_idx"][:64], "batch_size": 64}
+    with torch.no_grad():
+        s_sub = mod(prepare_batch(sub))
+    assert s_sub.shape == (64, 5) and torch.isfinite(s_sub).all()
+    assert float((s_sub - s1[:64]).abs().max()) > 1e-3
     # ragged batch with a padded candidate tail scores exactly 0 there
     rag = prepare_batch(make_batch(64, 70_000, "ragged", seed=7, device=DEV))
     with torch.no_grad():
@@ -700,7 +728,8 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["POR
 torch.cuda.set_device(0)
 params = O.make_params(2000, seed=8)
 mod = build_module(params, p_drop=0.2, device="cuda:0")
-tr = NRMSTrainer(mod, lr=1e-3)
+tr = NRMSTrainer(mod, lr=1e-3, grad_exchange=os.environ["GRAD_EXCHANGE"])
+assert tr.exchange_info()["mode"] == os.environ["GRAD_EXCHANGE"]
 assert tr.reduce.head == 2000 * 300 and mod.news_encoder.text_encoders["title"].table_grad_hook is not None
 batch = prepare_batch(make_batch(8, 2000, "ragged", seed=100 + rank, device="cuda:0"))   # rank-specific impressions
 # -- the reduced gradient == the MEAN of the per-rank ORACLE gradients (what reference DDP hands its optimizer;
@@ -738,7 +767,7 @@ tr.flat.grad.zero_()
 te.forward = plain_fwd
 fired = []
 orig = tr.reduce.start_head
-tr.reduce.start_head = lambda g=None: (fired.append(1), orig(g))[1]
+tr.reduce.start_head = lambda g=None, ids=None: (fired.append(1), orig(g, ids))[1]
 mod.news_encoder.text_encoders["title"].table_grad_hook = tr.reduce.start_head
 for _ in range(2):
     loss = tr.step(batch)
@@ -753,10 +782,12 @@ print("OK", rank)
 """
 
 
-def test_two_rank_data_parallel_steps_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("grad_exchange", ["dense", "rows"])
+def test_two_rank_data_parallel_steps_share_one_gpu(tmp_path, grad_exchange):
     """N>1 path with REAL kernels: two ranks (gloo, both on cuda:0 -- RCCL needs one GPU per rank, the
     box has one) take two train steps on different impressions; the table-gradient hook fires from
-    inside backward, the replicas stay bit-identical, and the result differs from training alone."""
+    inside backward, the replicas stay bit-identical, and the result differs from training alone.  Both gradient
+    exchanges: the dense all-reduce and the touched-row all-gather (trainer.TouchedRowsExchange)."""
     import os
     import subprocess
     import sys
@@ -766,7 +797,7 @@ def test_two_rank_data_parallel_steps_share_one_gpu(tmp_path):
     port = str(29600 + os.getpid() % 300)
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), PORT=port, REPO=root, OUT=str(tmp_path))
+        env = dict(os.environ, RANK=str(rank), PORT=port, REPO=root, OUT=str(tmp_path), GRAD_EXCHANGE=grad_exchange)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:

@@ -169,6 +169,65 @@ dist.destroy_process_group()
 print("OK", rank)
 """
 
+_ROWS_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from newsreclib_amd.trainer import FlatParams, OverlappedGradReduce, TouchedRowsExchange
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+V, D = 97, 12
+torch.manual_seed(0)
+def fresh():
+    params = [torch.nn.Parameter(torch.zeros(V, D)), torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(3))]
+    return params, FlatParams(params)
+def fill(params, r):
+    # what a backward leaves in main_grad: rows of the rank's own ids (duplicates, the pad id 0, ids shared with the
+    # other rank), dense gradients for the rest
+    g = torch.Generator().manual_seed(100 + r)
+    ids = torch.randint(0, V, (6, 9), generator=g)
+    ids[0, :3] = 0
+    ids[1, :] = torch.arange(40, 49)            # shared between the ranks
+    rows = torch.randn(ids.numel(), D, generator=g)
+    params[0].main_grad.index_add_(0, ids.reshape(-1), rows)
+    params[1].main_grad.add_(torch.randn(5, 7, generator=g))
+    params[2].main_grad.add_(torch.randn(3, generator=g))
+    return ids
+# dense reference
+pd, fd = fresh()
+fill(pd, rank)
+red = OverlappedGradReduce(fd, V * D)
+red.start_head(pd[0].main_grad)
+assert red.finish() == 0.5
+# touched-row exchange
+pr, fr = fresh()
+ids = fill(pr, rank)
+ex = TouchedRowsExchange(fr, V * D, pr[0])
+ex.start_head(pr[0].main_grad, ids)
+assert ex.finish() == 0.5
+assert torch.equal(fr.grad, fd.grad), "touched-row exchange != dense all-reduce (must be bit-identical at 2 ranks)"
+# == the sum of the two ranks' local gradients, and identical on both replicas
+tot = None
+for r in range(2):
+    p2, f2 = fresh()
+    fill(p2, r)
+    tot = f2.grad.clone() if tot is None else tot + f2.grad
+assert torch.allclose(fr.grad, tot, atol=1e-6)
+both = [torch.empty_like(fr.grad) for _ in range(2)]
+dist.all_gather(both, fr.grad)
+assert torch.equal(both[0], both[1]), "replicas diverged"
+info = ex.info()
+assert info["mode"] == "rows" and 0 < info["payload_bytes_per_rank"] < info["dense_payload_bytes_per_rank"], info
+# the hook never fired (or carried no ids): dense fallback
+pf, ff = fresh()
+fill(pf, rank)
+ex2 = TouchedRowsExchange(ff, V * D, pf[0])
+assert ex2.finish() == 0.5 and torch.equal(ff.grad, fd.grad)
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
 _DP_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["REPO"])
@@ -219,6 +278,13 @@ def test_overlapped_gradient_reduce_two_processes_gloo(tmp_path):
     """The two-piece all-reduce (async head launched from inside backward, tail afterwards) equals one
     sum all-reduce of the whole flat gradient; also when the hook never fires."""
     _run_two_ranks(tmp_path, _OVERLAP_SCRIPT, "overlap.py")
+
+
+def test_touched_row_exchange_two_processes_gloo(tmp_path):
+    """The optional touched-row gradient exchange (all-gather of unique ids + their table-gradient rows, dense rest
+    all-reduced) is bit-identical to the dense all-reduce at two ranks, equals the sum of the per-rank gradients,
+    leaves both replicas identical, ships fewer bytes, and falls back to the dense all-reduce when the hook did not fire."""
+    _run_two_ranks(tmp_path, _ROWS_SCRIPT, "rows.py")
 
 
 def test_data_parallel_allreduce_two_processes_gloo(tmp_path):

@@ -57,9 +57,9 @@ static float bf16_f(uint16_t h) {
   return f;
 }
 
-int main(int argc, char** argv) {
-  const int64_t N = argc > 1 ? atoll(argv[1]) : 7040;
-  const int L = argc > 2 ? atoi(argv[2]) : 30;
+template <int WV>
+static int run(int64_t N, int L) {
+  printf("======== %d waves per workgroup ========\n", WV);
   const int D = 300, H = 15, Q = 200, NCB = 19;
   const int64_t M = N * L, Mp = (M + 31) / 32 * 32;
   hipStream_t st;
@@ -126,7 +126,7 @@ int main(int argc, char** argv) {
   ae.y_planes = nullptr; ae.t = nullptr; ae.w = nullptr; ae.drop2 = make_dropout(0.0, 0, 0);
 
   // ---- correctness: training launch against the host restatement on a sample of news ----
-  if (launch_news_tail_fwd<0>(a, st) != NRL_OK) return 1;
+  if (launch_news_tail_fwd<WV, 0>(a, st) != NRL_OK) return 1;
   CK(hipStreamSynchronize(st));
   std::vector<float> gout((size_t)N * D), gt((size_t)M * Q), gw(M);
   std::vector<unsigned char> gy(hpl.size());
@@ -189,11 +189,11 @@ int main(int argc, char** argv) {
   {
     NewsTailArgs at = a;
     at.drop2 = make_dropout(0.0, 0, 0);
-    launch_news_tail_fwd<0>(at, st);
+    launch_news_tail_fwd<WV, 0>(at, st);
     CK(hipStreamSynchronize(st));
     std::vector<float> g1((size_t)N * D), g2((size_t)N * D);
     CK(hipMemcpy(g1.data(), out, g1.size() * 4, hipMemcpyDeviceToHost));
-    launch_news_tail_fwd<0>(ae, st);
+    launch_news_tail_fwd<WV, 0>(ae, st);
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(g2.data(), out, g2.size() * 4, hipMemcpyDeviceToHost));
     double d = 0;
@@ -204,22 +204,24 @@ int main(int argc, char** argv) {
 
   const double gf = 2.0 * M * (300.0 * 300 + 200.0 * 300) * 1e-9;
   auto report = [&](const char* name, float ms) { printf("%-44s %.3f ms  (%.0f TF fp32-equiv)\n", name, ms, gf / ms); fflush(stdout); };
-  report("eval", time_ms([&] { launch_news_tail_fwd<0>(ae, st); }, st));
-  report("train (y planes, t, w saved)", time_ms([&] { launch_news_tail_fwd<0>(a, st); }, st));
-  report("train no dropout hash", time_ms([&] { launch_news_tail_fwd<1>(a, st); }, st));
-  report("train no stores", time_ms([&] { launch_news_tail_fwd<2>(a, st); }, st));
-  report("eval  no weight DMA", time_ms([&] { launch_news_tail_fwd<4>(ae, st); }, st));
-  report("eval  no phase-1 MFMAs", time_ms([&] { launch_news_tail_fwd<8>(ae, st); }, st));
-  report("eval  no phase-2 MFMAs", time_ms([&] { launch_news_tail_fwd<16>(ae, st); }, st));
-  report("eval  no MFMAs at all", time_ms([&] { launch_news_tail_fwd<24>(ae, st); }, st));
-  report("eval  no MFMAs, no DMA", time_ms([&] { launch_news_tail_fwd<28>(ae, st); }, st));
-  report("eval  no pooling reduction", time_ms([&] { launch_news_tail_fwd<32>(ae, st); }, st));
-  report("eval, again", time_ms([&] { launch_news_tail_fwd<0>(ae, st); }, st));
-  report("train, again", time_ms([&] { launch_news_tail_fwd<0>(a, st); }, st));
+  report("eval", time_ms([&] { launch_news_tail_fwd<WV, 0>(ae, st); }, st));
+  report("train (y planes, t, w saved)", time_ms([&] { launch_news_tail_fwd<WV, 0>(a, st); }, st));
+  report("train no dropout hash", time_ms([&] { launch_news_tail_fwd<WV, 1>(a, st); }, st));
+  report("train no stores", time_ms([&] { launch_news_tail_fwd<WV, 2>(a, st); }, st));
+  report("eval  no weight DMA", time_ms([&] { launch_news_tail_fwd<WV, 4>(ae, st); }, st));
+  report("eval  no phase-1 MFMAs", time_ms([&] { launch_news_tail_fwd<WV, 8>(ae, st); }, st));
+  report("eval  no phase-2 MFMAs", time_ms([&] { launch_news_tail_fwd<WV, 16>(ae, st); }, st));
+  report("eval  no MFMAs at all", time_ms([&] { launch_news_tail_fwd<WV, 24>(ae, st); }, st));
+  report("eval  no MFMAs, no DMA", time_ms([&] { launch_news_tail_fwd<WV, 28>(ae, st); }, st));
+  report("eval  no pooling reduction", time_ms([&] { launch_news_tail_fwd<WV, 32>(ae, st); }, st));
+  report("eval, again", time_ms([&] { launch_news_tail_fwd<WV, 0>(ae, st); }, st));
+  report("train, again", time_ms([&] { launch_news_tail_fwd<WV, 0>(a, st); }, st));
   {
     NewsTailArgs a1 = a;
     a1.t = nullptr;
-    report("train without t (y planes, w saved)", time_ms([&] { launch_news_tail_fwd<0>(a1, st); }, st));
+    report("train without t (y planes, w saved)", time_ms([&] { launch_news_tail_fwd<WV, 0>(a1, st); }, st));
+    report("train without t, plain y stores", time_ms([&] { launch_news_tail_fwd<WV, 64>(a1, st); }, st));
+    report("train without t (y planes, w saved), again", time_ms([&] { launch_news_tail_fwd<WV, 0>(a1, st); }, st));
   }
 
   // ================= backward of the additive attention (news_tail_bwd_kernel) =================
@@ -248,14 +250,14 @@ int main(int argc, char** argv) {
     if (J->kblocks != NT_QS) { printf("unexpected k-block count %d\n", J->kblocks); return 1; }
     if (rp_jobs_launch(j2, st) != NRL_OK) return 1;
   }
-  launch_news_tail_fwd<0>(a, st);      // training forward: y planes + w (+ t, unused here)
+  launch_news_tail_fwd<WV, 0>(a, st);      // training forward: y planes + w (+ t, unused here)
   NewsTailBwdArgs b;
   b.y_planes = y_pl; b.w = w; b.d_out = d_out; b.img_a = img_a; b.img_ad = img_ad; b.q_a = qa; b.n_news = N; b.L = L;
   b.D = D; b.Q = Q; b.drop2 = a.drop2; b.dpre_planes = dpre_pl; b.dy_planes = dy_pl; b.dq_a = dq;
   const int64_t NS = N < 21 ? N : 21;        // small launch: every news checked, dq_a complete
   NewsTailBwdArgs bs = b;
   bs.n_news = NS;
-  if (launch_news_tail_bwd<0>(bs, st) != NRL_OK) return 1;
+  if (launch_news_tail_bwd<WV, 0>(bs, st) != NRL_OK) return 1;
   CK(hipStreamSynchronize(st));
   {
     std::vector<unsigned char> gdp(dpre_bytes), gdy(hpl.size());
@@ -317,13 +319,22 @@ int main(int argc, char** argv) {
            s_dp, e_dy, s_dy, e_dq, s_dq);
   }
   auto rep2 = [&](const char* name, float ms) { printf("%-44s %.3f ms\n", name, ms); fflush(stdout); };
-  rep2("tail bwd", time_ms([&] { launch_news_tail_bwd<0>(b, st); }, st));
-  rep2("tail bwd no dropout hash", time_ms([&] { launch_news_tail_bwd<1>(b, st); }, st));
-  rep2("tail bwd no stores", time_ms([&] { launch_news_tail_bwd<2>(b, st); }, st));
-  rep2("tail bwd no weight DMA", time_ms([&] { launch_news_tail_bwd<4>(b, st); }, st));
-  rep2("tail bwd no phase-A MFMAs", time_ms([&] { launch_news_tail_bwd<8>(b, st); }, st));
-  rep2("tail bwd no phase-C MFMAs", time_ms([&] { launch_news_tail_bwd<16>(b, st); }, st));
-  rep2("tail bwd no MFMAs, no DMA", time_ms([&] { launch_news_tail_bwd<28>(b, st); }, st));
-  rep2("tail bwd, again", time_ms([&] { launch_news_tail_bwd<0>(b, st); }, st));
+  rep2("tail bwd", time_ms([&] { launch_news_tail_bwd<WV, 0>(b, st); }, st));
+  rep2("tail bwd no dropout hash", time_ms([&] { launch_news_tail_bwd<WV, 1>(b, st); }, st));
+  rep2("tail bwd no stores", time_ms([&] { launch_news_tail_bwd<WV, 2>(b, st); }, st));
+  rep2("tail bwd no weight DMA", time_ms([&] { launch_news_tail_bwd<WV, 4>(b, st); }, st));
+  rep2("tail bwd no phase-A MFMAs", time_ms([&] { launch_news_tail_bwd<WV, 8>(b, st); }, st));
+  rep2("tail bwd no phase-C MFMAs", time_ms([&] { launch_news_tail_bwd<WV, 16>(b, st); }, st));
+  rep2("tail bwd no MFMAs, no DMA", time_ms([&] { launch_news_tail_bwd<WV, 28>(b, st); }, st));
+  rep2("tail bwd, again", time_ms([&] { launch_news_tail_bwd<WV, 0>(b, st); }, st));
+  rep2("tail bwd plain stores", time_ms([&] { launch_news_tail_bwd<WV, 64>(b, st); }, st));
+  rep2("tail bwd, once more", time_ms([&] { launch_news_tail_bwd<WV, 0>(b, st); }, st));
   return 0;
+}
+
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 7040;
+  const int L = argc > 2 ? atoi(argv[2]) : 30;
+  if (run<8>(N, L)) return 1;
+  return run<4>(N, L);
 }

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/quick/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-env "$@" NRL_PROFILE_STEPS=13 rocprofv3 --kernel-trace --stats -f csv -d $OUT -o t -- python $R/bench.py --steps 10 --warmup 3 --no-extras > $OUT/log.txt 2>&1
+env "$@" NRL_PROFILE_STEPS=23 rocprofv3 --kernel-trace --stats -f csv -d $OUT -o t -- python $R/bench.py --steps 10 --warmup 3 --no-extras > $OUT/log.txt 2>&1
 python - "$OUT" <<'PY'
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + '/**/t_kernel_stats.csv', recursive=True)[0]
