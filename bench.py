@@ -126,8 +126,9 @@ def extra_lstur(device, batch_size=128, steps=15):
 def extra_plm(device, batch_size=8, steps=3):
     """BASELINE.json configs[3]: NRMS with the PLM news encoder (roberta-base SHAPE, random init -- no network for the
     checkpoint; d = 768, 16 heads, L = 96, layers 0-7 frozen), B = 8 as in the reference's experiment file.  The
-    transformer body is HF on PyTorch-ROCm (third-party); the encoder tail, user encoder, scorer, loss and Adam are
-    this library's."""
+    transformer body is HF's module graph on PyTorch-ROCm (attention, layer norms, GELU: third-party) with its nn.Linear
+    projections swapped for this library's GEMM engine (news_encoder.swap_linears; NRL_PLM_LINEAR=0 keeps hipBLASLt:
+    205 -> 117 ms per step); the encoder tail, user encoder, scorer, loss and Adam are this library's."""
     import tempfile
     from functools import partial
 
@@ -156,8 +157,9 @@ def extra_plm(device, batch_size=8, steps=3):
         b[part]["title"] = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
     dt = _timed_steps(trainer, prepare_batch(b), steps, 1)
     return {"value": round(batch_size / dt, 2), "unit": "impressions/s", "ms_per_step": round(dt * 1e3, 1),
-            "config": "NRMS-PLM train step, roberta-base-shaped random body (HF on PyTorch-ROCm), d=768, 16 heads, L=96, "
-                      "B=8 (BASELINE.json configs[3])"}
+            "config": "NRMS-PLM train step, roberta-base-shaped random body (HF modules; its 72 projections on this library's "
+                      "GEMM engine via news_encoder.NrlLinear), d=768, 16 heads, L=96, B=8 (BASELINE.json configs[3])",
+            "body_linears_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_linears)}
 
 
 def self_launch(n_gpus: int) -> int:

@@ -434,6 +434,12 @@ int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, 
 size_t nrl_linear_workspace_bytes(int32_t n, int32_t k);
 int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n,
                    int32_t k, float* c, void* ws, size_t ws_bytes, void* stream);
+/* Backward of nrl_linear_fwd (nn.Linear inside a third-party stack -- the PLM body of text.py:89-109 -- on this library's
+ * matrix-core engines): d_a (m, k) = d_c (m, n) W; d_w (n, k) += d_c^T a; d_bias (n) += colsum(d_c).  d_a == NULL skips
+ * the activation gradient; d_w == d_bias == NULL skips the weight gradient (a frozen layer whose input still needs a
+ * gradient).  n, k multiples of 4; workspace as nrl_linear_workspace_bytes(n, k) (bf16x3 engine, d_a != NULL). */
+int nrl_linear_bwd(const float* a, const float* w, const float* d_c, int64_t m, int32_t n, int32_t k, float* d_a,
+                   float* d_w, float* d_bias, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

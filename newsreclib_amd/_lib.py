@@ -162,6 +162,8 @@ SIGNATURES = {
     "nrl_linear_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "nrl_linear_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                  c_size_t, c_void_p]),
+    "nrl_linear_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

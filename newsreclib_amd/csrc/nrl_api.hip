@@ -1056,6 +1056,33 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
   return gemm_fwd(KCPlain{a, k, m}, w, sw, epi, m, n, k, n <= 224, st);
 }
 
+// Backward of nrl_linear_fwd: d_a (m, k) = d_c W, d_w += d_c^T a, d_bias += colsum(d_c).  d_a == NULL skips the
+// activation gradient, d_w == NULL (with d_bias == NULL) the weight gradient -- a FROZEN nn.Linear inside a trainable
+// stack (the PLM body: layers 0-7 frozen, their inputs still need gradients, text.py:69-73).
+int nrl_linear_bwd(const float* a, const float* w, const float* d_c, int64_t m, int32_t n, int32_t k, float* d_a,
+                   float* d_w, float* d_bias, void* ws, size_t ws_bytes, void* stream) {
+  NRL_REQUIRE(w && d_c && m >= 0 && n > 0 && k > 0 && k % 4 == 0 && n % 4 == 0, "linear_bwd: bad arguments (n, k multiples of 4)");
+  NRL_REQUIRE((d_w == nullptr) == (d_bias == nullptr), "linear_bwd: d_w and d_bias come together");
+  NRL_REQUIRE(d_w == nullptr || a != nullptr, "linear_bwd: the weight gradient needs the forward's input");
+  NRL_REQUIRE((((uintptr_t)a | (uintptr_t)w | (uintptr_t)d_c | (uintptr_t)d_a) & 15) == 0, "linear_bwd: operands must be 16-byte aligned");
+  if (m == 0) return NRL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (d_a != nullptr) {
+    SplitWeight sw{};
+    if (cur_engine() == ENGINE_BF16X3) {
+      NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+      if (ws_bytes < nrl_linear_workspace_bytes(n, k)) {
+        set_error("workspace too small: %zu < %zu bytes", ws_bytes, nrl_linear_workspace_bytes(n, k));
+        return NRL_E_WORKSPACE;
+      }
+      NRL_TRY(split_weight(w, n, k, (uint16_t*)ws, &sw, st));
+    }
+    NRL_TRY(gemm_dgrad(d_c, w, sw, EpiStore{d_a, k}, m, n, k, st));
+  }
+  if (d_w != nullptr) NRL_TRY(gemm_wgrad(d_c, n, a, k, d_w, d_bias, m, st));
+  return NRL_OK;
+}
+
 }  // extern "C"
 
 #include "nrl_api_lstur.inc"

@@ -7,6 +7,7 @@ for the NRMS configuration (one text attribute) and the LSTUR one (shared text e
 abstract, category embedding, ``combine_type="concat"``).  Constructor signatures, attribute names
 and ``state_dict`` keys are the reference's.
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -170,6 +171,41 @@ class LinearEncoder(nn.Module):
         return vec
 
 
+class NrlLinear(nn.Module):
+    """Drop-in for an ``nn.Linear`` of a third-party stack (the transformer body of the PLM text encoder): the SAME
+    ``weight`` / ``bias`` Parameter objects (state-dict keys, freezing and optimizer membership unchanged), the GEMMs on
+    this library's engines (``ops_blocks.LinearFn`` -> ``nrl_linear_fwd`` / ``nrl_linear_bwd``)."""
+
+    def __init__(self, linear: nn.Linear) -> None:
+        super().__init__()
+        if linear.bias is None or linear.in_features % 4 or linear.out_features % 4:
+            raise ValueError("NrlLinear: needs a bias and in/out features that are multiples of 4")
+        self.in_features, self.out_features = linear.in_features, linear.out_features
+        self.weight, self.bias = linear.weight, linear.bias
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dtype != torch.float32 or not x.is_cuda:
+            return nn.functional.linear(x, self.weight, self.bias)      # (meta / CPU construction-time calls of HF)
+        params = (self.weight, self.bias)
+        return ops_blocks.LinearFn.apply(x.contiguous(), self.weight, self.bias, _grad_bufs(params))
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, engine=newsreclib_amd"
+
+
+def swap_linears(module: nn.Module) -> int:
+    """Replaces every eligible ``nn.Linear`` below ``module`` by ``NrlLinear`` in place; returns how many."""
+    n = 0
+    for name, child in list(module.named_children()):
+        if isinstance(child, nn.Linear) and child.bias is not None and child.in_features % 4 == 0 \
+                and child.out_features % 4 == 0:
+            setattr(module, name, NrlLinear(child))
+            n += 1
+        else:
+            n += swap_linears(child)
+    return n
+
+
 class PLM(nn.Module):
     """Text encoder over a pretrained language model, mirroring the reference ``PLM`` (text.py:15-109)
     for the NRMS configuration ``use_mhsa=True, apply_reduce_dim=False``: transformer body -> dropout
@@ -196,6 +232,11 @@ class PLM(nn.Module):
         from transformers import AutoModel
         self.use_mhsa, self.apply_reduce_dim = use_mhsa, apply_reduce_dim
         self.plm_model = AutoModel.from_pretrained(plm_model)
+        # the body's projections (q/k/v/out, the two feed-forward layers: > 90 % of a config-4 step) on this library's
+        # matrix-core engine instead of fp32 hipBLASLt; NRL_PLM_LINEAR=0 keeps the HF modules (A/B)
+        self.nrl_linears = 0
+        if os.environ.get("NRL_PLM_LINEAR", "1") != "0" and hasattr(self.plm_model, "encoder"):
+            self.nrl_linears = swap_linears(self.plm_model.encoder)
         for name, param in self.plm_model.base_model.named_parameters():   # text.py:69-73
             for layer in (frozen_layers or []):
                 if "layer." + str(layer) + "." in name:

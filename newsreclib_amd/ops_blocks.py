@@ -100,6 +100,54 @@ class LinearActFn(torch.autograd.Function):
         return (d_a, rets[0], rets[1], None, None)
 
 
+class LinearFn(torch.autograd.Function):
+    """``nn.Linear`` on this library's projection engines (bf16x3 / exact fp32 matrix cores): (..., K) -> (..., N).
+    The weight gradient is skipped for a frozen weight (the PLM body: layers 0-7 frozen while their inputs still need
+    gradients, reference text.py:69-73); the bf16 weight planes are rebuilt by the backward (10 us) rather than kept
+    alive for every layer of a transformer between its forward and backward."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, grad_bufs):
+        lib = _lib.load()
+        a, w, bias = _chk(a, torch.float32, "input"), _chk(w, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
+        if w.dim() != 2 or a.shape[-1] != w.shape[1] or bias.shape != (w.shape[0],):
+            raise ValueError("newsreclib_amd: inconsistent linear shapes")
+        N, K = w.shape
+        a2 = a.reshape(-1, K)
+        M = a2.shape[0]
+        ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=a.device)
+        c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _lib.check(lib.nrl_linear_fwd(a2.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, c.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), _stream()), "nrl_linear_fwd")
+        if any(ctx.needs_input_grad):
+            need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            ctx.save_for_backward(a2 if need_w else None, w, bias)
+            ctx.grad_bufs, ctx.engine, ctx.in_shape = grad_bufs, _lib.engine_code(), tuple(a.shape)
+        return c.view(*a.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, d_c):
+        lib = _lib.load()
+        _lib.require_engine(ctx.engine, "linear")
+        a2, w, bias = ctx.saved_tensors
+        N, K = w.shape
+        d_c = _chk(d_c.reshape(-1, N), torch.float32, "d_out")
+        M = d_c.shape[0]
+        need_a = ctx.needs_input_grad[0]
+        need_w = a2 is not None
+        rets = [None, None]
+        dw = db = None
+        if need_w:
+            bufs, rets = _grad_targets([w, bias], ctx.grad_bufs)
+            dw, db = bufs[0].data_ptr(), bufs[1].data_ptr()
+        d_a = torch.empty((M, K), dtype=torch.float32, device=d_c.device) if need_a else None
+        ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=d_c.device)
+        _lib.check(lib.nrl_linear_bwd(a2.data_ptr() if need_w else None, w.data_ptr(), d_c.data_ptr(), M, N, K,
+                                      d_a.data_ptr() if need_a else None, dw, db, ws.data_ptr(), ws.numel(), _stream()),
+                   "nrl_linear_bwd")
+        return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None)
+
+
 class MhaFn(torch.autograd.Function):
     """``nn.MultiheadAttention(x, x, x)[0]`` with ``batch_first=False``: x (S, Bt, D) -> (S, Bt, D), attention over
     S.  ``scale`` = the factor applied to q (None: 1/sqrt(D / heads))."""

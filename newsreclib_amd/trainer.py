@@ -61,9 +61,18 @@ class FusedAdam:
         self.step_count = 0
 
     def step(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+        self.begin_step()
+        self.step_range(0, self.flat.numel, grad_scale, zero_grad)
+
+    def begin_step(self) -> None:
         self.step_count += 1
-        ops.adam_step_(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.step_count,
-                       self.lr, self.betas, self.eps, grad_scale, zero_grad)
+
+    def step_range(self, lo: int, hi: int, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+        """The Adam update of elements [lo, hi) of the flat buffer (after ``begin_step``): lets the trainer update a slice
+        of the table as soon as ITS all-reduce has landed, while the next slice is still on the wire."""
+        if hi > lo:
+            ops.adam_step_(self.flat.flat[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                           self.step_count, self.lr, self.betas, self.eps, grad_scale, zero_grad)
 
 
 def allreduce_gradients(grad: torch.Tensor, group=None) -> float:
@@ -89,17 +98,23 @@ class OverlappedGradReduce:
     `finish` reduces the small tail and waits for the head.  With no process group (or world 1) both
     are no-ops and the scale is 1."""
 
-    def __init__(self, flat: "FlatParams", head_numel: int, group=None):
+    def __init__(self, flat: "FlatParams", head_numel: int, group=None, chunks: int = 1):
         self.flat, self.head, self.group = flat, int(head_numel), group
         self._work = None
+        # the head goes out as `chunks` all-reduces over equal, 256-byte aligned slices: `finish_pipelined` hands each
+        # slice to the optimizer as soon as it has landed, so the Adam pass over slice i runs under the transfer of
+        # slice i + 1.  (The table gradient itself cannot leave earlier: its last contribution is the LAST kernel of the
+        # activation-gradient chain, whichever id range one looks at.)
+        self.chunks = max(1, int(chunks))
+        self.bounds = [(self.head * i // self.chunks) // 64 * 64 for i in range(self.chunks)] + [self.head]
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def start_head(self, _grad=None, _ids=None) -> None:
         if self._active() and self.head > 0:
-            self._work = dist.all_reduce(self.flat.grad[: self.head], op=dist.ReduceOp.SUM, group=self.group,
-                                         async_op=True)
+            self._work = [dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                          for lo, hi in zip(self.bounds[:-1], self.bounds[1:]) if hi > lo]
 
     def finish(self) -> float:
         if not self._active():
@@ -109,13 +124,35 @@ class OverlappedGradReduce:
         else:
             if self.head < self.flat.numel:
                 dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
-            self._work.wait()
+            for w in self._work:
+                w.wait()
             self._work = None
         return 1.0 / dist.get_world_size(self.group)
 
+    def finish_pipelined(self):
+        """Generator form of ``finish``: yields (lo, hi, scale) slices of the flat gradient in the order they become final --
+        first the small tail (reduced here), then the head slices as their async all-reduces land."""
+        if not self._active():
+            yield 0, self.flat.numel, 1.0
+            return
+        scale = 1.0 / dist.get_world_size(self.group)
+        if self._work is None:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            yield 0, self.flat.numel, scale
+            return
+        if self.head < self.flat.numel:
+            dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
+            yield self.head, self.flat.numel, scale
+        live = [(lo, hi) for lo, hi in zip(self.bounds[:-1], self.bounds[1:]) if hi > lo]
+        for (lo, hi), w in zip(live, self._work):
+            w.wait()
+            yield lo, hi, scale
+        self._work = None
+
     def info(self) -> Dict:
-        return {"mode": "dense", "payload_bytes_per_rank": 4 * self.flat.numel,
-                "note": "sum all-reduce of the whole flat fp32 gradient (table head async under the weight gradients)"}
+        return {"mode": "dense", "payload_bytes_per_rank": 4 * self.flat.numel, "head_chunks": self.chunks,
+                "note": "sum all-reduce of the whole flat fp32 gradient (table head async under the weight gradients, in "
+                        "`head_chunks` slices whose Adam updates pipeline with the transfers)"}
 
 
 class TouchedRowsExchange:
@@ -197,7 +234,7 @@ class NRMSTrainer:
     """forward -> CE loss -> backward (table-gradient all-reduce overlapped) -> fused Adam."""
 
     def __init__(self, module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, group=None,
-                 grad_exchange: str = "dense"):
+                 grad_exchange: str = "dense", head_chunks: int = 4):
         if grad_exchange not in ("dense", "rows"):
             raise ValueError("grad_exchange must be 'dense' (all-reduce of the flat gradient) or 'rows' (touched table rows)")
         self.module = module
@@ -219,7 +256,7 @@ class NRMSTrainer:
         if grad_exchange == "rows" and head > 0:
             self.reduce = TouchedRowsExchange(self.flat, head, te.embedding_layer.weight, group)
         else:
-            self.reduce = OverlappedGradReduce(self.flat, head, group)
+            self.reduce = OverlappedGradReduce(self.flat, head, group, chunks=head_chunks)
         if head > 0:
             te.table_grad_hook = self.reduce.start_head
 
@@ -254,6 +291,12 @@ class NRMSTrainer:
             if p.grad is not None:
                 p.main_grad.add_(p.grad)
                 p.grad = None
-        scale = self.reduce.finish()
-        self.opt.step(grad_scale=scale, zero_grad=True)
+        if hasattr(self.reduce, "finish_pipelined"):
+            # dense exchange: Adam over each slice of the flat buffer as soon as its all-reduce has landed
+            self.opt.begin_step()
+            for lo, hi, scale in self.reduce.finish_pipelined():
+                self.opt.step_range(lo, hi, grad_scale=scale, zero_grad=True)
+        else:
+            scale = self.reduce.finish()
+            self.opt.step(grad_scale=scale, zero_grad=True)
         return loss.detach()

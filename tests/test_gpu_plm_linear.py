@@ -1,0 +1,83 @@
+"""Config 4 (BASELINE.json configs[3]): the projections of the PLM body on this library's matrix-core engines
+(news_encoder.NrlLinear / swap_linears -> nrl_linear_fwd / nrl_linear_bwd) against the same HF layer on fp32 torch."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _one_layer_roberta(layers=1):
+    from transformers import RobertaConfig, RobertaModel
+    cfg = RobertaConfig(vocab_size=1000, hidden_size=768, num_hidden_layers=layers, num_attention_heads=12,
+                        intermediate_size=3072, max_position_embeddings=130, type_vocab_size=1, pad_token_id=1,
+                        bos_token_id=0, eos_token_id=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    return RobertaModel(cfg, add_pooling_layer=False)
+
+
+@pytest.mark.parametrize("engine_name", ["bf16x3", "f32"])
+def test_full_width_encoder_layer_forward_backward_matches_torch(engine_name):
+    """One roberta-base-width encoder layer (D = 768, 12 heads, FFN 3072, L = 96): hidden states and EVERY parameter
+    gradient of the swapped model within 1e-4 x scale of the unswapped fp32 torch model; state-dict keys unchanged;
+    a frozen linear gets no weight gradient but still passes the gradient to its input (text.py:69-73)."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.news_encoder import NrlLinear, swap_linears
+    _lib.set_gemm_engine(engine_name)
+    try:
+        ref = _one_layer_roberta().to(DEV).train()
+        mod = copy.deepcopy(ref)
+        keys = list(mod.state_dict().keys())
+        n = swap_linears(mod.encoder)
+        assert n == 6 and list(mod.state_dict().keys()) == keys
+        assert isinstance(mod.encoder.layer[0].intermediate.dense, NrlLinear)
+        # freeze the feed-forward output projection in both: its input must still receive a gradient
+        for m in (ref, mod):
+            m.encoder.layer[0].output.dense.weight.requires_grad_(False)
+            m.encoder.layer[0].output.dense.bias.requires_grad_(False)
+        g = torch.Generator().manual_seed(1)
+        ids = torch.randint(3, 1000, (6, 96), generator=g).to(DEV)
+        d_out = torch.randn(6, 96, 768, generator=g).to(DEV)
+        outs = []
+        for m in (ref, mod):
+            h = m(input_ids=ids, attention_mask=torch.ones_like(ids))[0]
+            h.backward(d_out)
+            outs.append(h.detach())
+        scale = float(outs[0].abs().max())
+        err = float((outs[0] - outs[1]).abs().max())
+        print(f"{engine_name}: hidden max abs err {err:.3e} (scale {scale:.2f})")
+        assert err <= 1e-4 * max(1.0, scale)
+        worst = 0.0
+        for (k, p), (_, q) in zip(ref.named_parameters(), mod.named_parameters()):
+            if not p.requires_grad:
+                assert q.grad is None, k
+                continue
+            assert q.grad is not None, k
+            s = max(1.0, float(p.grad.abs().max()))
+            e = float((p.grad - q.grad).abs().max())
+            worst = max(worst, e / s)
+            assert e <= 1e-4 * s, (k, e, s)
+        print(f"{engine_name}: worst parameter-gradient error {worst:.3e} of the parameter's largest gradient")
+    finally:
+        _lib.set_gemm_engine("bf16x3")
+
+
+def test_plm_module_uses_the_library_for_its_body_projections(tmp_path):
+    """news_encoder.PLM swaps the body's nn.Linear modules (12 layers x 6) and still loads / saves reference-keyed
+    state dicts; NRL_PLM_LINEAR=0 keeps the HF modules."""
+    import os
+    from newsreclib_amd.news_encoder import PLM
+    _one_layer_roberta(layers=2).save_pretrained(str(tmp_path))
+    enc = PLM(str(tmp_path), [0], 768, True, False, None, 16, 200, 0.2)
+    assert enc.nrl_linears == 12
+    assert not enc.plm_model.encoder.layer[0].attention.self.query.weight.requires_grad
+    assert enc.plm_model.encoder.layer[1].attention.self.query.weight.requires_grad
+    os.environ["NRL_PLM_LINEAR"] = "0"
+    try:
+        plain = PLM(str(tmp_path), [0], 768, True, False, None, 16, 200, 0.2)
+    finally:
+        del os.environ["NRL_PLM_LINEAR"]
+    assert plain.nrl_linears == 0 and list(plain.state_dict().keys()) == list(enc.state_dict().keys())
+    plain.load_state_dict(enc.state_dict())

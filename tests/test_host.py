@@ -165,6 +165,20 @@ assert torch.allclose(params[2].main_grad * scale, torch.full_like(params[2], 15
 flat.grad.zero_()
 flat.grad.add_(float(rank + 1))
 assert red.finish() == 0.5 and torch.allclose(flat.grad, torch.full_like(flat.grad, 3.0))
+# chunked head + pipelined finish: the slices tile the flat buffer exactly once, each holds the summed gradient when it
+# is handed out (the trainer runs Adam on it while the next slice is still on the wire)
+red3 = OverlappedGradReduce(flat, red.head, chunks=3)
+assert red3.bounds[0] == 0 and red3.bounds[-1] == red.head and all(b % 64 == 0 for b in red3.bounds[:-1])
+flat.grad.zero_()
+flat.grad.add_(torch.arange(flat.numel, dtype=torch.float32) * (rank + 1))
+red3.start_head(params[0].main_grad)
+seen = torch.zeros(flat.numel)
+for lo, hi, scale in red3.finish_pipelined():
+    assert scale == 0.5
+    assert torch.equal(flat.grad[lo:hi], torch.arange(lo, hi, dtype=torch.float32) * 3.0)
+    seen[lo:hi] += 1
+assert torch.equal(seen, torch.ones(flat.numel))
+assert red3.info()["head_chunks"] == 3
 dist.destroy_process_group()
 print("OK", rank)
 """
