@@ -51,6 +51,8 @@ class CnnEncoderFn(torch.autograd.Function):
         if save:
             if order is None:
                 order = _sort_positions(ids, V)     # counting sort over the vocabulary (ops.sort_positions)
+            from .ops import order_event
+            ctx.order_ready = order_event(order)
             order = _chk(order, torch.int64, "order")
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (float(p_drop), int(seed), int(stream0)), grad_bufs
@@ -63,6 +65,8 @@ class CnnEncoderFn(torch.autograd.Function):
         _lib.require_engine(ctx.engine, "the CNN text encoder")
         _lib.require_options(ctx.options, "the CNN text encoder")
         ids, order, *params = ctx.saved_tensors
+        from .ops import wait_order
+        wait_order(ctx.order_ready)
         emb = params[0]
         p_drop, seed, stream0 = ctx.cfg
         N, L = ids.shape
@@ -198,6 +202,8 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
         if save:
             if order is None:
                 order = _sort_positions(ids, V)     # counting sort over the vocabulary (ops.sort_positions)
+            from .ops import order_event
+            ctx.order_ready = order_event(order)
             ctx.save_for_backward(ids, _chk(order, torch.int64, "order"), *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
             ctx.engine, ctx.options = engine, options
@@ -208,6 +214,8 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
         from .ops import _block_grads, _block_params
         lib = _lib.load()
         ids, order, *params = ctx.saved_tensors
+        from .ops import wait_order
+        wait_order(ctx.order_ready)
         emb, w_c, b_c = params[:3]
         heads, p_drop, seed, stream0 = ctx.cfg
         N, L = ids.shape
