@@ -112,6 +112,8 @@ int nrl_get_gemm_engine(void);
  *   9 "x3_dma"          LDS-DMA staged tiled GEMMs
  *  10 "news_tail"       out-projection + dropout + additive attention + pooling of the fused news path in ONE kernel
  *  11 "news_tail_bwd"   additive-attention backward of that path in ONE kernel that recomputes tanh from the y planes
+ *  12 "user_fork"       (default OFF, measured slower) user-encoder backward: the in-projection dgrad and the three weight gradients side by side on two
+ *                       library-internal streams (forked from and joined back into the caller's stream inside the call)
  * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
  * must see the same defaults (newsreclib_amd/ops*.py compare nrl_get_options() at both). */
 int nrl_set_option(const char* name, int32_t value);

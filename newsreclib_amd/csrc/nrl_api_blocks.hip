@@ -1,5 +1,7 @@
 // C ABI of two generic blocks shared by the sibling recommenders (NAML / TANR / MINS ... user and news
-// encoders): standalone additive attention and nn.Linear + activation.  Included at the end of nrl_api.hip.
+// encoders): standalone additive attention and nn.Linear + activation.  Its own translation unit (shared internals: nrl_api_internal.h).
+
+#include "nrl_api_internal.h"
 
 namespace nrl {
 
@@ -124,6 +126,8 @@ static int mha_planes(const NrlMhaParams* P, const MhaWs& w, bool fill, SplitWei
 }
 
 }  // namespace nrl
+
+using namespace nrl;
 
 extern "C" {
 

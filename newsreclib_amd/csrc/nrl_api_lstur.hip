@@ -1,6 +1,8 @@
 // C ABI of the LSTUR path (include/newsreclib_amd.h, second half): CNN text encoder, row-masked
-// embedding lookups, GRU user encoder.  Included at the end of nrl_api.hip (shares its engine switch,
-// tile choices and GEMM helpers).
+// embedding lookups, GRU user encoder.  Its own translation unit; the engine / option state, tile choices and GEMM
+// helpers it shares with nrl_api.hip come from nrl_api_internal.h.
+
+#include "nrl_api_internal.h"
 
 namespace nrl {
 
@@ -241,6 +243,8 @@ static int gru_check(const NrlGruParams* p, int64_t B, int64_t T, GruShape* s) {
 }
 
 }  // namespace nrl
+
+using namespace nrl;
 
 extern "C" {
 
