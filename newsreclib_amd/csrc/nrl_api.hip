@@ -64,6 +64,35 @@ static int fork_set(ForkSet** out) {
   return NRL_OK;
 }
 
+// ---- wide nn.Linear (N >= 256: the projections of a transformer body) on the row-panel kernel ------------------------
+// The output's columns go in panels of 256 (16 column blocks, grid axis y), one fragment-ordered weight image per panel:
+// the fp32 -> (hi, lo) split of an activation fragment then feeds 96 MFMAs, where the 128 x 160 tiles of the LDS-DMA
+// kernel re-split every fragment for each of their N / 160 column tiles (20 times at N = 3072).
+constexpr int LIN_PANEL_BLOCKS = 16;
+static inline int lin_panels(int n_out) { return (n_out + 16 * LIN_PANEL_BLOCKS - 1) / (16 * LIN_PANEL_BLOCKS); }
+static inline size_t lin_image_elems(int n_out, int k_red) {
+  return (size_t)lin_panels(n_out) * rp_image_elems(LIN_PANEL_BLOCKS, rp_kblocks(k_red, false));
+}
+static inline bool lin_panels_on(int n_out) { return opt(O_ROWPANEL) && n_out >= 16 * LIN_PANEL_BLOCKS; }
+// C (m, n_out) = epi(A (m, k_red) * B), element (column j, reduction i) of B = src[j * sn + i * sk]
+template <class Epi>
+static int linear_panels(const float* a, const float* src, int64_t sn, int64_t sk, int n_out, int k_red, const Epi& epi,
+                         int64_t m, uint16_t* img, hipStream_t st) {
+  const int P = lin_panels(n_out), kb = rp_kblocks(k_red, false), pw = 16 * LIN_PANEL_BLOCKS;
+  const size_t pe = rp_image_elems(LIN_PANEL_BLOCKS, kb);
+  for (int p0 = 0; p0 < P; p0 += RP_MAX_JOBS) {
+    RpImageJobs jobs;
+    rp_jobs_init(&jobs);
+    for (int p = p0; p < P && p < p0 + RP_MAX_JOBS; ++p)
+      rp_jobs_add(&jobs, src + (int64_t)p * pw * sn, sn, sk, n_out - p * pw < pw ? n_out - p * pw : pw, k_red, nullptr,
+                  img + (size_t)p * pe, LIN_PANEL_BLOCKS);
+    NRL_TRY(rp_jobs_launch(jobs, st));
+  }
+  RpImage im;
+  im.img = img; im.nblk = LIN_PANEL_BLOCKS; im.kblocks = kb;
+  return launch_rp_gemm<LIN_PANEL_BLOCKS, 4, 0, 2>(KCPlain{a, k_red, m}, im, epi, m, n_out, k_red, st, P);
+}
+
 }  // namespace nrl
 
 using namespace nrl;
@@ -412,7 +441,12 @@ int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, 
 }
 
 size_t nrl_linear_workspace_bytes(int32_t n, int32_t k) {
-  return align_up(split_weight_elems(n, k) * sizeof(uint16_t), 256);
+  // bf16 planes of W and W^T (tiled kernels), or the panel images of the forward (n columns over k) / the activation
+  // gradient (k columns over n), whichever is larger
+  size_t e = split_weight_elems(n, k);
+  if (lin_image_elems(n, k) > e) e = lin_image_elems(n, k);
+  if (lin_image_elems(k, n) > e) e = lin_image_elems(k, n);
+  return align_up(e * sizeof(uint16_t), 256);
 }
 
 int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k,
@@ -428,6 +462,8 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
     set_error("workspace too small: %zu < %zu bytes", ws_bytes, nrl_linear_workspace_bytes(n, k));
     return NRL_E_WORKSPACE;
   }
+  if (m == 0) return NRL_OK;
+  if (lin_panels_on(n)) return linear_panels(a, w, k, 1, n, k, epi, m, (uint16_t*)ws, st);   // element (n, k) = W[n][k]
   SplitWeight sw;
   NRL_TRY(split_weight(w, n, k, (uint16_t*)ws, &sw, st));
   return gemm_fwd(KCPlain{a, k, m}, w, sw, epi, m, n, k, n <= 224, st);
@@ -452,9 +488,15 @@ int nrl_linear_bwd(const float* a, const float* w, const float* d_c, int64_t m, 
         set_error("workspace too small: %zu < %zu bytes", ws_bytes, nrl_linear_workspace_bytes(n, k));
         return NRL_E_WORKSPACE;
       }
-      NRL_TRY(split_weight(w, n, k, (uint16_t*)ws, &sw, st));
+      if (lin_panels_on(k)) {        // d_a columns j over the reduction i: element = W[i][j]
+        NRL_TRY(linear_panels(d_c, w, 1, k, k, n, EpiStore{d_a, k}, m, (uint16_t*)ws, st));
+      } else {
+        NRL_TRY(split_weight(w, n, k, (uint16_t*)ws, &sw, st));
+        NRL_TRY(gemm_dgrad(d_c, w, sw, EpiStore{d_a, k}, m, n, k, st));
+      }
+    } else {
+      NRL_TRY(gemm_dgrad(d_c, w, sw, EpiStore{d_a, k}, m, n, k, st));
     }
-    NRL_TRY(gemm_dgrad(d_c, w, sw, EpiStore{d_a, k}, m, n, k, st));
   }
   if (d_w != nullptr) NRL_TRY(gemm_wgrad(d_c, n, a, k, d_w, d_bias, m, st));
   return NRL_OK;

@@ -295,8 +295,13 @@ struct RpPreSplit<T, std::enable_if_t<T::kPreSplit>> : std::true_type {};
 // NBLK = ceil(N / 16) column blocks per wave; LDS ring of 2 k-block chunks.
 template <int NBLK, int WAVES, class AOp, class Epi, int DEEP = 0, int RB = 2>
 __global__ void __launch_bounds__(WAVES * 64, 2)
-    rp_gemm_kernel(const AOp A, const uint16_t* __restrict__ img, const Epi epi, const int64_t M, const int N,
-                   const int K, const int kblocks) {
+    rp_gemm_kernel(const AOp A, const uint16_t* __restrict__ img_base, const Epi epi, const int64_t M, const int N,
+                   const int K, const int kblocks, const int64_t panel_elems) {
+  // blockIdx.y = column panel of a WIDE output (N > 16 NBLK: nn.Linear layers of a transformer body, nrl_linear_fwd): panel p
+  // owns columns [p * 16 NBLK, ...) and its own fragment-ordered image, `panel_elems` uint16 further on.  Row blocks are the
+  // fast grid axis, so the workgroups in flight share one panel image (L2-resident) and stream the activation rows.
+  const uint16_t* __restrict__ img = img_base + (int64_t)blockIdx.y * panel_elems;
+  const int n_panel0 = (int)blockIdx.y * (NBLK * 16);
   constexpr int CHUNK = NBLK * 2048;          // bytes of one k-block of the image
   constexpr int PIECES = 2 * NBLK;            // 1-KiB pieces per chunk
   constexpr int G = (PIECES + WAVES - 1) / WAVES;
@@ -464,17 +469,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     }
   }
 
-  store_accumulators<RB, NBLK>(epi, acc, m0, 0, wave, 0, l15, g, M, N);
+  store_accumulators<RB, NBLK>(epi, acc, m0, n_panel0, wave, 0, l15, g, M, N);
 }
 
 template <int NBLK, int WAVES = 4, int DEEP = 0, int RB = 2, class AOp, class Epi>
-int launch_rp_gemm(const AOp& A, const RpImage& B, const Epi& epi, int64_t M, int N, int K, hipStream_t stream) {
+int launch_rp_gemm(const AOp& A, const RpImage& B, const Epi& epi, int64_t M, int N, int K, hipStream_t stream, int panels = 1) {
   if (M <= 0 || N <= 0 || K <= 0) return NRL_OK;
-  NRL_REQUIRE(B.img != nullptr && B.nblk == NBLK && N <= NBLK * 16 && B.kblocks * 32 >= K, "row-panel GEMM: image / shape mismatch");
+  NRL_REQUIRE(B.img != nullptr && B.nblk == NBLK && N <= panels * NBLK * 16 && B.kblocks * 32 >= K && panels >= 1 && panels < 65536,
+              "row-panel GEMM: image / shape mismatch");
   const int64_t blocks = ceil_div(M, WAVES * 16 * RB);
   NRL_REQUIRE(blocks < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP, RB>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, stream, A,
-                     B.img, epi, M, N, K, B.kblocks);
+  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP, RB>), dim3((unsigned)blocks, (unsigned)panels), dim3(WAVES * 64), 0,
+                     stream, A, B.img, epi, M, N, K, B.kblocks, (int64_t)rp_image_elems(NBLK, B.kblocks));
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
