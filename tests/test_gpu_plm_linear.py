@@ -81,3 +81,35 @@ def test_plm_module_uses_the_library_for_its_body_projections(tmp_path):
         del os.environ["NRL_PLM_LINEAR"]
     assert plain.nrl_linears == 0 and list(plain.state_dict().keys()) == list(enc.state_dict().keys())
     plain.load_state_dict(enc.state_dict())
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 300, 100), (130, 256, 64), (1000, 520, 772), (33, 768, 3072), (70, 200, 300), (257, 1024, 256)])
+@pytest.mark.parametrize("engine_name", ["bf16x3", "f32"])
+def test_linear_fn_shapes_against_torch(M, N, K, engine_name):
+    """ops_blocks.LinearFn (nrl_linear_fwd / nrl_linear_bwd) over odd shapes: outputs narrower and wider than one 256-column
+    panel, a last panel that is only partly filled (N = 300, 520), reductions that are not multiples of 32, few rows;
+    forward, input gradient, weight / bias gradients, and the frozen-weight form (no weight gradient, input gradient kept)."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.ops_blocks import LinearFn
+    _lib.set_gemm_engine(engine_name)
+    try:
+        g = torch.Generator().manual_seed(M * 7 + N)
+        x = torch.randn(M, K, generator=g).to(DEV).requires_grad_(True)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+        b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
+        d = torch.randn(M, N, generator=g).to(DEV)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        gx, gw, gb = torch.autograd.grad(ref, (x, w, b), d.double())
+        out = LinearFn.apply(x, w, b, None)
+        ox, ow, ob = torch.autograd.grad(out, (x, w, b), d)
+        tol = 1e-4 if engine_name == "bf16x3" else 2e-5
+        for got, want, name in ((out, ref, "out"), (ox, gx, "d_x"), (ow, gw, "d_w"), (ob, gb, "d_b")):
+            scale = max(1.0, float(want.abs().max()))
+            err = float((got.double() - want).abs().max())
+            assert err <= tol * scale, (name, err, scale)
+        wf, bf_ = w.detach().clone(), b.detach().clone()            # frozen layer
+        out2 = LinearFn.apply(x, wf, bf_, None)
+        (ox2,) = torch.autograd.grad(out2, (x,), d)
+        assert float((ox2 - ox).abs().max()) <= 1e-6 * max(1.0, float(ox.abs().max()))
+    finally:
+        _lib.set_gemm_engine("bf16x3")
