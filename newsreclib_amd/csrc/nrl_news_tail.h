@@ -730,18 +730,20 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const News
       if (2 * s + 1 < NT_QB) v1 = pacc[2 * s + 1][tb];
       rp_split8(make_float4(v0[0], v0[1], v0[2], v0[3]), make_float4(v1[0], v1[1], v1[2], v1[3]), ph[s][tb], pl[s][tb]);
     }
+  // d_pre planes: (Q + 15) / 16 block columns per 16-row block -- what the weight gradient that reads them was sized for
+  const int ncb_q = (Q + 15) >> 4;
   auto store_dpre = [&](int s) {
-    if ((ABL & 2) || !news_ok) return;
+    if ((ABL & 2) || !news_ok || 2 * s >= ncb_q) return;
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
       if (!tok_ok[tb]) continue;              // (pad columns hold zeros, not a copy: masked)
       int64_t m = mrow[tb];
       asm volatile("" : "+v"(m));
-      unsigned char* dst = P.dpre_planes + ((m >> 4) * NT_QB + 2 * s) * 1024 + (m & 15) * 32 + 8 * g;
+      unsigned char* dst = P.dpre_planes + ((m >> 4) * ncb_q + 2 * s) * 1024 + (m & 15) * 32 + 8 * g;
       const uint4 h = __builtin_bit_cast(uint4, ph[s][tb]), l = __builtin_bit_cast(uint4, pl[s][tb]);
       nt_store8<STREAM>(dst, h.x, h.y);
       nt_store8<STREAM>(dst + 512, l.x, l.y);
-      if (2 * s + 1 < NT_QB) {
+      if (2 * s + 1 < NT_QB && 2 * s + 1 < ncb_q) {
         nt_store8<STREAM>(dst + 1024, h.z, h.w);
         nt_store8<STREAM>(dst + 1536, l.z, l.w);
       }

@@ -34,7 +34,7 @@ struct NewsTailBwdArgs {
   int64_t n_news;
   int L, D, Q;
   Dropout drop2;
-  unsigned char* dpre_planes;     // out: 13 block columns
+  unsigned char* dpre_planes;     // out: (Q + 15) / 16 block columns per 16-row block
   unsigned char* dy_planes;       // out: 19 block columns
   float* dq_a;                    // (Q), accumulated
 };

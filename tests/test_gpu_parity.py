@@ -200,6 +200,47 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
     print(f"   recomputing backward: worst gradient error vs oracle {worst:.3e} (relative to the largest gradient)")
 
 
+@pytest.mark.parametrize("Q", [64, 196, 204, 208, 224])
+@pytest.mark.parametrize("N,L,p_drop", [(9, 30, 0.2), (6, 32, 0.0), (5, 16, 0.2)])
+def test_fused_news_tail_query_widths(Q, N, L, p_drop, engine):
+    """The fused back half (nrl_news_tail.h) over the query widths its geometry admits and the ones it must decline:
+    Q = 64 (most query blocks of the image empty), 196 / 204 (the d_out row of the backward sits in another row of block 12),
+    208 (forward fused, backward NOT: no free query row -> pool_bwd_pre with the saved tanh output), 224 (not fused at all);
+    titles of 16, 30 and a full 32 tokens.  News vectors and every gradient against the oracle."""
+    from newsreclib_amd.news_encoder import MHSAAddAtt
+    if engine != "bf16x3":
+        pytest.skip("the fused kernels belong to the bf16x3 engine")
+    params = O.make_params(97, query_dim=Q, seed=Q + N)
+    gen = torch.Generator().manual_seed(Q * 3 + L)
+    ids = torch.randint(0, 97, (N, L), generator=gen)
+    d_out = torch.randn(N, 300, generator=gen)
+    enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, Q, 0.2)
+    enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+    enc = enc.to(DEV)
+    enc.train(p_drop > 0)
+    out = enc(ids.to(DEV), seed=11)
+    out.backward(d_out.to(DEV))
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith(O.NEWS_PREFIX)}
+    m1 = m2 = None
+    if p_drop > 0:
+        m1 = O.dropout_multiplier(11, 0, p_drop, (N, L, 300))
+        m2 = O.dropout_multiplier(11, 1, p_drop, (N, L, 300))
+    ref = O.news_encoder_fwd(ids, op, 15, m1, m2)
+    ref.backward(d_out)
+    assert _maxerr(out, ref) <= 1e-4
+    for k, p in enc.named_parameters():
+        rg = op[O.NEWS_PREFIX + k].grad.clone()
+        if k == "embedding_layer.weight":
+            rg[0].zero_()
+        scale = max(1.0, float(rg.abs().max()))
+        assert _maxerr(p.grad, rg) <= 2e-4 * scale, (k, Q)
+    with torch.no_grad():
+        enc.eval()
+        ev = enc(ids.to(DEV))
+    if p_drop == 0:
+        assert _maxerr(ev, out) <= 1e-6
+
+
 @pytest.mark.parametrize("option", ["news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes", "news_tail", "news_tail_bwd"])
 @pytest.mark.parametrize("N,L", [(9, 17), (70, 30)])
 def test_news_path_format_switches_agree(N, L, option):
