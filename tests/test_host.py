@@ -445,3 +445,22 @@ def test_per_call_engine_field_and_backward_guard():
         assert rc == -1 and b"gemm_engine" in lib.nrl_last_error()
     finally:
         _lib.set_gemm_engine(before)
+
+
+def test_library_build_id_is_the_content_hash_of_its_sources():
+    """The loaded library says which sources it was built from (nrl_build_id(), 32 hex digits); `_build.source_hash()` over
+    the translation units and the files they include must reproduce it -- `_lib.load()` refuses a library for which it does
+    not (file times play no part), and `_build.library_build_id()` reads the same id without loading the library."""
+    from newsreclib_amd import _build, _lib
+    lib = _lib.load()
+    have = lib.nrl_build_id().decode()
+    assert len(have) == 32 and all(c in "0123456789abcdef" for c in have)
+    assert have == _build.source_hash() == _build.library_build_id()
+    assert not _build._stale()
+    # every translation unit's hash covers the files it includes: the ABI header is in each closure
+    seen = {}
+    _build._closure(os.path.join(_build.CSRC, "nrl_api.hip"), seen)
+    names = {os.path.basename(p) for p in seen}
+    assert {"nrl_api.hip", "nrl_api_internal.h", "nrl_common.h", "newsreclib_amd.h", "nrl_news_tail_api.h"} <= names
+    assert "nrl_news_tail.h" not in names         # the tail kernels live in their own unit
+
