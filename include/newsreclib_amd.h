@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 10
+#define NRL_ABI_VERSION 11
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -136,9 +136,12 @@ int nrl_dropout_mask(uint8_t* keep, int64_t n_elems, double p, uint64_t seed, ui
                      void* stream_handle);
 
 /* ---- token-id grouping for the embedding-table gradient (embedding_dense_backward, text.py:215-217,224) -----
- * order (n) int64 <- the positions 0..n-1 of the flat id vector grouped by ASCENDING id (counting sort over the
- * vocabulary: LDS-merged histogram, scan, scatter; ids must lie in [0, vocab), vocab <= 2^20).  The order inside one
- * id's run is unspecified.  This is the `sorted_positions` argument of the *_encoder_bwd entry points. */
+ * order (n + 1) int64 <- order[0 .. n): the positions 0..n-1 of the flat id vector grouped by ASCENDING id (counting sort
+ * over the vocabulary: LDS-merged histogram, scan, scatter; ids must lie in [0, vocab), vocab <= 2^20; the order inside
+ * one id's run is unspecified); order[n]: the number of positions whose id is 0 -- they come first, so order[order[n] .. n)
+ * lists the LIVE positions (the padding id's embedding row has no gradient).  This is the `sorted_positions` argument of
+ * the *_encoder_bwd entry points; nrl_news_encoder_bwd reads the count too (ABI v11: it computes the gradient of the
+ * gathered rows for the live positions only), so a host that sorts by other means appends it. */
 size_t nrl_sort_positions_workspace_bytes(int64_t n, int64_t vocab);
 int nrl_sort_positions(const int64_t* ids, int64_t n, int64_t vocab, int64_t* order, void* ws, size_t ws_bytes,
                        void* stream);
@@ -161,9 +164,11 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
  * emb_table: the table the forward read (unchanged since).  On the fused path (bf16x3 engine, reference geometry)
  * the forward does NOT save q|k|v: the backward re-gathers the rows and recomputes them per head inside the
  * attention-backward kernel (nrl_news_fused.h); NULL is accepted only where that path is off.
- * sorted_positions: optional (may be NULL) argsort of the flat (N*L) id vector; when given, the
- * table gradient is reduced in id-sorted order (one atomic per (id, 64-row segment)) instead of one
- * atomic per element -- frequent tokens otherwise serialise on their row.
+ * sorted_positions: optional (may be NULL) output of nrl_sort_positions over the flat (N*L) id vector: N*L + 1 entries,
+ * the positions by ascending id and then the number of id-0 positions.  When given, the table gradient is reduced in
+ * id-sorted order (one atomic per (id, 64-row segment)) instead of one atomic per element -- frequent tokens otherwise
+ * serialise on their row -- and (fused path) the gradient of the gathered rows is computed for the LIVE positions only:
+ * the padding id's rows, ~60 % of a MIND title batch, have no table gradient and nothing else reads theirs.
  * phase: 0 = whole backward; 1 = activation-gradient chain + table gradient only; 2 = the three
  * weight/bias-gradient GEMMs only (call 1 then 2: a data-parallel caller starts the all-reduce of the
  * table gradient, >96 % of the bytes, between them so it overlaps the weight-gradient GEMMs). */

@@ -284,10 +284,20 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       // dx is materialised (in the now dead d_o buffer) and reduced in id-sorted order: no hot-row contention
       float* dx = w.d_o;
       const EpiLinear epi{dx, s.D, nullptr, 0, d1, s.D};
-      if (planes) NRL_TRY(rp_dispatch(dq_pl, bp.rp.in_d_hp, EpiNewsRows<EpiLinear>{epi, seq_len}, s.pad_rows, s.D, s.heads * 64, st));
-      else if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
-      else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
-      NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));
+      // (NRL_LIVE_ROWS=0: dx for every token row, for A/B runs)
+      static const bool live_env = [] { const char* e = getenv("NRL_LIVE_ROWS"); return !(e != nullptr && e[0] == '0'); }();
+      if (planes && live_env) {
+        // dx only for the LIVE token rows (id != 0: the padding id has no table gradient), compact and in the id-sorted order
+        // the scatter visits them in -- sorted_positions[n] holds the number of id-0 positions (nrl_sort_positions)
+        const KCPlanesLive dq_live{reinterpret_cast<const unsigned char*>(w.dqkv), s.pad_rows, sorted_positions, s.M, seq_len};
+        NRL_TRY(rp_dispatch(dq_live, bp.rp.in_d_hp, EpiDxSorted{dx, s.D, d1, sorted_positions, s.M}, s.M, s.D, s.heads * 64, st));
+        NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st, 1));
+      } else {
+        if (planes) NRL_TRY(rp_dispatch(dq_pl, bp.rp.in_d_hp, EpiNewsRows<EpiLinear>{epi, seq_len}, s.pad_rows, s.D, s.heads * 64, st));
+        else if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));
+        else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
+        NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));
+      }
     } else {
       const EpiScatter epi{d_emb_table, ids, s.D, d1};
       if (planes) NRL_TRY(rp_dispatch(dq_pl, bp.rp.in_d_hp, EpiNewsRows<EpiScatter>{epi, seq_len}, s.pad_rows, s.D, s.heads * 64, st));

@@ -138,6 +138,46 @@ struct KCPlanes {
   }
 };
 
+// KCPlanes over the LIVE token rows only.  The last dgrad of the news path (dx = dqkv W_in) feeds nothing but the embedding-
+// table scatter, and rows of the padding id 0 have no gradient there (nn.Embedding(padding_idx=0), text.py:215-217): with
+// ~11.5 real tokens in a 30-token title 62 % of the rows are dead.  The id-sorted visiting order the scatter
+// uses anyway (nrl_sort_positions) lists the positions of id 0 first and their count in order[n]: GEMM row r is the token
+// position order[n_zero + r], r < n - n_zero -- a compact list of exactly the rows whose dx somebody reads.
+struct KCPlanesLive {
+  static constexpr int kLayout = SRC_KC;
+  static constexpr bool kPreSplit = true;
+  static constexpr bool kLiveRows = true;
+  const unsigned char* p;
+  int64_t rows;            // padded rows (n_news * 32) of the planes
+  const int64_t* order;    // (n + 1): positions by ascending id, order[n] = number of id-0 positions
+  int64_t n;               // real token rows (n_news * L)
+  int L;
+  struct State {
+    const unsigned char* ptr;
+    bool ok;
+  };
+  __device__ __forceinline__ int64_t live_rows() const { return n - order[n]; }
+  __device__ __forceinline__ State init(int64_t r) const {
+    const int64_t n0 = order[n];
+    const bool ok = r < n - n0;
+    const int64_t m = order[ok ? n0 + r : 0];                    // token position news * L + t
+    const int64_t news = m / L;
+    const int64_t rr = news * 32 + (m - news * L);               // its padded row
+    return State{p + (rr >> 4) * 4096 + (rr & 15) * 32, ok};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int) const {
+    const int64_t off = (int64_t)(k >> 6) * (rows >> 4) * 4096 + ((k >> 4) & 3) * 1024 + ((k >> 3) & 1) * 16 + ((k & 4) ? 512 : 0);
+    return *reinterpret_cast<const float4*>(s.ptr + off);
+  }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int, int, bool) const {
+    if (!s.ok) v = f4zero();
+  }
+};
+template <class T, class = void>
+struct HasLiveRows : std::false_type {};
+template <class T>
+struct HasLiveRows<T, std::enable_if_t<T::kLiveRows>> : std::true_type {};
+
 // plain fragment-block planes over real rows: block (mb = row / 16, cb = k / 16) at ((mb * ncb + cb) * 2 + p) * 512
 // (the fused news path's `o` and `dy`, written by the fused forward / the row-panel epilogue EpiPoolBwdPlanes)
 struct KCPlanesG {
@@ -308,6 +348,37 @@ struct EpiLinear {
       v.z = sv.z > 0.f ? v.z : 0.f; v.w = sv.w > 0.f ? v.w : 0.f;
     }
     return v;
+  }
+};
+
+// dx of the live rows, COMPACT and in id-sorted order: GEMM row r (token position order[n_zero + r]) -> c[r]; the dropout
+// mask is the one of the token position (text.py:225 undone).  embedding_grad_sorted then reads c sequentially.
+struct EpiDxSorted {
+  float* c;
+  int64_t ldc;
+  Dropout drop;
+  const int64_t* order;
+  int64_t n;
+  struct Row {
+    float* out;
+    uint32_t idx0;
+  };
+  __device__ __forceinline__ Row row(int64_t r) const {
+    const int64_t m = order[order[n] + r];
+    return Row{c + r * ldc, (uint32_t)m * (uint32_t)ldc};
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n_, float v) const {
+    if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n_);
+    r.out[n_] = v;
+  }
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const { return (ldc & 3) == 0 && ((uintptr_t)c & 15) == 0; }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n_, float4 v) const {
+    if (drop.thresh != 0u) {
+      const uint32_t idx = r.idx0 + (uint32_t)n_;
+      v.x *= drop.mult(idx); v.y *= drop.mult(idx + 1); v.z *= drop.mult(idx + 2); v.w *= drop.mult(idx + 3);
+    }
+    store4(r.out + n_, v, 0);
   }
 };
 

@@ -68,7 +68,7 @@ int embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int 
                      hipStream_t stream);
 // d_table[ids[p]] += dx[p] for p in id-sorted order (`order` = argsort(ids)); id 0 skipped
 int embedding_grad_sorted(const float* dx, const int64_t* ids, const int64_t* order, int64_t n_rows, int D,
-                          float* d_table, hipStream_t stream);
+                          float* d_table, hipStream_t stream, int compact = 0);
 int dropout_mask(uint8_t* keep, int64_t n, Dropout d, hipStream_t stream);
 
 // ---- LSTUR path ------------------------------------------------------------------------------

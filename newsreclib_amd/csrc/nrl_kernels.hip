@@ -1052,7 +1052,16 @@ constexpr int EMB_SEG_ROWS = 64;
 __global__ void __launch_bounds__(256)
     embedding_grad_sorted_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
                                  const int64_t* __restrict__ order, int64_t n_rows, int D,
-                                 float* __restrict__ d_table) {
+                                 float* __restrict__ d_table, int compact) {
+  // compact != 0: dx holds ONLY the live rows (id != 0), already in sorted order -- row i of dx is the position
+  // order[n_zero + i], n_zero = order[n_rows] (EpiDxSorted); the segments then cover [0, n_rows - n_zero)
+  int64_t skip = 0;
+  if (compact) {
+    skip = order[n_rows];
+    if ((int64_t)blockIdx.x * EMB_SEG_ROWS >= n_rows - skip) return;
+    order += skip;
+    n_rows -= skip;
+  }
   // The segment's (position, id) pairs are fetched by 64 lanes at once and parked in LDS; the row loads of eight
   // positions are then in flight together.  (One position at a time, each iteration was a chain of three dependent
   // global loads -- order -> id -> row: ~50 us per launch however small the batch.)  Rows are still ADDED in sorted order.
@@ -1077,7 +1086,7 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < 8; ++u) {
       const int j = j0 + u < EMB_SEG_ROWS ? j0 + u : EMB_SEG_ROWS - 1;
       const bool live = j0 + u < n && s_id[j] != 0;
-      const float* row = dx + s_pos[j] * D;
+      const float* row = dx + (compact ? beg + j : s_pos[j]) * D;
       r0[u] = (live && d0) ? row[tid] : 0.f;
       r1[u] = (live && d1) ? row[tid + 256] : 0.f;
     }
@@ -1105,11 +1114,11 @@ __global__ void __launch_bounds__(256)
 }
 
 int embedding_grad_sorted(const float* dx, const int64_t* ids, const int64_t* order, int64_t n_rows, int D,
-                          float* d_table, hipStream_t stream) {
+                          float* d_table, hipStream_t stream, int compact) {
   if (n_rows == 0) return NRL_OK;
   NRL_REQUIRE(D <= 512, "embedding_grad_sorted: dim > 512 unsupported");
   hipLaunchKernelGGL(embedding_grad_sorted_kernel, dim3((unsigned)ceil_div(n_rows, EMB_SEG_ROWS)), dim3(256), 0,
-                     stream, dx, ids, order, n_rows, D, d_table);
+                     stream, dx, ids, order, n_rows, D, d_table, compact);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -326,6 +326,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     }
   };
 
+  // (an operand over a compact list of live rows, KCPlanesLive: the grid is sized for the worst case; workgroups past the
+  //  list's end leave together, before the first barrier, and the epilogue stores nothing past it)
+  int64_t m_end = M;
+  if constexpr (HasLiveRows<AOp>::value) {
+    m_end = A.live_rows();
+    if (m0 >= m_end) return;
+  }
   typename AOp::State st[RB];
   int64_t rowi[RB];
 #pragma unroll
@@ -469,7 +476,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
     }
   }
 
-  store_accumulators<RB, NBLK>(epi, acc, m0, n_panel0, wave, 0, l15, g, M, N);
+  store_accumulators<RB, NBLK>(epi, acc, m0, n_panel0, wave, 0, l15, g, m_end, N);
 }
 
 template <int NBLK, int WAVES = 4, int DEEP = 0, int RB = 2, class AOp, class Epi>

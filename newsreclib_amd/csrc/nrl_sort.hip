@@ -117,6 +117,9 @@ __global__ void __launch_bounds__(256) cs_scatter_kernel(const int64_t* __restri
   }
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+  // order[n] = number of positions holding id 0 (the padding id, whose embedding row has no gradient): the sorted order puts
+  // them first, so order[n_zero .. n) are the LIVE positions -- the news-encoder backward computes dx for those only
+  if (p == 0) order[n] = vocab > 1 ? start[1] : n;
   if (p < n) {
     const int id = cs_clamp_id(ids[p], vocab);
     order[pre[id >> 10] + start[id] + rank[p]] = p;
@@ -137,7 +140,11 @@ int nrl_sort_positions(const int64_t* ids, int64_t n, int64_t vocab, int64_t* or
                        void* stream) {
   NRL_REQUIRE(n >= 0 && n < (1LL << 31) && vocab > 0 && vocab <= (1LL << 20),
               "sort_positions: bad arguments (n < 2^31, 0 < vocab <= 2^20)");
-  if (n == 0) return NRL_OK;
+  NRL_REQUIRE(order != nullptr, "sort_positions: null argument");
+  if (n == 0) {                       // order[0] = 0 positions of id 0
+    NRL_HIP(hipMemsetAsync(order, 0, sizeof(int64_t), (hipStream_t)stream));
+    return NRL_OK;
+  }
   NRL_REQUIRE(ids && order, "sort_positions: null argument");
   NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
   if (ws_bytes < nrl_sort_positions_workspace_bytes(n, vocab)) {

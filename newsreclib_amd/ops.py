@@ -97,6 +97,8 @@ class NewsEncoderFn(torch.autograd.Function):
                 order = sort_positions(ids, V)
             ctx.order_ready = order_event(order)      # (side-stream sort of prepare_batch: the backward waits for it)
             order = _chk(order, torch.int64, "order")
+            if order.numel() == ids.numel():          # an order from elsewhere (argsort): append the count of id-0 positions
+                order = torch.cat([order.reshape(-1), (ids == 0).sum().reshape(1)])
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (heads, float(p_drop), int(seed), int(stream0)), grad_bufs
             ctx.table_grad_hook, ctx.engine, ctx.options = table_grad_hook, engine, options
@@ -387,13 +389,15 @@ def sort_positions(ids: torch.Tensor, vocab: Optional[int] = None) -> torch.Tens
     """Positions of the flat id vector grouped by ascending id: the visiting order of the embedding-table gradient
     (what ``embedding_dense_backward`` gets from its own sort).  With ``vocab`` (exclusive upper bound of the ids) a
     three-launch counting sort in the HIP library; the order INSIDE one id's run is unspecified.  Without it,
-    ``torch.argsort`` (index bookkeeping on int64, no arithmetic)."""
+    ``torch.argsort`` (index bookkeeping on int64, no arithmetic).  The result has n + 1 entries: the last one is the number
+    of positions holding id 0 (they sort first), which lets the news-encoder backward skip the rows of the padding id."""
     flat = _chk(ids, torch.int64, "ids").reshape(-1)
     n = flat.numel()
     if not vocab or vocab > (1 << 20):
-        return torch.argsort(flat, stable=True)
+        # (n + 1) entries like the library's sort: the positions by ascending id, then the number of id-0 positions
+        return torch.cat([torch.argsort(flat, stable=True), (flat == 0).sum().reshape(1)])
     lib = _lib.load()
-    order = torch.empty(n, dtype=torch.int64, device=flat.device)
+    order = torch.empty(n + 1, dtype=torch.int64, device=flat.device)
     ws = torch.empty(max(lib.nrl_sort_positions_workspace_bytes(n, int(vocab)), 256), dtype=torch.uint8,
                      device=flat.device)
     _lib.check(lib.nrl_sort_positions(flat.data_ptr(), n, int(vocab), order.data_ptr(), ws.data_ptr(), ws.numel(),

@@ -46,19 +46,24 @@ def test_dropout_mask_bit_exact():
 
 def test_sort_positions_groups_every_position_by_ascending_id():
     """The counting sort that orders the embedding-gradient visits: a permutation of 0..n-1 whose ids ascend (the
-    order inside one id's run is free), incl. a hot id filling a third of the vector, vocab = 2 and n = 0."""
+    order inside one id's run is free) followed by the number of id-0 positions, incl. a hot id filling a third of the
+    vector, vocab = 2 and n = 0."""
     from newsreclib_amd import ops
     g = torch.Generator().manual_seed(1)
     for n, vocab in [(211_200, 70_000), (1, 5), (777, 150_000), (4096, 2), (100_000, 1 << 20), (300, 1), (5000, 1025)]:
         ids = torch.randint(0, vocab, (n,), generator=g)
         ids[: n // 3] = 7 % vocab
-        order = ops.sort_positions(ids.to(DEV), vocab).cpu()
+        full = ops.sort_positions(ids.to(DEV), vocab).cpu()
+        assert full.numel() == n + 1 and int(full[n]) == int((ids == 0).sum())      # the count of id-0 positions rides along
+        order = full[:n]
         assert torch.equal(torch.sort(order).values, torch.arange(n))
         srt = ids[order]
         assert bool((srt[1:] >= srt[:-1]).all())
         assert torch.equal(srt, torch.sort(ids).values)
-    assert torch.equal(ops.sort_positions(ids.to(DEV)).cpu(), torch.argsort(ids, stable=True))   # no bound: torch
-    assert ops.sort_positions(torch.empty(0, dtype=torch.int64, device=DEV), 10).numel() == 0
+    unb = ops.sort_positions(ids.to(DEV)).cpu()                                      # no bound: torch.argsort
+    assert torch.equal(unb[:-1], torch.argsort(ids, stable=True)) and int(unb[-1]) == int((ids == 0).sum())
+    empty = ops.sort_positions(torch.empty(0, dtype=torch.int64, device=DEV), 10).cpu()
+    assert empty.numel() == 1 and int(empty[0]) == 0
 
 
 def test_embedding_gather_bit_exact():
