@@ -286,7 +286,8 @@ int nrl_cnn_encoder_fwd(const NrlCnnParams* p, const float* emb_table, int64_t v
                         uint64_t seed, uint32_t stream0, int32_t save_for_backward, float* out,
                         void* ws, size_t ws_bytes, void* stream);
 /* Backward (autograd of text.py:163-176 incl. embedding_dense_backward, padding_idx = 0).  d_out (N, F).
- * Adds into `g` and d_emb_table.  sorted_positions as in nrl_news_encoder_bwd (may be NULL). */
+ * Adds into `g` and d_emb_table.  sorted_positions as in nrl_news_encoder_bwd (may be NULL; N*L + 1 entries: the
+ * count of id-0 positions in the last one -- the convolution's activation gradient runs over the live positions only). */
 int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_emb_table,
                         int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
                         int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed,

@@ -48,6 +48,29 @@ struct KCWindow {
   }
 };
 
+// KCWindow over the LIVE token rows only (see KCPlanesLive, nrl_gemm.h): the convolution's activation gradient dx feeds
+// nothing but the embedding-table scatter, which has no use for the rows of the padding id.  GEMM row r is the token
+// position order[n_zero + r], n_zero = order[n].
+struct KCWindowLive {
+  static constexpr int kLayout = SRC_KC;
+  static constexpr bool kLiveRows = true;
+  KCWindow w;
+  const int64_t* order;
+  int64_t n;
+  using State = KCWindow::State;
+  __device__ __forceinline__ int64_t live_rows() const { return n - order[n]; }
+  __device__ __forceinline__ State init(int64_t r) const {
+    const int64_t n0 = order[n];
+    const bool ok = r < n - n0;
+    State s = w.init(order[ok ? n0 + r : 0]);
+    if (!ok) { s.lo = 0; s.hi = 0; }
+    return s;
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int K) const { return w.load(s, k, K); }
+  __device__ __forceinline__ const float* src(const State& s, int k, int K) const { return w.src(s, k, K); }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t m, int k, int kend, bool b) const { w.finish(v, s, m, k, kend, b); }
+};
+
 // k-major windowed source for the conv weight gradient: element (k = m, r = t*inner + j) is
 // x[m + t - pad][j] (0 outside the news); `ones` appends the bias column as in RCPlain.
 // n / d for n < 2^31 as one v_mul_hi_u32 + shift (round-up magic, 31-bit dividend): the windowed accessor below

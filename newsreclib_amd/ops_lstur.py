@@ -54,6 +54,8 @@ class CnnEncoderFn(torch.autograd.Function):
             from .ops import order_event
             ctx.order_ready = order_event(order)
             order = _chk(order, torch.int64, "order")
+            if order.numel() == ids.numel():          # an order from elsewhere (argsort): append the count of id-0 positions
+                order = torch.cat([order.reshape(-1), (ids == 0).sum().reshape(1)])
             ctx.save_for_backward(ids, order, *params)
             ctx.ws, ctx.cfg, ctx.grad_bufs = ws, (float(p_drop), int(seed), int(stream0)), grad_bufs
             ctx.engine, ctx.options = _lib.engine_code(), _lib.options_mask()
