@@ -287,11 +287,14 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       // (NRL_LIVE_ROWS=0: dx for every token row, for A/B runs)
       static const bool live_env = [] { const char* e = getenv("NRL_LIVE_ROWS"); return !(e != nullptr && e[0] == '0'); }();
       if (planes && live_env) {
-        // dx only for the LIVE token rows (id != 0: the padding id has no table gradient), compact and in the id-sorted order
-        // the scatter visits them in -- sorted_positions[n] holds the number of id-0 positions (nrl_sort_positions)
-        const KCPlanesLive dq_live{reinterpret_cast<const unsigned char*>(w.dqkv), s.pad_rows, sorted_positions, s.M, seq_len};
-        NRL_TRY(rp_dispatch(dq_live, bp.rp.in_d_hp, EpiDxSorted{dx, s.D, d1, sorted_positions, s.M}, s.M, s.D, s.heads * 64, st));
-        NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st, 1));
+        // dx only for the LIVE token rows (id != 0: the padding id has no table gradient), compact in position order; the
+        // list of live positions is built here in two small launches (scratch: the log-sum-exp buffer, dead by now)
+        NRL_REQUIRE((size_t)s.M * s.heads >= live_compact_ints(s.M), "news_encoder_bwd: scratch for the live-row list");
+        const int32_t *list = nullptr, *cidx = nullptr, *n_live = nullptr;
+        NRL_TRY(live_compact(ids, s.M, reinterpret_cast<int32_t*>(w.lse), &list, &cidx, &n_live, st));
+        const KCPlanesLive dq_live{reinterpret_cast<const unsigned char*>(w.dqkv), s.pad_rows, list, n_live, seq_len};
+        NRL_TRY(rp_dispatch(dq_live, bp.rp.in_d_hp, EpiDxLive{dx, s.D, d1, list}, s.M, s.D, s.heads * 64, st));
+        NRL_TRY(embedding_grad_sorted(dx, ids, sorted_positions, s.M, s.D, d_emb_table, st, cidx));
       } else {
         if (planes) NRL_TRY(rp_dispatch(dq_pl, bp.rp.in_d_hp, EpiNewsRows<EpiLinear>{epi, seq_len}, s.pad_rows, s.D, s.heads * 64, st));
         else if (slabs) NRL_TRY(rp_dispatch(dq_hp, bp.rp.in_d_hp, epi, s.M, s.D, s.heads * 64, st));

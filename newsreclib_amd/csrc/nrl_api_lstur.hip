@@ -343,11 +343,13 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
     }
     static const bool live_env = [] { const char* e = getenv("NRL_LIVE_ROWS"); return !(e != nullptr && e[0] == '0'); }();
     if (sorted_positions != nullptr && rpd != nullptr && live_env) {
-      // dx for the LIVE token rows only (id != 0), compact and in the scatter's id-sorted order (sorted_positions[n] =
-      // number of id-0 positions): the padding id has no table gradient and nothing else reads dx
-      NRL_TRY(rp_dispatch(KCWindowLive{a, sorted_positions, s.M}, *rpd, EpiDxSorted{w.dx, s.D, drop1, sorted_positions, s.M}, s.M,
-                          s.D, KF, st));
-      NRL_TRY(embedding_grad_sorted(w.dx, ids, sorted_positions, s.M, s.D, d_emb_table, st, 1));
+      // dx for the LIVE token rows only (id != 0), compact in position order: the padding id has no table gradient and
+      // nothing else reads dx.  The list of live positions goes into the tanh / d_pre buffer (dead by now).
+      NRL_REQUIRE((size_t)s.M * s.Q >= live_compact_ints(s.M), "cnn_encoder_bwd: scratch for the live-row list");
+      const int32_t *list = nullptr, *cidx = nullptr, *n_live = nullptr;
+      NRL_TRY(live_compact(ids, s.M, reinterpret_cast<int32_t*>(w.t), &list, &cidx, &n_live, st));
+      NRL_TRY(rp_dispatch(KCWindowLive{a, list, n_live}, *rpd, EpiDxLive{w.dx, s.D, drop1, list}, s.M, s.D, KF, st));
+      NRL_TRY(embedding_grad_sorted(w.dx, ids, sorted_positions, s.M, s.D, d_emb_table, st, cidx));
     } else if (sorted_positions != nullptr) {
       NRL_TRY(gemm_any(a, b_rc, hi, lo, 2 * Kp, EpiLinear{w.dx, s.D, nullptr, 0, drop1, s.D}, s.M, s.D, KF, st, rpd));
       NRL_TRY(embedding_grad_sorted(w.dx, ids, sorted_positions, s.M, s.D, d_emb_table, st));

@@ -49,20 +49,19 @@ struct KCWindow {
 };
 
 // KCWindow over the LIVE token rows only (see KCPlanesLive, nrl_gemm.h): the convolution's activation gradient dx feeds
-// nothing but the embedding-table scatter, which has no use for the rows of the padding id.  GEMM row r is the token
-// position order[n_zero + r], n_zero = order[n].
+// nothing but the embedding-table scatter, which has no use for the rows of the padding id.  GEMM row r is the r-th live
+// token position (`list`, position order).
 struct KCWindowLive {
   static constexpr int kLayout = SRC_KC;
   static constexpr bool kLiveRows = true;
   KCWindow w;
-  const int64_t* order;
-  int64_t n;
+  const int32_t* list;
+  const int32_t* n_live;
   using State = KCWindow::State;
-  __device__ __forceinline__ int64_t live_rows() const { return n - order[n]; }
+  __device__ __forceinline__ int64_t live_rows() const { return *n_live; }
   __device__ __forceinline__ State init(int64_t r) const {
-    const int64_t n0 = order[n];
-    const bool ok = r < n - n0;
-    State s = w.init(order[ok ? n0 + r : 0]);
+    const bool ok = r < *n_live;
+    State s = w.init(list[ok ? r : 0]);
     if (!ok) { s.lo = 0; s.hi = 0; }
     return s;
   }

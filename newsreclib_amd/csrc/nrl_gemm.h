@@ -140,27 +140,27 @@ struct KCPlanes {
 
 // KCPlanes over the LIVE token rows only.  The last dgrad of the news path (dx = dqkv W_in) feeds nothing but the embedding-
 // table scatter, and rows of the padding id 0 have no gradient there (nn.Embedding(padding_idx=0), text.py:215-217): with
-// ~11.5 real tokens in a 30-token title 62 % of the rows are dead.  The id-sorted visiting order the scatter
-// uses anyway (nrl_sort_positions) lists the positions of id 0 first and their count in order[n]: GEMM row r is the token
-// position order[n_zero + r], r < n - n_zero -- a compact list of exactly the rows whose dx somebody reads.
+// ~11.5 real tokens in a 30-token title 62 % of the rows are dead.  GEMM row r is the r-th live token position
+// in POSITION order (`list`, live_compact in nrl_kernels.hip): the live tokens of a news are neighbours, so the 16 lanes of a
+// row block read from one or two 16-row blocks of the planes (in id-sorted order every lane pulled its own cache lines:
+// 1.27 GB of traffic for 0.33 GB of operands).
 struct KCPlanesLive {
   static constexpr int kLayout = SRC_KC;
   static constexpr bool kPreSplit = true;
   static constexpr bool kLiveRows = true;
   const unsigned char* p;
   int64_t rows;            // padded rows (n_news * 32) of the planes
-  const int64_t* order;    // (n + 1): positions by ascending id, order[n] = number of id-0 positions
-  int64_t n;               // real token rows (n_news * L)
+  const int32_t* list;     // live token positions news * L + t, ascending
+  const int32_t* n_live;   // device scalar: their number
   int L;
   struct State {
     const unsigned char* ptr;
     bool ok;
   };
-  __device__ __forceinline__ int64_t live_rows() const { return n - order[n]; }
+  __device__ __forceinline__ int64_t live_rows() const { return *n_live; }
   __device__ __forceinline__ State init(int64_t r) const {
-    const int64_t n0 = order[n];
-    const bool ok = r < n - n0;
-    const int64_t m = order[ok ? n0 + r : 0];                    // token position news * L + t
+    const bool ok = r < *n_live;
+    const int64_t m = list[ok ? r : 0];                          // token position news * L + t
     const int64_t news = m / L;
     const int64_t rr = news * 32 + (m - news * L);               // its padded row
     return State{p + (rr >> 4) * 4096 + (rr & 15) * 32, ok};
@@ -351,21 +351,19 @@ struct EpiLinear {
   }
 };
 
-// dx of the live rows, COMPACT and in id-sorted order: GEMM row r (token position order[n_zero + r]) -> c[r]; the dropout
-// mask is the one of the token position (text.py:225 undone).  embedding_grad_sorted then reads c sequentially.
-struct EpiDxSorted {
+// dx of the live rows, COMPACT in position order: GEMM row r (token position list[r]) -> c[r]; the dropout mask is the one
+// of the token position (text.py:225 undone).  embedding_grad_sorted finds the row of a position through cidx.
+struct EpiDxLive {
   float* c;
   int64_t ldc;
   Dropout drop;
-  const int64_t* order;
-  int64_t n;
+  const int32_t* list;
   struct Row {
     float* out;
     uint32_t idx0;
   };
   __device__ __forceinline__ Row row(int64_t r) const {
-    const int64_t m = order[order[n] + r];
-    return Row{c + r * ldc, (uint32_t)m * (uint32_t)ldc};
+    return Row{c + r * ldc, (uint32_t)list[r] * (uint32_t)ldc};
   }
   __device__ __forceinline__ void operator()(const Row& r, int64_t, int n_, float v) const {
     if (drop.thresh != 0u) v *= drop.mult(r.idx0 + (uint32_t)n_);

@@ -68,7 +68,12 @@ int embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int 
                      hipStream_t stream);
 // d_table[ids[p]] += dx[p] for p in id-sorted order (`order` = argsort(ids)); id 0 skipped
 int embedding_grad_sorted(const float* dx, const int64_t* ids, const int64_t* order, int64_t n_rows, int D,
-                          float* d_table, hipStream_t stream, int compact = 0);
+                          float* d_table, hipStream_t stream, const int32_t* cidx = nullptr);
+// live (id != 0) token positions in position order: scratch of live_compact_ints(n) int32 -> list (n_live entries), cidx (n),
+// *n_live (device scalar); two small launches
+size_t live_compact_ints(int64_t n);
+int live_compact(const int64_t* ids, int64_t n, int32_t* scratch, const int32_t** list, const int32_t** cidx,
+                 const int32_t** n_live, hipStream_t stream);
 int dropout_mask(uint8_t* keep, int64_t n, Dropout d, hipStream_t stream);
 
 // ---- LSTUR path ------------------------------------------------------------------------------

@@ -1052,10 +1052,12 @@ constexpr int EMB_SEG_ROWS = 64;
 __global__ void __launch_bounds__(256)
     embedding_grad_sorted_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids,
                                  const int64_t* __restrict__ order, int64_t n_rows, int D,
-                                 float* __restrict__ d_table, int compact) {
-  // compact != 0: dx holds ONLY the live rows (id != 0), already in sorted order -- row i of dx is the position
-  // order[n_zero + i], n_zero = order[n_rows] (EpiDxSorted); the segments then cover [0, n_rows - n_zero)
+                                 float* __restrict__ d_table, const int32_t* __restrict__ cidx) {
+  // cidx != nullptr: dx holds ONLY the live rows (id != 0), compact in position order -- the row of token position p is
+  // dx[cidx[p]] (live_compact below); the segments then cover the live part of the sorted order, [n_zero, n_rows), with
+  // n_zero = order[n_rows]
   int64_t skip = 0;
+  const bool compact = cidx != nullptr;
   if (compact) {
     skip = order[n_rows];
     if ((int64_t)blockIdx.x * EMB_SEG_ROWS >= n_rows - skip) return;
@@ -1086,7 +1088,7 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < 8; ++u) {
       const int j = j0 + u < EMB_SEG_ROWS ? j0 + u : EMB_SEG_ROWS - 1;
       const bool live = j0 + u < n && s_id[j] != 0;
-      const float* row = dx + (compact ? beg + j : s_pos[j]) * D;
+      const float* row = dx + (compact ? (int64_t)cidx[s_pos[j]] : s_pos[j]) * D;
       r0[u] = (live && d0) ? row[tid] : 0.f;
       r1[u] = (live && d1) ? row[tid + 256] : 0.f;
     }
@@ -1114,11 +1116,107 @@ __global__ void __launch_bounds__(256)
 }
 
 int embedding_grad_sorted(const float* dx, const int64_t* ids, const int64_t* order, int64_t n_rows, int D,
-                          float* d_table, hipStream_t stream, int compact) {
+                          float* d_table, hipStream_t stream, const int32_t* cidx) {
   if (n_rows == 0) return NRL_OK;
   NRL_REQUIRE(D <= 512, "embedding_grad_sorted: dim > 512 unsupported");
   hipLaunchKernelGGL(embedding_grad_sorted_kernel, dim3((unsigned)ceil_div(n_rows, EMB_SEG_ROWS)), dim3(256), 0,
-                     stream, dx, ids, order, n_rows, D, d_table, compact);
+                     stream, dx, ids, order, n_rows, D, d_table, cidx);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// ---- compaction of the LIVE token positions (id != 0) in position order -------------------------------------------------
+// list[c] = c-th live position, cidx[p] = number of live positions before p, counts[nb] = their total.  The last dgrad of a
+// text encoder runs over list (rows of one news stay together: its fragment loads share the 16-row blocks of the planes);
+// the table-gradient pass finds the dx row of a sorted position through cidx.
+constexpr int LC_THREADS = 256, LC_ITEMS = 8, LC_BLOCK = LC_THREADS * LC_ITEMS;
+__global__ void __launch_bounds__(LC_THREADS) live_count_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t* __restrict__ counts) {
+  __shared__ int wsum[LC_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * LC_BLOCK + (int64_t)tid * LC_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < LC_ITEMS; ++q) c += (p0 + q < n && ids[p0 + q] != 0) ? 1 : 0;
+  c = (int)wave_sum((float)c);                   // (<= 512 per wave: exact in fp32)
+  if ((tid & 63) == 0) wsum[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void __launch_bounds__(LC_THREADS) live_scatter_kernel(const int64_t* __restrict__ ids, int64_t n, int nb,
+                                                                  int32_t* __restrict__ counts, int32_t* __restrict__ list,
+                                                                  int32_t* __restrict__ cidx) {
+  __shared__ int red[LC_THREADS];
+  __shared__ int wbase[LC_THREADS / 64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // live positions in the blocks before this one (and, block 0, the grand total for the consumers)
+  int before = 0, total = 0;
+  for (int j = tid; j < nb; j += LC_THREADS) {
+    const int c = counts[j];
+    total += c;
+    if (j < (int)blockIdx.x) before += c;
+  }
+  red[tid] = before;
+  __syncthreads();
+  for (int off = LC_THREADS / 2; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  const int base = red[0];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    red[tid] = total;
+    __syncthreads();
+    for (int off = LC_THREADS / 2; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) counts[nb] = red[0];
+    __syncthreads();
+  }
+  // this thread's 8 consecutive positions; exclusive scan of the per-thread counts across the workgroup
+  const int64_t p0 = (int64_t)blockIdx.x * LC_BLOCK + (int64_t)tid * LC_ITEMS;
+  bool live[LC_ITEMS];
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < LC_ITEMS; ++q) {
+    live[q] = p0 + q < n && ids[p0 + q] != 0;
+    c += live[q] ? 1 : 0;
+  }
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wbase[wave + 1] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    wbase[0] = 0;
+    for (int w = 1; w <= LC_THREADS / 64; ++w) wbase[w] += wbase[w - 1];
+  }
+  __syncthreads();
+  int pos = base + wbase[wave] + incl - c;
+#pragma unroll
+  for (int q = 0; q < LC_ITEMS; ++q) {
+    if (p0 + q < n) {
+      cidx[p0 + q] = pos;
+      if (live[q]) list[pos++] = (int32_t)(p0 + q);
+    }
+  }
+}
+
+size_t live_compact_ints(int64_t n) { return (size_t)(2 * n + ceil_div(n, LC_BLOCK) + 8); }
+int live_compact(const int64_t* ids, int64_t n, int32_t* scratch, const int32_t** list, const int32_t** cidx,
+                 const int32_t** n_live, hipStream_t stream) {
+  NRL_REQUIRE(n >= 0 && n < (1LL << 31), "live_compact: n < 2^31");
+  const int nb = (int)ceil_div(n > 0 ? n : 1, LC_BLOCK);
+  int32_t* l = scratch;
+  int32_t* c = scratch + n;
+  int32_t* counts = scratch + 2 * n;
+  *list = l; *cidx = c; *n_live = counts + nb;
+  hipLaunchKernelGGL(live_count_kernel, dim3((unsigned)nb), dim3(LC_THREADS), 0, stream, ids, n, counts);
+  NRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(live_scatter_kernel, dim3((unsigned)nb), dim3(LC_THREADS), 0, stream, ids, n, nb, counts, l, c);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
