@@ -189,6 +189,9 @@ WORKLOADS = {
     "mindsmall": {"batch": 128, "vocab": 70_000,
                   "name": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDsmall-shaped train step: B=128/GPU, H=50, C=5, "
                           "L=30, V=70000, dropout 0.2, Adam lr 1e-4 (BASELINE.json configs[1])"},
+    "mind32": {"batch": 32, "vocab": 70_000,
+               "name": "NRMS pretrained-emb (d=300, 15 heads, Q=200) train step at the reference's own CPU-runnable size: B=32, "
+                       "H=50, C=5, L=30, V=70000, dropout 0.2, Adam lr 1e-4 (BASELINE.json configs[0])"},
     "mindlarge": {"batch": 64, "vocab": 150_000,
                   "name": "NRMS pretrained-emb (d=300, 15 heads, Q=200) MINDlarge-shaped train step: B=64/GPU (512 global on "
                           "8 GPUs), H=50, C=5, L=30, V=150000, dropout 0.2, Adam lr 1e-4 (BASELINE.json configs[2])"},
@@ -207,7 +210,7 @@ def main():
     ap.add_argument("--engine", choices=["f32", "bf16x3"], default="bf16x3",
                     help="projection-GEMM engine: exact fp32 MFMA, or fp32 via 3 bf16 MFMAs per product")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mindsmall",
-                    help="mindsmall = BASELINE.json configs[1] (headline); mindlarge = configs[2]'s per-rank shape (V=150k, B=64/GPU)")
+                    help="mindsmall = BASELINE.json configs[1] (headline); mind32 = configs[0] (B=32); mindlarge = configs[2]'s per-rank shape (V=150k, B=64/GPU)")
     ap.add_argument("--grad-exchange", choices=["dense", "rows"], default="dense",
                     help="N > 1: all-reduce of the whole flat gradient, or all-gather of the touched table rows + dense rest")
     args = ap.parse_args()

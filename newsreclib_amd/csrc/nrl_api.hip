@@ -24,14 +24,15 @@ thread_local int64_t t_opts = -1;
 
 static const char* const kOptName[O_COUNT] = {"news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes",
                                               "news_aa_planes", "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail",
-                                              "news_tail_bwd", "user_fork"};
+                                              "news_tail_bwd", "user_fork", "news_fork"};
 static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_BWD", "NRL_NEWS_ATTN_MFMA", "NRL_NEWS_PLANES",
                                              "NRL_NEWS_OD_PLANES", "NRL_NEWS_AA_PLANES", "NRL_WGRAD_2STEP", "NRL_WGRAD_WS",
-                                             "NRL_ROWPANEL", "NRL_X3_DMA", "NRL_NEWS_TAIL", "NRL_NEWS_TAIL_BWD", "NRL_USER_FORK"};
+                                             "NRL_ROWPANEL", "NRL_X3_DMA", "NRL_NEWS_TAIL", "NRL_NEWS_TAIL_BWD", "NRL_USER_FORK",
+                                             "NRL_NEWS_FORK"};
 std::atomic<uint32_t> g_opt_default{[] {
   uint32_t m = 0;
   for (int i = 0; i < O_COUNT; ++i) {
-    const bool dflt = i != O_NEWS_FUSED_BWD && i != O_USER_FORK;   // everything on but the two measured losers
+    const bool dflt = i != O_NEWS_FUSED_BWD && i != O_USER_FORK && i != O_NEWS_FORK;   // (off: the measured losers; news_fork: A/B pending)
     const char* e = getenv(kOptEnv[i]);
     const bool v = e == nullptr ? dflt : (dflt ? e[0] != '0' : e[0] == '1');
     m |= v ? (1u << i) : 0u;
@@ -258,8 +259,17 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   sb_.tail = news_tail_on(sb_, seq_len, w);
   sb_.tail_bwd = sb_.tail && sb_.aa_planes && news_tail_bwd_on(sb_, seq_len, w);
   NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
+  // news_fork: the back-half weight gradients leave phase 2 for a side stream of phase 1 (a phase-2 call of a two-phase
+  // caller evaluates the same predicate and skips them)
+  sb_.forked = news_fork_on(sb_);
+  SideFork side;
   if (phase != 2) {
-    NRL_TRY(block_bwd_phase1(p, g, sb_, w, bp, d2, d_out, st, fused || slabs));
+    if (sb_.forked) {
+      ForkSet* fs = nullptr;
+      NRL_TRY(fork_set(&fs));
+      side.s = fs->s[0]; side.fork = fs->fork; side.join = fs->join[0];
+    }
+    NRL_TRY(block_bwd_phase1(p, g, sb_, w, bp, d2, d_out, st, fused || slabs, sb_.forked ? &side : nullptr));
     if (slabs) {
       // token attention backward on the matrix cores from the head-major q|k|v slabs (nrl_news_fused.h)
       NewsAttnBwdArgs a;
@@ -308,6 +318,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       else NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, epi, s.M, 3 * s.D, s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));
     }
   }
+  if (phase != 2 && sb_.forked) NRL_HIP(hipStreamWaitEvent(st, side.join, 0));   // the side stream's work is part of this call
   if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, sb_, w, st, slabs, planes));
   return NRL_OK;
 }

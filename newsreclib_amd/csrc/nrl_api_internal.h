@@ -124,9 +124,13 @@ static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 //                                          side by side on two internal streams instead of one after the other -- measured
 //                                          SLOWER on one box (3.36-3.40 vs 3.31 ms per step at B = 128): the cross-stream
 //                                          event waits cost more than the ~75 us of small launches they overlap
+//   news_fork       NRL_NEWS_FORK=1        the two back-half weight gradients of the fused news path (additive attention,
+//                                          out-projection) on an internal side stream beside the HBM-write-bound chain
+//                                          out-projection dgrad -> token-attention backward -> in-projection dgrad -> table
+//                                          gradient of phase 1, joined before the call returns
 enum {
   O_NEWS_FUSED = 0, O_NEWS_FUSED_BWD, O_NEWS_ATTN_MFMA, O_NEWS_PLANES, O_NEWS_OD_PLANES, O_NEWS_AA_PLANES, O_WGRAD_2STEP,
-  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_COUNT
+  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_COUNT
 };
 extern std::atomic<uint32_t> g_opt_default;  // (nrl_api.hip)
 extern thread_local int64_t t_opts;
@@ -166,6 +170,7 @@ struct BlockShape {
   bool tail = false;       // fused news path: the forward's back half ran as ONE kernel (nrl_news_tail.h): y exists only as planes
   bool od_planes = false;  // fused news path: `o` and `dy` are (hi, lo) bf16 fragment-block planes over the real rows (19
                            // block columns at D = 300; `o` in the head-permuted feature order), not fp32 rows
+  bool forked = false;     // phase 1 ran (or, in a phase-2 call, has run) the back-half weight gradients on the side stream
 };
 
 struct BlockWs {
@@ -532,9 +537,47 @@ static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const Bl
 //   phase 1: everything on the activation-gradient chain down to d(qkv)  (the caller then runs the
 //            in-projection dgrad -> table gradient / d_hist)
 //   phase 2: the three weight(+bias)-gradient GEMMs, which only READ saved activations/gradients.
+// A side stream of the caller's (nrl_api.hip: ForkSet) for work that is off the activation-gradient chain
+struct SideFork {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+// The weight gradients of the back half from planes: dW_a += d_pre^T y, dW_o += dy^T o (+ biases).  Partial tiles of the
+// two-step split-K go to `scratch` (scratch_floats of it), or straight to atomics when it is too small.
+static int block_wgrads_back_half(const NrlBlockGrads* G, const BlockShape& s, const BlockWs& w, hipStream_t st,
+                                  float* scratch, size_t scratch_floats) {
+  const int D = s.D, Q = s.Q;
+  auto scratch_for = [&](size_t need) -> float* { return need <= scratch_floats ? scratch : nullptr; };
+  {
+    // d_pre (pool_bwd_pre) and y (out-projection epilogue, with its ones column) as planes over the same rows
+    static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
+    NRL_TRY((launch_wgrad_planes_g<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
+                                         EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st,
+                                         scratch_for(wgrad_planes_g_scratch_floats(7, 5, (Q + 15) / 16, (D + 16) / 16, sp)))));
+  }
+  {
+    // both operands are planes over the same (real) rows: DMA + transpose-read + MFMA only (wgrad_planes_g_kernel)
+    static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_G_SPLITS"); return e ? atoi(e) : 64; }();
+    const int ncb_o = s.heads + (s.heads + 3) / 4, ncb_dy = (D + 15) / 16;
+    NRL_TRY((launch_wgrad_planes_g<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
+                                         EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st,
+                                         scratch_for(wgrad_planes_g_scratch_floats(5, 5, ncb_dy, ncb_o, sp)))));
+  }
+  return NRL_OK;
+}
+
+// news_fork: the two weight gradients above depend on nothing past the tail backward and are matrix-core work over operands
+// that are read-only from then on; the chain they would otherwise wait behind (out-projection dgrad -> token-attention
+// backward -> in-projection dgrad -> table gradient) is HBM-write-bound.  With a side stream they run beside it; their
+// split-K partial tiles go to the tanh buffer (unused on the fused-tail path) because the q|k|v slabs are still live.
+static inline bool news_fork_on(const BlockShape& s) {
+  return s.tail_bwd && s.aa_planes && s.od_planes && opt(O_NEWS_FORK) && opt(O_WGRAD_2STEP);
+}
+
 static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, const BlockShape& s, const BlockWs& w,
                             const BlockPlanes& bp, Dropout drop2, const float* d_out, hipStream_t st,
-                            bool attention_elsewhere = false) {
+                            bool attention_elsewhere = false, const SideFork* side = nullptr) {
   const int D = s.D, Q = s.Q;
   // additive attention backward: t -> d_pre in place, dq_a
   const int ncb_q = (Q + 15) / 16;
@@ -552,6 +595,12 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
     b.img_ad = bp.rp.tail_ad.img; b.q_a = P->att_query; b.n_news = s.pool_groups; b.L = s.pool_len; b.D = D; b.Q = Q;
     b.drop2 = drop2; b.dpre_planes = tpl; b.dy_planes = dyp; b.dq_a = G->att_query;
     NRL_TRY(news_tail_bwd(b, st));
+    if (side != nullptr && side->s != nullptr && news_fork_on(s)) {
+      NRL_HIP(hipEventRecord(side->fork, st));
+      NRL_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+      NRL_TRY(block_wgrads_back_half(G, s, w, side->s, w.t, (size_t)s.M * Q));
+      NRL_HIP(hipEventRecord(side->join, side->s));      // the caller makes `st` wait for it at the end of phase 1
+    }
     // d_o = dy W_o
     NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
     if (!attention_elsewhere) NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
@@ -593,26 +642,29 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
   // q|k|v rows being dead by now as well (attention backward and in-projection dgrad have run)
   float* const sc = opt(O_WGRAD_2STEP) && !dqkv_head_planes && !bf16_planes ? w.qkv : nullptr;
   const size_t sc_n = sc != nullptr ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
-  // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
-  if (s.aa_planes) {
-    // d_pre (pool_bwd_pre) and y (out-projection epilogue, with its ones column) as planes over the same rows
-    static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
-    NRL_TRY((launch_wgrad_planes_g<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
-                                         EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st,
-                                         scratch_for(wgrad_planes_g_scratch_floats(7, 5, (Q + 15) / 16, (D + 16) / 16, sp)))));
-  } else {
-    NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st, sc, sc_n));
-  }
-  // dW_o += dy^T o ; db_o += colsum(dy)
-  if (s.od_planes) {
-    // both operands are planes over the same (real) rows: DMA + transpose-read + MFMA only (wgrad_planes_g_kernel)
-    static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_G_SPLITS"); return e ? atoi(e) : 64; }();
-    const int ncb_o = s.heads + (s.heads + 3) / 4, ncb_dy = (D + 15) / 16;
-    NRL_TRY((launch_wgrad_planes_g<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
-                                         EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st,
-                                         scratch_for(wgrad_planes_g_scratch_floats(5, 5, ncb_dy, ncb_o, sp)))));
-  } else {
-    NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st, sc, sc_n));
+  const bool forked = news_fork_on(s) && s.forked;      // the two back-half weight gradients ran beside phase 1
+  if (!forked && s.aa_planes && s.od_planes) {
+    NRL_TRY(block_wgrads_back_half(G, s, w, st, w.qkv, scratch_avail));
+  } else if (!forked) {
+    // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
+    if (s.aa_planes) {
+      static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
+      NRL_TRY((launch_wgrad_planes_g<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
+                                           EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st,
+                                           scratch_for(wgrad_planes_g_scratch_floats(7, 5, (Q + 15) / 16, (D + 16) / 16, sp)))));
+    } else {
+      NRL_TRY(gemm_wgrad(w.t, Q, w.y, D, G->att_weight, G->att_bias, s.M, st, sc, sc_n));
+    }
+    // dW_o += dy^T o ; db_o += colsum(dy)
+    if (s.od_planes) {
+      static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_G_SPLITS"); return e ? atoi(e) : 64; }();
+      const int ncb_o = s.heads + (s.heads + 3) / 4, ncb_dy = (D + 15) / 16;
+      NRL_TRY((launch_wgrad_planes_g<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
+                                           EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st,
+                                           scratch_for(wgrad_planes_g_scratch_floats(5, 5, ncb_dy, ncb_o, sp)))));
+    } else {
+      NRL_TRY(gemm_wgrad(w.dy, D, w.o, D, G->out_proj_weight, G->out_proj_bias, s.M, st, sc, sc_n));
+    }
   }
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
   if (bf16_planes) {

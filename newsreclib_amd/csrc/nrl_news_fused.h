@@ -99,7 +99,8 @@ __device__ __forceinline__ void nf_kfrag(const float* colp, int ld, int g, float
 }
 
 // ABL (tools/nf_probe.hip only; product code uses 0): 1 = no attention phase, 2 = no in-projection MFMAs,
-// 4 = no weight DMA, 8 = no o / q|k|v / lse stores, 16 = streaming saves, 32 = streaming `o` stores
+// 4 = no weight DMA, 8 = no o / q|k|v / lse stores, 16 = streaming saves, 32 = streaming `o` stores,
+// 64 = vmcnt(0) at every head top (the counted wait off)
 template <int DH, bool SAVE, int ABL = 0>
 __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
   static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
@@ -283,9 +284,14 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
     if (SAVE && ln < L) P.lse[(news * heads + hp) * L + ln] = image[ln * NF_IMG_LD + 60];
   };
 
+  // The vector-memory counter retires in issue order.  After the LAST weight DMA of a head's successor (chunk 4, step 18)
+  // a wave issues exactly the eight 16-byte stores of its q|k|v slab (head-major saves, L >= 29: every pass has live lanes,
+  // so none of the eight is branched around) -- so the next head's weights have landed once all but the newest eight
+  // operations have: the head-top wait does not have to sit out the slab stores' latency (they get the whole next head).
+  const bool slab_tail = SAVE && !(ABL & (8 | 64)) && P.qkv_save != nullptr && P.qkv_head_major && news_ok && L >= 29;
   for (int h = 0; h < heads; ++h) {
     // every chunk of head h was issued while head h - 1 ran: landed for this wave, then (barrier) for all
-    wait_vmcnt<0>();
+    if (h > 0 && slab_tail) wait_vmcnt<8>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     f32x4 acc[2][4];
 #pragma unroll

@@ -205,6 +205,55 @@ def test_fused_news_encoder_equals_separate_kernels(N, L, p_drop, engine):
     print(f"   recomputing backward: worst gradient error vs oracle {worst:.3e} (relative to the largest gradient)")
 
 
+@pytest.mark.parametrize("pattern", ["all_pad", "no_pad", "interleaved", "one_live_token", "block_edge"])
+def test_live_row_dgrad_edge_cases(pattern, engine):
+    """The news path computes dx only for the rows of real tokens (id != 0: padding_idx has no table gradient; KCPlanesLive /
+    live_compact, nrl_gemm.h / nrl_kernels.hip).  The cases its row list has to get right: no live row at all, no dead row,
+    dead rows in front of / between live ones, a single live token, and row counts at the edges of the scan's 2048-position
+    blocks -- table gradient and every other gradient against the oracle."""
+    from newsreclib_amd.news_encoder import MHSAAddAtt
+    if engine != "bf16x3":
+        pytest.skip("the live-row dgrad belongs to the bf16x3 engine's fused news path")
+    V = 97
+    gen = torch.Generator().manual_seed(len(pattern))
+    N, L = (137, 30) if pattern != "block_edge" else (128, 16)          # 128 * 16 = exactly one 2048-position block
+    ids = torch.randint(1, V, (N, L), generator=gen)
+    if pattern == "all_pad":
+        ids.zero_()
+    elif pattern == "interleaved":
+        ids[:, ::3] = 0
+        ids[::5] = 0                                                    # whole news of padding between live ones
+    elif pattern == "one_live_token":
+        ids.zero_()
+        ids[N - 1, L - 1] = 5
+    elif pattern == "block_edge":
+        ids[:, 0] = 0                                                   # position 0 and the block's last position: one dead, one live
+    params = _news_params(vocab=V, seed=7)
+    enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
+    enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+    enc = enc.to(DEV)
+    enc.train(True)
+    d_out = torch.randn(N, 300, generator=gen)
+    out = enc(ids.to(DEV), seed=11)
+    out.backward(d_out.to(DEV))
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith(O.NEWS_PREFIX)}
+    m1 = O.dropout_multiplier(11, 0, 0.2, (N, L, 300))
+    m2 = O.dropout_multiplier(11, 1, 0.2, (N, L, 300))
+    ref = O.news_encoder_fwd(ids, op, 15, m1, m2)
+    ref.backward(d_out)
+    assert _maxerr(out, ref) <= 1e-4
+    for k, p in enc.named_parameters():
+        rg = op[O.NEWS_PREFIX + k].grad.clone()
+        if k == "embedding_layer.weight":
+            rg[0].zero_()
+            assert float(p.grad[0].abs().max()) == 0.0                  # the padding row gets no gradient, exactly
+            untouched = torch.ones(V, dtype=torch.bool)
+            untouched[ids.unique()] = False
+            assert float(p.grad[untouched.to(DEV)].abs().max() if untouched.any() else 0.0) == 0.0
+        scale = max(1.0, float(rg.abs().max()))
+        assert _maxerr(p.grad, rg) <= 2e-4 * scale, (pattern, k)
+
+
 @pytest.mark.parametrize("Q", [64, 196, 204, 208, 224])
 @pytest.mark.parametrize("N,L,p_drop", [(9, 30, 0.2), (6, 32, 0.0), (5, 16, 0.2)])
 def test_fused_news_tail_query_widths(Q, N, L, p_drop, engine):

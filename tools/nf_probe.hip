@@ -2,6 +2,7 @@
 // BASELINE configs[1] shape (7040 news x 30 tokens, D = 300, 15 heads, V = 70000).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Inewsreclib_amd/csrc tools/nf_probe.hip -o tools/bin/nf_probe
 #include <stdarg.h>
+#include <string.h>
 
 #include <vector>
 
@@ -102,6 +103,41 @@ int main(int argc, char** argv) {
   report("eval  (no saves), again", time_ms([&] { launch_news_fused_fwd<0>(a, st); }, st));
   report("train (x, q|k|v, lse saved), again", time_ms([&] { launch_news_fused_fwd<0>(as, st); }, st));
   report("train streaming saves, again", time_ms([&] { launch_news_fused_fwd<16>(as, st); }, st));
+  // ---- the product's training form: x and o as fragment-block planes, q|k|v as head-major slabs; the head-top wait counted
+  // (vmcnt(8): the slab stores stay in flight) against vmcnt(0) (ABL 64), and the two outputs compared bit for bit
+  {
+    unsigned char *xp, *op, *op2;
+    float *qkv2, *lse2;
+    const size_t xp_bytes = (size_t)N * 2 * 20 * 1024, op_bytes = (size_t)((N * L + 15) / 16) * 19 * 1024;
+    CK(hipMalloc(&xp, xp_bytes));
+    CK(hipMalloc(&op, op_bytes));
+    CK(hipMalloc(&op2, op_bytes));
+    CK(hipMalloc(&qkv2, (size_t)N * L * 15 * 64 * 4));
+    CK(hipMalloc(&lse2, (size_t)N * H * L * 4));
+    CK(hipMemset(op, 0, op_bytes));
+    CK(hipMemset(op2, 0, op_bytes));
+    NewsFusedArgs ap = as;
+    ap.x_save = nullptr; ap.x_planes = xp; ap.o = nullptr; ap.o_planes = op;
+    NewsFusedArgs ap2 = ap;
+    ap2.o_planes = op2; ap2.qkv_save = qkv2; ap2.lse = lse2;
+    for (int rep = 0; rep < 3; ++rep) {
+      report("train planes, counted head-top wait", time_ms([&] { launch_news_fused_fwd<0>(ap, st); }, st));
+      report("train planes, vmcnt(0) at head tops", time_ms([&] { launch_news_fused_fwd<64>(ap2, st); }, st));
+    }
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned char> h1(op_bytes), h2(op_bytes);
+    CK(hipMemcpy(h1.data(), op, op_bytes, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h2.data(), op2, op_bytes, hipMemcpyDeviceToHost));
+    size_t diff = 0;
+    for (size_t i = 0; i < op_bytes; ++i) diff += h1[i] != h2[i];
+    std::vector<float> q1((size_t)N * L * 15 * 64), q2(q1.size());
+    CK(hipMemcpy(q1.data(), qkv, q1.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(q2.data(), qkv2, q2.size() * 4, hipMemcpyDeviceToHost));
+    size_t qdiff = 0;
+    for (size_t i = 0; i < q1.size(); ++i) qdiff += memcmp(&q1[i], &q2[i], 4) != 0;
+    printf("counted vs vmcnt(0): o planes differ in %zu bytes, q|k|v slabs in %zu floats\n", diff, qdiff);
+    CK(hipFree(xp)); CK(hipFree(op)); CK(hipFree(op2)); CK(hipFree(qkv2)); CK(hipFree(lse2));
+  }
   // ---- token-attention backward from the head-major slabs the training forward just wrote ----
   float *d_o, *dqkv;
   CK(hipMalloc(&d_o, (size_t)N * L * D * 4));
