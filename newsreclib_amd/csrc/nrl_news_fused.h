@@ -100,7 +100,9 @@ __device__ __forceinline__ void nf_kfrag(const float* colp, int ld, int g, float
 
 // ABL (tools/nf_probe.hip only; product code uses 0): 1 = no attention phase, 2 = no in-projection MFMAs,
 // 4 = no weight DMA, 8 = no o / q|k|v / lse stores, 16 = streaming saves, 32 = streaming `o` stores,
-// 64 = vmcnt(0) at every head top (the counted wait off)
+// 64 = counted head-top wait (vmcnt(8): the q|k|v slab stores stay in flight), 128 = every slab store of a wave lands on
+// the same 7.5 KB (cache-resident: the stores are issued, nothing drains to HBM), 256 = slab stores in front of the attention phase instead of after the score MFMAs,
+// 512 = half of them there, half after the P V MFMAs
 template <int DH, bool SAVE, int ABL = 0>
 __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
   static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
@@ -284,11 +286,12 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
     if (SAVE && ln < L) P.lse[(news * heads + hp) * L + ln] = image[ln * NF_IMG_LD + 60];
   };
 
-  // The vector-memory counter retires in issue order.  After the LAST weight DMA of a head's successor (chunk 4, step 18)
-  // a wave issues exactly the eight 16-byte stores of its q|k|v slab (head-major saves, L >= 29: every pass has live lanes,
-  // so none of the eight is branched around) -- so the next head's weights have landed once all but the newest eight
-  // operations have: the head-top wait does not have to sit out the slab stores' latency (they get the whole next head).
-  const bool slab_tail = SAVE && !(ABL & (8 | 64)) && P.qkv_save != nullptr && P.qkv_head_major && news_ok && L >= 29;
+  // (Probe only, ABL 64: a COUNTED head-top wait.  The vector-memory counter retires in issue order and after the last weight
+  //  DMA of the next head (chunk 4, step 18) a wave issues exactly the eight 16-byte stores of its q|k|v slab (L >= 29: every
+  //  pass has live lanes), so vmcnt(8) is enough for the weights and lets the slab stores fly through the next head.  Measured:
+  //  0.643 vs 0.645 ms, bit-identical output -- the stores' latency is not what the kernel waits for; its 1.49 GB of output
+  //  drain at the ~3 TB/s a larger-than-cache write stream gets (profiles/r01_store_probe.txt).  Product code waits vmcnt(0).)
+  const bool slab_tail = (ABL & 64) && SAVE && !(ABL & 8) && P.qkv_save != nullptr && P.qkv_head_major && news_ok && L >= 29;
   for (int h = 0; h < heads; ++h) {
     // every chunk of head h was issued while head h - 1 ran: landed for this wave, then (barrier) for all
     if (h > 0 && slab_tail) wait_vmcnt<8>(); else wait_vmcnt<0>();
@@ -358,39 +361,45 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) image[(i * 16 + 4 * g + r) * NF_IMG_LD + nb * 16 + l15] = acc[i][nb][r];
 
+    auto save_qkv = [&](int pass_lo, int pass_hi) {
     // ---- save q|k|v for the backward kernels: (row, 3D) layout, q at head*dh, k at D + .., v at 2D + .. ---
-    // (the output base pointers are made opaque per head: hipcc otherwise hoists the per-pass store addresses out
-    //  of the head loop and spills them)
-    // wave-uniform bases + 32-bit lane offsets (scalar-base addressing)
-    float* qkv_out = P.qkv_save + row0 * (int64_t)(3 * D);
-    if (P.qkv_head_major) qkv_out = P.qkv_save + ((news_ok ? news : 0) * heads + h) * (int64_t)L * 64;
-    asm volatile("" : "+s"(qkv_out));
-    if (SAVE && P.qkv_save != nullptr && news_ok && !(ABL & 8)) {
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      if (P.qkv_head_major) {
-        // whole image rows: 1 KiB per pass, every 128-byte line written in full (the packed-row form below writes
-        // 80-byte pieces at a 3.6 KB stride)
+      // (the output base pointers are made opaque per head: hipcc otherwise hoists the per-pass store addresses out
+      //  of the head loop and spills them)
+      // wave-uniform bases + 32-bit lane offsets (scalar-base addressing)
+      float* qkv_out = P.qkv_save + row0 * (int64_t)(3 * D);
+      if (P.qkv_head_major) qkv_out = P.qkv_save + ((news_ok ? news : 0) * heads + h) * (int64_t)L * 64;
+      if constexpr (ABL & 128) qkv_out = P.qkv_save + ((int64_t)(blockIdx.x & 255) * NF_WAVES + wave) * (int64_t)L * 64;
+      asm volatile("" : "+s"(qkv_out));
+      if (SAVE && P.qkv_save != nullptr && news_ok && !(ABL & 8)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        if (P.qkv_head_major) {
+          // whole image rows: 1 KiB per pass, every 128-byte line written in full (the packed-row form below writes
+          // 80-byte pieces at a 3.6 KB stride)
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-          const int slot_i = pass * 64 + ln;
-          const int row = slot_i >> 4, ch = slot_i & 15;
-          if (row < L)
-            store4(qkv_out + 4 * slot_i, *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * ch), NT);
-        }
-      } else {
+          for (int pass = 0; pass < 8; ++pass) {
+            if (pass < pass_lo || pass >= pass_hi) continue;
+            const int slot_i = pass * 64 + ln;
+            const int row = slot_i >> 4, ch = slot_i & 15;
+            if (row < L)
+              store4(qkv_out + 4 * slot_i, *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * ch), NT);
+          }
+        } else {
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {            // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
-          const int slot_i = pass * 64 + ln;
-          const int row = slot_i >> 4, ch = slot_i & 15;
-          if (ch < 15 && row < L) {
-            const int part = ch / 5, c4 = ch - part * 5;
-            const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + part * DH + 4 * c4);
-            *reinterpret_cast<float4*>(qkv_out + (row * 3 * D + part * D + h * DH + 4 * c4)) = v;
+          for (int pass = 0; pass < 8; ++pass) {            // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
+            if (pass < pass_lo || pass >= pass_hi) continue;
+            const int slot_i = pass * 64 + ln;
+            const int row = slot_i >> 4, ch = slot_i & 15;
+            if (ch < 15 && row < L) {
+              const int part = ch / 5, c4 = ch - part * 5;
+              const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + part * DH + 4 * c4);
+              *reinterpret_cast<float4*>(qkv_out + (row * 3 * D + part * D + h * DH + 4 * c4)) = v;
+            }
           }
         }
       }
-    }
+    };
+    if constexpr (ABL & 256) save_qkv(0, 8);                 // (probe: the stores in front of the attention phase)
 
     if constexpr (ABL & 1) continue;
     // ---- S^T = K Q^T on the matrix cores ---------------------------------------------------------------
@@ -413,6 +422,10 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
         for (int ib = 0; ib < 2; ++ib)
           s[jb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? kl[jb] : kh[jb], pass == 0 ? ql[ib] : qh[ib],
                                                               s[jb][ib], 0, 0, 0);
+    // the slab stores go out under the latency of the score MFMAs (in front of the attention phase they cost 8-15 us more per
+    // launch at B = 128, tools/nf_probe.hip; the q columns are overwritten by O only at the end of the phase)
+    if constexpr (!(ABL & (256 | 512))) save_qkv(0, 8);
+    if constexpr (ABL & 512) save_qkv(0, 4);                // (probe: half here, half under the P V MFMAs)
     // lane (query = ib * 16 + l15, g) holds keys jb * 16 + 4g + r: softmax over all L keys of the query
     bf16x8 ph[2], pl[2];
 #pragma unroll
@@ -466,6 +479,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
         for (int db = 0; db < 2; ++db)
           oacc[ib][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? pl[ib] : ph[ib], pass == 0 ? vl[db] : vh[db],
                                                                  oacc[ib][db], 0, 0, 0);
+    if constexpr (ABL & 512) save_qkv(4, 8);
     // O -> image (over the q columns, dead by now) -> 16-byte row stores into o[:, head * dh ..]
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)

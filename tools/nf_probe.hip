@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
   report("train (x, q|k|v, lse saved), again", time_ms([&] { launch_news_fused_fwd<0>(as, st); }, st));
   report("train streaming saves, again", time_ms([&] { launch_news_fused_fwd<16>(as, st); }, st));
   // ---- the product's training form: x and o as fragment-block planes, q|k|v as head-major slabs; the head-top wait counted
-  // (vmcnt(8): the slab stores stay in flight) against vmcnt(0) (ABL 64), and the two outputs compared bit for bit
+  // (ABL 64, vmcnt(8): the slab stores stay in flight) against the product's vmcnt(0), and the two outputs compared bit for bit
   {
     unsigned char *xp, *op, *op2;
     float *qkv2, *lse2;
@@ -121,9 +121,25 @@ int main(int argc, char** argv) {
     NewsFusedArgs ap2 = ap;
     ap2.o_planes = op2; ap2.qkv_save = qkv2; ap2.lse = lse2;
     for (int rep = 0; rep < 3; ++rep) {
-      report("train planes, counted head-top wait", time_ms([&] { launch_news_fused_fwd<0>(ap, st); }, st));
-      report("train planes, vmcnt(0) at head tops", time_ms([&] { launch_news_fused_fwd<64>(ap2, st); }, st));
+      report("train planes, vmcnt(0) at head tops", time_ms([&] { launch_news_fused_fwd<0>(ap, st); }, st));
+      report("train planes, counted head-top wait", time_ms([&] { launch_news_fused_fwd<64>(ap2, st); }, st));
     }
+    CK(hipStreamSynchronize(st));
+    // where the saves' 0.17-0.19 ms go: the same stores onto cache-resident lines (ABL 128), and no slab stores at all
+    {
+      NewsFusedArgs ap3 = ap2;
+      for (int rep = 0; rep < 3; ++rep) {
+        report("train planes, slab stores onto resident lines", time_ms([&] { launch_news_fused_fwd<128>(ap3, st); }, st));
+        NewsFusedArgs ap4 = ap2;
+        ap4.qkv_save = nullptr;
+        report("train planes, no q|k|v save (x, o planes, lse)", time_ms([&] { launch_news_fused_fwd<0>(ap4, st); }, st));
+        report("train planes (all saves)", time_ms([&] { launch_news_fused_fwd<0>(ap2, st); }, st));
+        report("train planes, slab stores before the attention phase", time_ms([&] { launch_news_fused_fwd<256>(ap2, st); }, st));
+        report("train planes, slab stores half / half", time_ms([&] { launch_news_fused_fwd<512>(ap2, st); }, st));
+      }
+      CK(hipStreamSynchronize(st));
+    }
+    launch_news_fused_fwd<64>(ap2, st);
     CK(hipStreamSynchronize(st));
     std::vector<unsigned char> h1(op_bytes), h2(op_bytes);
     CK(hipMemcpy(h1.data(), op, op_bytes, hipMemcpyDeviceToHost));
