@@ -117,6 +117,8 @@ int nrl_get_gemm_engine(void);
  *  13 "news_fork"       news-encoder backward: the additive-attention and out-projection weight gradients on a
  *                       library-internal stream beside the activation-gradient chain of phase 1 (forked after the tail
  *                       backward, joined before the phase-1 call returns; a phase-2 call then runs only the in-projection one)
+ *  14 "news_qkv_planes" token-attention backward of the fused news path: q|k|v / d_o split once into (hi, lo) bf16 planes in LDS, operand
+ *                       fragments read from them (bit-identical to the kernel that builds each fragment from fp32)
  * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
  * must see the same defaults (newsreclib_amd/ops*.py compare nrl_get_options() at both). */
 int nrl_set_option(const char* name, int32_t value);

@@ -217,6 +217,12 @@ def get_gemm_engine() -> str:
     return {v: k for k, v in ENGINES.items()}[code]
 
 
+# bit order of the switch mask (include/newsreclib_amd.h, nrl_set_option)
+OPTION_NAMES = ("news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes",
+                "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail", "news_tail_bwd", "user_fork", "news_fork",
+                "news_qkv_planes")
+
+
 def set_option(name: str, value: bool) -> None:
     """Kernel-selection switch ("news_fused", "rowpanel", "x3_dma") for A/B measurements and equivalence tests."""
     check(load().nrl_set_option(name.encode(), int(bool(value))), "nrl_set_option")

@@ -24,11 +24,11 @@ thread_local int64_t t_opts = -1;
 
 static const char* const kOptName[O_COUNT] = {"news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes",
                                               "news_aa_planes", "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail",
-                                              "news_tail_bwd", "user_fork", "news_fork"};
+                                              "news_tail_bwd", "user_fork", "news_fork", "news_qkv_planes"};
 static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_BWD", "NRL_NEWS_ATTN_MFMA", "NRL_NEWS_PLANES",
                                              "NRL_NEWS_OD_PLANES", "NRL_NEWS_AA_PLANES", "NRL_WGRAD_2STEP", "NRL_WGRAD_WS",
                                              "NRL_ROWPANEL", "NRL_X3_DMA", "NRL_NEWS_TAIL", "NRL_NEWS_TAIL_BWD", "NRL_USER_FORK",
-                                             "NRL_NEWS_FORK"};
+                                             "NRL_NEWS_FORK", "NRL_NEWS_QKV_PLANES"};
 std::atomic<uint32_t> g_opt_default{[] {
   uint32_t m = 0;
   for (int i = 0; i < O_COUNT; ++i) {
@@ -275,7 +275,8 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       NewsAttnBwdArgs a;
       a.qkv_hm = w.qkv; a.d_o = w.d_o; a.lse = w.lse; a.dqkv = w.dqkv; a.n_news = n_news; a.L = seq_len; a.D = s.D;
       a.heads = s.heads; a.scale = s.geom.scale; a.hpw = 1; a.planes = planes ? 1 : 0;
-      NRL_TRY(launch_news_attn_bwd(a, st));
+      if (planes && opt(O_NEWS_QKV_PLANES)) NRL_TRY(launch_news_attn_bwd_p(a, st));   // operands split once, into LDS planes
+      else NRL_TRY(launch_news_attn_bwd(a, st));
     }
     if (fused) {
       // q|k|v recomputed per head + the attention backward on the matrix cores in one kernel (nrl_news_fused.h)

@@ -98,6 +98,17 @@ __device__ __forceinline__ void nf_kfrag(const float* colp, int ld, int g, float
   rp_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
 }
 
+// ---- (hi, lo) bf16 planes of one (news, head) in LDS ("nap"), news_attn_bwd_p_kernel ------------------------------------
+//   [part q|k|v][row block 0|1][plane hi|lo] = 12 planes of 640 bytes; a plane holds 16 token rows x 20 features CHUNK-major:
+//     [features 0..7: 16 rows x 16 B][features 8..15: 16 rows x 16 B][features 16..19: 16 rows x 8 B]
+//   = what the lanes g = 0, 1, 2 of a row-form fragment hold, each piece 16- (8-) byte aligned.
+constexpr int NAP_PLANE = 640, NAP_SLAB = 12 * NAP_PLANE;
+__device__ __forceinline__ constexpr int nap_off(int part, int rb, int plane) { return ((part * 2 + rb) * 2 + plane) * NAP_PLANE; }
+// byte offset inside a plane of features 4q .. 4q + 3 (q = 0 .. 4) of token row r
+__device__ __forceinline__ int nap_quad(int r, int q) { return q < 4 ? (q >> 1) * 256 + r * 16 + (q & 1) * 8 : 512 + r * 8; }
+typedef uint2 __attribute__((may_alias)) nap_u2;           // the LDS planes are written as pairs, read as pairs / quads, reused as floats
+typedef uint4 __attribute__((may_alias)) nap_u4a;
+
 // ABL (tools/nf_probe.hip only; product code uses 0): 1 = no attention phase, 2 = no in-projection MFMAs,
 // 4 = no weight DMA, 8 = no o / q|k|v / lse stores, 16 = streaming saves, 32 = streaming `o` stores,
 // 64 = counted head-top wait (vmcnt(8): the q|k|v slab stores stay in flight), 128 = every slab store of a wave lands on
@@ -874,6 +885,357 @@ static inline int launch_news_attn_bwd(const NewsAttnBwdArgs& a_in, hipStream_t 
   const int64_t blocks = ceil_div(units, NAB_WAVES);
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   hipLaunchKernelGGL((news_attn_bwd_kernel<20, OCC, ABL>), dim3((unsigned)blocks), dim3(NAB_WAVES * 64), 0, st, a);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+
+// =====================================================================================================
+// The same backward with every operand split ONCE, into (hi, lo) bf16 planes in LDS.
+//
+// news_attn_bwd_kernel builds fourteen operand fragments of q, k, v and d_o per head from its fp32 image -- each value up to
+// twice, once in row form (reduction over features) and once token-strided (reduction over tokens), 112 elements per lane
+// turned into (hi, lo) -- against 84 MFMAs.  Here the slab's 32 and the d_o slice's 12 elements per lane are split on their
+// way INTO LDS (nap_* planes above; q times 1/sqrt(dh) first, as the fragment builders did), and both fragment forms are
+// plain reads of bf16: 16- / 8-byte pieces for the row form, `ds_read_b64_tr_b16` for the token-strided form (a 16-lane group
+// transposes 4 token rows x 16 features: lane (feature, g) receives tokens 4g .. 4g + 3; two row blocks = the eight slots of
+// kappa).  Left to split besides: P, dS, dS^T (accumulators).  Same products in the same order on the same operand bits as
+// news_attn_bwd_kernel: the output is bit-identical (tools/nf_probe.hip compares the 1 GB of dqkv planes).
+// (Measured on the way: with the FORWARD saving q|k|v pre-split -- its score fragments are exactly scale * q and k in row form --
+//  this kernel needs no q|k|v split at all and ran 0.418 vs 0.456 ms, but the forward's 24 narrow stores per head from
+//  fragment registers, instead of 8 whole-row stores from its image, cost it 0.04-0.07 ms: net loss, forward left alone.)
+constexpr int NAP_DO = 4 * NAP_PLANE;                       // d_o planes: [hi | lo][row block 0 | 1], chunk-major like the slab's
+constexpr int NAP_IN = NAP_SLAB + NAP_DO;                   // 10240 bytes; reused as the fp32 output image
+constexpr int NAP_WAVE_BYTES = NAP_IN + NAB_VEC_FLOATS * 4;
+static_assert(NF_IMG_FLOATS * 4 <= NAP_IN, "the output image lives in the input planes' space");
+
+template <int DH, int OCC, int ABL = 0>
+__global__ void __launch_bounds__(NAB_WAVES * 64, OCC) news_attn_bwd_p_kernel(const NewsAttnBwdArgs P) {
+  static_assert(DH == 20, "plane rows hold 20 features");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NAB_WAVES * NAP_WAVE_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  unsigned char* const in = smem + wave * NAP_WAVE_BYTES;
+  float* const image = reinterpret_cast<float*>(in);       // [32][NF_IMG_LD] output staging, once every input fragment is read
+  float* const vec = reinterpret_cast<float*>(in + NAP_IN);   // lse | delta
+  const uint32_t in_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (uint32_t)wave * NAP_WAVE_BYTES;
+
+  const int L = P.L, D = P.D, heads = P.heads, hpw = P.hpw;
+  const int groups = heads / hpw;
+  const int64_t unit = (int64_t)blockIdx.x * NAB_WAVES + wave;
+  const int64_t news = unit / groups;
+  if (news >= P.n_news) return;
+  const int h0 = (int)(unit - news * groups) * hpw;
+  const int64_t row0 = news * L;
+  const float* const do_base = P.d_o + row0 * (int64_t)D;
+
+  // slab (8 float4 per lane), d_o slice (32 x 20, rows >= L zero) and lse of head `hd`: global -> registers
+  auto get_head_inputs = [&](int hd, f32x4 (&qv)[8], float4 (&dv)[3], float& ls) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const float* slab = P.qkv_hm + (news * heads + hd) * (int64_t)L * 64;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int slot_i = pass * 64 + ln;
+      const bool ok = (slot_i >> 4) < L;
+      qv[pass] = *reinterpret_cast<const f32x4*>(slab + (ok ? 4 * slot_i : 0));
+      if (!ok) qv[pass] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      const int slot_i = pass * 64 + ln;
+      const int row = slot_i / 5, c4 = slot_i - row * 5;
+      const bool ok = slot_i < 160 && row < L;
+      dv[pass] = *reinterpret_cast<const float4*>(do_base + (ok ? row * D + hd * DH + 4 * c4 : 0));
+      if (!ok) dv[pass] = f4zero();
+    }
+    const bool lok = ln < L;
+    ls = P.lse[(news * heads + hd) * L + (lok ? ln : 0)];
+    if (!lok) ls = 1e30f;                                  // pad queries: P = exp(s - 1e30) = 0
+  };
+  // registers -> (hi, lo) planes: a lane's float4 = features 4 c4 .. 4 c4 + 3 of one part (q | k | v) of one token row
+  auto put_head_inputs = [&](const f32x4 (&qv)[8], const float4 (&dv)[3], float ls) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int slot_i = pass * 64 + lane;
+      const int row = slot_i >> 4, ch = slot_i & 15;
+      const int part = ch / 5, c4 = ch - part * 5;          // ch == 15: the slab's four pad columns
+      const float mul = part == 0 ? P.scale : 1.0f;
+      uint32_t h0_, l0_, h1_, l1_;
+      split_pair(qv[pass][0] * mul, qv[pass][1] * mul, h0_, l0_);
+      split_pair(qv[pass][2] * mul, qv[pass][3] * mul, h1_, l1_);
+      if (ch < 15) {
+        unsigned char* dst = in + nap_off(part, row >> 4, 0) + nap_quad(row & 15, c4);
+        *reinterpret_cast<nap_u2*>(dst) = make_uint2(h0_, h1_);
+        *reinterpret_cast<nap_u2*>(dst + NAP_PLANE) = make_uint2(l0_, l1_);
+      }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      const int slot_i = pass * 64 + lane;
+      if (slot_i < 160) {
+        const int row = slot_i / 5, c4 = slot_i - row * 5;
+        uint32_t h0_, l0_, h1_, l1_;
+        split_pair(dv[pass].x, dv[pass].y, h0_, l0_);
+        split_pair(dv[pass].z, dv[pass].w, h1_, l1_);
+        unsigned char* dst = in + NAP_SLAB + (row >> 4) * NAP_PLANE + nap_quad(row & 15, c4);
+        *reinterpret_cast<nap_u2*>(dst) = make_uint2(h0_, h1_);
+        *reinterpret_cast<nap_u2*>(dst + 2 * NAP_PLANE) = make_uint2(l0_, l1_);
+      }
+    }
+    if (lane < 32) vec[lane] = ls;
+  };
+  {
+    f32x4 qv[8];
+    float4 dv[3];
+    float ls;
+    get_head_inputs(h0, qv, dv, ls);
+    put_head_inputs(qv, dv, ls);
+  }
+
+  // row form: lane (row l15 of the block, g) <- features 8g .. 8g + 7 of its row (20 per row: g = 2 keeps four, g = 3 none)
+  auto rowfrag = [&](int hi_off, int plane_stride, bf16x8& hi, bf16x8& lo) __attribute__((always_inline)) {
+    // every lane reads a 16-byte piece (chunk g & 1) and an 8-byte piece (features 16 .. 19) and keeps the one that is its own
+    const unsigned char* p16 = in + hi_off + (g & 1) * 256 + l15 * 16;
+    const unsigned char* p8 = in + hi_off + 512 + l15 * 8;
+    const uint4 a16 = *reinterpret_cast<const nap_u4a*>(p16), b16 = *reinterpret_cast<const nap_u4a*>(p16 + plane_stride);
+    const uint2 a8 = *reinterpret_cast<const nap_u2*>(p8), b8 = *reinterpret_cast<const nap_u2*>(p8 + plane_stride);
+    const uint32_t m8 = g == 2 ? 0xFFFFFFFFu : 0u;
+    hi = __builtin_bit_cast(bf16x8, g < 2 ? a16 : make_uint4(a8.x & m8, a8.y & m8, 0u, 0u));
+    lo = __builtin_bit_cast(bf16x8, g < 2 ? b16 : make_uint4(b8.x & m8, b8.y & m8, 0u, 0u));
+  };
+  // token-strided form: lane (feature d = db * 16 + l15, g) <- tokens kappa(g, e), e = 0 .. 7, of feature d
+  typedef short nap_v4i16 __attribute__((ext_vector_type(4)));
+  typedef short nap_v8i16 __attribute__((ext_vector_type(8)));
+  auto trfrag = [&](int rb0_off, int rb1_off, int db, bf16x8& out) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) nap_v4i16* lds_v4;
+    const uint32_t off = (uint32_t)nap_quad(4 * g + (l15 >> 2), db == 0 ? (l15 & 3) : 4);
+    const nap_v4i16 e03 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(in_lds + (uint32_t)rb0_off + off));
+    const nap_v4i16 e47 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(in_lds + (uint32_t)rb1_off + off));
+    uint4 v = __builtin_bit_cast(uint4, (nap_v8i16)__builtin_shufflevector(e03, e47, 0, 1, 2, 3, 4, 5, 6, 7));
+    const uint32_t m = (db == 0 || l15 < DH - 16) ? 0xFFFFFFFFu : 0u;   // features past dh: zero
+    out = __builtin_bit_cast(bf16x8, make_uint4(v.x & m, v.y & m, v.z & m, v.w & m));
+  };
+
+  for (int hh = 0; hh < hpw; ++hh) {
+    const int h = h0 + hh;
+    const int hn = hh + 1 < hpw ? h + 1 : h;
+    f32x4 nx_qv[8];
+    float4 nx_dv[3];
+    float nx_ls;
+    get_head_inputs(hn, nx_qv, nx_dv, nx_ls);
+    __builtin_amdgcn_wave_barrier();
+
+    auto mm3 = [&](f32x4& c, const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b_hi, const bf16x8& b_lo) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, c, 0, 0, 0);
+    };
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // ---- scores in both orientations: s[ib][jb] = (queries x keys), sT[jb][ib] = (keys x queries) --------
+    f32x4 s[2][2], sT[2][2];
+    {
+      bf16x8 qh[2], ql[2], kh[2], kl[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        rowfrag(nap_off(0, b, 0), NAP_PLANE, qh[b], ql[b]);          // (scale * q)
+        rowfrag(nap_off(1, b, 0), NAP_PLANE, kh[b], kl[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          s[a][b] = z4; sT[a][b] = z4;
+          mm3(s[a][b], qh[a], ql[a], kh[b], kl[b]);
+          mm3(sT[a][b], kh[a], kl[a], qh[b], ql[b]);
+        }
+    }
+    // ---- dP = dO V^T (queries x keys), dP^T = V dO^T --------------------------------------------------------
+    f32x4 dp[2][2], dpT[2][2];
+    {
+      bf16x8 oh[2], ol[2], vh[2], vl[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        rowfrag(NAP_SLAB + b * NAP_PLANE, 2 * NAP_PLANE, oh[b], ol[b]);
+        rowfrag(nap_off(2, b, 0), NAP_PLANE, vh[b], vl[b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          dp[a][b] = z4; dpT[a][b] = z4;
+          mm3(dp[a][b], oh[a], ol[a], vh[b], vl[b]);
+          mm3(dpT[a][b], vh[a], vl[a], oh[b], ol[b]);
+        }
+    }
+    // ---- P^T, delta (per query = per column of the transposed orientation), dS^T ---------------------------
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const float lse2 = vec[ib * 16 + l15] * LOG2E;
+      float dl = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = jb * 16 + 4 * g + r;
+          const float p = key < L ? __builtin_amdgcn_exp2f(fmaf(sT[jb][ib][r], LOG2E, -lse2)) : 0.f;
+          dl += p * dpT[jb][ib][r];
+          sT[jb][ib][r] = p;
+        }
+      dl += nf_xor16(dl, lane);
+      dl += nf_xor32(dl, lane);
+      if (g == 0) vec[32 + ib * 16 + l15] = dl;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sT[jb][ib][r] *= dpT[jb][ib][r] - dl;          // sT now holds dS^T
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- P, dS in the (queries x keys) orientation: rows 4g + r need lse / delta of THEIR query ------------
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const float4 lse_r = *reinterpret_cast<const float4*>(vec + ib * 16 + 4 * g);
+      const float4 dl_r = *reinterpret_cast<const float4*>(vec + 32 + ib * 16 + 4 * g);
+      const float ls4[4] = {lse_r.x * LOG2E, lse_r.y * LOG2E, lse_r.z * LOG2E, lse_r.w * LOG2E};
+      const float dl4[4] = {dl_r.x, dl_r.y, dl_r.z, dl_r.w};
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const bool kok = jb * 16 + l15 < L;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = kok ? __builtin_amdgcn_exp2f(fmaf(s[ib][jb][r], LOG2E, -ls4[r])) : 0.f;
+          s[ib][jb][r] = p;                                                          // s now holds P
+          dp[ib][jb][r] = p * (dp[ib][jb][r] - dl4[r]);                              // dp now holds dS
+        }
+      }
+    }
+    // ---- dV = P^T dO: A = P with the query slots kappa-permuted (exactly what a key-column lane holds) --------
+    f32x4 dv_[2][2], dk_[2][2], dq_[2][2];
+    {
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        trfrag(NAP_SLAB, NAP_SLAB + NAP_PLANE, db, bh[db]);
+        trfrag(NAP_SLAB + 2 * NAP_PLANE, NAP_SLAB + 3 * NAP_PLANE, db, bl[db]);
+      }
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        bf16x8 a_hi, a_lo;
+        rp_split8(make_float4(s[0][jb][0], s[0][jb][1], s[0][jb][2], s[0][jb][3]),
+                  make_float4(s[1][jb][0], s[1][jb][1], s[1][jb][2], s[1][jb][3]), a_hi, a_lo);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv_[jb][db] = z4;
+          mm3(dv_[jb][db], a_hi, a_lo, bh[db], bl[db]);
+        }
+      }
+    }
+    // ---- dK = dS^T (scale Q): A = dS in the same key-column form; dQ = scale dS K: A = dS^T (query-column form) ---
+    {
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        trfrag(nap_off(0, 0, 0), nap_off(0, 1, 0), db, bh[db]);
+        trfrag(nap_off(0, 0, 1), nap_off(0, 1, 1), db, bl[db]);
+      }
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        bf16x8 a_hi, a_lo;
+        rp_split8(make_float4(dp[0][jb][0], dp[0][jb][1], dp[0][jb][2], dp[0][jb][3]),
+                  make_float4(dp[1][jb][0], dp[1][jb][1], dp[1][jb][2], dp[1][jb][3]), a_hi, a_lo);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dk_[jb][db] = z4;
+          mm3(dk_[jb][db], a_hi, a_lo, bh[db], bl[db]);
+        }
+      }
+    }
+    {
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        trfrag(nap_off(1, 0, 0), nap_off(1, 1, 0), db, bh[db]);
+        trfrag(nap_off(1, 0, 1), nap_off(1, 1, 1), db, bl[db]);
+      }
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        bf16x8 a_hi, a_lo;
+        rp_split8(make_float4(sT[0][ib][0], sT[0][ib][1], sT[0][ib][2], sT[0][ib][3]),
+                  make_float4(sT[1][ib][0], sT[1][ib][1], sT[1][ib][2], sT[1][ib][3]), a_hi, a_lo);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dq_[ib][db] = z4;
+          mm3(dq_[ib][db], a_hi, a_lo, bh[db], bl[db]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // every read of the input planes is done: dQ (x scale) | dK | dV -> the fp32 image in their place
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (db * 16 + l15 < DH) {
+            image[(b * 16 + 4 * g + r) * NF_IMG_LD + db * 16 + l15] = dq_[b][db][r] * P.scale;
+            image[(b * 16 + 4 * g + r) * NF_IMG_LD + DH + db * 16 + l15] = dk_[b][db][r];
+            image[(b * 16 + 4 * g + r) * NF_IMG_LD + 2 * DH + db * 16 + l15] = dv_[b][db][r];
+          }
+    __builtin_amdgcn_wave_barrier();
+    // ---- image [token][dq | dk | dv | 0] -> registers -> this head's plane of dqkv (as news_attn_bwd_kernel) -----------
+    float4 stv[8];
+    {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int ch = pass * 64 + ln;
+        const int blk = ch >> 5, r16 = (ch >> 1) & 15, half = ch & 1;
+        const float* src = image + ((blk >> 2) * 16 + r16) * NF_IMG_LD + ((blk & 3) * 2 + half) * 8;
+        float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+        if ((blk & 3) == 3 && half == 1) v1 = f4zero();    // columns 60 .. 63: nobody wrote them
+        bf16x8 hi, lo;
+        rp_split8(v0, v1, hi, lo);
+        stv[2 * pass] = __builtin_bit_cast(float4, hi);
+        stv[2 * pass + 1] = __builtin_bit_cast(float4, lo);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    put_head_inputs(nx_qv, nx_dv, nx_ls);
+    if constexpr (!(ABL & 1)) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      float* out = P.dqkv + (((int64_t)h * P.n_news + news) * 2) * 4 * 256;   // 8 KiB per (head, news)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int ch = pass * 64 + ln;
+        float* dst = out + (ch >> 5) * 256 + (ch & 31) * 4;
+        store4(dst, stv[2 * pass], !(ABL & 8));
+        store4(dst + 128, stv[2 * pass + 1], !(ABL & 8));
+      }
+    } else {
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass)
+        asm volatile("" ::"v"(stv[pass].x), "v"(stv[pass].y), "v"(stv[pass].z), "v"(stv[pass].w));
+    }
+  }
+}
+
+template <int OCC = 2, int ABL = 0>
+static inline int launch_news_attn_bwd_p(const NewsAttnBwdArgs& a_in, hipStream_t st) {
+  if (a_in.n_news <= 0) return NRL_OK;
+  NRL_REQUIRE(a_in.planes == 1, "news_attn_bwd_p: dqkv goes out as fragment-block planes");
+  NewsAttnBwdArgs a = a_in;
+  a.hpw = a.heads % 5 == 0 ? 5 : (a.heads % 3 == 0 ? 3 : 1);
+  const int64_t units = a.n_news * (a.heads / a.hpw);
+  const int64_t blocks = ceil_div(units, NAB_WAVES);
+  NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
+  hipLaunchKernelGGL((news_attn_bwd_p_kernel<20, OCC, ABL>), dim3((unsigned)blocks), dim3(NAB_WAVES * 64), 0, st, a);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

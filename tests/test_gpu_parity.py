@@ -295,7 +295,8 @@ def test_fused_news_tail_query_widths(Q, N, L, p_drop, engine):
         assert _maxerr(ev, out) <= 1e-6
 
 
-@pytest.mark.parametrize("option", ["news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes", "news_tail", "news_tail_bwd"])
+@pytest.mark.parametrize("option", ["news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes", "news_tail", "news_tail_bwd",
+                                    "news_qkv_planes", "news_fork"])
 @pytest.mark.parametrize("N,L", [(9, 17), (70, 30)])
 def test_news_path_format_switches_agree(N, L, option):
     """The measurement switches of the fused news path select private workspace formats (head-major q|k|v slabs, bf16
@@ -309,6 +310,7 @@ def test_news_path_format_switches_agree(N, L, option):
     ids = torch.randint(0, 97, (N, L), generator=gen)
     d_out = torch.randn(N, 300, generator=gen)
     res = []
+    was = bool((_lib.load().nrl_get_options() >> _lib.OPTION_NAMES.index(option)) & 1)     # (news_fork is off by default)
     for on in (True, False):
         _lib.set_option(option, on)
         try:
@@ -320,7 +322,7 @@ def test_news_path_format_switches_agree(N, L, option):
             out.backward(d_out.to(DEV))
             res.append((out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in enc.named_parameters()}))
         finally:
-            _lib.set_option(option, True)
+            _lib.set_option(option, was)
     # (the fused tail pools y as hi + lo bf16 -- 16 mantissa bits -- and uses the v_exp / v_rcp tanh: rounding-level, not bitwise)
     assert _maxerr(res[0][0], res[1][0]) <= (5e-5 if option == "news_tail" else 5e-6)
     for k, g0 in res[0][1].items():

@@ -464,3 +464,18 @@ def test_library_build_id_is_the_content_hash_of_its_sources():
     assert {"nrl_api.hip", "nrl_api_internal.h", "nrl_common.h", "newsreclib_amd.h", "nrl_news_tail_api.h"} <= names
     assert "nrl_news_tail.h" not in names         # the tail kernels live in their own unit
 
+
+
+def test_option_names_agree_between_header_library_source_and_python():
+    """The kernel-selection switches are addressed by bit: the order in include/newsreclib_amd.h (the ABI's statement),
+    in the library (kOptName, nrl_api.hip) and in _lib.OPTION_NAMES must be one list."""
+    import re
+    from newsreclib_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "newsreclib_amd.h")).read()
+    doc = re.findall(r'^ \*\s+(\d+) "(\w+)"', hdr, re.M)
+    assert [int(i) for i, _ in doc] == list(range(len(doc)))
+    src = open(os.path.join(root, "newsreclib_amd", "csrc", "nrl_api.hip")).read()
+    body = src[src.index("kOptName[O_COUNT] = {"):]
+    names = re.findall(r'"(\w+)"', body[:body.index("};")])
+    assert tuple(n for _, n in doc) == tuple(names) == tuple(_lib.OPTION_NAMES)

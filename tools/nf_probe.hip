@@ -157,7 +157,7 @@ int main(int argc, char** argv) {
   // ---- token-attention backward from the head-major slabs the training forward just wrote ----
   float *d_o, *dqkv;
   CK(hipMalloc(&d_o, (size_t)N * L * D * 4));
-  CK(hipMalloc(&dqkv, (size_t)N * L * 15 * 64 * 4));
+  CK(hipMalloc(&dqkv, (size_t)N * 32 * 15 * 64 * 4));      // (planes: 32 padded rows per news)
   CK(hipMemcpy(d_o, o, (size_t)N * L * D * 4, hipMemcpyDeviceToDevice));
   NewsAttnBwdArgs ab;
   ab.qkv_hm = qkv; ab.d_o = d_o; ab.lse = lse; ab.dqkv = dqkv; ab.n_news = N; ab.L = L; ab.D = D; ab.heads = H;
@@ -167,6 +167,37 @@ int main(int argc, char** argv) {
   rep2("attn bwd  3 waves/SIMD", time_ms([&] { launch_news_attn_bwd<3, 0>(ab, st); }, st));
   rep2("attn bwd  plain (write-allocate) stores", time_ms([&] { launch_news_attn_bwd<2, 8>(ab, st); }, st));
   rep2("attn bwd  no arithmetic, plain stores", time_ms([&] { launch_news_attn_bwd<2, 10>(ab, st); }, st));
+  {
+    NewsAttnBwdArgs abp = ab;
+    abp.planes = 1;                                         // the product's form: dqkv as (hi, lo) fragment-block planes
+    for (int rep = 0; rep < 3; ++rep) {
+      rep2("attn bwd  planes, streaming stores (product)", time_ms([&] { launch_news_attn_bwd<2, 0>(abp, st); }, st));
+      rep2("attn bwd  planes, plain stores", time_ms([&] { launch_news_attn_bwd<2, 8>(abp, st); }, st));
+    }
+  }
+  {
+    // every operand split once into LDS planes (news_attn_bwd_p_kernel) against per-fragment splits: time and bits
+    float* dqkv2;
+    CK(hipMalloc(&dqkv2, (size_t)N * 32 * 15 * 64 * 4));
+    NewsAttnBwdArgs b1 = ab, b2 = ab;
+    b1.planes = 1;
+    b2.planes = 1; b2.dqkv = dqkv2;
+    for (int rep = 0; rep < 3; ++rep) {
+      rep2("attn bwd  fragments built from fp32", time_ms([&] { launch_news_attn_bwd<2, 0>(b1, st); }, st));
+      rep2("attn bwd  operands split once into LDS planes", time_ms([&] { launch_news_attn_bwd_p<2, 0>(b2, st); }, st));
+    }
+    rep2("attn bwd  LDS planes, 3 waves/SIMD", time_ms([&] { launch_news_attn_bwd_p<3, 0>(b2, st); }, st));
+    rep2("attn bwd  LDS planes, no dqkv stores", time_ms([&] { launch_news_attn_bwd_p<2, 1>(b2, st); }, st));
+    CK(hipStreamSynchronize(st));
+    const size_t nb = (size_t)N * 32 * 15 * 64 * 4;
+    std::vector<unsigned char> h1(nb), h2(nb);
+    CK(hipMemcpy(h1.data(), dqkv, nb, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h2.data(), dqkv2, nb, hipMemcpyDeviceToHost));
+    size_t diff = 0, first = 0;
+    for (size_t i = 0; i < nb; ++i) if (h1[i] != h2[i]) { if (!diff) first = i; ++diff; }
+    printf("dqkv planes, LDS-plane kernel vs fragment-building kernel: %zu of %zu bytes differ (first at %zu)\n", diff, nb, first);
+    CK(hipFree(dqkv2));
+  }
   rep2("attn bwd  no dqkv stores", time_ms([&] { launch_news_attn_bwd<2, 1>(ab, st); }, st));
   rep2("attn bwd  no arithmetic", time_ms([&] { launch_news_attn_bwd<2, 2>(ab, st); }, st));
   rep2("attn bwd  no arithmetic, no stores", time_ms([&] { launch_news_attn_bwd<2, 3>(ab, st); }, st));
