@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 11
+#define NRL_ABI_VERSION 12
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -201,6 +201,14 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
                          int64_t batch, int64_t hist_len, double p_drop, uint64_t seed,
                          uint32_t stream0, int32_t input_dropout, const float* d_out, float* d_hist,
                          void* ws, size_t ws_bytes, void* stream);
+/* The same backward in two parts (ABI v12).  phase 1: everything up to d_hist (and the additive-attention query gradient);
+ * phase 2: the three weight gradients, which only read what phase 1 left in `ws` (d_out / d_hist are not touched and may be
+ * NULL) -- they are off the path into the news-encoder backward, so a caller may issue them on another stream, ordered after
+ * phase 1, and join before the optimizer; phase 0 = nrl_user_encoder_bwd. */
+int nrl_user_encoder_bwd_phase(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
+                               int64_t batch, int64_t hist_len, double p_drop, uint64_t seed,
+                               uint32_t stream0, int32_t input_dropout, const float* d_out,
+                               float* d_hist, int32_t phase, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- to_dense_batch (torch_geometric 2.3.0; call sites nrms_module.py:233,237,277-284) ---------
  * x (N, D) + offsets (B+1) int64 (prefix sums of the sorted assignment vector) ->

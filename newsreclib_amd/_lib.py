@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -105,6 +105,9 @@ SIGNATURES = {
     "nrl_user_encoder_bwd": (c_int32, [POINTER(NrlBlockParams), POINTER(NrlBlockGrads), c_void_p, c_int64,
                                        c_int64, c_double, c_uint64, c_uint32, c_int32, c_void_p, c_void_p, c_void_p,
                                        c_size_t, c_void_p]),
+    "nrl_user_encoder_bwd_phase": (c_int32, [POINTER(NrlBlockParams), POINTER(NrlBlockGrads), c_void_p, c_int64,
+                                             c_int64, c_double, c_uint64, c_uint32, c_int32, c_void_p, c_void_p, c_int32,
+                                             c_void_p, c_size_t, c_void_p]),
     "nrl_to_dense_batch_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "nrl_to_dense_batch_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_void_p,
                                          c_void_p]),

@@ -358,21 +358,37 @@ int nrl_user_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
                          int64_t batch, int64_t hist_len, double p_drop, uint64_t seed, uint32_t stream0,
                          int32_t input_dropout, const float* d_out, float* d_hist, void* ws, size_t ws_bytes,
                          void* stream) {
+  return nrl_user_encoder_bwd_phase(p, g, hist, batch, hist_len, p_drop, seed, stream0, input_dropout, d_out, d_hist, 0, ws,
+                                    ws_bytes, stream);
+}
+
+// phase 1: everything up to d_hist (+ the additive-attention query gradient, which the pooling backward produces);
+// phase 2: the three weight gradients, which only READ what phase 1 left in the workspace -- a caller may run it on another
+// stream (ordered after phase 1) beside whatever consumes d_hist; phase 0: both, in that order.
+int nrl_user_encoder_bwd_phase(const NrlBlockParams* p, const NrlBlockGrads* g, const float* hist,
+                               int64_t batch, int64_t hist_len, double p_drop, uint64_t seed, uint32_t stream0,
+                               int32_t input_dropout, const float* d_out, float* d_hist, int32_t phase, void* ws,
+                               size_t ws_bytes, void* stream) {
   NRL_TRY(check_params(p));
   const EngineScope engine_scope(p->gemm_engine);
   const OptScope opt_scope(p->options);
   NRL_TRY(check_grads(g));
-  NRL_REQUIRE(hist && d_out && d_hist && batch > 0 && hist_len > 0, "user_encoder_bwd: bad arguments");
+  NRL_REQUIRE(phase >= 0 && phase <= 2, "user_encoder_bwd: phase must be 0 (both), 1 or 2");
+  NRL_REQUIRE(hist && batch > 0 && hist_len > 0 && (phase == 2 || (d_out && d_hist)), "user_encoder_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const BlockShape s = user_shape(p, batch, hist_len);
   BlockWs w;
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
   const bool in_drop = p_drop > 0.0 && input_dropout;
   const Dropout d1 = make_dropout(in_drop ? p_drop : 0.0, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
+  const float* x_rows = in_drop ? w.x : hist;
+  if (phase == 2) return block_bwd_phase2(g, x_rows, s, w, st);
   BlockPlanes bp;
   NRL_TRY(block_planes(p, s, w, false, &bp, st));
   NRL_TRY(block_bwd_phase1(p, g, s, w, bp, d2, d_out, st));
-  const float* x_rows = in_drop ? w.x : hist;
+  if (phase == 1)
+    return gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{d_hist, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D, s.D, st,
+                      bp.rp.on ? &bp.rp.in_d : nullptr);
   if (!opt(O_USER_FORK) || s.M > 65536) {       // (large calls -- the PLM tail -- fill the chip with every launch)
     NRL_TRY(gemm_dgrad(w.dqkv, p->in_proj_weight, bp.in, EpiLinear{d_hist, s.D, nullptr, 0, d1, s.D}, s.M, 3 * s.D,
                        s.D, st, bp.rp.on ? &bp.rp.in_d : nullptr));

@@ -183,17 +183,17 @@ int attn_fwd_mfma(const float* qkv, float* o, float* lse, const AttnGeom& G, hip
 // dS^T Q).  Per 16 x 16 tile: 36 + 48 MFMAs (forward: 24).
 // ---------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ void __launch_bounds__(256)
-    attn_bwd_dq_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                            const float* __restrict__ d_o, const float* __restrict__ lse,
-                            float* __restrict__ dqkv, const AttnGeom G, const int q_tiles) {
+__device__ __forceinline__ void attn_bwd_dq_body(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                 float* __restrict__ dqkv, const AttnGeom& G, const int q_tiles,
+                                                 const int64_t bid, float* __restrict__ smem) {
   constexpr int DHP = DH + 4, KS = DH / 4, DB = (DH + 15) / 16;
-  __shared__ __attribute__((aligned(16))) float Ks[FA_BK * DHP];
-  __shared__ __attribute__((aligned(16))) float Vs[FA_BK * DHP];
+  float* const Ks = smem;
+  float* const Vs = smem + FA_BK * DHP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int64_t grp = blockIdx.x / q_tiles;
-  const int qt = (int)(blockIdx.x % q_tiles);
+  const int64_t grp = bid / q_tiles;
+  const int qt = (int)(bid % q_tiles);
   const int64_t outer = grp / G.heads;
   const int head = (int)(grp % G.heads);
   const float* qb = qkv + outer * G.q_outer + head * DH;
@@ -279,18 +279,19 @@ __global__ void __launch_bounds__(256)
 }
 
 template <int DH>
-__global__ void __launch_bounds__(256)
-    attn_bwd_dkv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                             const float* __restrict__ d_o, const float* __restrict__ lse,
-                             float* __restrict__ dqkv, const AttnGeom G, const int k_tiles) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                  const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                  float* __restrict__ dqkv, const AttnGeom& G, const int k_tiles,
+                                                  const int64_t bid, float* __restrict__ smem) {
   constexpr int DHP = DH + 4, KS = DH / 4, DB = (DH + 15) / 16;
-  __shared__ __attribute__((aligned(16))) float Qs[FA_BQ * DHP];   // scaled queries of the current block
-  __shared__ __attribute__((aligned(16))) float dOs[FA_BQ * DHP];
-  __shared__ float lse_s[FA_BQ], delta_s[FA_BQ];
+  float* const Qs = smem;                          // scaled queries of the current block
+  float* const dOs = smem + FA_BQ * DHP;
+  float* const lse_s = smem + 2 * FA_BQ * DHP;
+  float* const delta_s = lse_s + FA_BQ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int64_t grp = blockIdx.x / k_tiles;
-  const int kt = (int)(blockIdx.x % k_tiles);
+  const int64_t grp = bid / k_tiles;
+  const int kt = (int)(bid % k_tiles);
   const int64_t outer = grp / G.heads;
   const int head = (int)(grp % G.heads);
   const float* qb = qkv + outer * G.q_outer + head * DH;
@@ -396,16 +397,30 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ONE launch for both roles: workgroup 2i computes dQ of (group, query tile) i, workgroup 2i + 1 the dK / dV of (group, key
+// tile) i.  The two read the same q|k|v / dO rows (the neighbour's fetches hit the L2) and neither depends on the other;
+// as two launches they ran back to back (36 + 44 us over the 1500 tiles of the NRMS user encoder at B = 128, each launch
+// bound by its own load -> LDS -> MFMA chain, not by the chip).
+template <int DH>
+__global__ void __launch_bounds__(256)
+    attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
+                         const float* __restrict__ lse, float* __restrict__ dqkv, const AttnGeom G, const int tiles) {
+  constexpr int DHP = DH + 4;
+  __shared__ __attribute__((aligned(16))) float smem[2 * FA_BQ * DHP + 2 * FA_BQ];
+  const int64_t bid = blockIdx.x >> 1;
+  if ((blockIdx.x & 1) == 0) attn_bwd_dq_body<DH>(qkv, o, d_o, lse, dqkv, G, tiles, bid, smem);
+  else attn_bwd_dkv_body<DH>(qkv, o, d_o, lse, dqkv, G, tiles, bid, smem);
+}
+
 int attn_bwd_mfma(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                   const AttnGeom& G, hipStream_t stream) {
   if (G.groups == 0) return NRL_OK;
   const int tiles = (G.S + FA_BQ - 1) / FA_BQ;
   const int64_t blocks = G.groups * tiles;
   NRL_REQUIRE(blocks < (1LL << 31), "attention grid too large");
+  NRL_REQUIRE(2 * blocks < (1LL << 31), "attention grid too large");
   NRL_FA_DISPATCH(G.dh, {
-    hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DH>), dim3((unsigned)blocks), dim3(256), 0, stream, qkv, o, d_o, lse,
-                       dqkv, G, tiles);
-    hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<DH>), dim3((unsigned)blocks), dim3(256), 0, stream, qkv, o, d_o, lse,
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<DH>), dim3((unsigned)(2 * blocks)), dim3(256), 0, stream, qkv, o, d_o, lse,
                        dqkv, G, tiles);
   });
   NRL_LAUNCH_CHECK();

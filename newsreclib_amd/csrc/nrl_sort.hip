@@ -38,14 +38,21 @@ __global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __re
   }
   __syncthreads();
   const int64_t p0 = (int64_t)blockIdx.x * CS_BLOCK + tid;
-  int slot[CS_ITEMS], lrank[CS_ITEMS];
+  int slot[CS_ITEMS], lrank[CS_ITEMS], idv[CS_ITEMS];
+  int64_t raw[CS_ITEMS];
+#pragma unroll
+  for (int q = 0; q < CS_ITEMS; ++q) {                    // all eight id loads in flight before the first hash probe
+    const int64_t p = p0 + q * CS_THREADS;
+    raw[q] = ids[p < n ? p : n - 1];                      // (clamped address, unconditional load: no branch, no wait per item)
+  }
+#pragma unroll
+  for (int q = 0; q < CS_ITEMS; ++q) idv[q] = p0 + q * CS_THREADS < n ? cs_clamp_id(raw[q], vocab) : -1;
 #pragma unroll
   for (int q = 0; q < CS_ITEMS; ++q) {
-    const int64_t p = p0 + q * CS_THREADS;
     slot[q] = 0;
     lrank[q] = 0;
-    if (p < n) {
-      const int id = cs_clamp_id(ids[p], vocab);
+    if (idv[q] >= 0) {
+      const int id = idv[q];
       int s = (int)(((uint32_t)id * 0x9E3779B1u) >> 20) & (CS_SLOTS - 1);
       while (true) {                                      // <= CS_BLOCK distinct ids per workgroup in 2 x CS_BLOCK slots
         const int prev = atomicCAS(&keys[s], -1, id);
@@ -57,8 +64,19 @@ __global__ void __launch_bounds__(CS_THREADS) cs_rank_kernel(const int64_t* __re
     }
   }
   __syncthreads();
-  for (int s = tid; s < CS_SLOTS; s += CS_THREADS)
-    if (keys[s] != -1) base[s] = atomicAdd(&hist[keys[s]], cnt[s]);
+  // one RETURNING global atomic per occupied slot.  All 16 of a thread are issued before the first result is used: as a
+  // loop of `if (occupied) base[s] = atomicAdd(..)` each LDS store waited for its own atomic, 16 serial L2 round trips
+  // (~1.5 us each) that were most of this kernel's time.
+  int got[CS_SLOTS / CS_THREADS];
+#pragma unroll
+  for (int i = 0; i < CS_SLOTS / CS_THREADS; ++i) {
+    const int s = tid + i * CS_THREADS;
+    const int k = keys[s];
+    got[i] = 0;
+    if (k != -1) got[i] = atomicAdd(&hist[k], cnt[s]);
+  }
+#pragma unroll
+  for (int i = 0; i < CS_SLOTS / CS_THREADS; ++i) base[tid + i * CS_THREADS] = got[i];
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < CS_ITEMS; ++q) {

@@ -63,6 +63,32 @@ def _grad_targets(params: Sequence[torch.Tensor], grad_bufs: Optional[Sequence[O
     return bufs, rets
 
 
+class deferred_weight_grads:
+    """While active, ``UserEncoderFn.backward`` issues its three weight gradients (phase 2 of ``nrl_user_encoder_bwd_phase``)
+    on ``stream`` instead of the caller's: they are ~100 us of few-row launches that nothing in the rest of the backward reads,
+    so they run beside the chip-filling news-encoder backward instead of in front of it.  Leaving the context makes the
+    current stream wait for ``stream`` (the join) -- do it before anything reads the gradient buffers (all-reduce, Adam).
+    Only calls that accumulate into caller-owned ``grad_bufs`` defer (gradients handed back to autograd are consumed on the
+    caller's stream right after the backward returns).  Used by ``trainer.NRMSTrainer``; off everywhere else."""
+
+    _active = None
+
+    def __init__(self, stream: "torch.cuda.Stream"):
+        self.stream = stream
+        self.keep = []          # tensors the side stream still reads: kept alive until the join
+
+    def __enter__(self):
+        deferred_weight_grads._active = self
+        return self
+
+    def __exit__(self, *exc):
+        deferred_weight_grads._active = None
+        if self.keep:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.keep = []
+        return False
+
+
 class NewsEncoderFn(torch.autograd.Function):
     """``MHSAAddAtt.forward`` (reference text.py:222-236): ids (N, L) -> (N, D)."""
 
@@ -181,10 +207,22 @@ class UserEncoderFn(torch.autograd.Function):
         bg = _block_grads(bufs)
         d_hist = torch.empty_like(hist)
         ws = ctx.ws
-        _lib.check(lib.nrl_user_encoder_bwd(ctypes.byref(bp), ctypes.byref(bg), hist.data_ptr(), B, H,
-                                            ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], d_out.data_ptr(),
-                                            d_hist.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-                   "nrl_user_encoder_bwd")
+
+        def run(phase):
+            _lib.check(lib.nrl_user_encoder_bwd_phase(ctypes.byref(bp), ctypes.byref(bg), hist.data_ptr(), B, H,
+                                                      ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], d_out.data_ptr(),
+                                                      d_hist.data_ptr(), phase, ws.data_ptr(), ws.numel(), _stream()),
+                       "nrl_user_encoder_bwd_phase")
+
+        defer = deferred_weight_grads._active
+        if defer is None or any(r is not None for r in rets):
+            run(0)
+        else:
+            run(1)
+            defer.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(defer.stream):
+                run(2)
+            defer.keep.append((ws, hist, params, bufs))
         ctx.ws = None
         return (d_hist, *rets, None, None, None, None, None, None)
 

@@ -8,6 +8,7 @@ GPUs, "gloo" in the CPU tests of the communication logic.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, List
 
 import torch
@@ -259,6 +260,10 @@ class NRMSTrainer:
             self.reduce = OverlappedGradReduce(self.flat, head, group, chunks=head_chunks)
         if head > 0:
             te.table_grad_hook = self.reduce.start_head
+        self._side = None
+        dev = self.flat.params[0].device
+        if dev.type == "cuda" and os.environ.get("NRL_DEFER_USER_WGRAD", "1") not in ("", "0"):
+            self._side = torch.cuda.Stream(device=dev)
 
     def epoch_end(self) -> Dict[str, float]:
         """Mean train loss over the steps since the last call (all ranks' steps under data parallelism), then reset --
@@ -284,7 +289,12 @@ class NRMSTrainer:
         # nothing here runs the epoch-end hook that clears them; the loss is still tracked for `epoch_end()`
         loss = self.module.model_step(batch)[0]
         self._losses.append(loss.detach())
-        loss.backward()
+        if self._side is not None:
+            # the user encoder's weight gradients on a side stream beside the news-encoder backward; joined on exit
+            with ops.deferred_weight_grads(self._side):
+                loss.backward()
+        else:
+            loss.backward()
         # parameters whose gradient came through ordinary autograd (``.grad``: a transformer body, a small
         # head fed through torch ops) rather than through a kernel writing ``main_grad``: fold them in
         for p in self.flat.params:

@@ -1045,3 +1045,45 @@ def test_sibling_modules_with_plm_text_encoder(tmp_path, model):
     assert all(torch.isfinite(p.grad).all() for p in mod.parameters() if p.grad is not None)
     body_grads = [p.grad for n, p in mod.named_parameters() if "plm_model" in n and p.grad is not None]
     assert body_grads and any(float(g.abs().max()) > 0 for g in body_grads)
+
+
+@pytest.mark.parametrize("B", [6, 128])
+def test_trainer_deferred_user_weight_gradients_match_the_in_line_backward(B, monkeypatch):
+    """``nrl_user_encoder_bwd_phase``: the trainer issues the user encoder's three weight gradients (phase 2) on a side
+    stream beside the news-encoder backward and joins before Adam.  The flat gradient of one step must agree with the
+    single-stream backward (same kernels, same operands; only atomics' arrival order differs), over ragged and full batches,
+    and three steps in a row (the join, the zeroing of the gradient by Adam and the next fork must stay ordered)."""
+    from newsreclib_amd.nrms_module import prepare_batch
+    from newsreclib_amd.synthetic import make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    vocab = 3000
+    params = O.make_params(vocab, seed=11)
+    batches = [prepare_batch(batch_to(make_batch(B, vocab, "ragged" if B < 64 else "fixed", seed=70 + i), DEV)) for i in range(3)]
+    grads, finals = {}, {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("NRL_DEFER_USER_WGRAD", defer)
+        mod = build_module(params, p_drop=0.2)
+        te = mod.news_encoder.text_encoders["title"]
+        orig = te.forward
+        te.forward = lambda text, seed=None, _o=orig, **kw: _o(text, seed=99, **kw)
+        tr = NRMSTrainer(mod, lr=1e-4)
+        assert (tr._side is not None) == (defer == "1")
+        seen = []
+        real = tr.opt.step_range
+        def spy(lo, hi, grad_scale=1.0, zero_grad=True, _real=real, _tr=tr, _seen=seen):
+            if lo == 0:
+                torch.cuda.synchronize()
+                _seen.append(_tr.flat.grad.clone())
+            _real(lo, hi, grad_scale, zero_grad)
+        tr.opt.step_range = spy
+        for b in batches:
+            tr.step(b)
+        torch.cuda.synchronize()
+        grads[defer] = seen
+        finals[defer] = tr.flat.flat.clone()
+    assert len(grads["0"]) == len(grads["1"]) == 3
+    for a, b in zip(grads["0"], grads["1"]):
+        scale = float(a.abs().max())
+        assert scale > 0 and _maxerr(a, b) <= 2e-5 * scale, (_maxerr(a, b), scale)
+    # parameters after three Adam steps: a noise-level gradient may flip the sign of a +-lr step, nothing more
+    assert _maxerr(finals["0"], finals["1"]) <= 2.1e-4 * 3
