@@ -91,14 +91,17 @@ class AbstractRecommender(LightningModuleBase):
         out = self.forward(batch)
         scores, aux = out if isinstance(out, tuple) else (out, None)
         y_true = dense_rows(batch["labels"], batch["batch_cand"], B, batch["max_cand"],
-                                   batch["cand_offsets"], batch["cand_flat_idx"])
+                            batch["cand_offsets"], batch["cand_flat_idx"], max_is_exact=True)
         loss = self._loss(scores, y_true.float(), batch)
         if aux is not None:          # recommenders with an auxiliary task (TANR topic prediction)
             loss = loss + self._aux_loss(batch, aux)
 
         # outputs for metric computation: gathering the valid slots in row-major order == the
         # reference's per-user concatenation (abstract_recommender.py:126-130), no loops, no syncs
-        preds = scores.detach().reshape(-1)[batch["cand_flat_idx"]]
+        if batch["labels"].shape[0] == scores.numel():      # every row full: the valid slots are all slots, in order
+            preds = scores.detach().reshape(-1)
+        else:
+            preds = scores.detach().reshape(-1)[batch["cand_flat_idx"]]
         targets = batch["labels"]
         cand_news_size, hist_news_size = batch["cand_sizes"], batch["hist_sizes"]    # == the mask row sums (:331-345)
 

@@ -26,6 +26,21 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int FA_BQ = 64, FA_BK = 64;
 
+// Workgroup id -> work item, XCD-aware.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own
+// L2, and consecutive items here share cache lines: the heads of one (outer, row) sit side by side in a packed q|k|v row
+// (dh = 20: 80-byte pieces of 128-byte lines), the query tiles of a group re-read the same K / V.  XCD x takes the contiguous
+// range [x * per, (x + 1) * per) of the items.  Grid = 8 * per workgroups; ids past the end return at once.
+// (What these kernels are bound by at the user encoder's S = 128 is the fp32 matrix pipe itself: 64 tiles x (36 + 48) MFMAs x
+//  750 groups = 4.0 M v_mfma_f32_16x16x4_f32 of 32 cycles on 1024 SIMDs = 52 us of the backward's 72; neither this order, nor
+//  one launch for both roles, nor fetching the K | V blocks a block ahead into registers -- 27.6 / 75.5 vs 27.9 / 72.3 us,
+//  not kept -- moves that.  A bf16x3 form as in nrl_news_fused.h would: 3 x 16 cycles per 32-deep product instead of 8 x 32.)
+__device__ __forceinline__ int64_t fa_item(int64_t n_items) {
+  const int64_t per = (n_items + 7) / 8;
+  const int64_t v = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  return v < n_items ? v : -1;
+}
+static inline unsigned fa_grid(int64_t n_items) { return (unsigned)(8 * ((n_items + 7) / 8)); }
+
 template <int DH>
 __global__ void __launch_bounds__(256)
     attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
@@ -38,8 +53,10 @@ __global__ void __launch_bounds__(256)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int64_t grp = blockIdx.x / q_tiles;
-  const int qt = (int)(blockIdx.x % q_tiles);
+  const int64_t item = fa_item(G.groups * q_tiles);
+  if (item < 0) return;
+  const int64_t grp = item / q_tiles;
+  const int qt = (int)(item % q_tiles);
   const int64_t outer = grp / G.heads;
   const int head = (int)(grp % G.heads);
   const float* qb = qkv + outer * G.q_outer + head * DH;
@@ -167,7 +184,7 @@ int attn_fwd_mfma(const float* qkv, float* o, float* lse, const AttnGeom& G, hip
   const int64_t blocks = G.groups * q_tiles;
   NRL_REQUIRE(blocks < (1LL << 31), "attention grid too large");
   NRL_FA_DISPATCH(G.dh, {
-    hipLaunchKernelGGL((attn_fwd_mfma_kernel<DH>), dim3((unsigned)blocks), dim3(256), 0, stream, qkv, o, lse, G, q_tiles);
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<DH>), dim3(fa_grid(blocks)), dim3(256), 0, stream, qkv, o, lse, G, q_tiles);
   });
   NRL_LAUNCH_CHECK();
   return NRL_OK;
@@ -397,18 +414,20 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const float* __restrict__ qkv,
   }
 }
 
-// ONE launch for both roles: workgroup 2i computes dQ of (group, query tile) i, workgroup 2i + 1 the dK / dV of (group, key
-// tile) i.  The two read the same q|k|v / dO rows (the neighbour's fetches hit the L2) and neither depends on the other;
-// as two launches they ran back to back (36 + 44 us over the 1500 tiles of the NRMS user encoder at B = 128, each launch
-// bound by its own load -> LDS -> MFMA chain, not by the chip).
+// ONE launch for both roles: item 2i computes dQ of (group, query tile) i, item 2i + 1 the dK / dV of (group, key
+// tile) i (items -> workgroups: fa_item).  The two read the same q|k|v / dO rows (the neighbour's fetches hit the L2) and
+// neither depends on the other; as two launches they ran back to back (36 + 44 us over the 1500 tiles of the NRMS user
+// encoder at B = 128, 72-75 us as one: the drain of one and the ramp of the other are all there was to gain, see fa_item).
 template <int DH>
 __global__ void __launch_bounds__(256)
     attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
                          const float* __restrict__ lse, float* __restrict__ dqkv, const AttnGeom G, const int tiles) {
   constexpr int DHP = DH + 4;
   __shared__ __attribute__((aligned(16))) float smem[2 * FA_BQ * DHP + 2 * FA_BQ];
-  const int64_t bid = blockIdx.x >> 1;
-  if ((blockIdx.x & 1) == 0) attn_bwd_dq_body<DH>(qkv, o, d_o, lse, dqkv, G, tiles, bid, smem);
+  const int64_t item = fa_item(2 * G.groups * tiles);
+  if (item < 0) return;
+  const int64_t bid = item >> 1;
+  if ((item & 1) == 0) attn_bwd_dq_body<DH>(qkv, o, d_o, lse, dqkv, G, tiles, bid, smem);
   else attn_bwd_dkv_body<DH>(qkv, o, d_o, lse, dqkv, G, tiles, bid, smem);
 }
 
@@ -420,7 +439,7 @@ int attn_bwd_mfma(const float* qkv, const float* o, const float* d_o, const floa
   NRL_REQUIRE(blocks < (1LL << 31), "attention grid too large");
   NRL_REQUIRE(2 * blocks < (1LL << 31), "attention grid too large");
   NRL_FA_DISPATCH(G.dh, {
-    hipLaunchKernelGGL((attn_bwd_mfma_kernel<DH>), dim3((unsigned)(2 * blocks)), dim3(256), 0, stream, qkv, o, d_o, lse,
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<DH>), dim3(fa_grid(2 * blocks)), dim3(256), 0, stream, qkv, o, d_o, lse,
                        dqkv, G, tiles);
   });
   NRL_LAUNCH_CHECK();

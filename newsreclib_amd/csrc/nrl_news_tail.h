@@ -481,6 +481,10 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_fwd_kernel(const News
   static_assert(2 * 5 * 4 <= NT_SLOT / 1024 || KPARTS == 3, "phase-2 chunk must fit a ring slot");
 }
 
+// (Tail balancing measured and NOT adopted: cutting the grid at the last multiple of the 512 workgroup slots and sending the
+// remainder -- 224 workgroups at B = 128 -- as a second launch forced to one workgroup per CU by 32 KB of unused dynamic LDS.
+// Step 3.05-3.08 vs 3.01 ms; forward 2 x 130 vs 250 us, backward 2 x 177 vs ~300 us: the drain of the first launch and the
+// ramp of the second cost more than the SIMD sharing in the last round.)
 template <int WAVES = 4, int ABL = 0>
 static inline int launch_news_tail_fwd(const NewsTailArgs& a, hipStream_t st) {
   if (a.n_news <= 0) return NRL_OK;

@@ -1,9 +1,13 @@
 """``to_dense_batch`` (torch_geometric 2.3.0; reference call sites nrms_module.py:233,237,277-284)."""
+import os
 from typing import Optional, Tuple
 
 import torch
 
 from . import ops
+
+# NRL_FULL_RESHAPE=0: always run the dense-batch kernels, also over full batches (A/B runs)
+_FULL_IS_RESHAPE = os.environ.get("NRL_FULL_RESHAPE", "1") not in ("", "0")
 
 
 def to_dense_batch(x: torch.Tensor, batch: torch.Tensor, batch_size: Optional[int] = None,
@@ -32,10 +36,17 @@ def _resolve(batch, batch_size, max_num_nodes, offsets):
 
 def dense_rows(x: torch.Tensor, batch: torch.Tensor, batch_size: Optional[int] = None,
                max_num_nodes: Optional[int] = None, offsets: Optional[torch.Tensor] = None,
-               flat_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+               flat_idx: Optional[torch.Tensor] = None, max_is_exact: bool = False) -> torch.Tensor:
     """The dense tensor of ``to_dense_batch`` without the mask (every call site on the step path discards it, and
-    building it costs three small launches per call)."""
+    building it costs three small launches per call).
+
+    ``max_is_exact``: the caller vouches that ``max_num_nodes`` is the true largest group (the layout metadata of
+    ``attach_layout`` / ``input_pipeline.build_batch``, not a truncating cap).  Then ``N == B * max`` means every group is
+    full and the dense tensor IS the row-major reshape of ``x``: no launch forward or backward (training candidates are
+    always 1 + K per impression; full histories whenever every user has >= max_history_len clicks)."""
     batch_size, max_num_nodes, offsets = _resolve(batch, batch_size, max_num_nodes, offsets)
+    if max_is_exact and _FULL_IS_RESHAPE and batch_size > 0 and x.shape[0] == batch_size * max_num_nodes:
+        return x.reshape((batch_size, max_num_nodes) + tuple(x.shape[1:]))
     if x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0:
         return ops.ToDenseBatchFn.apply(x, offsets, batch_size, max_num_nodes)
     # label / category vectors: (N,) of any dtype -- tiny index bookkeeping, not arithmetic;

@@ -78,10 +78,11 @@ def prepare_batch(batch: Dict, vocab: Optional[int] = None) -> Dict:
             if torch.is_tensor(h):
                 ids = torch.cat([h, c], dim=0)
                 out.setdefault("x_all", {})[attr] = ids
-                # counting sort over the vocabulary, in front of the forward on the launch stream.  NRL_SORT_ASYNC=1 moves it to
-                # a side stream (the order is needed by the backward only) -- measured SLOWER on one box, 3.30 vs 3.26 ms per
-                # step at B = 128: its three small launches then contend with the fused forward instead of preceding it
-                sort = ops.sort_positions_async if os.environ.get("NRL_SORT_ASYNC", "0") == "1" else ops.sort_positions
+                # counting sort over the vocabulary on a side stream: the order is needed by the backward only, so its four
+                # small launches (~50 us at B = 128) run beside the fused forward instead of in front of it.  Measured slower
+                # mid-round (3.30 vs 3.26 ms: the sort was 80 us of atomics then); with the current sort, two alternating pairs
+                # of 100 steps: 2.98 / 3.00 vs 3.03 / 3.02 ms.  NRL_SORT_ASYNC=0 keeps it on the launch stream.
+                sort = ops.sort_positions_async if os.environ.get("NRL_SORT_ASYNC", "1") == "1" else ops.sort_positions
                 out["x_all"][attr + "_order"] = sort(ids, vocab)
             # (PLM tokenizer output -- a dict of (N, L) tensors, rec_dataset.py:180-190 -- is NOT merged: the
             #  two sides are padded to their own longest text and the PLM encoder must see them in separate calls)
@@ -183,9 +184,9 @@ class NRMSModule(AbstractRecommender):
         encodes every unique news once, ``evaluation.NewsVectorCache``)."""
         B = batch["batch_size"]
         hist_news_vector_agg = dense_rows(hist_news_vector, batch["batch_hist"], B,
-                                                 batch["max_hist"], batch["hist_offsets"])
+                                          batch["max_hist"], batch["hist_offsets"], max_is_exact=True)
         cand_news_vector_agg = dense_rows(cand_news_vector, batch["batch_cand"], B,
-                                                 batch["max_cand"], batch["cand_offsets"])
+                                          batch["max_cand"], batch["cand_offsets"], max_is_exact=True)
         if not self.hparams.late_fusion:
             user_vector = self.user_encoder(hist_news_vector_agg)
         else:  # aggregate embeddings of clicked news (nrms_module.py:243-248)

@@ -332,7 +332,21 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d_scores,) = ctx.saved_tensors
+        if g.data_ptr() in _UNIT_GRADS:      # the root gradient of a trainer (a registered tensor holding 1.0): d_scores as is
+            return d_scores, None, None
         return d_scores * g, None, None
+
+
+# Root gradients known to hold exactly 1.0 (``register_unit_grad``): a loss that receives one of them as its incoming gradient
+# IS the root of the backward and hands its stored gradient on without the multiply (one small launch per step; autograd's own
+# ``ones_like`` fill is the other one a trainer saves by passing the tensor to ``loss.backward(gradient=...)``).  The registry
+# keeps the tensors alive, so an address can never come back as some other tensor's.
+_UNIT_GRADS = {}
+
+
+def register_unit_grad(t: torch.Tensor) -> torch.Tensor:
+    _UNIT_GRADS[t.data_ptr()] = t
+    return t
 
 
 class SupConFn(torch.autograd.Function):

@@ -262,6 +262,9 @@ class NRMSTrainer:
             te.table_grad_hook = self.reduce.start_head
         self._side = None
         dev = self.flat.params[0].device
+        # d(loss)/d(loss): one cached tensor instead of autograd's per-step fill; losses recognise it (ops.register_unit_grad)
+        self._unit_root = os.environ.get("NRL_UNIT_ROOT_GRAD", "1") not in ("", "0")     # (0: plain loss.backward(), A/B runs)
+        self._one = ops.register_unit_grad(torch.ones((), dtype=torch.float32, device=dev))
         if dev.type == "cuda" and os.environ.get("NRL_DEFER_USER_WGRAD", "1") not in ("", "0"):
             self._side = torch.cuda.Stream(device=dev)
 
@@ -289,12 +292,13 @@ class NRMSTrainer:
         # nothing here runs the epoch-end hook that clears them; the loss is still tracked for `epoch_end()`
         loss = self.module.model_step(batch)[0]
         self._losses.append(loss.detach())
+        root = self._one if self._unit_root and loss.dim() == 0 and loss.dtype == torch.float32 and loss.device == self._one.device else None
         if self._side is not None:
             # the user encoder's weight gradients on a side stream beside the news-encoder backward; joined on exit
             with ops.deferred_weight_grads(self._side):
-                loss.backward()
+                loss.backward(gradient=root)
         else:
-            loss.backward()
+            loss.backward(gradient=root)
         # parameters whose gradient came through ordinary autograd (``.grad``: a transformer body, a small
         # head fed through torch ops) rather than through a kernel writing ``main_grad``: fold them in
         for p in self.flat.params:
