@@ -479,6 +479,13 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
 static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const BlockWs& w, const BlockPlanes& bp,
                           Dropout drop2, float* out, hipStream_t st);
 
+// 64 <= S <= 128 with dh = 20 under the bf16x3 engine: the (hi, lo) split matrix-core attention of nrl_attn_x3.hip (the NRMS
+// user encoder at 64 .. 128 users per rank); everything else -- and the exact-fp32 engine -- on attn_fwd / attn_bwd.  Forward
+// and backward of a call agree on it: the engine travels with the call, the geometry is the call's.
+static inline bool block_attn_x3(const BlockShape& s) {
+  return cur_engine() == ENGINE_BF16X3 && s.geom.S >= 64 && attn_x3_ok(s.geom);
+}
+
 // forward of the shared block given an A-operand accessor for the in-projection
 template <class AOp>
 static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape& s, const BlockWs& w,
@@ -494,7 +501,8 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
                      s.M, 3 * D, D, false, st));
   }
   // per (group, head): softmax(q k^T / sqrt(dh)) v
-  NRL_TRY(attn_fwd(w.qkv, w.o, save ? w.lse : nullptr, s.geom, st));
+  if (block_attn_x3(s)) NRL_TRY(attn_fwd_x3(w.qkv, w.o, save ? w.lse : nullptr, s.geom, st));
+  else NRL_TRY(attn_fwd(w.qkv, w.o, save ? w.lse : nullptr, s.geom, st));
   return block_fwd_tail(P, s, w, bp, drop2, out, st);
 }
 
@@ -606,7 +614,10 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
     }
     // d_o = dy W_o
     NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
-    if (!attention_elsewhere) NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+    if (!attention_elsewhere) {
+    if (block_attn_x3(s)) NRL_TRY(attn_bwd_x3(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+    else NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+  }
     return NRL_OK;
   }
   NRL_TRY(pool_bwd_pre(d_out, s.tail ? nullptr : w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st,
@@ -631,7 +642,10 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
                        bp.rp.on ? &bp.rp.out_d : nullptr));
   }
   // attention backward -> dqkv
-  if (!attention_elsewhere) NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+  if (!attention_elsewhere) {
+    if (block_attn_x3(s)) NRL_TRY(attn_bwd_x3(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+    else NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+  }
   return NRL_OK;
 }
 

@@ -1,0 +1,343 @@
+// Attention over SHORT sequences of short heads (S <= 128, dh = 20) on the bf16 matrix cores with (hi, lo) split operands
+// ("bf16x3": hi*lo + lo*hi + hi*hi into fp32, the arithmetic of every projection of the bf16x3 engine), gfx950.
+//
+// Where it is used: the seq-first nn.MultiheadAttention of the NRMS user encoder (user/nrms.py:32-41; SURVEY.md headline
+// fact 3) attends ACROSS THE USERS of the batch for every history slot and head: 50 x 15 = 750 attentions of S = B = 128
+// (64 per rank in BASELINE configs[2]) with dh = 20.  The flash kernels of nrl_attn_mfma.hip serve them in exact fp32 --
+// v_mfma_f32_16x16x4_f32, 32 cycles per 4-deep product -- and at this size they are bound by exactly that pipe: 4.0 M MFMAs
+// = 52 us of the backward's 72 at B = 128.  Here a 32-deep product costs 3 x 16 cycles.
+//
+// One workgroup of 8 wavefronts owns one (slot, head) group; wave w owns rows 16w .. 16w + 15.  q (pre-scaled) | k | v
+// (| d_o) of the group are staged ONCE into LDS as fp32 rows [row][24] (20 features + 4 zeros; rows past S are copies of
+// row S - 1, so that a masked probability of 0 never meets a non-finite operand), and every operand is then a fragment read of
+// that image -- the same two readers as the token attention of nrl_news_fused.h:
+//   row form   nf_frag8: lane (l15, g) <- features 8g .. 8g + 7 of row l15       (A or B operand of a product over features)
+//   column form nf_kfrag: lane (d, g) <- rows kappa(g, e) of column d            (B operand of a product over rows)
+// with kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4) inside a 32-row group.  A 16 x 16 accumulator block holds rows 4g + r
+// of column l15 per lane, so TWO blocks (rows 32t .. 32t + 31 of one column) are exactly the A fragment of the next product
+// under kappa: P, dS never leave registers (forward: S^T = K Q^T -> softmax -> O = P V; backward: both orientations, as two
+// roles per wave -- its 16 queries' dQ, then its 16 keys' dK / dV -- each recomputing the scores from the saved log-sum-exp).
+#include <math.h>
+
+#include "nrl_kernels.h"
+#include "nrl_news_fused.h"
+
+namespace nrl {
+
+constexpr int UA_S = 128;            // keys / queries per group the image holds
+constexpr int UA_LD = 24;            // floats per image row
+constexpr int UA_WAVES = 8;
+constexpr int UA_MAT = UA_S * UA_LD + 8;   // (+ 8: the masked lanes of the last row's column-form reads run past it)
+constexpr int UA_DH = 20;
+
+// group -> workgroup, XCD-aware (see fa_item, nrl_attn_mfma.hip): the heads of a slot share the cache lines of its packed rows
+__device__ __forceinline__ int64_t ua_item(int64_t n_items) {
+  const int64_t per = (n_items + 7) / 8;
+  const int64_t v = (int64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  return v < n_items ? v : -1;
+}
+
+// rows [0, UA_S) of one strided operand -> image: six float4 slots per row (five of data, one of zeros)
+__device__ __forceinline__ void ua_stage(float* __restrict__ dst, const float* __restrict__ src, int64_t row_stride, int S,
+                                         float mul, int tid) {
+#pragma unroll
+  for (int i = 0; i < (UA_S * 6 + UA_WAVES * 64 - 1) / (UA_WAVES * 64); ++i) {
+    const int idx = tid + i * UA_WAVES * 64;
+    if (idx < UA_S * 6) {
+      const int row = idx / 6, c = idx - row * 6;
+      const int r = row < S ? row : S - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < 5) {
+        v = *reinterpret_cast<const float4*>(src + (int64_t)r * row_stride + 4 * c);
+        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+      }
+      *reinterpret_cast<float4*>(dst + row * UA_LD + 4 * c) = v;
+    }
+  }
+}
+
+#define UA_MFMA3(acc, ah, al, bh, bl)                                          \
+  do {                                                                         \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);       \
+  } while (0)
+
+__global__ void __launch_bounds__(UA_WAVES * 64)
+    ua_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse, const AttnGeom G) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * UA_MAT];
+  float* const Qs = smem;
+  float* const Ks = smem + UA_MAT;
+  float* const Vs = smem + 2 * UA_MAT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int64_t grp = ua_item(G.groups);
+  if (grp < 0) return;
+  const int64_t outer = grp / G.heads;
+  const int head = (int)(grp % G.heads);
+  const int S = G.S;
+  const float* qb = qkv + outer * G.q_outer + head * UA_DH;
+  ua_stage(Qs, qb, G.q_seq, S, G.scale, tid);
+  ua_stage(Ks, qb + G.D, G.q_seq, S, 1.0f, tid);
+  ua_stage(Vs, qb + 2 * G.D, G.q_seq, S, 1.0f, tid);
+  if (tid < 8) smem[3 * UA_MAT - 8 + tid] = 0.f;
+  __syncthreads();
+  const int q0 = wave * 16;
+  if (q0 >= S) return;
+
+  // ---- S^T = K Q^T: lane (query l15, g) <- keys 16 jb + 4g + r ---------------------------------------------------
+  bf16x8 qh, ql;
+  nf_frag8(Qs + (q0 + l15) * UA_LD, g, 1.0f, qh, ql);
+  float e[32];
+  float m = -INFINITY;
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    bf16x8 kh, kl;
+    nf_frag8(Ks + (16 * jb + l15) * UA_LD, g, 1.0f, kh, kl);
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    UA_MFMA3(s, kh, kl, qh, ql);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * jb + 4 * g + r;
+      e[4 * jb + r] = key < S ? s[r] : -INFINITY;
+      m = fmaxf(m, e[4 * jb + r]);
+    }
+  }
+  m = fmaxf(m, nf_xor16(m, lane));
+  m = fmaxf(m, nf_xor32(m, lane));
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float m2 = m * LOG2E;
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    e[q] = __builtin_amdgcn_exp2f(fmaf(e[q], LOG2E, -m2));      // masked keys: 2^(-inf) = 0
+    sum += e[q];
+  }
+  sum += nf_xor16(sum, lane);
+  sum += nf_xor32(sum, lane);
+  const float inv = __builtin_amdgcn_rcpf(sum);
+  if (lse != nullptr && g == 0 && q0 + l15 < S) lse[grp * S + q0 + l15] = m + logf(sum);
+
+  // ---- O = P V: A = P (two key blocks of a lane = one fragment under kappa), B = V in column form -------------------
+  f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    bf16x8 ph, pl;
+    rp_split8(make_float4(e[8 * t] * inv, e[8 * t + 1] * inv, e[8 * t + 2] * inv, e[8 * t + 3] * inv),
+              make_float4(e[8 * t + 4] * inv, e[8 * t + 5] * inv, e[8 * t + 6] * inv, e[8 * t + 7] * inv), ph, pl);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int d = db * 16 + l15;
+      bf16x8 vh, vl;
+      nf_kfrag(Vs + 32 * t * UA_LD + d, UA_LD, g, d < UA_DH ? 1.0f : 0.f, vh, vl);
+      UA_MFMA3(oacc[db], ph, pl, vh, vl);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = q0 + 4 * g + r;
+    if (qi < S) {
+      float* orow = o + outer * G.o_outer + (int64_t)qi * G.o_seq + head * UA_DH;
+      orow[l15] = oacc[0][r];
+      if (l15 < UA_DH - 16) orow[16 + l15] = oacc[1][r];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(UA_WAVES * 64)
+    ua_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
+                  const float* __restrict__ lse, float* __restrict__ dqkv, const AttnGeom G) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * UA_MAT + 2 * UA_S];
+  float* const Qs = smem;                       // scale * q
+  float* const Ks = smem + UA_MAT;
+  float* const Vs = smem + 2 * UA_MAT;
+  float* const dOs = smem + 3 * UA_MAT;
+  float* const lse_s = smem + 4 * UA_MAT;       // rows past S: +inf (probability 0)
+  float* const delta_s = lse_s + UA_S;          // delta[q] = <dO[q], O[q]>
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int64_t grp = ua_item(G.groups);
+  if (grp < 0) return;
+  const int64_t outer = grp / G.heads;
+  const int head = (int)(grp % G.heads);
+  const int S = G.S;
+  const float* qb = qkv + outer * G.q_outer + head * UA_DH;
+  const float* dob = d_o + outer * G.o_outer + head * UA_DH;
+  const float* ob = o + outer * G.o_outer + head * UA_DH;
+  // the O row of thread `tid` (delta) is requested before the staging loads are waited for
+  float4 orow[5];
+  float lse_r = INFINITY;
+  if (tid < UA_S) {
+    const int r = tid < S ? tid : S - 1;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) orow[c] = *reinterpret_cast<const float4*>(ob + (int64_t)r * G.o_seq + 4 * c);
+    if (tid < S) lse_r = lse[grp * S + tid];
+  }
+  ua_stage(Qs, qb, G.q_seq, S, G.scale, tid);
+  ua_stage(Ks, qb + G.D, G.q_seq, S, 1.0f, tid);
+  ua_stage(Vs, qb + 2 * G.D, G.q_seq, S, 1.0f, tid);
+  ua_stage(dOs, dob, G.o_seq, S, 1.0f, tid);
+  if (tid < 8) {
+    smem[UA_MAT - 8 + tid] = 0.f;
+    smem[2 * UA_MAT - 8 + tid] = 0.f;
+    smem[3 * UA_MAT - 8 + tid] = 0.f;
+    smem[4 * UA_MAT - 8 + tid] = 0.f;
+  }
+  __syncthreads();
+  if (tid < UA_S) {
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(dOs + tid * UA_LD + 4 * c);
+      dl = fmaf(a.x, orow[c].x, dl); dl = fmaf(a.y, orow[c].y, dl); dl = fmaf(a.z, orow[c].z, dl); dl = fmaf(a.w, orow[c].w, dl);
+    }
+    delta_s[tid] = tid < S ? dl : 0.f;
+    lse_s[tid] = lse_r;
+  }
+  __syncthreads();
+  const int r0 = wave * 16;
+  if (r0 >= S) return;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  // ================= role 1: dQ of queries r0 .. r0 + 15 ==============================================================
+  {
+    bf16x8 qh, ql, doh, dol;
+    nf_frag8(Qs + (r0 + l15) * UA_LD, g, 1.0f, qh, ql);
+    nf_frag8(dOs + (r0 + l15) * UA_LD, g, 1.0f, doh, dol);
+    const float lse_q = lse_s[r0 + l15] * LOG2E, delta_q = delta_s[r0 + l15];
+    f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float ds[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int jb = 2 * t + half;
+        bf16x8 kh, kl, vh, vl;
+        nf_frag8(Ks + (16 * jb + l15) * UA_LD, g, 1.0f, kh, kl);
+        nf_frag8(Vs + (16 * jb + l15) * UA_LD, g, 1.0f, vh, vl);
+        f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+        UA_MFMA3(st, kh, kl, qh, ql);              // S^T[key][query]
+        UA_MFMA3(dpt, vh, vl, doh, dol);           // dP^T[key][query] = V dO^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * jb + 4 * g + r;
+          const float p = key < S ? __builtin_amdgcn_exp2f(fmaf(st[r], LOG2E, -lse_q)) : 0.f;
+          ds[4 * half + r] = p * (dpt[r] - delta_q);
+        }
+      }
+      bf16x8 dsh, dsl;
+      rp_split8(make_float4(ds[0], ds[1], ds[2], ds[3]), make_float4(ds[4], ds[5], ds[6], ds[7]), dsh, dsl);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int d = db * 16 + l15;
+        bf16x8 bh, bl;
+        nf_kfrag(Ks + 32 * t * UA_LD + d, UA_LD, g, d < UA_DH ? 1.0f : 0.f, bh, bl);
+        UA_MFMA3(dq[db], dsh, dsl, bh, bl);        // dQ += dS K
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = r0 + 4 * g + r;
+      if (qi < S) {
+        float* row = dqkv + outer * G.q_outer + (int64_t)qi * G.q_seq + head * UA_DH;
+        row[l15] = dq[0][r] * G.scale;
+        if (l15 < UA_DH - 16) row[16 + l15] = dq[1][r] * G.scale;
+      }
+    }
+  }
+
+  // ================= role 2: dK, dV of keys r0 .. r0 + 15 =============================================================
+  {
+    bf16x8 kh, kl, vh, vl;
+    nf_frag8(Ks + (r0 + l15) * UA_LD, g, 1.0f, kh, kl);
+    nf_frag8(Vs + (r0 + l15) * UA_LD, g, 1.0f, vh, vl);
+    f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float pp[8], ds[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int ib = 2 * t + half;
+        bf16x8 qh, ql, doh, dol;
+        nf_frag8(Qs + (16 * ib + l15) * UA_LD, g, 1.0f, qh, ql);
+        nf_frag8(dOs + (16 * ib + l15) * UA_LD, g, 1.0f, doh, dol);
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        UA_MFMA3(sc, qh, ql, kh, kl);              // S[query][key]
+        UA_MFMA3(dp, doh, dol, vh, vl);            // dP[query][key] = dO V^T
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 16 * ib + 4 * g);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + 16 * ib + 4 * g);
+        const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f((sc[r] - lq[r]) * LOG2E);    // queries past S: lse = +inf -> 0
+          pp[4 * half + r] = p;
+          ds[4 * half + r] = p * (dp[r] - dq4[r]);
+        }
+      }
+      bf16x8 ph, pl, dsh, dsl;
+      rp_split8(make_float4(pp[0], pp[1], pp[2], pp[3]), make_float4(pp[4], pp[5], pp[6], pp[7]), ph, pl);
+      rp_split8(make_float4(ds[0], ds[1], ds[2], ds[3]), make_float4(ds[4], ds[5], ds[6], ds[7]), dsh, dsl);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int d = db * 16 + l15;
+        const float mk = d < UA_DH ? 1.0f : 0.f;
+        bf16x8 bh, bl;
+        nf_kfrag(dOs + 32 * t * UA_LD + d, UA_LD, g, mk, bh, bl);
+        UA_MFMA3(dv[db], ph, pl, bh, bl);          // dV += P^T dO
+        nf_kfrag(Qs + 32 * t * UA_LD + d, UA_LD, g, mk, bh, bl);
+        UA_MFMA3(dk[db], dsh, dsl, bh, bl);        // dK += dS^T (scale Q)
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ki = r0 + 4 * g + r;
+      if (ki < S) {
+        float* row = dqkv + outer * G.q_outer + (int64_t)ki * G.q_seq + head * UA_DH;
+        row[G.D + l15] = dk[0][r];
+        row[2 * G.D + l15] = dv[0][r];
+        if (l15 < UA_DH - 16) {
+          row[G.D + 16 + l15] = dk[1][r];
+          row[2 * G.D + 16 + l15] = dv[1][r];
+        }
+      }
+    }
+  }
+}
+
+bool attn_x3_ok(const AttnGeom& G) {
+  static const bool on = [] {
+    const char* e = getenv("NRL_ATTN_X3");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  // (rows are read as float4: 16-byte aligned strides and head offsets)
+  return on && G.dh == UA_DH && G.S >= 1 && G.S <= UA_S && G.D % 4 == 0 && G.q_seq % 4 == 0 && G.q_outer % 4 == 0 &&
+         G.o_seq % 4 == 0 && G.o_outer % 4 == 0;
+}
+
+int attn_fwd_x3(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream) {
+  if (G.groups == 0) return NRL_OK;
+  NRL_REQUIRE(attn_x3_ok(G), "attn_fwd_x3: unsupported geometry");
+  NRL_REQUIRE(G.groups + 7 < (1LL << 31), "attention grid too large");
+  NRL_REQUIRE((((uintptr_t)qkv | (uintptr_t)o) & 15) == 0, "attn_fwd_x3: 16-byte alignment");
+  hipLaunchKernelGGL(ua_fwd_kernel, dim3((unsigned)(8 * ((G.groups + 7) / 8))), dim3(UA_WAVES * 64), 0, stream, qkv, o, lse, G);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int attn_bwd_x3(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, const AttnGeom& G,
+                hipStream_t stream) {
+  if (G.groups == 0) return NRL_OK;
+  NRL_REQUIRE(attn_x3_ok(G), "attn_bwd_x3: unsupported geometry");
+  NRL_REQUIRE(lse != nullptr, "attention backward needs the saved log-sum-exp");
+  NRL_REQUIRE(G.groups + 7 < (1LL << 31), "attention grid too large");
+  NRL_REQUIRE((((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dqkv) & 15) == 0, "attn_bwd_x3: 16-byte alignment");
+  hipLaunchKernelGGL(ua_bwd_kernel, dim3((unsigned)(8 * ((G.groups + 7) / 8))), dim3(UA_WAVES * 64), 0, stream, qkv, o, d_o, lse,
+                     dqkv, G);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+}  // namespace nrl

@@ -370,7 +370,8 @@ def test_switches_travel_with_the_call():
         _lib.require_options(_lib.options_mask() ^ 1, "a test call")
 
 
-@pytest.mark.parametrize("B,H", [(3, 4), (5, 50), (40, 7), (130, 3)])
+# (64 <= B <= 128: the across-users attention runs on nrl_attn_x3.hip -- full image, a partly filled last row block, the lower edge)
+@pytest.mark.parametrize("B,H", [(3, 4), (5, 50), (40, 7), (130, 3), (128, 5), (77, 6), (64, 3), (113, 2)])
 def test_user_encoder_fwd_and_bwd_vs_oracle(B, H):
     from newsreclib_amd.user_encoder import UserEncoder
     params = _news_params()
