@@ -8,12 +8,17 @@
 // = 52 us of the backward's 72 at B = 128.  Here a 32-deep product costs 3 x 16 cycles.
 //
 // One workgroup of 8 wavefronts owns one (slot, head) group; wave w owns rows 16w .. 16w + 15.  q (pre-scaled) | k | v
-// (| d_o) of the group are staged ONCE into LDS as fp32 rows [row][24] (20 features + 4 zeros; rows past S are copies of
-// row S - 1, so that a masked probability of 0 never meets a non-finite operand), and every operand is then a fragment read of
-// that image -- the same two readers as the token attention of nrl_news_fused.h:
-//   row form   nf_frag8: lane (l15, g) <- features 8g .. 8g + 7 of row l15       (A or B operand of a product over features)
-//   column form nf_kfrag: lane (d, g) <- rows kappa(g, e) of column d            (B operand of a product over rows)
-// with kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4) inside a 32-row group.  A 16 x 16 accumulator block holds rows 4g + r
+// (| d_o) of the group are split ONCE -- one 8-feature piece per thread -- into (hi, lo) bf16 planes in LDS, laid out as
+// 16 x 16 blocks [row block 0..7][feature block 0..1][16 rows][16 features] (features 20 .. 31 zero; rows past S are copies of
+// row S - 1, so that a masked probability of 0 never meets a non-finite operand).  Every operand is then a plain read of that
+// image, no VALU (the first version kept fp32 rows and split each fragment where it was used: every wave re-split the same K / V
+// rows, ~10 splits of ~30 VALU instructions per 24 MFMAs -- 45.7 us backward / 20.5 us forward at B = 128 for 6.5 / 2 us of MFMAs):
+//   row form    ua_row: lane (l15, g) <- features 8g .. 8g + 7 of row l15: one ds_read_b128 per plane
+//                                                                         (A or B operand of a product over features)
+//   column form ua_col: lane (d, g) <- rows kappa(g, e) of feature d: two ds_read_b64_tr_b16 per plane
+//                                                                         (B operand of a product over rows)
+// with kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4) inside a 32-row group -- the transpose read hands lane (d, g) rows
+// 4g .. 4g + 3 of a block, two row blocks make the 8 k of a 16 x 16 x 32 operand.  A 16 x 16 accumulator block holds rows 4g + r
 // of column l15 per lane, so TWO blocks (rows 32t .. 32t + 31 of one column) are exactly the A fragment of the next product
 // under kappa: P, dS never leave registers (forward: S^T = K Q^T -> softmax -> O = P V; backward: both orientations, as two
 // roles per wave -- its 16 queries' dQ, then its 16 keys' dK / dV -- each recomputing the scores from the saved log-sum-exp).
@@ -25,10 +30,10 @@
 namespace nrl {
 
 constexpr int UA_S = 128;            // keys / queries per group the image holds
-constexpr int UA_LD = 24;            // floats per image row
 constexpr int UA_WAVES = 8;
-constexpr int UA_MAT = UA_S * UA_LD + 8;   // (+ 8: the masked lanes of the last row's column-form reads run past it)
 constexpr int UA_DH = 20;
+constexpr int UA_PLANE = 16 * 512;   // bytes per plane: 8 row blocks x 2 feature blocks x (16 x 16 bf16)
+constexpr int UA_MATB = 2 * UA_PLANE;  // (hi, lo) of one operand
 
 // group -> workgroup, XCD-aware (see fa_item, nrl_attn_mfma.hip): the heads of a slot share the cache lines of its packed rows
 __device__ __forceinline__ int64_t ua_item(int64_t n_items) {
@@ -37,23 +42,45 @@ __device__ __forceinline__ int64_t ua_item(int64_t n_items) {
   return v < n_items ? v : -1;
 }
 
-// rows [0, UA_S) of one strided operand -> image: six float4 slots per row (five of data, one of zeros)
-__device__ __forceinline__ void ua_stage(float* __restrict__ dst, const float* __restrict__ src, int64_t row_stride, int S,
+// rows [0, UA_S) of one strided operand -> (hi, lo) block planes: thread = (row, 8-feature piece)
+__device__ __forceinline__ void ua_stage(unsigned char* __restrict__ dst, const float* __restrict__ src, int64_t row_stride, int S,
                                          float mul, int tid) {
-#pragma unroll
-  for (int i = 0; i < (UA_S * 6 + UA_WAVES * 64 - 1) / (UA_WAVES * 64); ++i) {
-    const int idx = tid + i * UA_WAVES * 64;
-    if (idx < UA_S * 6) {
-      const int row = idx / 6, c = idx - row * 6;
-      const int r = row < S ? row : S - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < 5) {
-        v = *reinterpret_cast<const float4*>(src + (int64_t)r * row_stride + 4 * c);
-        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
-      }
-      *reinterpret_cast<float4*>(dst + row * UA_LD + 4 * c) = v;
-    }
+  static_assert(UA_WAVES * 64 == UA_S * 4, "one piece per thread");
+  const int row = tid >> 2, c8 = tid & 3;
+  const int r = row < S ? row : S - 1;
+  const float* rp = src + (int64_t)r * row_stride;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (c8 < 2) {
+    v0 = *reinterpret_cast<const float4*>(rp + 8 * c8);
+    v1 = *reinterpret_cast<const float4*>(rp + 8 * c8 + 4);
+  } else if (c8 == 2) {
+    v0 = *reinterpret_cast<const float4*>(rp + 16);
   }
+  v0.x *= mul; v0.y *= mul; v0.z *= mul; v0.w *= mul;
+  v1.x *= mul; v1.y *= mul; v1.z *= mul; v1.w *= mul;
+  bf16x8 hi, lo;
+  rp_split8(v0, v1, hi, lo);
+  const int off = ((row >> 4) * 2 + (c8 >> 1)) * 512 + (row & 15) * 32 + (c8 & 1) * 16;
+  *reinterpret_cast<bf16x8*>(dst + off) = hi;
+  *reinterpret_cast<bf16x8*>(dst + UA_PLANE + off) = lo;
+}
+__device__ __forceinline__ void ua_row(const unsigned char* __restrict__ mat, int row, int g, bf16x8& hi, bf16x8& lo) {
+  const int off = ((row >> 4) * 2 + (g >> 1)) * 512 + (row & 15) * 32 + (g & 1) * 16;
+  hi = *reinterpret_cast<const bf16x8*>(mat + off);
+  lo = *reinterpret_cast<const bf16x8*>(mat + UA_PLANE + off);
+}
+// rows 32t + kappa(g, e) of feature db * 16 + l15; lane_off = (4g + (l15 >> 2)) * 32 + (l15 & 3) * 8 (ds_read_b64_tr_b16)
+__device__ __forceinline__ void ua_col(uint32_t mat_lds, int t, int db, uint32_t lane_off, bf16x8& hi, bf16x8& lo) {
+  typedef short ua_v4i16 __attribute__((ext_vector_type(4)));
+  typedef short ua_v8i16 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) ua_v4i16* lds_v4;
+  const uint32_t b0 = mat_lds + (uint32_t)((4 * t + db) * 512) + lane_off;        // row block 2t; row block 2t + 1 is 1 KiB on
+  const ua_v4i16 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)b0);
+  const ua_v4i16 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(b0 + 1024u));
+  const ua_v4i16 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(b0 + (uint32_t)UA_PLANE));
+  const ua_v4i16 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(b0 + (uint32_t)UA_PLANE + 1024u));
+  hi = __builtin_bit_cast(bf16x8, (ua_v8i16)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+  lo = __builtin_bit_cast(bf16x8, (ua_v8i16)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 #define UA_MFMA3(acc, ah, al, bh, bl)                                          \
@@ -65,13 +92,14 @@ __device__ __forceinline__ void ua_stage(float* __restrict__ dst, const float* _
 
 __global__ void __launch_bounds__(UA_WAVES * 64)
     ua_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse, const AttnGeom G) {
-  __shared__ __attribute__((aligned(16))) float smem[3 * UA_MAT];
-  float* const Qs = smem;
-  float* const Ks = smem + UA_MAT;
-  float* const Vs = smem + 2 * UA_MAT;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * UA_MATB];
+  unsigned char* const Qs = smem;
+  unsigned char* const Ks = smem + UA_MATB;
+  const uint32_t Vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + 2u * UA_MATB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
+  const uint32_t lane_off = (uint32_t)((4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8);
   const int64_t grp = ua_item(G.groups);
   if (grp < 0) return;
   const int64_t outer = grp / G.heads;
@@ -80,21 +108,20 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
   const float* qb = qkv + outer * G.q_outer + head * UA_DH;
   ua_stage(Qs, qb, G.q_seq, S, G.scale, tid);
   ua_stage(Ks, qb + G.D, G.q_seq, S, 1.0f, tid);
-  ua_stage(Vs, qb + 2 * G.D, G.q_seq, S, 1.0f, tid);
-  if (tid < 8) smem[3 * UA_MAT - 8 + tid] = 0.f;
+  ua_stage(smem + 2 * UA_MATB, qb + 2 * G.D, G.q_seq, S, 1.0f, tid);
   __syncthreads();
   const int q0 = wave * 16;
   if (q0 >= S) return;
 
   // ---- S^T = K Q^T: lane (query l15, g) <- keys 16 jb + 4g + r ---------------------------------------------------
   bf16x8 qh, ql;
-  nf_frag8(Qs + (q0 + l15) * UA_LD, g, 1.0f, qh, ql);
+  ua_row(Qs, q0 + l15, g, qh, ql);
   float e[32];
   float m = -INFINITY;
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
     bf16x8 kh, kl;
-    nf_frag8(Ks + (16 * jb + l15) * UA_LD, g, 1.0f, kh, kl);
+    ua_row(Ks, 16 * jb + l15, g, kh, kl);
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     UA_MFMA3(s, kh, kl, qh, ql);
 #pragma unroll
@@ -128,9 +155,8 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
               make_float4(e[8 * t + 4] * inv, e[8 * t + 5] * inv, e[8 * t + 6] * inv, e[8 * t + 7] * inv), ph, pl);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      const int d = db * 16 + l15;
       bf16x8 vh, vl;
-      nf_kfrag(Vs + 32 * t * UA_LD + d, UA_LD, g, d < UA_DH ? 1.0f : 0.f, vh, vl);
+      ua_col(Vs_lds, t, db, lane_off, vh, vl);
       UA_MFMA3(oacc[db], ph, pl, vh, vl);
     }
   }
@@ -148,16 +174,19 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
 __global__ void __launch_bounds__(UA_WAVES * 64)
     ua_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
                   const float* __restrict__ lse, float* __restrict__ dqkv, const AttnGeom G) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * UA_MAT + 2 * UA_S];
-  float* const Qs = smem;                       // scale * q
-  float* const Ks = smem + UA_MAT;
-  float* const Vs = smem + 2 * UA_MAT;
-  float* const dOs = smem + 3 * UA_MAT;
-  float* const lse_s = smem + 4 * UA_MAT;       // rows past S: +inf (probability 0)
-  float* const delta_s = lse_s + UA_S;          // delta[q] = <dO[q], O[q]>
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * UA_MATB + 2 * UA_S * 4];
+  unsigned char* const Qs = smem;                      // scale * q
+  unsigned char* const Ks = smem + UA_MATB;
+  unsigned char* const Vs = smem + 2 * UA_MATB;
+  unsigned char* const dOs = smem + 3 * UA_MATB;
+  float* const lse_s = reinterpret_cast<float*>(smem + 4 * UA_MATB);   // rows past S: +inf (probability 0)
+  float* const delta_s = lse_s + UA_S;                                  // delta[q] = <dO[q], O[q]>
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t Qs_lds = smem_lds, Ks_lds = smem_lds + UA_MATB, dOs_lds = smem_lds + 3u * UA_MATB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
+  const uint32_t lane_off = (uint32_t)((4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8);
   const int64_t grp = ua_item(G.groups);
   if (grp < 0) return;
   const int64_t outer = grp / G.heads;
@@ -166,35 +195,23 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
   const float* qb = qkv + outer * G.q_outer + head * UA_DH;
   const float* dob = d_o + outer * G.o_outer + head * UA_DH;
   const float* ob = o + outer * G.o_outer + head * UA_DH;
-  // the O row of thread `tid` (delta) is requested before the staging loads are waited for
-  float4 orow[5];
-  float lse_r = INFINITY;
-  if (tid < UA_S) {
-    const int r = tid < S ? tid : S - 1;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) orow[c] = *reinterpret_cast<const float4*>(ob + (int64_t)r * G.o_seq + 4 * c);
-    if (tid < S) lse_r = lse[grp * S + tid];
-  }
   ua_stage(Qs, qb, G.q_seq, S, G.scale, tid);
   ua_stage(Ks, qb + G.D, G.q_seq, S, 1.0f, tid);
   ua_stage(Vs, qb + 2 * G.D, G.q_seq, S, 1.0f, tid);
   ua_stage(dOs, dob, G.o_seq, S, 1.0f, tid);
-  if (tid < 8) {
-    smem[UA_MAT - 8 + tid] = 0.f;
-    smem[2 * UA_MAT - 8 + tid] = 0.f;
-    smem[3 * UA_MAT - 8 + tid] = 0.f;
-    smem[4 * UA_MAT - 8 + tid] = 0.f;
-  }
-  __syncthreads();
-  if (tid < UA_S) {
-    float dl = 0.f;
+  if (tid < UA_S) {          // row statistics in fp32 from the rows themselves (the d_o row is in the caches by now)
+    float dl = 0.f, ls = INFINITY;
+    if (tid < S) {
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(dOs + tid * UA_LD + 4 * c);
-      dl = fmaf(a.x, orow[c].x, dl); dl = fmaf(a.y, orow[c].y, dl); dl = fmaf(a.z, orow[c].z, dl); dl = fmaf(a.w, orow[c].w, dl);
+      for (int c = 0; c < 5; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(dob + (int64_t)tid * G.o_seq + 4 * c);
+        const float4 b = *reinterpret_cast<const float4*>(ob + (int64_t)tid * G.o_seq + 4 * c);
+        dl = fmaf(a.x, b.x, dl); dl = fmaf(a.y, b.y, dl); dl = fmaf(a.z, b.z, dl); dl = fmaf(a.w, b.w, dl);
+      }
+      ls = lse[grp * S + tid];
     }
-    delta_s[tid] = tid < S ? dl : 0.f;
-    lse_s[tid] = lse_r;
+    delta_s[tid] = dl;
+    lse_s[tid] = ls;
   }
   __syncthreads();
   const int r0 = wave * 16;
@@ -204,8 +221,8 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
   // ================= role 1: dQ of queries r0 .. r0 + 15 ==============================================================
   {
     bf16x8 qh, ql, doh, dol;
-    nf_frag8(Qs + (r0 + l15) * UA_LD, g, 1.0f, qh, ql);
-    nf_frag8(dOs + (r0 + l15) * UA_LD, g, 1.0f, doh, dol);
+    ua_row(Qs, r0 + l15, g, qh, ql);
+    ua_row(dOs, r0 + l15, g, doh, dol);
     const float lse_q = lse_s[r0 + l15] * LOG2E, delta_q = delta_s[r0 + l15];
     f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -215,8 +232,8 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
       for (int half = 0; half < 2; ++half) {
         const int jb = 2 * t + half;
         bf16x8 kh, kl, vh, vl;
-        nf_frag8(Ks + (16 * jb + l15) * UA_LD, g, 1.0f, kh, kl);
-        nf_frag8(Vs + (16 * jb + l15) * UA_LD, g, 1.0f, vh, vl);
+        ua_row(Ks, 16 * jb + l15, g, kh, kl);
+        ua_row(Vs, 16 * jb + l15, g, vh, vl);
         f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
         UA_MFMA3(st, kh, kl, qh, ql);              // S^T[key][query]
         UA_MFMA3(dpt, vh, vl, doh, dol);           // dP^T[key][query] = V dO^T
@@ -231,9 +248,8 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
       rp_split8(make_float4(ds[0], ds[1], ds[2], ds[3]), make_float4(ds[4], ds[5], ds[6], ds[7]), dsh, dsl);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const int d = db * 16 + l15;
         bf16x8 bh, bl;
-        nf_kfrag(Ks + 32 * t * UA_LD + d, UA_LD, g, d < UA_DH ? 1.0f : 0.f, bh, bl);
+        ua_col(Ks_lds, t, db, lane_off, bh, bl);
         UA_MFMA3(dq[db], dsh, dsl, bh, bl);        // dQ += dS K
       }
     }
@@ -251,8 +267,8 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
   // ================= role 2: dK, dV of keys r0 .. r0 + 15 =============================================================
   {
     bf16x8 kh, kl, vh, vl;
-    nf_frag8(Ks + (r0 + l15) * UA_LD, g, 1.0f, kh, kl);
-    nf_frag8(Vs + (r0 + l15) * UA_LD, g, 1.0f, vh, vl);
+    ua_row(Ks, r0 + l15, g, kh, kl);
+    ua_row(Vs, r0 + l15, g, vh, vl);
     f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -262,8 +278,8 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
       for (int half = 0; half < 2; ++half) {
         const int ib = 2 * t + half;
         bf16x8 qh, ql, doh, dol;
-        nf_frag8(Qs + (16 * ib + l15) * UA_LD, g, 1.0f, qh, ql);
-        nf_frag8(dOs + (16 * ib + l15) * UA_LD, g, 1.0f, doh, dol);
+        ua_row(Qs, 16 * ib + l15, g, qh, ql);
+        ua_row(dOs, 16 * ib + l15, g, doh, dol);
         f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
         UA_MFMA3(sc, qh, ql, kh, kl);              // S[query][key]
         UA_MFMA3(dp, doh, dol, vh, vl);            // dP[query][key] = dO V^T
@@ -282,12 +298,10 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
       rp_split8(make_float4(ds[0], ds[1], ds[2], ds[3]), make_float4(ds[4], ds[5], ds[6], ds[7]), dsh, dsl);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const int d = db * 16 + l15;
-        const float mk = d < UA_DH ? 1.0f : 0.f;
         bf16x8 bh, bl;
-        nf_kfrag(dOs + 32 * t * UA_LD + d, UA_LD, g, mk, bh, bl);
+        ua_col(dOs_lds, t, db, lane_off, bh, bl);
         UA_MFMA3(dv[db], ph, pl, bh, bl);          // dV += P^T dO
-        nf_kfrag(Qs + 32 * t * UA_LD + d, UA_LD, g, mk, bh, bl);
+        ua_col(Qs_lds, t, db, lane_off, bh, bl);
         UA_MFMA3(dk[db], dsh, dsl, bh, bl);        // dK += dS^T (scale Q)
       }
     }
