@@ -483,7 +483,9 @@ static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const Bl
 // user encoder at 64 .. 128 users per rank); everything else -- and the exact-fp32 engine -- on attn_fwd / attn_bwd.  Forward
 // and backward of a call agree on it: the engine travels with the call, the geometry is the call's.
 static inline bool block_attn_x3(const BlockShape& s) {
-  return cur_engine() == ENGINE_BF16X3 && s.geom.S >= 64 && attn_x3_ok(s.geom);
+  // (NRL_ATTN_X3_MIN_S: A/B runs of the lower edge; below it the vector-ALU kernels pack 4-8 groups into a workgroup)
+  static const int min_s = [] { const char* e = getenv("NRL_ATTN_X3_MIN_S"); return e ? atoi(e) : 64; }();
+  return cur_engine() == ENGINE_BF16X3 && s.geom.S >= min_s && attn_x3_ok(s.geom);
 }
 
 // forward of the shared block given an A-operand accessor for the in-projection
