@@ -479,3 +479,28 @@ def test_option_names_agree_between_header_library_source_and_python():
     body = src[src.index("kOptName[O_COUNT] = {"):]
     names = re.findall(r'"(\w+)"', body[:body.index("};")])
     assert tuple(n for _, n in doc) == tuple(names) == tuple(_lib.OPTION_NAMES)
+
+
+def test_dense_rows_of_a_full_batch_is_the_reshape_and_its_adjoint():
+    """``dense_rows(..., max_is_exact=True)``: when every group is full (N == B * max with the TRUE maximum) the dense tensor of
+    ``to_dense_batch`` is the row-major reshape -- checked against the oracle's to_dense_batch, forward and backward; a
+    batch that merely has B * cap rows under a truncating cap is NOT taken for full unless the caller vouches for the maximum."""
+    from newsreclib_amd.dense_batch import dense_rows
+    from oracle import nrms_oracle as O
+    gen = torch.Generator().manual_seed(5)
+    B, H, D = 4, 3, 8
+    x = torch.randn(B * H, D, generator=gen, requires_grad=True)
+    batch = torch.arange(B).repeat_interleave(H)
+    offsets = torch.arange(B + 1) * H
+    dense = dense_rows(x, batch, B, H, offsets, max_is_exact=True)
+    ref, mask = O.to_dense_batch(x.detach(), batch)
+    assert torch.equal(dense.detach(), ref) and bool(mask.all())
+    g = torch.randn(B, H, D, generator=gen)
+    dense.backward(g)
+    assert torch.equal(x.grad, g.reshape(B * H, D))
+    labels = torch.arange(B * H, dtype=torch.float32)
+    y = dense_rows(labels, batch, B, H, offsets, max_is_exact=True)
+    assert torch.equal(y, O.to_dense_batch(labels, batch)[0])
+    # without the caller's word the product path is taken (and, with no GPU here, refuses loudly rather than guessing)
+    with pytest.raises((RuntimeError, ValueError, OSError)):
+        dense_rows(x.detach(), batch, B, H, offsets)
