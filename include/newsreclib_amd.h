@@ -461,6 +461,15 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
  * gradient).  n, k multiples of 4; workspace as nrl_linear_workspace_bytes(n, k) (bf16x3 engine, d_a != NULL). */
 int nrl_linear_bwd(const float* a, const float* w, const float* d_c, int64_t m, int32_t n, int32_t k, float* d_a,
                    float* d_w, float* d_bias, void* ws, size_t ws_bytes, void* stream);
+/* The same two calls for a weight whose matrix-core images the caller keeps across calls (ABI v12): with image_ready != 0,
+ * `ws` already holds the images a previous call of the SAME entry point built for this (w, n, k) under the same engine and
+ * switches -- the forward's in one buffer, the backward's (the transposed weight, for d_a) in another -- and the build is
+ * skipped.  For FROZEN weights only (the PLM body's layers 0-7, text.py:69-73): nothing here can tell that `w` changed.
+ * Applies to the wide (n >= 256, resp. k >= 256) bf16x3 panel path; elsewhere the flag is ignored and the images rebuilt. */
+int nrl_linear_fwd_img(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k,
+                       float* c, void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
+int nrl_linear_bwd_img(const float* a, const float* w, const float* d_c, int64_t m, int32_t n, int32_t k, float* d_a,
+                       float* d_w, float* d_bias, void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
 
 #ifdef __cplusplus
 }

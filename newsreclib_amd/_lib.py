@@ -167,6 +167,10 @@ SIGNATURES = {
                                  c_size_t, c_void_p]),
     "nrl_linear_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
+    "nrl_linear_fwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                     c_size_t, c_int32, c_void_p]),
+    "nrl_linear_bwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_int32, c_void_p]),
 }
 
 _lib = None

@@ -78,10 +78,11 @@ static inline bool lin_panels_on(int n_out) { return opt(O_ROWPANEL) && n_out >=
 // C (m, n_out) = epi(A (m, k_red) * B), element (column j, reduction i) of B = src[j * sn + i * sk]
 template <class Epi>
 static int linear_panels(const float* a, const float* src, int64_t sn, int64_t sk, int n_out, int k_red, const Epi& epi,
-                         int64_t m, uint16_t* img, hipStream_t st) {
+                         int64_t m, uint16_t* img, hipStream_t st, bool build = true) {
   const int P = lin_panels(n_out), kb = rp_kblocks(k_red, false), pw = 16 * LIN_PANEL_BLOCKS;
   const size_t pe = rp_image_elems(LIN_PANEL_BLOCKS, kb);
-  for (int p0 = 0; p0 < P; p0 += RP_MAX_JOBS) {
+  // (build == false: `img` already holds this weight's panel images -- a frozen weight's, kept by the caller across calls)
+  for (int p0 = 0; build && p0 < P; p0 += RP_MAX_JOBS) {
     RpImageJobs jobs;
     rp_jobs_init(&jobs);
     for (int p = p0; p < P && p < p0 + RP_MAX_JOBS; ++p)
@@ -492,6 +493,11 @@ size_t nrl_linear_workspace_bytes(int32_t n, int32_t k) {
 
 int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k,
                    float* c, void* ws, size_t ws_bytes, void* stream) {
+  return nrl_linear_fwd_img(a, w, bias, m, n, k, c, ws, ws_bytes, 0, stream);
+}
+
+int nrl_linear_fwd_img(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k,
+                       float* c, void* ws, size_t ws_bytes, int32_t image_ready, void* stream) {
   NRL_REQUIRE(a && w && c && m >= 0 && n > 0 && k > 0 && k % 4 == 0, "linear_fwd: bad arguments (k % 4 == 0)");
   NRL_REQUIRE((((uintptr_t)a | (uintptr_t)w) & 15) == 0, "linear_fwd: operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -504,7 +510,7 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
     return NRL_E_WORKSPACE;
   }
   if (m == 0) return NRL_OK;
-  if (lin_panels_on(n)) return linear_panels(a, w, k, 1, n, k, epi, m, (uint16_t*)ws, st);   // element (n, k) = W[n][k]
+  if (lin_panels_on(n)) return linear_panels(a, w, k, 1, n, k, epi, m, (uint16_t*)ws, st, image_ready == 0);   // element (n, k) = W[n][k]
   SplitWeight sw;
   NRL_TRY(split_weight(w, n, k, (uint16_t*)ws, &sw, st));
   return gemm_fwd(KCPlain{a, k, m}, w, sw, epi, m, n, k, n <= 224, st);
@@ -515,6 +521,11 @@ int nrl_linear_fwd(const float* a, const float* w, const float* bias, int64_t m,
 // stack (the PLM body: layers 0-7 frozen, their inputs still need gradients, text.py:69-73).
 int nrl_linear_bwd(const float* a, const float* w, const float* d_c, int64_t m, int32_t n, int32_t k, float* d_a,
                    float* d_w, float* d_bias, void* ws, size_t ws_bytes, void* stream) {
+  return nrl_linear_bwd_img(a, w, d_c, m, n, k, d_a, d_w, d_bias, ws, ws_bytes, 0, stream);
+}
+
+int nrl_linear_bwd_img(const float* a, const float* w, const float* d_c, int64_t m, int32_t n, int32_t k, float* d_a,
+                       float* d_w, float* d_bias, void* ws, size_t ws_bytes, int32_t image_ready, void* stream) {
   NRL_REQUIRE(w && d_c && m >= 0 && n > 0 && k > 0 && k % 4 == 0 && n % 4 == 0, "linear_bwd: bad arguments (n, k multiples of 4)");
   NRL_REQUIRE((d_w == nullptr) == (d_bias == nullptr), "linear_bwd: d_w and d_bias come together");
   NRL_REQUIRE(d_w == nullptr || a != nullptr, "linear_bwd: the weight gradient needs the forward's input");
@@ -530,7 +541,7 @@ int nrl_linear_bwd(const float* a, const float* w, const float* d_c, int64_t m, 
         return NRL_E_WORKSPACE;
       }
       if (lin_panels_on(k)) {        // d_a columns j over the reduction i: element = W[i][j]
-        NRL_TRY(linear_panels(d_c, w, 1, k, k, n, EpiStore{d_a, k}, m, (uint16_t*)ws, st));
+        NRL_TRY(linear_panels(d_c, w, 1, k, k, n, EpiStore{d_a, k}, m, (uint16_t*)ws, st, image_ready == 0));
       } else {
         NRL_TRY(split_weight(w, n, k, (uint16_t*)ws, &sw, st));
         NRL_TRY(gemm_dgrad(d_c, w, sw, EpiStore{d_a, k}, m, n, k, st));

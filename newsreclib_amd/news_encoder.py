@@ -182,12 +182,15 @@ class NrlLinear(nn.Module):
             raise ValueError("NrlLinear: needs a bias and in/out features that are multiples of 4")
         self.in_features, self.out_features = linear.in_features, linear.out_features
         self.weight, self.bias = linear.weight, linear.bias
+        # a frozen weight's matrix-core images are built once, not twice per step (NRL_PLM_IMAGE_CACHE=0: every call, A/B)
+        self._images = ops_blocks.FrozenImages() if os.environ.get("NRL_PLM_IMAGE_CACHE", "1") != "0" else None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype != torch.float32 or not x.is_cuda:
             return nn.functional.linear(x, self.weight, self.bias)      # (meta / CPU construction-time calls of HF)
         params = (self.weight, self.bias)
-        return ops_blocks.LinearFn.apply(x.contiguous(), self.weight, self.bias, _grad_bufs(params))
+        images = self._images if not (self.weight.requires_grad or self.bias.requires_grad) else None
+        return ops_blocks.LinearFn.apply(x.contiguous(), self.weight, self.bias, _grad_bufs(params), images)
 
     def extra_repr(self) -> str:
         return f"in_features={self.in_features}, out_features={self.out_features}, engine=newsreclib_amd"

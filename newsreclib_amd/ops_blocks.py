@@ -107,7 +107,7 @@ class LinearFn(torch.autograd.Function):
     alive for every layer of a transformer between its forward and backward."""
 
     @staticmethod
-    def forward(ctx, a, w, bias, grad_bufs):
+    def forward(ctx, a, w, bias, grad_bufs, images=None):
         lib = _lib.load()
         a, w, bias = _chk(a, torch.float32, "input"), _chk(w, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
         if w.dim() != 2 or a.shape[-1] != w.shape[1] or bias.shape != (w.shape[0],):
@@ -115,14 +115,18 @@ class LinearFn(torch.autograd.Function):
         N, K = w.shape
         a2 = a.reshape(-1, K)
         M = a2.shape[0]
-        ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=a.device)
+        # `images` (FrozenImages, a frozen weight only): the matrix-core images of the weight kept across calls
+        ws, ready = images.buffer("fwd", w, lib, a.device) if images is not None else (None, 0)
+        if ws is None:
+            ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=a.device)
         c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-        _lib.check(lib.nrl_linear_fwd(a2.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, c.data_ptr(), ws.data_ptr(),
-                                      ws.numel(), _stream()), "nrl_linear_fwd")
+        _lib.check(lib.nrl_linear_fwd_img(a2.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, c.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), ready, _stream()), "nrl_linear_fwd")
         if any(ctx.needs_input_grad):
             need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             ctx.save_for_backward(a2 if need_w else None, w, bias)
             ctx.grad_bufs, ctx.engine, ctx.in_shape = grad_bufs, _lib.engine_code(), tuple(a.shape)
+            ctx.images = images if not need_w else None
         return c.view(*a.shape[:-1], N)
 
     @staticmethod
@@ -141,11 +145,39 @@ class LinearFn(torch.autograd.Function):
             bufs, rets = _grad_targets([w, bias], ctx.grad_bufs)
             dw, db = bufs[0].data_ptr(), bufs[1].data_ptr()
         d_a = torch.empty((M, K), dtype=torch.float32, device=d_c.device) if need_a else None
-        ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=d_c.device)
-        _lib.check(lib.nrl_linear_bwd(a2.data_ptr() if need_w else None, w.data_ptr(), d_c.data_ptr(), M, N, K,
-                                      d_a.data_ptr() if need_a else None, dw, db, ws.data_ptr(), ws.numel(), _stream()),
-                   "nrl_linear_bwd")
-        return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None)
+        ws, ready = ctx.images.buffer("bwd", w, lib, d_c.device) if ctx.images is not None else (None, 0)
+        if ws is None:
+            ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=d_c.device)
+        _lib.check(lib.nrl_linear_bwd_img(a2.data_ptr() if need_w else None, w.data_ptr(), d_c.data_ptr(), M, N, K,
+                                          d_a.data_ptr() if need_a else None, dw, db, ws.data_ptr(), ws.numel(), ready,
+                                          _stream()), "nrl_linear_bwd")
+        return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None, None)
+
+
+class FrozenImages:
+    """The matrix-core weight images of ONE frozen ``nn.Linear`` weight, kept across calls (``nrl_linear_fwd_img`` /
+    ``nrl_linear_bwd_img``): the forward's and the backward's (transposed) image each in its own buffer, rebuilt when the
+    weight tensor was modified in place or replaced (its version counter / storage address), or when the engine or the
+    kernel-selection switches changed.  For weights NO optimizer updates: the fused Adam writes parameters through raw
+    pointers, which no version counter sees -- ``NrlLinear`` therefore uses this for ``requires_grad == False`` weights only
+    (the PLM body's frozen layers, text.py:69-73: two thirds of a config-4 step's image builds)."""
+
+    def __init__(self):
+        self._buf = {}
+        self._key = {}
+
+    def buffer(self, which: str, w: torch.Tensor, lib, device):
+        if w.requires_grad:
+            return None, 0
+        key = (w.data_ptr(), w._version, tuple(w.shape), _lib.engine_code(), _lib.options_word(), str(device))
+        buf = self._buf.get(which)
+        if buf is None or buf.device != device:
+            N, K = w.shape
+            buf = self._buf[which] = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=device)
+            self._key[which] = None
+        ready = 1 if self._key.get(which) == key else 0
+        self._key[which] = key
+        return buf, ready
 
 
 class MhaFn(torch.autograd.Function):

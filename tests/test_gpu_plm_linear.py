@@ -113,3 +113,42 @@ def test_linear_fn_shapes_against_torch(M, N, K, engine_name):
         assert float((ox2 - ox).abs().max()) <= 1e-6 * max(1.0, float(ox.abs().max()))
     finally:
         _lib.set_gemm_engine("bf16x3")
+
+
+def test_frozen_linear_keeps_its_weight_images_and_rebuilds_them_when_the_weight_changes():
+    """``NrlLinear`` over a FROZEN weight builds the matrix-core images once (``nrl_linear_fwd_img`` / ``_bwd_img``,
+    ``ops_blocks.FrozenImages``): repeated calls give bit-identical outputs and input gradients, an in-place change of the
+    weight (version counter) is seen by the next call, and a trainable weight never uses the cache."""
+    from newsreclib_amd.news_encoder import NrlLinear
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(768, 768).to(DEV)
+    nl = NrlLinear(lin)
+    for p in nl.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(300, 768, device=DEV, requires_grad=True)
+    g = torch.randn(300, 768, device=DEV)
+
+    def run():
+        x.grad = None
+        y = nl(x)
+        y.backward(g)
+        return y.detach().clone(), x.grad.clone()
+
+    y0, dx0 = run()
+    assert nl._images._key.get("fwd") is not None and nl._images._key.get("bwd") is not None
+    y1, dx1 = run()                                         # second call: images reused
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    ref = torch.nn.functional.linear(x.detach(), lin.weight, lin.bias)
+    assert float((y0 - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    with torch.no_grad():
+        lin.weight.mul_(2.0)                                # in place: the version counter moves, the images are rebuilt
+    y2, dx2 = run()
+    ref2 = torch.nn.functional.linear(x.detach(), lin.weight, lin.bias)
+    assert float((y2 - ref2).abs().max()) <= 1e-4 * float(ref2.abs().max())
+    assert float((dx2 - 2.0 * dx0).abs().max()) <= 1e-4 * float(dx2.abs().max())
+    # a trainable weight: no cache (the fused Adam changes it through raw pointers, which no version counter sees)
+    lin.weight.requires_grad_(True)
+    lin.bias.requires_grad_(True)
+    before = dict(nl._images._key)
+    nl(x).sum().backward()
+    assert nl._images._key == before
