@@ -471,6 +471,23 @@ int nrl_linear_fwd_img(const float* a, const float* w, const float* bias, int64_
 int nrl_linear_bwd_img(const float* a, const float* w, const float* d_c, int64_t m, int32_t n, int32_t k, float* d_a,
                        float* d_w, float* d_bias, void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
 
+/* ---- scaled dot-product attention of a transformer body: the self-attention inside `self.plm_model(**text)`, text.py:89
+ * (HF RobertaSelfAttention -> F.scaled_dot_product_attention), ABI v12.  q, k, v, out (and their gradients): (n_batch, seq_len,
+ * num_heads * head_dim) fp32, contiguous -- the projections' outputs as they are, no head transpose; key_keep (n_batch, seq_len)
+ * uint8, 1 = the key takes part (the tokenizer's attention_mask), or NULL; `scale` multiplies q k^T; attention-probability
+ * dropout with probability p_drop under the counter-based mask spec of nrl_dropout_mask: element (batch b, head h, query i,
+ * key j) has flat index ((b * num_heads + h) * 128 + i) * 128 + j (uint32 arithmetic) in stream `stream0` of `seed`.
+ * lse (n_batch * num_heads, seq_len): log-sum-exp of each query's scores, written by _fwd (may be NULL in inference), read by
+ * _bwd.  bf16x3 arithmetic (hi, lo split operands on the bf16 matrix cores); seq_len <= 128, head_dim == 64
+ * (nrl_sdpa_supported); anything else stays on the framework's attention. */
+int32_t nrl_sdpa_supported(int64_t n_batch, int32_t seq_len, int32_t num_heads, int32_t head_dim);
+int nrl_sdpa_fwd(const float* q, const float* k, const float* v, const uint8_t* key_keep, int64_t n_batch, int32_t seq_len,
+                 int32_t num_heads, int32_t head_dim, float scale, double p_drop, uint64_t seed, uint32_t stream0, float* out,
+                 float* lse, void* stream);
+int nrl_sdpa_bwd(const float* q, const float* k, const float* v, const uint8_t* key_keep, const float* out, const float* d_out,
+                 const float* lse, int64_t n_batch, int32_t seq_len, int32_t num_heads, int32_t head_dim, float scale,
+                 double p_drop, uint64_t seed, uint32_t stream0, float* dq, float* dk, float* dv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,11 @@ SIGNATURES = {
                                  c_size_t, c_void_p]),
     "nrl_linear_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
+    "nrl_sdpa_supported": (c_int32, [c_int64, c_int32, c_int32, c_int32]),
+    "nrl_sdpa_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_float, c_double,
+                               c_uint64, c_uint32, c_void_p, c_void_p, c_void_p]),
+    "nrl_sdpa_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                               c_int32, c_float, c_double, c_uint64, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nrl_linear_fwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                      c_size_t, c_int32, c_void_p]),
     "nrl_linear_bwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops, ops_blocks, ops_lstur
+from . import _lib, ops, ops_blocks, ops_lstur
 from .attention import AdditiveAttention
 
 # dropout stream pair of each text attribute (fixed by NAME: the reference iterates its text encoders
@@ -209,6 +209,48 @@ def swap_linears(module: nn.Module) -> int:
     return n
 
 
+NRL_ATTENTION = "nrl_x3"
+
+
+def _nrl_body_attention(module, query, key, value, attention_mask, dropout: float = 0.0, scaling=None, **kwargs):
+    """HF attention interface (``ALL_ATTENTION_FUNCTIONS[config._attn_implementation]``) of the PLM body on this library's
+    bf16x3 attention kernels: query / key / value arrive as (N, H, L, dh) transposes of the projections' (N, L, H*dh) outputs;
+    returns (N, L, H, dh).  The body is a bidirectional encoder, so its 4-D mask is a key-padding mask repeated over the query
+    rows: row 0 is read as (N, L).  Shapes, devices or engines the kernels do not cover go to the framework's SDPA path."""
+    from transformers.integrations.sdpa_attention import sdpa_attention_forward
+    N, H, L, dh = query.shape
+    ok = (query.is_cuda and query.dtype == torch.float32 and key.shape == query.shape and value.shape == query.shape
+          and _lib.engine_code() == 2 and ops_blocks.sdpa_supported(N, L, H, dh))     # (2 = the bf16x3 engine)
+    keep = None
+    if ok and attention_mask is not None:
+        m = attention_mask
+        if m.dim() == 4 and m.shape[0] == N and m.shape[1] == 1 and m.shape[3] == L:
+            row = m[:, 0, 0, :]
+            keep = (row if row.dtype == torch.bool else (row == 0)).to(torch.uint8)
+        else:
+            ok = False
+    if not ok:
+        return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
+    scale = float(scaling) if scaling is not None else float(dh) ** -0.5
+    p = float(dropout)
+    out = ops_blocks.SdpaFn.apply(query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2), keep, scale, p,
+                                  _draw_seed() if p > 0.0 else 0)
+    return out, None
+
+
+def register_body_attention() -> bool:
+    """Registers ``NRL_ATTENTION`` with the HF attention / mask interfaces (idempotent); False when this transformers
+    version has no such registry (the body then keeps its own attention)."""
+    try:
+        from transformers.masking_utils import AttentionMaskInterface, sdpa_mask
+        from transformers.modeling_utils import AttentionInterface
+    except ImportError:
+        return False
+    AttentionInterface.register(NRL_ATTENTION, _nrl_body_attention)
+    AttentionMaskInterface.register(NRL_ATTENTION, sdpa_mask)
+    return True
+
+
 class PLM(nn.Module):
     """Text encoder over a pretrained language model, mirroring the reference ``PLM`` (text.py:15-109)
     for the NRMS configuration ``use_mhsa=True, apply_reduce_dim=False``: transformer body -> dropout
@@ -240,6 +282,15 @@ class PLM(nn.Module):
         self.nrl_linears = 0
         if os.environ.get("NRL_PLM_LINEAR", "1") != "0" and hasattr(self.plm_model, "encoder"):
             self.nrl_linears = swap_linears(self.plm_model.encoder)
+        # ... and its self-attention on this library's bf16x3 kernels (nrl_sdpa_fwd / _bwd: heads of 64 over <= 128 tokens; other
+        # shapes fall through to the framework's SDPA inside the interface); NRL_PLM_ATTENTION=0 keeps the HF path (A/B)
+        self.nrl_attention = False
+        if os.environ.get("NRL_PLM_ATTENTION", "1") != "0" and register_body_attention():
+            try:
+                self.plm_model.config._attn_implementation = NRL_ATTENTION
+                self.nrl_attention = True
+            except Exception:      # (a transformers version that validates the name against a closed list)
+                self.nrl_attention = False
         for name, param in self.plm_model.base_model.named_parameters():   # text.py:69-73
             for layer in (frozen_layers or []):
                 if "layer." + str(layer) + "." in name:

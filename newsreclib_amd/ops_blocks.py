@@ -154,6 +154,53 @@ class LinearFn(torch.autograd.Function):
         return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None, None)
 
 
+class SdpaFn(torch.autograd.Function):
+    """``F.scaled_dot_product_attention`` of a transformer body on the bf16x3 matrix-core kernels (``nrl_sdpa_fwd`` / ``_bwd``):
+    q, k, v (N, L, H, dh) -- the projections' outputs viewed per head, NOT transposed -- -> (N, L, H, dh).  ``keep`` (N, L) uint8
+    or None: the key-padding mask (1 = attend).  Attention-probability dropout ``p_drop`` under the library's counter-based
+    mask spec (``seed``); L <= 128, dh == 64 (``nrl_sdpa_supported``)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, keep, scale, p_drop, seed):
+        lib = _lib.load()
+        q, k, v = _chk(q, torch.float32, "query"), _chk(k, torch.float32, "key"), _chk(v, torch.float32, "value")
+        if q.dim() != 4 or k.shape != q.shape or v.shape != q.shape:
+            raise ValueError("newsreclib_amd: sdpa expects q, k, v of one shape (batch, seq, heads, head_dim)")
+        N, L, H, dh = q.shape
+        if keep is not None:
+            keep = _chk(keep, torch.uint8, "key mask")
+            if tuple(keep.shape) != (N, L):
+                raise ValueError("newsreclib_amd: sdpa key mask must be (batch, seq)")
+        save = any(ctx.needs_input_grad[:3])
+        out = torch.empty_like(q)
+        lse = torch.empty((N * H, L), dtype=torch.float32, device=q.device) if save else None
+        _lib.check(lib.nrl_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), keep.data_ptr() if keep is not None else None,
+                                    N, L, H, dh, float(scale), float(p_drop), int(seed), 0, out.data_ptr(),
+                                    lse.data_ptr() if save else None, _stream()), "nrl_sdpa_fwd")
+        if save:
+            ctx.save_for_backward(q, k, v, out, lse, *([keep] if keep is not None else []))
+            ctx.cfg = (float(scale), float(p_drop), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        q, k, v, out, lse, *rest = ctx.saved_tensors
+        keep = rest[0] if rest else None
+        N, L, H, dh = q.shape
+        scale, p_drop, seed = ctx.cfg
+        d_out = _chk(d_out, torch.float32, "d_out")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        _lib.check(lib.nrl_sdpa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), keep.data_ptr() if keep is not None else None,
+                                    out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), N, L, H, dh, scale, p_drop, seed, 0,
+                                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _stream()), "nrl_sdpa_bwd")
+        return dq, dk, dv, None, None, None, None
+
+
+def sdpa_supported(n_batch: int, seq_len: int, heads: int, head_dim: int) -> bool:
+    return bool(_lib.load().nrl_sdpa_supported(int(n_batch), int(seq_len), int(heads), int(head_dim)))
+
+
 class FrozenImages:
     """The matrix-core weight images of ONE frozen ``nn.Linear`` weight, kept across calls (``nrl_linear_fwd_img`` /
     ``nrl_linear_bwd_img``): the forward's and the backward's (transposed) image each in its own buffer, rebuilt when the

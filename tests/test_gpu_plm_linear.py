@@ -152,3 +152,80 @@ def test_frozen_linear_keeps_its_weight_images_and_rebuilds_them_when_the_weight
     before = dict(nl._images._key)
     nl(x).sum().backward()
     assert nl._images._key == before
+
+
+def _sdpa_reference(q, k, v, keep, scale, mult=None):
+    """fp64 attention over (N, L, H, dh) tensors: softmax((q k^T) scale + key mask) [o dropout multiplier] v."""
+    qh, kh, vh = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))          # (N, H, L, dh)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if keep is not None:
+        s = s.masked_fill(~keep.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    if mult is not None:
+        p = p * mult.double()
+    return (p @ vh).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("N,L,H", [(5, 96, 12), (3, 128, 2), (4, 50, 3), (2, 17, 1)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_body_attention_kernels_match_fp64_attention(N, L, H, masked):
+    """``nrl_sdpa_fwd`` / ``_bwd`` (the PLM body's self-attention, heads of 64 over <= 128 tokens, bf16x3 arithmetic) against
+    fp64 attention: outputs and all three input gradients, with and without a key-padding mask, full / partly filled row
+    blocks; then with attention dropout, against the same reference under the library's own mask (``ops.dropout_mask`` over
+    the documented flat index ((n * H + h) * 128 + query) * 128 + key)."""
+    from newsreclib_amd import ops, ops_blocks
+    torch.manual_seed(N * 1000 + L)
+    dh, scale = 64, 64 ** -0.5
+    q, k, v = (torch.randn(N, L, H, dh, device=DEV, requires_grad=True) for _ in range(3))
+    keep = None
+    if masked:
+        lens = torch.randint(max(1, L // 3), L + 1, (N,))
+        keep = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(DEV)
+    g = torch.randn(N, L, H, dh, device=DEV)
+
+    def compare(p_drop, seed):
+        mult = None
+        if p_drop > 0.0:
+            km = ops.dropout_mask(N * H * 128 * 128, p_drop, seed, 0, DEV).view(N, H, 128, 128)[:, :, :L, :L]
+            mult = km.float() / (1.0 - p_drop)
+        for t in (q, k, v):
+            t.grad = None
+        out = ops_blocks.SdpaFn.apply(q, k, v, keep, scale, p_drop, seed)
+        out.backward(g)
+        got = [out.detach()] + [t.grad.clone() for t in (q, k, v)]
+        q64, k64, v64 = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+        ref = _sdpa_reference(q64, k64, v64, keep, scale, mult)
+        ref.backward(g.double())
+        want = [ref.detach(), q64.grad, k64.grad, v64.grad]
+        for name, a, b in zip(("out", "dq", "dk", "dv"), got, want):
+            scale_b = max(1e-3, float(b.abs().max()))
+            err = float((a.double() - b).abs().max()) / scale_b
+            assert err <= 2e-4, (name, p_drop, err)
+
+    compare(0.0, 0)
+    compare(0.1, 1234)
+
+
+def test_plm_body_runs_its_attention_on_the_library_kernels(tmp_path):
+    """The HF body of ``news_encoder.PLM`` is switched to the registered attention interface; in eval mode (no dropout) its
+    hidden states agree with the same body on the framework's SDPA, padded batch included."""
+    from transformers import RobertaConfig, RobertaModel
+    from newsreclib_amd.news_encoder import NRL_ATTENTION, PLM
+    torch.manual_seed(0)
+    cfg = RobertaConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                        max_position_embeddings=80, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    RobertaModel(cfg, add_pooling_layer=False).save_pretrained(tmp_path)
+    enc = PLM(plm_model=str(tmp_path), frozen_layers=[0], embed_dim=128, use_mhsa=True, apply_reduce_dim=False,
+              reduced_embed_dim=None, num_heads=4, query_dim=32, dropout_probability=0.2).to(DEV).eval()
+    assert enc.nrl_attention and enc.plm_model.config._attn_implementation == NRL_ATTENTION
+    ids = torch.randint(3, 300, (6, 40), device=DEV)
+    am = torch.ones_like(ids)
+    am[1, 25:] = 0
+    am[4, 9:] = 0
+    with torch.no_grad():
+        ours = enc.plm_model(input_ids=ids, attention_mask=am)[0]
+        enc.plm_model.config._attn_implementation = "sdpa"
+        ref = enc.plm_model(input_ids=ids, attention_mask=am)[0]
+    valid = am.bool()[:, :, None]
+    err = float(((ours - ref) * valid).abs().max())
+    assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
