@@ -157,9 +157,11 @@ def extra_plm(device, batch_size=8, steps=3):
         b[part]["title"] = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
     dt = _timed_steps(trainer, prepare_batch(b), steps, 1)
     return {"value": round(batch_size / dt, 2), "unit": "impressions/s", "ms_per_step": round(dt * 1e3, 1),
-            "config": "NRMS-PLM train step, roberta-base-shaped random body (HF modules; its 72 projections on this library's "
-                      "GEMM engine via news_encoder.NrlLinear), d=768, 16 heads, L=96, B=8 (BASELINE.json configs[3])",
-            "body_linears_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_linears)}
+            "config": "NRMS-PLM train step, roberta-base-shaped random body (HF module graph; its 72 projections on this library's "
+                      "GEMM engine via news_encoder.NrlLinear, its self-attention on nrl_sdpa_fwd / _bwd via the HF attention "
+                      "registry), d=768, 16 heads, L=96, B=8 (BASELINE.json configs[3])",
+            "body_linears_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_linears),
+            "body_attention_on_this_library": bool(mod.news_encoder.text_encoders["title"].nrl_attention)}
 
 
 def self_launch(n_gpus: int) -> int:
