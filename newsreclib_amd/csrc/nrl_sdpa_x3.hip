@@ -139,11 +139,13 @@ __global__ void __launch_bounds__(SA_WAVES * 64) sa_fwd_kernel(const SdpaArgs P)
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
     f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (16 * jb < S) {                       // (wave-uniform: key blocks past the sequence cost nothing; their scores are masked below)
 #pragma unroll
-    for (int s = 0; s < SA_KS; ++s) {
-      bf16x8 kh, kl;
-      sa_row(Ks, 16 * jb + l15, s, g, kh, kl);
-      SA_MFMA3(sc, kh, kl, qh[s], ql[s]);
+      for (int s = 0; s < SA_KS; ++s) {
+        bf16x8 kh, kl;
+        sa_row(Ks, 16 * jb + l15, s, g, kh, kl);
+        SA_MFMA3(sc, kh, kl, qh[s], ql[s]);
+      }
     }
     const float4 a4 = *reinterpret_cast<const float4*>(add_s + 16 * jb + 4 * g);
     e[4 * jb + 0] = sc[0] + a4.x; e[4 * jb + 1] = sc[1] + a4.y; e[4 * jb + 2] = sc[2] + a4.z; e[4 * jb + 3] = sc[3] + a4.w;
@@ -173,6 +175,7 @@ __global__ void __launch_bounds__(SA_WAVES * 64) sa_fwd_kernel(const SdpaArgs P)
   for (int db = 0; db < SA_FB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
+    if (32 * t >= S) continue;               // (their probabilities are exactly 0)
     float p[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -257,6 +260,7 @@ __global__ void __launch_bounds__(SA_WAVES * 64) sa_bwd_kernel(const SdpaArgs P)
     for (int db = 0; db < SA_FB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if (32 * t >= S) continue;             // keys past the sequence: dS = 0
       float ds[8];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -349,6 +353,7 @@ __global__ void __launch_bounds__(SA_WAVES * 64) sa_bwd_kernel(const SdpaArgs P)
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
+    if (32 * t >= S) continue;               // queries past the sequence: P = dS = 0
     float pp[8], ds[8];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
