@@ -18,6 +18,7 @@
 #include "nrl_gemm_ws.h"
 #include "nrl_news_fused.h"
 #include "nrl_news_tail_api.h"
+#include "nrl_user_tail.h"
 #include "nrl_wgrad_planes.h"
 #include "nrl_kernels.h"
 #include "nrl_conv.h"
@@ -513,6 +514,16 @@ static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const Bl
                           Dropout drop2, float* out, hipStream_t st) {
   const int D = s.D, Q = s.Q;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
+  // one user (<= 64 pooled rows) per workgroup: out-projection, tanh-linear and pooling in ONE launch (nrl_user_tail.hip);
+  // writes the y / t / w the row-panel launches below would, so the backward is the same either way
+  if (!s.od_planes && !s.aa_planes && bp.rp.on &&
+      user_tail_ok(s.pool_groups, s.pool_len, D, Q, bp.rp.out_f.nblk, bp.rp.att_f.nblk) && s.pool_groups * s.pool_len == s.M) {
+    UserTailArgs a;
+    a.o = w.o; a.img_o = bp.rp.out_f.img; a.img_a = bp.rp.att_f.img; a.nblk_o = bp.rp.out_f.nblk; a.nblk_a = bp.rp.att_f.nblk;
+    a.b_o = P->out_proj_bias; a.b_a = P->att_bias; a.q_a = P->att_query; a.groups = s.pool_groups; a.H = s.pool_len; a.D = D;
+    a.Q = Q; a.drop2 = drop2; a.y = w.y; a.t = w.t; a.w = w.w; a.out = out;
+    return user_tail_fwd(a, st);
+  }
   // y = dropout(o W_o^T + b_o)        (out-projection, text.py:229-230)
   const int ncb_y = (D + 16) / 16;                       // y planes: D features + the ones column
   unsigned char* const ypl = reinterpret_cast<unsigned char*>(w.yp);

@@ -1,0 +1,244 @@
+// Fused back half of the NRMS USER encoder's forward (user/nrms.py:37-41 -> layers/attention.py:24-42), gfx950:
+//
+//   y = dropout(o W_o^T + b_o)       out-projection of nn.MultiheadAttention (+ the dropout of the PLM-style callers; p = 0 here)
+//   t = tanh(y W_a^T + b_a);  a = t . q_a;  w = softmax over the H history slots of a user;  out = sum_h w_h y_h
+//
+// On the row-panel path this is three launches over M = B * H = 6400 rows (28 + 23 + 16 us at B = 128), each one panel's
+// latency: 3 % of the step's arithmetic, 2 % of its time.  Here ONE workgroup of 8 waves owns ONE user (H <= 64 rows = 4 row
+// blocks) and nothing but y, t, w (the backward's operands, in the layouts the existing backward reads) and `out` leaves it:
+//   stage    the user's `o` rows are split once into (hi, lo) 16 x 16 block planes in LDS (the layout of nrl_attn_x3.hip);
+//   phase 1  y = o W_o^T: the 19 output blocks are dealt to the waves (w, w + 8, w + 16); A = row-form reads of the planes, B =
+//            the wave's fragments of the forward weight image (rp_weight_image_kernel: fragment-ordered, read straight from
+//            global, the next k-block's fragments in flight under the current one's 12 MFMAs); + b_o, dropout; y goes to
+//            HBM (fp32 rows), stays in the accumulator registers for the pooling, and overwrites the `o` planes as planes of y;
+//   phase 2  pre = y W_a^T the same way (13 blocks: w, w + 8); t = tanh(pre + b_a) to HBM; a[row] = sum over the waves' partial t . q_a, in wave order;
+//   pooling  softmax over the user's rows (one wave), out[col] = sum_rows w[row] y[row][col] from the registers of phase 1.
+#include <math.h>
+
+#include "nrl_kernels.h"
+#include "nrl_news_fused.h"
+#include "nrl_user_tail.h"
+
+namespace nrl {
+
+constexpr int UT_WAVES = 8, UT_RB = 4, UT_KB = 10, UT_FBK = 2 * UT_KB;   // 4 row blocks, 10 k-blocks = 20 feature blocks
+constexpr int UT_NCB_Y = 19, UT_NCB_T = 13;
+constexpr int UT_PLANE = UT_RB * UT_FBK * 512;      // 40 KB
+constexpr int UT_CB1 = 3, UT_CB2 = 2;                // column blocks per wave in phase 1 / 2
+
+#define UT_MFMA3(acc, ah, al, bh, bl)                                          \
+  do {                                                                         \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);       \
+  } while (0)
+
+__device__ __forceinline__ void ut_arow(const unsigned char* __restrict__ planes, int rb, int kb, int l15, int g, bf16x8& hi,
+                                        bf16x8& lo) {
+  const int off = ((rb * UT_FBK) + 2 * kb + (g >> 1)) * 512 + l15 * 32 + (g & 1) * 16;
+  hi = *reinterpret_cast<const bf16x8*>(planes + off);
+  lo = *reinterpret_cast<const bf16x8*>(planes + UT_PLANE + off);
+}
+// B fragments of (k-block kb, column block cb) of a forward weight image with nblk column blocks
+__device__ __forceinline__ void ut_bfrag(const uint16_t* __restrict__ img, int nblk, int kb, int cb, int lane, bf16x8& hi, bf16x8& lo) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(img) + ((size_t)(kb * nblk + cb) * 2) * 1024 + lane * 16;
+  hi = *reinterpret_cast<const bf16x8*>(p);
+  lo = *reinterpret_cast<const bf16x8*>(p + 1024);
+}
+
+// sum over the 16 lanes of a lane group (the 16 columns of an accumulator block)
+__device__ __forceinline__ float ut_row_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// acc[ci][rb] += A(planes)[rb] * B(img)[column block cbs[ci]] over the UT_KB k-blocks; the fragments of k-block kb + 1 are
+// requested before the MFMAs of k-block kb
+template <int NC>
+__device__ __forceinline__ void ut_gemm(const unsigned char* __restrict__ planes, const uint16_t* __restrict__ img, int nblk,
+                                        const int (&cbs)[NC], int ncb_valid, int l15, int g, int lane, f32x4 (&acc)[NC][UT_RB]) {
+  bf16x8 bh[2][NC], bl[2][NC];
+#pragma unroll
+  for (int ci = 0; ci < NC; ++ci) ut_bfrag(img, nblk, 0, cbs[ci] < ncb_valid ? cbs[ci] : ncb_valid - 1, lane, bh[0][ci], bl[0][ci]);
+#pragma unroll
+  for (int kb = 0; kb < UT_KB; ++kb) {
+    const int cur = kb & 1, nxt = cur ^ 1;
+    if (kb + 1 < UT_KB) {
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci)
+        ut_bfrag(img, nblk, kb + 1, cbs[ci] < ncb_valid ? cbs[ci] : ncb_valid - 1, lane, bh[nxt][ci], bl[nxt][ci]);
+    }
+    bf16x8 ah[UT_RB], al[UT_RB];
+#pragma unroll
+    for (int rb = 0; rb < UT_RB; ++rb) ut_arow(planes, rb, kb, l15, g, ah[rb], al[rb]);
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci)
+#pragma unroll
+      for (int rb = 0; rb < UT_RB; ++rb) UT_MFMA3(acc[ci][rb], ah[rb], al[rb], bh[cur][ci], bl[cur][ci]);
+  }
+}
+
+__global__ void __launch_bounds__(UT_WAVES * 64) ut_fwd_kernel(const UserTailArgs P) {
+  __shared__ __attribute__((aligned(1024))) unsigned char planes[2 * UT_PLANE];
+  __shared__ float a_part[UT_WAVES][64], w_s[64];   // per-wave partial logits, summed in wave order (run-to-run bitwise forward)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int64_t grp = blockIdx.x;
+  const int H = P.H, D = P.D, Q = P.Q;
+  const int64_t row0 = grp * H;
+
+  // ---- stage the user's `o` rows: thread = (row, 8-feature piece), 64 rows x 40 pieces = 2560 items, 5 per thread ----------
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int idx = tid + i * UT_WAVES * 64;
+    const int row = idx / 40, c8 = idx - row * 40;
+    const int r = row < H ? row : H - 1;
+    const float* rp = P.o + (row0 + r) * D + 8 * c8;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (8 * c8 < D) v0 = *reinterpret_cast<const float4*>(rp);
+    if (8 * c8 + 4 < D) v1 = *reinterpret_cast<const float4*>(rp + 4);
+    bf16x8 hi, lo;
+    rp_split8(v0, v1, hi, lo);
+    const int off = ((row >> 4) * UT_FBK + (c8 >> 1)) * 512 + (row & 15) * 32 + (c8 & 1) * 16;
+    *reinterpret_cast<bf16x8*>(planes + off) = hi;
+    *reinterpret_cast<bf16x8*>(planes + UT_PLANE + off) = lo;
+  }
+  __syncthreads();
+
+  // ---- phase 1: y = o W_o^T + b_o, dropout ---------------------------------------------------------------------------------
+  const int cb1[UT_CB1] = {wave, wave + 8, wave + 16};
+  f32x4 y[UT_CB1][UT_RB];
+#pragma unroll
+  for (int ci = 0; ci < UT_CB1; ++ci)
+#pragma unroll
+    for (int rb = 0; rb < UT_RB; ++rb) y[ci][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ut_gemm<UT_CB1>(planes, P.img_o, P.nblk_o, cb1, UT_NCB_Y, l15, g, lane, y);
+  __syncthreads();                                   // every wave is done reading the `o` planes
+#pragma unroll
+  for (int ci = 0; ci < UT_CB1; ++ci) {
+    const int cb = cb1[ci];
+    if (cb >= UT_NCB_Y) continue;
+    const int col = 16 * cb + l15;
+    const bool col_ok = col < D;
+    const float bias = col_ok ? P.b_o[col] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < UT_RB; ++rb) {
+      uint16_t* ph = reinterpret_cast<uint16_t*>(planes + (rb * UT_FBK + cb) * 512) + l15;
+      uint16_t* pl = reinterpret_cast<uint16_t*>(planes + UT_PLANE + (rb * UT_FBK + cb) * 512) + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rb + 4 * g + r;
+        const int64_t m = row0 + (row < H ? row : H - 1);
+        float v = col_ok ? y[ci][rb][r] + bias : 0.f;
+        if (P.drop2.thresh != 0u) v *= P.drop2.mult((uint32_t)m * (uint32_t)D + (uint32_t)col);
+        y[ci][rb][r] = v;
+        if (row < H && col_ok) P.y[m * D + col] = v;
+        uint32_t h, l;
+        split_pair(v, 0.f, h, l);
+        ph[(4 * g + r) * 16] = (uint16_t)(h & 0xFFFFu);
+        pl[(4 * g + r) * 16] = (uint16_t)(l & 0xFFFFu);
+      }
+    }
+  }
+  __syncthreads();                                   // planes now hold y (feature block 19 keeps the zeros `o` staged there)
+
+  // ---- phase 2: t = tanh(y W_a^T + b_a), a = t . q_a -----------------------------------------------------------------------
+  const int cb2[UT_CB2] = {wave, wave + 8};
+  const int ncb_t = (Q + 15) / 16;
+  f32x4 pre[UT_CB2][UT_RB];
+#pragma unroll
+  for (int ci = 0; ci < UT_CB2; ++ci)
+#pragma unroll
+    for (int rb = 0; rb < UT_RB; ++rb) pre[ci][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ut_gemm<UT_CB2>(planes, P.img_a, P.nblk_a, cb2, ncb_t, l15, g, lane, pre);
+  float apart[UT_RB][4];
+#pragma unroll
+  for (int rb = 0; rb < UT_RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) apart[rb][r] = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < UT_CB2; ++ci) {
+    const int cb = cb2[ci];
+    if (cb >= ncb_t) continue;
+    const int col = 16 * cb + l15;
+    const bool col_ok = col < Q;
+    const float bias = col_ok ? P.b_a[col] : 0.f, qa = col_ok ? P.q_a[col] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < UT_RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rb + 4 * g + r;
+        const float tv = tanhf(pre[ci][rb][r] + bias);
+        if (row < H && col_ok) P.t[(row0 + row) * Q + col] = tv;
+        apart[rb][r] = fmaf(tv, qa, apart[rb][r]);
+      }
+  }
+#pragma unroll
+  for (int rb = 0; rb < UT_RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = ut_row_sum(apart[rb][r]);       // over the 16 columns of the lane group
+      if (l15 == 0) a_part[wave][16 * rb + 4 * g + r] = v;
+    }
+  __syncthreads();
+
+  // ---- softmax over the user's H rows (one wave) ---------------------------------------------------------------------------
+  if (wave == 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < UT_WAVES; ++wv) a += a_part[wv][lane];
+    if (lane >= H) a = -INFINITY;
+    const float mx = wave_max(a);
+    const float e = lane < H ? expf(a - mx) : 0.f;
+    const float inv = 1.0f / wave_sum(e);
+    const float wl = e * inv;
+    w_s[lane] = wl;
+    if (lane < H) P.w[row0 + lane] = wl;
+  }
+  __syncthreads();
+
+  // ---- out[col] = sum_rows w[row] y[row][col], y from the registers of phase 1 ----------------------------------------------
+  float wr[UT_RB][4];
+#pragma unroll
+  for (int rb = 0; rb < UT_RB; ++rb) {
+    const float4 w4 = *reinterpret_cast<const float4*>(w_s + 16 * rb + 4 * g);
+    wr[rb][0] = w4.x; wr[rb][1] = w4.y; wr[rb][2] = w4.z; wr[rb][3] = w4.w;
+  }
+#pragma unroll
+  for (int ci = 0; ci < UT_CB1; ++ci) {
+    const int cb = cb1[ci];
+    if (cb >= UT_NCB_Y) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < UT_RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s = fmaf(wr[rb][r], y[ci][rb][r], s);
+    s += nf_xor16(s, lane);
+    s += nf_xor32(s, lane);
+    const int col = 16 * cb + l15;
+    if (g == 0 && col < D) P.out[grp * D + col] = s;
+  }
+}
+
+bool user_tail_ok(int64_t groups, int H, int D, int Q, int nblk_o, int nblk_a) {
+  static const bool on = [] {
+    const char* e = getenv("NRL_USER_TAIL");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on && groups > 0 && groups < (1LL << 31) && H >= 1 && H <= 64 && D == 300 && Q % 4 == 0 && Q >= 16 && Q <= 16 * UT_NCB_T &&
+         nblk_o >= UT_NCB_Y && nblk_a >= (Q + 15) / 16;
+}
+
+int user_tail_fwd(const UserTailArgs& a, hipStream_t st) {
+  NRL_REQUIRE(user_tail_ok(a.groups, a.H, a.D, a.Q, a.nblk_o, a.nblk_a), "fused user tail: unsupported geometry");
+  NRL_REQUIRE((((uintptr_t)a.o) & 15) == 0, "fused user tail: 16-byte alignment");
+  hipLaunchKernelGGL(ut_fwd_kernel, dim3((unsigned)a.groups), dim3(UT_WAVES * 64), 0, st, a);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+}  // namespace nrl
