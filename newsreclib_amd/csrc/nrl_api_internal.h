@@ -633,6 +633,20 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
   }
     return NRL_OK;
   }
+  // one user per workgroup: pooling backward, additive-attention dgrad and out-projection dgrad in ONE launch (nrl_user_tail.hip)
+  if (!s.tail && !s.od_planes && !s.aa_planes && bp.rp.on && s.pool_groups * s.pool_len == s.M &&
+      user_tail_bwd_ok(s.pool_groups, s.pool_len, D, Q, bp.rp.att_d.nblk, bp.rp.out_d.nblk, bp.rp.att_d.kblocks, bp.rp.out_d.kblocks)) {
+    UserTailBwdArgs a;
+    a.d_out = d_out; a.y = w.y; a.t = w.t; a.w = w.w; a.q_a = P->att_query; a.img_ad = bp.rp.att_d.img; a.img_od = bp.rp.out_d.img;
+    a.nblk_ad = bp.rp.att_d.nblk; a.nblk_od = bp.rp.out_d.nblk; a.groups = s.pool_groups; a.H = s.pool_len; a.D = D; a.Q = Q;
+    a.drop2 = drop2; a.dy = w.dy; a.d_o = w.d_o; a.dq_a = G->att_query;
+    NRL_TRY(user_tail_bwd(a, st));
+    if (!attention_elsewhere) {
+      if (block_attn_x3(s)) NRL_TRY(attn_bwd_x3(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+      else NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
+    }
+    return NRL_OK;
+  }
   NRL_TRY(pool_bwd_pre(d_out, s.tail ? nullptr : w.y, w.w, w.t, P->att_query, G->att_query, s.pool_groups, s.pool_len, Q, D, st,
                        s.aa_planes ? tpl : nullptr, s.tail ? w.yp : nullptr));
   if (s.od_planes) {

@@ -16,6 +16,23 @@ struct UserTailArgs {
   float *y, *t, *w, *out;  // (M, D), (M, Q), (M), (groups, D)
 };
 
+struct UserTailBwdArgs {
+  const float* d_out;      // (groups, D)
+  const float* y;          // (M, D) post-dropout out-projection rows
+  float* t;                // (M, Q): tanh output in, d_pre out (in place: the additive-attention weight gradient's operand)
+  const float* w;          // (M) pooling weights
+  const float* q_a;
+  const uint16_t* img_ad;  // dgrad image of W_a: N = D columns over K = Q (7 k-blocks)
+  const uint16_t* img_od;  // dgrad image of W_o: N = D over K = D
+  int nblk_ad, nblk_od;
+  int64_t groups;
+  int H, D, Q;
+  Dropout drop2;
+  float *dy, *d_o, *dq_a;  // (M, D), (M, D), (Q) accumulated
+};
+
+bool user_tail_bwd_ok(int64_t groups, int H, int D, int Q, int nblk_ad, int nblk_od, int kb_ad, int kb_od);
+int user_tail_bwd(const UserTailBwdArgs& a, hipStream_t st);
 bool user_tail_ok(int64_t groups, int H, int D, int Q, int nblk_o, int nblk_a);
 int user_tail_fwd(const UserTailArgs& a, hipStream_t st);
 

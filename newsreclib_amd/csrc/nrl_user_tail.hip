@@ -33,11 +33,12 @@ constexpr int UT_CB1 = 3, UT_CB2 = 2;                // column blocks per wave i
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);       \
   } while (0)
 
+template <int FBK>
 __device__ __forceinline__ void ut_arow(const unsigned char* __restrict__ planes, int rb, int kb, int l15, int g, bf16x8& hi,
                                         bf16x8& lo) {
-  const int off = ((rb * UT_FBK) + 2 * kb + (g >> 1)) * 512 + l15 * 32 + (g & 1) * 16;
+  const int off = ((rb * FBK) + 2 * kb + (g >> 1)) * 512 + l15 * 32 + (g & 1) * 16;
   hi = *reinterpret_cast<const bf16x8*>(planes + off);
-  lo = *reinterpret_cast<const bf16x8*>(planes + UT_PLANE + off);
+  lo = *reinterpret_cast<const bf16x8*>(planes + UT_RB * FBK * 512 + off);
 }
 // B fragments of (k-block kb, column block cb) of a forward weight image with nblk column blocks
 __device__ __forceinline__ void ut_bfrag(const uint16_t* __restrict__ img, int nblk, int kb, int cb, int lane, bf16x8& hi, bf16x8& lo) {
@@ -55,25 +56,25 @@ __device__ __forceinline__ float ut_row_sum(float v) {
   return v;
 }
 
-// acc[ci][rb] += A(planes)[rb] * B(img)[column block cbs[ci]] over the UT_KB k-blocks; the fragments of k-block kb + 1 are
+// acc[ci][rb] += A(planes)[rb] * B(img)[column block cbs[ci]] over KB k-blocks (planes of FBK feature blocks per row block); the fragments of k-block kb + 1 are
 // requested before the MFMAs of k-block kb
-template <int NC>
+template <int NC, int KB = UT_KB, int FBK = UT_FBK>
 __device__ __forceinline__ void ut_gemm(const unsigned char* __restrict__ planes, const uint16_t* __restrict__ img, int nblk,
                                         const int (&cbs)[NC], int ncb_valid, int l15, int g, int lane, f32x4 (&acc)[NC][UT_RB]) {
   bf16x8 bh[2][NC], bl[2][NC];
 #pragma unroll
   for (int ci = 0; ci < NC; ++ci) ut_bfrag(img, nblk, 0, cbs[ci] < ncb_valid ? cbs[ci] : ncb_valid - 1, lane, bh[0][ci], bl[0][ci]);
 #pragma unroll
-  for (int kb = 0; kb < UT_KB; ++kb) {
+  for (int kb = 0; kb < KB; ++kb) {
     const int cur = kb & 1, nxt = cur ^ 1;
-    if (kb + 1 < UT_KB) {
+    if (kb + 1 < KB) {
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci)
         ut_bfrag(img, nblk, kb + 1, cbs[ci] < ncb_valid ? cbs[ci] : ncb_valid - 1, lane, bh[nxt][ci], bl[nxt][ci]);
     }
     bf16x8 ah[UT_RB], al[UT_RB];
 #pragma unroll
-    for (int rb = 0; rb < UT_RB; ++rb) ut_arow(planes, rb, kb, l15, g, ah[rb], al[rb]);
+    for (int rb = 0; rb < UT_RB; ++rb) ut_arow<FBK>(planes, rb, kb, l15, g, ah[rb], al[rb]);
 #pragma unroll
     for (int ci = 0; ci < NC; ++ci)
 #pragma unroll
@@ -237,6 +238,179 @@ int user_tail_fwd(const UserTailArgs& a, hipStream_t st) {
   NRL_REQUIRE(user_tail_ok(a.groups, a.H, a.D, a.Q, a.nblk_o, a.nblk_a), "fused user tail: unsupported geometry");
   NRL_REQUIRE((((uintptr_t)a.o) & 15) == 0, "fused user tail: 16-byte alignment");
   hipLaunchKernelGGL(ut_fwd_kernel, dim3((unsigned)a.groups), dim3(UT_WAVES * 64), 0, st, a);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =====================================================================================================================
+// The same fusion for the backward of that back half (attention.py:34-40 and the out-projection, in reverse): per user
+//   c_l = d_out . y_l;  da_l = w_l (c_l - sum_l' w_l' c_l');  d_pre = da q_a (1 - t^2) (in place over t);  dq_a += sum_l da_l t_l
+//   dy = (d_pre W_a + w_l d_out) * dropout;  d_o = dy W_o
+// instead of pool_bwd_pre + two row-panel launches (14 + 18 + 17 us at B = 128).  MEASURED NULL, opt-in (user_tail_bwd_ok).  d_pre and dy go through LDS block planes
+// exactly as o and y do in the forward; the weight images are the row-panel dgrad images (att_d: 7 k-blocks over the queries,
+// out_d: 10 over the features).
+constexpr int UT_KBQ = 7, UT_FBQ = 2 * UT_KBQ;
+constexpr int UT_PLANE_Q = UT_RB * UT_FBQ * 512;    // 28 KB
+
+__global__ void __launch_bounds__(UT_WAVES * 64) ut_bwd_kernel(const UserTailBwdArgs P) {
+  __shared__ __attribute__((aligned(1024))) unsigned char pq[2 * UT_PLANE_Q];      // d_pre planes
+  __shared__ __attribute__((aligned(1024))) unsigned char py[2 * UT_PLANE];        // dy planes
+  __shared__ __attribute__((aligned(16))) float d_s[320];
+  __shared__ __attribute__((aligned(16))) float c_s[64], w_s[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int64_t grp = blockIdx.x;
+  const int H = P.H, D = P.D, Q = P.Q;
+  const int64_t row0 = grp * H;
+  const int D4 = D >> 2;
+
+  if (tid < 320) d_s[tid] = tid < D ? P.d_out[grp * D + tid] : 0.f;
+  {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < 2 * UT_PLANE_Q / (UT_WAVES * 64 * 16); ++i) reinterpret_cast<uint4*>(pq)[tid + i * UT_WAVES * 64] = z;
+    if (tid < 256) {        // feature block 19 of the dy planes (features 304 .. 319) is never written below
+      const int pl = tid >> 7, rb = (tid >> 5) & 3, q16 = tid & 31;
+      reinterpret_cast<uint4*>(py + pl * UT_PLANE + (rb * UT_FBK + 19) * 512)[q16] = z;
+    }
+  }
+  __syncthreads();
+  // ---- c_l = d_out . y_l: sixteen lanes per row --------------------------------------------------------------------------
+  {
+    const int gi = tid >> 4, li = tid & 15;
+    const float4* d4 = reinterpret_cast<const float4*>(d_s);
+    for (int l = gi; l < H; l += UT_WAVES * 4) {
+      const float4* yr = reinterpret_cast<const float4*>(P.y + (row0 + l) * D);
+      float acc = 0.f;
+      for (int d = li; d < D4; d += 16) {
+        const float4 a = d4[d], b = yr[d];
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+      }
+      acc = ut_row_sum(acc);
+      if (li == 0) c_s[l] = acc;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float wl = lane < H ? P.w[row0 + lane] : 0.f;
+    const float c = lane < H ? c_s[lane] : 0.f;
+    const float dbar = wave_sum(wl * c);
+    c_s[lane] = wl * (c - dbar);                      // da_l (0 past H)
+    w_s[lane] = wl;
+  }
+  __syncthreads();
+  // ---- d_pre = da q_a (1 - t^2) in place over t and into the planes; dq_a += sum_l da_l t_l: one thread per query -----------
+  if (tid < Q) {
+    const int q = tid;
+    const float qa = P.q_a[q];
+    float sumq = 0.f;
+    float* tcol = P.t + row0 * Q + q;
+    uint16_t* ph = reinterpret_cast<uint16_t*>(pq + (q >> 4) * 512) + (q & 15);
+    uint16_t* pl = reinterpret_cast<uint16_t*>(pq + UT_PLANE_Q + (q >> 4) * 512) + (q & 15);
+    for (int l0 = 0; l0 < H; l0 += 8) {
+      float tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tv[u] = l0 + u < H ? tcol[(int64_t)(l0 + u) * Q] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int l = l0 + u;
+        if (l < H) {
+          const float da = c_s[l];
+          sumq = fmaf(da, tv[u], sumq);
+          const float dp = da * qa * (1.0f - tv[u] * tv[u]);
+          tcol[(int64_t)l * Q] = dp;
+          uint32_t h, lo;
+          split_pair(dp, 0.f, h, lo);
+          const int o16 = ((l >> 4) * UT_FBQ * 512) / 2 + (l & 15) * 16;
+          ph[o16] = (uint16_t)(h & 0xFFFFu);
+          pl[o16] = (uint16_t)(lo & 0xFFFFu);
+        }
+      }
+    }
+    atomicAdd(P.dq_a + q, sumq);
+  }
+  __syncthreads();
+
+  // ---- phase 1: dy = (d_pre W_a + w_l d_out) * dropout -------------------------------------------------------------------------
+  const int cb1[UT_CB1] = {wave, wave + 8, wave + 16};
+  {
+    f32x4 acc[UT_CB1][UT_RB];
+#pragma unroll
+    for (int ci = 0; ci < UT_CB1; ++ci)
+#pragma unroll
+      for (int rb = 0; rb < UT_RB; ++rb) acc[ci][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ut_gemm<UT_CB1, UT_KBQ, UT_FBQ>(pq, P.img_ad, P.nblk_ad, cb1, UT_NCB_Y, l15, g, lane, acc);
+#pragma unroll
+    for (int ci = 0; ci < UT_CB1; ++ci) {
+      const int cb = cb1[ci];
+      if (cb >= UT_NCB_Y) continue;
+      const int col = 16 * cb + l15;
+      const bool col_ok = col < D;
+      const float dv = d_s[col];
+#pragma unroll
+      for (int rb = 0; rb < UT_RB; ++rb) {
+        uint16_t* ph = reinterpret_cast<uint16_t*>(py + (rb * UT_FBK + cb) * 512) + l15;
+        uint16_t* pl = reinterpret_cast<uint16_t*>(py + UT_PLANE + (rb * UT_FBK + cb) * 512) + l15;
+        const float4 w4 = *reinterpret_cast<const float4*>(w_s + 16 * rb + 4 * g);
+        const float wr[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rb + 4 * g + r;
+          const int64_t m = row0 + (row < H ? row : H - 1);
+          float v = col_ok && row < H ? fmaf(wr[r], dv, acc[ci][rb][r]) : 0.f;
+          if (P.drop2.thresh != 0u) v *= P.drop2.mult((uint32_t)m * (uint32_t)D + (uint32_t)col);
+          if (row < H && col_ok) P.dy[m * D + col] = v;
+          uint32_t h, lo;
+          split_pair(v, 0.f, h, lo);
+          ph[(4 * g + r) * 16] = (uint16_t)(h & 0xFFFFu);
+          pl[(4 * g + r) * 16] = (uint16_t)(lo & 0xFFFFu);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: d_o = dy W_o -------------------------------------------------------------------------------------------------
+  {
+    f32x4 acc[UT_CB1][UT_RB];
+#pragma unroll
+    for (int ci = 0; ci < UT_CB1; ++ci)
+#pragma unroll
+      for (int rb = 0; rb < UT_RB; ++rb) acc[ci][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ut_gemm<UT_CB1, UT_KB, UT_FBK>(py, P.img_od, P.nblk_od, cb1, UT_NCB_Y, l15, g, lane, acc);
+#pragma unroll
+    for (int ci = 0; ci < UT_CB1; ++ci) {
+      const int cb = cb1[ci];
+      if (cb >= UT_NCB_Y) continue;
+      const int col = 16 * cb + l15;
+      if (col >= D) continue;
+#pragma unroll
+      for (int rb = 0; rb < UT_RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * rb + 4 * g + r;
+          if (row < H) P.d_o[(row0 + row) * D + col] = acc[ci][rb][r];
+        }
+    }
+  }
+}
+
+bool user_tail_bwd_ok(int64_t groups, int H, int D, int Q, int nblk_ad, int nblk_od, int kb_ad, int kb_od) {
+  // OFF unless NRL_USER_TAIL_BWD=1: correct (the user-encoder, golden, quirk and full-size parity tests pass with it: 38 passed)
+  // but no faster than the three launches it replaces -- 2.92 / 2.94 vs 2.92 / 2.92 ms per step in two alternating pairs; its
+  // per-query column loop (d_pre, dq_a) and 138 KB of LDS (one workgroup per CU) take what the two saved launches gave.
+  static const bool on = [] {
+    const char* e = getenv("NRL_USER_TAIL_BWD");
+    return e != nullptr && e[0] == '1';
+  }();
+  return on && user_tail_ok(groups, H, D, Q, nblk_od, 16 * UT_NCB_T) && nblk_ad >= UT_NCB_Y && kb_ad == UT_KBQ && kb_od == UT_KB && Q <= 224;
+}
+
+int user_tail_bwd(const UserTailBwdArgs& a, hipStream_t st) {
+  NRL_REQUIRE(a.groups > 0 && a.H >= 1 && a.H <= 64 && a.D == 300, "fused user tail backward: unsupported geometry");
+  NRL_REQUIRE((((uintptr_t)a.y | (uintptr_t)a.d_out) & 15) == 0, "fused user tail backward: 16-byte alignment");
+  hipLaunchKernelGGL(ut_bwd_kernel, dim3((unsigned)a.groups), dim3(UT_WAVES * 64), 0, st, a);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
