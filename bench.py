@@ -349,8 +349,8 @@ def main():
         roof.update({"traffic": traffic, "traffic_profile": prof_meta, "launches": launches.value,
                      "avg_launch_ms": round(avg_s * 1e3, 4), "measured": "HIP events on the launch stream, instrumented second pass"})
         out = {
-            "metric": "impressions/sec (train step) NRMS MINDsmall-shape" if args.workload == "mindsmall"
-                      else "impressions/sec (train step) NRMS MINDlarge-shape", "value": round(value, 1),
+            "metric": "impressions/sec (train step) NRMS MINDlarge-shape" if args.workload == "mindlarge"
+                      else "impressions/sec (train step) NRMS MINDsmall-shape", "value": round(value, 1),
             "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "median_ms_per_step": round(median_ms, 4), "value_basis": "median step" if args.steps >= 50 else "mean of the timed region",
