@@ -82,8 +82,12 @@ def prepare_batch(batch: Dict, vocab: Optional[int] = None) -> Dict:
                 # small launches (~50 us at B = 128) run beside the fused forward instead of in front of it.  Measured slower
                 # mid-round (3.30 vs 3.26 ms: the sort was 80 us of atomics then); with the current sort, two alternating pairs
                 # of 100 steps: 2.98 / 3.00 vs 3.03 / 3.02 ms.  NRL_SORT_ASYNC=0 keeps it on the launch stream.
-                sort = ops.sort_positions_async if os.environ.get("NRL_SORT_ASYNC", "1") == "1" else ops.sort_positions
-                out["x_all"][attr + "_order"] = sort(ids, vocab)
+                # NRL_SORT_ASYNC=2: not here at all -- the news encoder's forward issues it on the side stream AFTER its own launches,
+                # so it runs beside the user encoder's few-row launches instead of beside the fused forward
+                mode = os.environ.get("NRL_SORT_ASYNC", "1")
+                if mode != "2":
+                    sort = ops.sort_positions_async if mode == "1" else ops.sort_positions
+                    out["x_all"][attr + "_order"] = sort(ids, vocab)
             # (PLM tokenizer output -- a dict of (N, L) tensors, rec_dataset.py:180-190 -- is NOT merged: the
             #  two sides are padded to their own longest text and the PLM encoder must see them in separate calls)
     for attr in ("category", "subcategory"):

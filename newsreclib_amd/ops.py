@@ -11,6 +11,7 @@ no 84 MB zero-fill + add per encoder call.  Without it the functions return ordi
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -120,8 +121,8 @@ class NewsEncoderFn(torch.autograd.Function):
             if order is None:
                 # id-sorted visiting order for the table gradient (index bookkeeping on the int64 ids;
                 # `prepare_batch` precomputes it once per batch so the step does not pay the sort)
-                order = sort_positions(ids, V)
-            ctx.order_ready = order_event(order)      # (side-stream sort of prepare_batch: the backward waits for it)
+                order = sort_positions_async(ids, V) if os.environ.get("NRL_SORT_ASYNC", "1") == "2" else sort_positions(ids, V)
+            ctx.order_ready = order_event(order)      # (side-stream sort: the backward waits for it)
             order = _chk(order, torch.int64, "order")
             if order.numel() == ids.numel():          # an order from elsewhere (argsort): append the count of id-0 positions
                 order = torch.cat([order.reshape(-1), (ids == 0).sum().reshape(1)])
