@@ -442,6 +442,9 @@ int nrl_sdpa_fwd(const float* q, const float* k, const float* v, const uint8_t* 
   NRL_REQUIRE(q && k && v && out, "sdpa_fwd: null argument");
   NRL_REQUIRE(sdpa_x3_ok(n_batch, seq_len, num_heads, head_dim), "sdpa_fwd: unsupported geometry (seq_len <= 128, head_dim == 64)");
   NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
+  // the dropout counter of element (group, query, key) is the 32-bit index (group * 128 + query) * 128 + key: it would wrap -- masks
+  // repeating across groups -- from 2^18 groups on
+  NRL_REQUIRE(p_drop == 0.0 || n_batch * num_heads < (1LL << 18), "sdpa: attention dropout covers batch * heads < 2^18");
   NRL_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "sdpa_fwd: 16-byte alignment");
   SdpaArgs a{};
   a.q = q; a.k = k; a.v = v; a.key_keep = key_keep; a.out = out; a.lse = lse;
@@ -456,6 +459,9 @@ int nrl_sdpa_bwd(const float* q, const float* k, const float* v, const uint8_t* 
   NRL_REQUIRE(q && k && v && out && d_out && lse && dq && dk && dv, "sdpa_bwd: null argument");
   NRL_REQUIRE(sdpa_x3_ok(n_batch, seq_len, num_heads, head_dim), "sdpa_bwd: unsupported geometry (seq_len <= 128, head_dim == 64)");
   NRL_REQUIRE(p_drop >= 0.0 && p_drop < 1.0, "dropout probability must be in [0, 1)");
+  // the dropout counter of element (group, query, key) is the 32-bit index (group * 128 + query) * 128 + key: it would wrap -- masks
+  // repeating across groups -- from 2^18 groups on
+  NRL_REQUIRE(p_drop == 0.0 || n_batch * num_heads < (1LL << 18), "sdpa: attention dropout covers batch * heads < 2^18");
   NRL_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)dq | (uintptr_t)dk |
                 (uintptr_t)dv) & 15) == 0, "sdpa_bwd: 16-byte alignment");
   SdpaArgs a{};

@@ -49,7 +49,8 @@ class MHSAAddAtt(nn.Module):
         self.additive_attention = AdditiveAttention(input_dim=embed_dim, query_dim=query_dim)
         self.dropout = nn.Dropout(dropout_probability)  # holds p; the kernels draw the mask
         self.num_heads = num_heads
-        self.table_grad_hook = None   # optional callable(grad_tensor), see trainer.NRMSTrainer
+        self.table_grad_hook = None   # optional callable(table_grad, ids) (or callable(table_grad)): called from the backward once the
+        # table gradient is complete, before the weight-gradient GEMMs (trainer.NRMSTrainer starts its all-reduce there)
 
     def _params(self):
         mha, att = self.multihead_attention, self.additive_attention
@@ -185,11 +186,24 @@ class NrlLinear(nn.Module):
         # a frozen weight's matrix-core images are built once, not twice per step (NRL_PLM_IMAGE_CACHE=0: every call, A/B)
         self._images = ops_blocks.FrozenImages() if os.environ.get("NRL_PLM_IMAGE_CACHE", "1") != "0" else None
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        # load_state_dict copies into the Parameter under no_grad (the version counter moves) -- but a caller may also have
+        # swapped storage behind it; a load is rare and an image build is 10 us, so drop the cached images outright
+        if self._images is not None:
+            self._images.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype != torch.float32 or not x.is_cuda:
-            return nn.functional.linear(x, self.weight, self.bias)      # (meta / CPU construction-time calls of HF)
+            # meta / CPU construction-time calls of HF.  Counted: a GPU step that lands here is NOT on this library's engine
+            # (bench.py's `plm` extra and test_plm_full_width_step report the counters, which must stay 0 on the device)
+            FALLBACK_CALLS["linear_cuda" if x.is_cuda else "linear_host"] += 1
+            return nn.functional.linear(x, self.weight, self.bias)
         params = (self.weight, self.bias)
-        images = self._images if not (self.weight.requires_grad or self.bias.requires_grad) else None
+        trainable = self.weight.requires_grad or self.bias.requires_grad
+        if trainable and self._images is not None:
+            self._images.invalidate()        # trained now, maybe frozen again later: never meet an image of the old values
+        images = self._images if not trainable else None
         return ops_blocks.LinearFn.apply(x.contiguous(), self.weight, self.bias, _grad_bufs(params), images)
 
     def extra_repr(self) -> str:
@@ -210,6 +224,13 @@ def swap_linears(module: nn.Module) -> int:
 
 
 NRL_ATTENTION = "nrl_x3"
+# calls of the PLM body that did NOT run on this library's kernels (framework fallbacks), by kind; `reset_fallback_calls()` zeroes
+FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0}
+
+
+def reset_fallback_calls() -> None:
+    for k in FALLBACK_CALLS:
+        FALLBACK_CALLS[k] = 0
 
 
 def _nrl_body_attention(module, query, key, value, attention_mask, dropout: float = 0.0, scaling=None, **kwargs):
@@ -221,15 +242,33 @@ def _nrl_body_attention(module, query, key, value, attention_mask, dropout: floa
     N, H, L, dh = query.shape
     ok = (query.is_cuda and query.dtype == torch.float32 and key.shape == query.shape and value.shape == query.shape
           and _lib.engine_code() == 2 and ops_blocks.sdpa_supported(N, L, H, dh))     # (2 = the bf16x3 engine)
+    # a causal / query-dependent mask is NOT a key-padding mask.  HF materialises the bidirectional encoder's mask as (N, 1, L, L);
+    # whether its query rows are all the same row is a property of the MODEL (encoder vs decoder), so it is verified on the
+    # first call of each attention module (one device comparison + sync) and remembered on the module
+    if kwargs.get("is_causal") or getattr(module, "is_causal", False):
+        ok = False
     keep = None
     if ok and attention_mask is not None:
         m = attention_mask
-        if m.dim() == 4 and m.shape[0] == N and m.shape[1] == 1 and m.shape[3] == L:
-            row = m[:, 0, 0, :]
-            keep = (row if row.dtype == torch.bool else (row == 0)).to(torch.uint8)
+        if m.dim() == 4 and m.shape[0] == N and m.shape[1] == 1 and m.shape[3] == L and m.shape[2] in (1, L):
+            if m.shape[2] == L:
+                invariant = getattr(module, "_nrl_mask_query_invariant", None)
+                if invariant is None:
+                    invariant = bool(torch.equal(m, m[:, :, :1, :].expand_as(m)))
+                    try:
+                        module._nrl_mask_query_invariant = invariant
+                    except Exception:
+                        pass
+                ok = invariant
+            if ok:
+                row = m[:, 0, 0, :]
+                keep = (row if row.dtype == torch.bool else (row == 0)).to(torch.uint8)
         else:
             ok = False
+    if ok and float(dropout) > 0.0 and N * H >= (1 << 18):     # (the kernels' 32-bit dropout counter: nrl_sdpa_x3.hip)
+        ok = False
     if not ok:
+        FALLBACK_CALLS["attention"] += 1
         return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     scale = float(scaling) if scaling is not None else float(dh) ** -0.5
     p = float(dropout)

@@ -160,10 +160,26 @@ class NewsEncoderFn(torch.autograd.Function):
             # the embedding-table gradient (>96 % of all gradient bytes) is complete after phase 1: let the
             # data-parallel trainer start its all-reduce now, under the weight-gradient GEMMs of phase 2
             run(1)
-            hook(bufs[0], ids)
+            _call_table_grad_hook(hook, bufs[0], ids)
             run(2)
         ctx.ws = None
         return (None, *rets, None, None, None, None, None, None, None)
+
+
+def _call_table_grad_hook(hook, grad: torch.Tensor, ids: torch.Tensor) -> None:
+    """``hook(grad, ids)`` -- or ``hook(grad)`` for a callable that takes one positional argument (the signature the hook had
+    before the touched-row exchange needed the ids)."""
+    import inspect
+    try:
+        params = [p for p in inspect.signature(hook).parameters.values()
+                  if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD, p.VAR_POSITIONAL)]
+        two = any(p.kind == p.VAR_POSITIONAL for p in params) or len(params) >= 2
+    except (TypeError, ValueError):
+        two = True
+    if two:
+        hook(grad, ids)
+    else:
+        hook(grad)
 
 
 class UserEncoderFn(torch.autograd.Function):
@@ -459,15 +475,18 @@ def sort_positions(ids: torch.Tensor, vocab: Optional[int] = None) -> torch.Tens
 
 
 _SIDE_STREAMS = {}
-_ORDER_EVENTS = {}       # data_ptr of an order tensor produced on the side stream -> its completion event
 
 
 def sort_positions_async(ids: torch.Tensor, vocab: Optional[int] = None) -> torch.Tensor:
     """``sort_positions`` on a side stream: the visiting order is needed by the news encoder's BACKWARD only, so the three
     small, latency-bound launches of the counting sort (~45 us at B = 128) run beside the forward instead of in front of
-    it.  The completion event is filed under the tensor's storage address; the autograd forward that receives the tensor
-    picks it up (``order_event``) and its backward waits for it on the launch stream (``wait_order``)."""
+    it.  The completion event travels WITH the tensor (``order._nrl_ready``): every autograd forward that receives the
+    tensor reads it (``order_event``, which does not consume it) and its backward waits for it on the launch stream
+    (``wait_order``) -- a second encoder call on the same order, or a re-forwarded prepared batch, waits just the same.
+    Ids that are not on a GPU are sorted in place (no stream to fork from)."""
     dev = ids.device
+    if dev.type != "cuda":
+        return sort_positions(ids, vocab)
     main = torch.cuda.current_stream(dev)
     side = _SIDE_STREAMS.get(dev.index)
     if side is None:
@@ -479,16 +498,13 @@ def sort_positions_async(ids: torch.Tensor, vocab: Optional[int] = None) -> torc
         ready.record(side)
     ids.record_stream(side)                      # allocator: neither tensor may be recycled under the other stream
     order.record_stream(main)
-    if len(_ORDER_EVENTS) >= 64:                 # orders nobody consumed: make the launch stream wait for them and forget them
-        for key in list(_ORDER_EVENTS)[:32]:
-            main.wait_event(_ORDER_EVENTS.pop(key))
-    _ORDER_EVENTS[order.data_ptr()] = ready
+    order._nrl_ready = ready                     # lives and dies with the tensor: no stale event can meet a recycled address
     return order
 
 
 def order_event(order: Optional[torch.Tensor]):
-    """The pending side-stream event of an order tensor (None for an order computed on the launch stream)."""
-    return _ORDER_EVENTS.pop(order.data_ptr(), None) if order is not None else None
+    """The side-stream completion event of an order tensor (None for an order computed on the launch stream)."""
+    return getattr(order, "_nrl_ready", None) if order is not None else None
 
 
 def wait_order(event) -> None:

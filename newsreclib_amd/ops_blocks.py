@@ -116,12 +116,14 @@ class LinearFn(torch.autograd.Function):
         a2 = a.reshape(-1, K)
         M = a2.shape[0]
         # `images` (FrozenImages, a frozen weight only): the matrix-core images of the weight kept across calls
-        ws, ready = images.buffer("fwd", w, lib, a.device) if images is not None else (None, 0)
+        ws, ready, key = images.buffer("fwd", w, lib, a.device) if images is not None else (None, 0, None)
         if ws is None:
             ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=a.device)
         c = torch.empty((M, N), dtype=torch.float32, device=a.device)
         _lib.check(lib.nrl_linear_fwd_img(a2.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, c.data_ptr(), ws.data_ptr(),
                                           ws.numel(), ready, _stream()), "nrl_linear_fwd")
+        if key is not None:
+            images.commit("fwd", key)
         if any(ctx.needs_input_grad):
             need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             ctx.save_for_backward(a2 if need_w else None, w, bias)
@@ -145,12 +147,14 @@ class LinearFn(torch.autograd.Function):
             bufs, rets = _grad_targets([w, bias], ctx.grad_bufs)
             dw, db = bufs[0].data_ptr(), bufs[1].data_ptr()
         d_a = torch.empty((M, K), dtype=torch.float32, device=d_c.device) if need_a else None
-        ws, ready = ctx.images.buffer("bwd", w, lib, d_c.device) if ctx.images is not None else (None, 0)
+        ws, ready, key = ctx.images.buffer("bwd", w, lib, d_c.device) if ctx.images is not None else (None, 0, None)
         if ws is None:
             ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=d_c.device)
         _lib.check(lib.nrl_linear_bwd_img(a2.data_ptr() if need_w else None, w.data_ptr(), d_c.data_ptr(), M, N, K,
                                           d_a.data_ptr() if need_a else None, dw, db, ws.data_ptr(), ws.numel(), ready,
                                           _stream()), "nrl_linear_bwd")
+        if key is not None:
+            ctx.images.commit("bwd", key)
         return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None, None)
 
 
@@ -201,30 +205,53 @@ def sdpa_supported(n_batch: int, seq_len: int, heads: int, head_dim: int) -> boo
     return bool(_lib.load().nrl_sdpa_supported(int(n_batch), int(seq_len), int(heads), int(head_dim)))
 
 
+_IMAGE_GENERATION = [0]
+
+
+def invalidate_frozen_images() -> None:
+    """Drops every cached weight image of every ``FrozenImages`` (a generation counter that is part of their keys): call it
+    after writing a frozen weight through a path no version counter sees (``w.data.copy_()``, raw-pointer writes)."""
+    _IMAGE_GENERATION[0] += 1
+
+
 class FrozenImages:
     """The matrix-core weight images of ONE frozen ``nn.Linear`` weight, kept across calls (``nrl_linear_fwd_img`` /
     ``nrl_linear_bwd_img``): the forward's and the backward's (transposed) image each in its own buffer, rebuilt when the
-    weight tensor was modified in place or replaced (its version counter / storage address), or when the engine or the
-    kernel-selection switches changed.  For weights NO optimizer updates: the fused Adam writes parameters through raw
+    weight tensor was modified in place or replaced (its version counter / storage address), when the engine or the
+    kernel-selection switches changed, after ``invalidate()`` (``NrlLinear`` calls it from ``load_state_dict`` and whenever
+    it sees the weight trainable, so a trained-then-refrozen layer never meets an old image) or after the module-wide
+    ``invalidate_frozen_images()``.  For weights NO optimizer updates: the fused Adam writes parameters through raw
     pointers, which no version counter sees -- ``NrlLinear`` therefore uses this for ``requires_grad == False`` weights only
-    (the PLM body's frozen layers, text.py:69-73: two thirds of a config-4 step's image builds)."""
+    (the PLM body's frozen layers, text.py:69-73: two thirds of a config-4 step's image builds).
+    A buffer is marked ready only by ``commit`` AFTER the C call that built its image returned NRL_OK."""
 
     def __init__(self):
         self._buf = {}
         self._key = {}
 
+    def invalidate(self) -> None:
+        self._key = {}
+
     def buffer(self, which: str, w: torch.Tensor, lib, device):
+        """-> (buffer, ready flag, key to ``commit`` once the call succeeded); (None, 0, None) for a trainable weight."""
         if w.requires_grad:
-            return None, 0
-        key = (w.data_ptr(), w._version, tuple(w.shape), _lib.engine_code(), _lib.options_word(), str(device))
+            self.invalidate()
+            return None, 0, None
+        key = (w.data_ptr(), w._version, tuple(w.shape), _lib.engine_code(), _lib.options_word(), str(device),
+               _IMAGE_GENERATION[0])
         buf = self._buf.get(which)
         if buf is None or buf.device != device:
             N, K = w.shape
             buf = self._buf[which] = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=device)
             self._key[which] = None
         ready = 1 if self._key.get(which) == key else 0
-        self._key[which] = key
-        return buf, ready
+        if not ready:
+            self._key[which] = None          # a failed build must not leave the previous key standing over a half-written image
+        return buf, ready, key
+
+    def commit(self, which: str, key) -> None:
+        if key is not None:
+            self._key[which] = key
 
 
 class MhaFn(torch.autograd.Function):

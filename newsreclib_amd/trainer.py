@@ -9,7 +9,7 @@ GPUs, "gloo" in the CPU tests of the communication logic.
 from __future__ import annotations
 
 import os
-from typing import Dict, Iterable, List
+from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -151,9 +151,32 @@ class OverlappedGradReduce:
         self._work = None
 
     def info(self) -> Dict:
+        world = dist.get_world_size(self.group) if self._active() else 1
         return {"mode": "dense", "payload_bytes_per_rank": 4 * self.flat.numel, "head_chunks": self.chunks,
+                "predicted_wire_ms": {"dense": predicted_wire_ms("dense", 4 * self.flat.numel, world), "link_GBps": 153.0,
+                                      "unmeasured": True},
                 "note": "sum all-reduce of the whole flat fp32 gradient (table head async under the weight gradients, in "
                         "`head_chunks` slices whose Adam updates pipeline with the transfers)"}
+
+
+XGMI_LINK_GBPS = 153.0      # MI355X: 7 point-to-point xGMI links per GPU, ~153 GB/s each (MI355X_MICROARCH.md)
+
+
+def predicted_wire_ms(mode: str, payload_bytes: float, world: int) -> Dict[str, float]:
+    """Back-of-envelope wire time of one gradient exchange over xGMI (no RCCL protocol overhead):
+    dense = sum all-reduce of `payload_bytes`; rows = all-gather where every rank contributes `payload_bytes`.
+    `ring`: every byte crosses one link per hop; `direct`: reduce-scatter + all-gather (or the all-gather) spread over all
+    world - 1 links of the fully connected node."""
+    if world <= 1:
+        return {"ring": 0.0, "direct": 0.0}
+    bw = XGMI_LINK_GBPS * 1e9
+    if mode == "dense":
+        ring = 2.0 * (world - 1) / world * payload_bytes / bw
+        direct = 2.0 * (payload_bytes / world) / bw
+    else:
+        ring = (world - 1) * payload_bytes / bw
+        direct = payload_bytes / bw
+    return {"ring": round(ring * 1e3, 6), "direct": round(direct * 1e3, 6)}
 
 
 class TouchedRowsExchange:
@@ -161,19 +184,30 @@ class TouchedRowsExchange:
     "optional later"): the (V, D) table gradient is > 96 % of the flat gradient and a rank's batch touches at most
     B * (H + C) * L of its V rows.
 
-    After phase 1 of the news-encoder backward (``start_head``, called from inside the backward with the token ids):
-    each rank gathers its unique sorted ids and their gradient rows, all ranks all-gather (counts, ids, rows) -- async,
-    under the weight-gradient GEMMs.  ``finish`` all-reduces the small dense rest, zeroes the rank's own touched rows and
-    adds EVERY rank's rows (its own included, from the gathered buffer) in ascending rank order: each replica performs the
-    same additions in the same order, so the replicas stay bit-identical, and with two ranks the result is bit-identical to
-    the dense all-reduce (a + b == b + a).  Dense Adam is unchanged (rows nobody touched carry a zero gradient).
-    Costs one host sync per step (the unique counts size the gather buffers); the dense path has none."""
+    ``prepare(ids, order)`` -- called by the trainer BEFORE the forward, as soon as the step's token ids exist -- builds the
+    rank's sorted unique ids into a fixed-size buffer with device-side arithmetic only (flags of the id-sorted positions,
+    prefix sum, scatter: no ``torch.unique``, no read-back), all-gathers the unique COUNTS of all ranks asynchronously and
+    copies them to pinned host memory behind an event.  After phase 1 of the news-encoder backward (``start_head``, called from
+    inside the backward): the host waits for THAT event only -- recorded a whole forward + backward chain earlier, so the wait
+    is over before it starts and the launch queue never drains (the round-3 form called ``torch.unique`` and ``.tolist()`` here:
+    two device-wide syncs in the middle of the backward) -- sizes the buffers from the largest count, gathers the rank's
+    gradient rows and all-gathers (ids, rows) asynchronously under the weight-gradient GEMMs.  ``finish`` all-reduces the small
+    dense rest, zeroes the rank's own touched rows and adds EVERY rank's rows (its own included, from the gathered buffer) in
+    ascending rank order: each replica performs the same additions in the same order, so the replicas stay bit-identical,
+    and with two ranks the result is bit-identical to the dense all-reduce (a + b == b + a).  Dense Adam is unchanged (rows
+    nobody touched carry a zero gradient).
 
-    def __init__(self, flat: "FlatParams", head_numel: int, table: torch.Tensor, group=None):
-        self.flat, self.head, self.group = flat, int(head_numel), group
+    ``auto=True`` (``--grad-exchange auto``): per step, from the gathered counts (identical on every rank, so every rank takes
+    the same branch): rows when ``max_count * (8 + 4 D) * world < 0.5 * 4 V D``, else the dense all-reduce of the head."""
+
+    def __init__(self, flat: "FlatParams", head_numel: int, table: torch.Tensor, group=None, auto: bool = False):
+        self.flat, self.head, self.group, self.auto = flat, int(head_numel), group, bool(auto)
         self.rows, self.dim = int(table.shape[0]), int(table.shape[1])
+        self._prepared = None
         self._pending = None
+        self._dense_work = None
         self._payload = 0
+        self._last = {"choice": "rows", "max_unique_rows": 0}
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -181,35 +215,90 @@ class TouchedRowsExchange:
     def _table_grad(self) -> torch.Tensor:
         return self.flat.grad[: self.rows * self.dim].view(self.rows, self.dim)
 
-    def start_head(self, _grad=None, ids=None) -> None:
+    def prepare(self, ids: torch.Tensor, order: Optional[torch.Tensor] = None) -> None:
+        """Unique ids of this rank (fixed-size buffer + device count) and the async exchange of the counts.  ``order``: the
+        id-sorted visiting order of ``ids`` if the caller has it (``ops.sort_positions``: n + 1 entries), else sorted here."""
         if not self._active() or self.head <= 0 or ids is None:
+            self._prepared = None
             return
         world = dist.get_world_size(self.group)
-        g = self._table_grad()
-        uniq = torch.unique(ids.reshape(-1))                                  # sorted unique ids of this rank
-        count = torch.tensor([uniq.numel()], dtype=torch.int64, device=g.device)
-        counts = [torch.zeros_like(count) for _ in range(world)]
-        dist.all_gather(counts, count, group=self.group)
-        counts = [int(c) for c in torch.cat(counts).tolist()]                 # (host sync: sizes of the gather buffers)
+        flat_ids = ids.reshape(-1)
+        n = flat_ids.numel()
+        dev = flat_ids.device
+        if order is not None:
+            ev = getattr(order, "_nrl_ready", None)
+            if ev is not None:
+                torch.cuda.current_stream(dev).wait_event(ev)
+            sorted_ids = flat_ids.index_select(0, order[:n])
+        else:
+            sorted_ids = torch.sort(flat_ids).values
+        first = torch.ones(n, dtype=torch.bool, device=dev)
+        if n > 1:
+            first[1:] = sorted_ids[1:] != sorted_ids[:-1]
+        slot = torch.cumsum(first, 0) - 1                       # rank of each position's id among the unique ids
+        uniq = torch.zeros(n, dtype=torch.int64, device=dev)
+        uniq.scatter_(0, slot, sorted_ids)                      # (equal ids write equal values: deterministic)
+        count = (slot[-1:] + 1) if n > 0 else torch.zeros(1, dtype=torch.int64, device=dev)
+        parts = [torch.zeros_like(count) for _ in range(world)]
+        work = dist.all_gather(parts, count.contiguous(), group=self.group, async_op=True)
+        work.wait()                                               # (RCCL: a stream-side wait, the host does not block)
+        counts_dev = torch.cat(parts)
+        if dev.type == "cuda":
+            counts_host = torch.empty(world, dtype=torch.int64, pin_memory=True)
+            counts_host.copy_(counts_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        else:
+            counts_host, ev = counts_dev, None
+        self._prepared = (uniq, counts_host, ev, counts_dev)
+
+    def start_head(self, _grad=None, ids=None) -> None:
+        if not self._active() or self.head <= 0:
+            return
+        if self._prepared is None:
+            if ids is None:
+                return
+            self.prepare(ids)                                     # (callers without the early hook: same result, later)
+        uniq, counts_host, ev, _keep = self._prepared
+        self._prepared = None
+        if ev is not None:
+            ev.synchronize()                                      # an event of the step's first microseconds: no drain
+        world = dist.get_world_size(self.group)
+        counts = [int(c) for c in counts_host.tolist()]
         cap = max(max(counts), 1)
-        ids_pad = torch.zeros(cap, dtype=torch.int64, device=g.device)
-        ids_pad[: uniq.numel()] = uniq
-        rows_pad = torch.zeros(cap, self.dim, dtype=g.dtype, device=g.device)
-        rows_pad[: uniq.numel()] = g.index_select(0, uniq)
+        g = self._table_grad()
+        rows_bytes = cap * (8 + 4 * self.dim)
+        self._last = {"choice": "rows", "max_unique_rows": cap}
+        if self.auto and rows_bytes * world >= 0.5 * 4 * self.rows * self.dim:
+            self._last["choice"] = "dense"
+            self._dense_work = dist.all_reduce(self.flat.grad[: self.head], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._payload = 4 * self.flat.numel
+            return
+        ids_pad = uniq[:cap].contiguous()                         # entries past the rank's own count: id 0, never added
+        rows_pad = g.index_select(0, ids_pad)
         ids_all = [torch.empty_like(ids_pad) for _ in range(world)]
         rows_all = [torch.empty_like(rows_pad) for _ in range(world)]
         w1 = dist.all_gather(ids_all, ids_pad, group=self.group, async_op=True)
         w2 = dist.all_gather(rows_all, rows_pad, group=self.group, async_op=True)
-        self._pending = (uniq, counts, ids_all, rows_all, w1, w2)
-        self._payload = cap * (8 + 4 * self.dim) + 8 + 4 * (self.flat.numel - self.head)
+        own = counts[dist.get_rank(self.group)]
+        self._pending = (ids_pad[:own], counts, ids_all, rows_all, w1, w2)
+        self._payload = rows_bytes + 8 + 4 * (self.flat.numel - self.head)
 
     def finish(self) -> float:
         if not self._active():
             return 1.0
         world = dist.get_world_size(self.group)
+        if self._dense_work is not None:            # auto chose the dense all-reduce for this step
+            if self.head < self.flat.numel:
+                dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
+            self._dense_work.wait()
+            self._dense_work = None
+            return 1.0 / world
         if self._pending is None:                   # the hook did not fire (or carried no ids): dense fallback
+            self._prepared = None
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
             self._payload = 4 * self.flat.numel
+            self._last = {"choice": "dense (hook did not fire)", "max_unique_rows": 0}
             return 1.0 / world
         if self.head < self.flat.numel:
             dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
@@ -226,9 +315,18 @@ class TouchedRowsExchange:
         return 1.0 / world
 
     def info(self) -> Dict:
-        return {"mode": "rows", "payload_bytes_per_rank": int(self._payload), "dense_payload_bytes_per_rank": 4 * self.flat.numel,
+        world = dist.get_world_size(self.group) if self._active() else 1
+        dense = 4 * self.flat.numel
+        rows = self._last["max_unique_rows"] * (8 + 4 * self.dim)
+        return {"mode": "auto" if self.auto else "rows", "last_step_choice": self._last["choice"],
+                "max_unique_rows_per_rank": self._last["max_unique_rows"],
+                "payload_bytes_per_rank": int(self._payload), "dense_payload_bytes_per_rank": dense,
+                "rule": "rows when max_unique_rows * (8 + 4 D) * world < 0.5 * 4 V D" if self.auto else None,
+                "predicted_wire_ms": {"dense": predicted_wire_ms("dense", dense, world),
+                                      "rows": predicted_wire_ms("rows", rows, world),
+                                      "link_GBps": XGMI_LINK_GBPS, "unmeasured": True},
                 "note": "all-gather of (unique ids, their table-gradient rows) padded to the largest rank + dense all-reduce of "
-                        "the non-table gradient; last step's sizes"}
+                        "the non-table gradient; last step's sizes; no host sync beyond one early event"}
 
 
 class NRMSTrainer:
@@ -236,13 +334,15 @@ class NRMSTrainer:
 
     def __init__(self, module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, group=None,
                  grad_exchange: str = "dense", head_chunks: int = 4):
-        if grad_exchange not in ("dense", "rows"):
-            raise ValueError("grad_exchange must be 'dense' (all-reduce of the flat gradient) or 'rows' (touched table rows)")
+        if grad_exchange not in ("dense", "rows", "auto"):
+            raise ValueError("grad_exchange must be 'dense' (all-reduce of the flat gradient), 'rows' (touched table rows) or "
+                             "'auto' (per step, whichever ships fewer bytes)")
         self.module = module
         self.flat = FlatParams(module.parameters())
         self.opt = FusedAdam(self.flat, lr, betas, eps)
         self.group = group
-        self._losses: List[torch.Tensor] = []
+        self._losses: List[torch.Tensor] = []        # folded into (_loss_sum, _loss_count) every LOSS_FOLD steps: bounded
+        self._loss_sum, self._loss_count = None, 0
         # leading segment = first parameter = the embedding table when the news encoder is MHSAAddAtt
         head = 0
         te = None
@@ -254,8 +354,8 @@ class NRMSTrainer:
         if te is not None and hasattr(te, "table_grad_hook") and len(enc.text_encoders) == 1 \
                 and self.flat.params[0] is te.embedding_layer.weight:
             head = self.flat.offsets[1] if len(self.flat.offsets) > 1 else self.flat.numel
-        if grad_exchange == "rows" and head > 0:
-            self.reduce = TouchedRowsExchange(self.flat, head, te.embedding_layer.weight, group)
+        if grad_exchange in ("rows", "auto") and head > 0:
+            self.reduce = TouchedRowsExchange(self.flat, head, te.embedding_layer.weight, group, auto=grad_exchange == "auto")
         else:
             self.reduce = OverlappedGradReduce(self.flat, head, group, chunks=head_chunks)
         if head > 0:
@@ -268,19 +368,51 @@ class NRMSTrainer:
         if dev.type == "cuda" and os.environ.get("NRL_DEFER_USER_WGRAD", "1") not in ("", "0"):
             self._side = torch.cuda.Stream(device=dev)
 
+    LOSS_FOLD = 256
+
+    def _fold_losses(self) -> None:
+        if self._losses:
+            tot = torch.stack(self._losses).sum().double()
+            self._loss_sum = tot if self._loss_sum is None else self._loss_sum + tot
+            self._loss_count += len(self._losses)
+            self._losses = []
+
     def epoch_end(self) -> Dict[str, float]:
         """Mean train loss over the steps since the last call (all ranks' steps under data parallelism), then reset --
-        what ``on_train_epoch_end`` logs as train/loss when Lightning drives the module (nrms_module.py:380-396)."""
-        if not self._losses:
+        what ``on_train_epoch_end`` logs as train/loss when Lightning drives the module (nrms_module.py:380-396).  A caller
+        that never asks (bench loops) holds at most LOSS_FOLD loss scalars: ``step`` folds them into a running device sum."""
+        self._fold_losses()
+        if self._loss_count == 0:
             return {}
-        tot = torch.stack(self._losses).sum().reshape(1).double()
-        cnt = torch.tensor([float(len(self._losses))], dtype=torch.float64, device=tot.device)
-        self._losses = []
+        tot = self._loss_sum.reshape(1)
+        cnt = torch.tensor([float(self._loss_count)], dtype=torch.float64, device=tot.device)
+        self._loss_sum, self._loss_count = None, 0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             both = torch.cat([tot, cnt])
             dist.all_reduce(both, op=dist.ReduceOp.SUM, group=self.group)
             tot, cnt = both[:1], both[1:]
         return {"train/loss": float(tot / cnt)}
+
+    def state_dict(self) -> Dict:
+        """Everything a resumed run needs that the module's own ``state_dict`` does not hold: Adam's step count and its two
+        moment buffers (flat, in ``FlatParams`` order -- ``layout`` names the slices), plus the hyper-parameters they were
+        built under.  (Lightning checkpoints ``optimizer.state_dict()`` next to the module; this is that half for the flat
+        optimizer of the bench / test loop.)"""
+        names = {id(p): n for n, p in self.module.named_parameters()}
+        layout = [(names.get(id(p), f"param{i}"), int(o), int(p.numel())) for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets))]
+        return {"step_count": int(self.opt.step_count), "exp_avg": self.opt.exp_avg.detach().clone(),
+                "exp_avg_sq": self.opt.exp_avg_sq.detach().clone(), "lr": self.opt.lr, "betas": tuple(self.opt.betas),
+                "eps": self.opt.eps, "layout": layout, "numel": int(self.flat.numel)}
+
+    def load_state_dict(self, state: Dict) -> None:
+        names = {id(p): n for n, p in self.module.named_parameters()}
+        layout = [(names.get(id(p), f"param{i}"), int(o), int(p.numel())) for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets))]
+        if int(state["numel"]) != self.flat.numel or [tuple(x) for x in state["layout"]] != layout:
+            raise ValueError("NRMSTrainer.load_state_dict: the optimizer state was saved for a different parameter layout")
+        self.opt.step_count = int(state["step_count"])
+        self.opt.exp_avg.copy_(state["exp_avg"])
+        self.opt.exp_avg_sq.copy_(state["exp_avg_sq"])
+        self.opt.lr, self.opt.betas, self.opt.eps = float(state["lr"]), tuple(state["betas"]), float(state["eps"])
 
     def exchange_info(self) -> Dict:
         """What the data-parallel gradient exchange ships per rank and step (bench.py prints it for N > 1)."""
@@ -290,8 +422,18 @@ class NRMSTrainer:
         self.module.train()
         # model_step directly: training_step would append preds / targets to training_step_outputs every step, and
         # nothing here runs the epoch-end hook that clears them; the loss is still tracked for `epoch_end()`
+        if hasattr(self.reduce, "prepare") and self.reduce._active():
+            # touched-row exchange: the step's ids exist now -- unique ids + the async exchange of their counts go out before
+            # the forward, so the backward's hook finds the sizes on the host without draining the launch queue
+            from .nrms_module import prepare_batch, text_vocab
+            batch = prepare_batch(batch, text_vocab(self.module))
+            xa = batch.get("x_all", {})
+            if torch.is_tensor(xa.get("title")):
+                self.reduce.prepare(xa["title"], xa.get("title_order"))
         loss = self.module.model_step(batch)[0]
         self._losses.append(loss.detach())
+        if len(self._losses) >= self.LOSS_FOLD:
+            self._fold_losses()
         root = self._one if self._unit_root and loss.dim() == 0 and loss.dtype == torch.float32 and loss.device == self._one.device else None
         if self._side is not None:
             # the user encoder's weight gradients on a side stream beside the news-encoder backward; joined on exit

@@ -232,6 +232,37 @@ dist.all_gather(both, fr.grad)
 assert torch.equal(both[0], both[1]), "replicas diverged"
 info = ex.info()
 assert info["mode"] == "rows" and 0 < info["payload_bytes_per_rank"] < info["dense_payload_bytes_per_rank"], info
+assert info["last_step_choice"] == "rows" and info["predicted_wire_ms"]["dense"]["ring"] > 0, info
+# the early form: unique ids + the async count exchange prepared BEFORE the backward (what NRMSTrainer.step does), here
+# with the id-sorted visiting order the library's sort would hand over (n + 1 entries)
+pp, fp = fresh()
+ids = fill(pp, rank)
+exp = TouchedRowsExchange(fp, V * D, pp[0])
+flat_ids = ids.reshape(-1)
+order = torch.cat([torch.argsort(flat_ids, stable=True), (flat_ids == 0).sum().reshape(1)])
+exp.prepare(ids, order)
+exp.start_head(pp[0].main_grad)                 # (no ids here: the prepared state carries them)
+assert exp.finish() == 0.5 and torch.equal(fp.grad, fd.grad), "prepared touched-row exchange != dense all-reduce"
+assert exp.info()["max_unique_rows_per_rank"] == max(int(torch.unique(i).numel()) for i in
+                                                     [fill(fresh()[0], 0), fill(fresh()[0], 1)])
+# auto: V = 97 rows, ~50 unique per rank -> 2 ranks x rows payload >= half the dense table -> the rule picks dense; with a
+# table 40x larger (same ids) it picks rows.  Either way the result is the dense all-reduce's.
+pa, fa = fresh()
+ids = fill(pa, rank)
+exa = TouchedRowsExchange(fa, V * D, pa[0], auto=True)
+exa.start_head(pa[0].main_grad, ids)
+assert exa.finish() == 0.5 and torch.equal(fa.grad, fd.grad)
+assert exa.info()["mode"] == "auto" and exa.info()["last_step_choice"] == "dense", exa.info()
+V2 = 40 * V
+big = [torch.nn.Parameter(torch.zeros(V2, D)), torch.nn.Parameter(torch.zeros(3))]
+fb = FlatParams(big)
+fill([big[0], torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(3))][:1] + [type("P", (), {"main_grad": torch.zeros(5, 7)})(), type("P", (), {"main_grad": torch.zeros(3)})()], rank)
+ref = fb.grad.clone()
+dist.all_reduce(ref)
+exb = TouchedRowsExchange(fb, V2 * D, big[0], auto=True)
+exb.start_head(big[0].main_grad, fill(fresh()[0], rank))
+assert exb.finish() == 0.5 and torch.equal(fb.grad, ref)
+assert exb.info()["last_step_choice"] == "rows", exb.info()
 # the hook never fired (or carried no ids): dense fallback
 pf, ff = fresh()
 fill(pf, rank)
@@ -504,3 +535,149 @@ def test_dense_rows_of_a_full_batch_is_the_reshape_and_its_adjoint():
     # without the caller's word the product path is taken (and, with no GPU here, refuses loudly rather than guessing)
     with pytest.raises((RuntimeError, ValueError, OSError)):
         dense_rows(x.detach(), batch, B, H, offsets)
+
+
+def test_product_matches_the_reference_contract_fixture():
+    """The drop-in contract as the REFERENCE's files state it (tests/golden/reference_contract.json, generated by
+    tests/golden/make_contract.py with `ast` / `yaml` over the reference sources and by instantiating its importable
+    components): constructor keywords in the reference's order (the product may append defaulted extras), forward
+    arguments, every scalar key of configs/model/<name>.yaml accepted by the mirrored module, and the components' state_dict
+    keys + shapes at the configs' sizes."""
+    import importlib
+    import inspect
+    import json
+    c = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_contract.json")))
+
+    def product(name):
+        mod, cls = name.rsplit(".", 1)
+        return getattr(importlib.import_module("newsreclib_amd." + mod), cls)
+
+    for group in ("modules", "components"):
+        for name, ref in c[group].items():
+            cls = product(name)
+            for fn in ("__init__", "forward"):
+                if fn not in ref:
+                    continue
+                sig = inspect.signature(getattr(cls, fn))
+                mine = [p for p in sig.parameters.values() if p.name != "self" and p.kind == p.POSITIONAL_OR_KEYWORD]
+                names = [p.name for p in mine]
+                want = ref[fn]["args"]
+                assert names[: len(want)] == want, (name, fn, names, want)
+                for p in mine[len(want):]:            # extras must be optional, or the reference's call sites break
+                    assert p.default is not inspect.Parameter.empty, (name, fn, p.name)
+    # Hydra: overriding `model._target_` alone must work, so every key of the reference's model config is a ctor keyword
+    for cfg_name, cfg in c["configs"].items():
+        target = cfg["values"]["_target_"]
+        assert target.startswith("newsreclib.models.general_rec."), target
+        mod_name, cls_name = target[len("newsreclib.models.general_rec."):].rsplit(".", 1)
+        cls = product(mod_name + "." + cls_name)
+        params = inspect.signature(cls.__init__).parameters
+        for key in cfg["values"]:
+            if not key.startswith("_"):
+                assert key in params, (cfg_name, key)
+    # state_dict keys + shapes of the components, built with the same constructor calls as make_contract.py
+    from newsreclib_amd.attention import AdditiveAttention
+    from newsreclib_amd.news_encoder import CNNAddAtt, CNNMHSAAddAtt, LinearEncoder, MHSAAddAtt
+    from newsreclib_amd.user_encoder import UserEncoder as NrmsUser
+    from newsreclib_amd.user_encoder_cen_news_rec import UserEncoder as CenUser
+    from newsreclib_amd.user_encoder_lstur import UserEncoder as LsturUser
+    from newsreclib_amd.user_encoder_mins import UserEncoder as MinsUser
+    from newsreclib_amd.user_encoder_naml import UserEncoder as NamlUser
+    V = c["state_dicts"]["vocab_rows_used"]
+    emb = torch.zeros(V, 300)
+    built = {
+        "news_encoder.MHSAAddAtt": MHSAAddAtt(pretrained_embeddings=emb, embed_dim=300, num_heads=15, query_dim=200,
+                                              dropout_probability=0.2),
+        "news_encoder.CNNAddAtt": CNNAddAtt(pretrained_embeddings=emb, embed_dim=300, num_filters=300, window_size=3,
+                                            query_dim=200, dropout_probability=0.2),
+        "news_encoder.CNNMHSAAddAtt": CNNMHSAAddAtt(pretrained_embeddings=emb, embed_dim=300, num_filters=400, window_size=3,
+                                                    num_heads=20, query_dim=200, dropout_probability=0.2),
+        "news_encoder.LinearEncoder": LinearEncoder(pretrained_embeddings=None, from_pretrained=False, freeze_pretrained_emb=False,
+                                                    num_categories=19, embed_dim=100, use_dropout=False,
+                                                    dropout_probability=None, linear_transform=False, output_dim=None),
+        "attention.AdditiveAttention": AdditiveAttention(input_dim=300, query_dim=200),
+        "user_encoder.UserEncoder": NrmsUser(news_embed_dim=300, num_heads=15, query_dim=200),
+        "user_encoder_lstur.UserEncoder": LsturUser(num_users=100, input_dim=700, user_masking_probability=0.5,
+                                                    long_short_term_method="ini"),
+        "user_encoder_naml.UserEncoder": NamlUser(news_embed_dim=400, query_dim=200),
+        "user_encoder_mins.UserEncoder": MinsUser(news_embed_dim=300, query_dim=200, num_filters=300, num_gru_channels=6),
+        "user_encoder_cen_news_rec.UserEncoder": CenUser(num_filters=400, num_heads=20, query_dim=200, gru_hidden_dim=400,
+                                                         num_recent_news=20, dropout_probability=0.2),
+    }
+    for name, m in built.items():
+        got = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert got == c["state_dicts"][name], (name, set(got) ^ set(c["state_dicts"][name]))
+
+
+def test_trainer_losses_are_bounded_and_optimizer_state_round_trips():
+    """NRMSTrainer keeps at most LOSS_FOLD loss scalars whatever the caller does, `epoch_end` still reports the exact mean,
+    and state_dict / load_state_dict carry Adam's step count and moments (CPU: the bookkeeping only, no kernels)."""
+    from newsreclib_amd.trainer import NRMSTrainer
+    lin = torch.nn.Linear(4, 3)
+    tr = NRMSTrainer.__new__(NRMSTrainer)
+    tr._losses, tr._loss_sum, tr._loss_count, tr.group = [], None, 0, None
+    vals = torch.arange(1.0, 1001.0)
+    for v in vals:
+        tr._losses.append(v.clone())
+        if len(tr._losses) >= tr.LOSS_FOLD:
+            tr._fold_losses()
+        assert len(tr._losses) < tr.LOSS_FOLD
+    assert abs(tr.epoch_end()["train/loss"] - float(vals.mean())) < 1e-9
+    assert tr.epoch_end() == {}
+    from newsreclib_amd.trainer import FlatParams, FusedAdam
+    flat = FlatParams(lin.parameters())
+    tr.module, tr.flat, tr.opt = lin, flat, FusedAdam(flat, lr=3e-4)
+    tr.opt.step_count = 7
+    tr.opt.exp_avg.normal_()
+    tr.opt.exp_avg_sq.uniform_()
+    state = tr.state_dict()
+    assert [n for n, _, _ in state["layout"]] == ["weight", "bias"]
+    lin2 = torch.nn.Linear(4, 3)
+    tr2 = NRMSTrainer.__new__(NRMSTrainer)
+    flat2 = FlatParams(lin2.parameters())
+    tr2.module, tr2.flat, tr2.opt = lin2, flat2, FusedAdam(flat2, lr=1e-4)
+    tr2.load_state_dict(state)
+    assert tr2.opt.step_count == 7 and tr2.opt.lr == 3e-4
+    assert torch.equal(tr2.opt.exp_avg, tr.opt.exp_avg) and torch.equal(tr2.opt.exp_avg_sq, tr.opt.exp_avg_sq)
+    other = NRMSTrainer.__new__(NRMSTrainer)
+    lin3 = torch.nn.Linear(5, 3)
+    flat3 = FlatParams(lin3.parameters())
+    other.module, other.flat, other.opt = lin3, flat3, FusedAdam(flat3)
+    with pytest.raises(ValueError, match="different parameter layout"):
+        other.load_state_dict(state)
+
+
+def test_frozen_image_cache_keys_and_invalidation():
+    """FrozenImages: a buffer is ready only after `commit`, never for a trainable weight, and `invalidate`,
+    the module-wide generation, an in-place modification and a re-freeze all force a rebuild."""
+    from newsreclib_amd import ops_blocks
+
+    class FakeLib:
+        @staticmethod
+        def nrl_linear_workspace_bytes(n, k):
+            return 64
+
+    w = torch.zeros(8, 4)
+    im = ops_blocks.FrozenImages()
+    dev = torch.device("cpu")
+    buf, ready, key = im.buffer("fwd", w, FakeLib, dev)
+    assert ready == 0 and key is not None
+    assert im.buffer("fwd", w, FakeLib, dev)[1] == 0, "an un-committed build must not count as ready (failed call)"
+    im.commit("fwd", key)
+    assert im.buffer("fwd", w, FakeLib, dev)[1] == 1
+    w.add_(1.0)                                   # version counter moves
+    _, ready, key = im.buffer("fwd", w, FakeLib, dev)
+    assert ready == 0
+    im.commit("fwd", key)
+    im.invalidate()
+    _, ready, key = im.buffer("fwd", w, FakeLib, dev)
+    assert ready == 0
+    im.commit("fwd", key)
+    ops_blocks.invalidate_frozen_images()
+    _, ready, key = im.buffer("fwd", w, FakeLib, dev)
+    assert ready == 0
+    im.commit("fwd", key)
+    w.requires_grad_(True)                        # trained ...
+    assert im.buffer("fwd", w, FakeLib, dev) == (None, 0, None)
+    w.requires_grad_(False)                       # ... and frozen again: the old image must not be trusted
+    assert im.buffer("fwd", w, FakeLib, dev)[1] == 0
