@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 12
+#define NRL_ABI_VERSION 13
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -119,6 +119,9 @@ int nrl_get_gemm_engine(void);
  *                       backward, joined before the phase-1 call returns; a phase-2 call then runs only the in-projection one)
  *  14 "news_qkv_planes" token-attention backward of the fused news path: q|k|v / d_o split once into (hi, lo) bf16 planes in LDS, operand
  *                       fragments read from them (bit-identical to the kernel that builds each fragment from fp32)
+ *  15 "news_pad_share"  (ABI v13) evaluation forward of the fused news path (nothing saved, p_drop == 0): the run of padding tokens
+ *                       from token 15 on is ONE row (identical embedding row, no dropout), so a news whose tokens 15 .. L - 1 are
+ *                       all the padding id is computed on its first 16 token rows only; bit-identical to computing every row
  * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
  * must see the same defaults (newsreclib_amd/ops*.py compare nrl_get_options() at both). */
 int nrl_set_option(const char* name, int32_t value);

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -232,7 +232,7 @@ def get_gemm_engine() -> str:
 # bit order of the switch mask (include/newsreclib_amd.h, nrl_set_option)
 OPTION_NAMES = ("news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes",
                 "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail", "news_tail_bwd", "user_fork", "news_fork",
-                "news_qkv_planes")
+                "news_qkv_planes", "news_pad_share")
 
 
 def set_option(name: str, value: bool) -> None:

@@ -24,11 +24,11 @@ thread_local int64_t t_opts = -1;
 
 static const char* const kOptName[O_COUNT] = {"news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes",
                                               "news_aa_planes", "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail",
-                                              "news_tail_bwd", "user_fork", "news_fork", "news_qkv_planes"};
+                                              "news_tail_bwd", "user_fork", "news_fork", "news_qkv_planes", "news_pad_share"};
 static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_BWD", "NRL_NEWS_ATTN_MFMA", "NRL_NEWS_PLANES",
                                              "NRL_NEWS_OD_PLANES", "NRL_NEWS_AA_PLANES", "NRL_WGRAD_2STEP", "NRL_WGRAD_WS",
                                              "NRL_ROWPANEL", "NRL_X3_DMA", "NRL_NEWS_TAIL", "NRL_NEWS_TAIL_BWD", "NRL_USER_FORK",
-                                             "NRL_NEWS_FORK", "NRL_NEWS_QKV_PLANES"};
+                                             "NRL_NEWS_FORK", "NRL_NEWS_QKV_PLANES", "NRL_NEWS_PAD_SHARE"};
 std::atomic<uint32_t> g_opt_default{[] {
   uint32_t m = 0;
   for (int i = 0; i < O_COUNT; ++i) {
@@ -146,7 +146,8 @@ int nrl_set_option(const char* name, int32_t value) {
       return NRL_OK;
     }
   set_error("set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, "
-            "news_aa_planes, wgrad_2step, wgrad_ws, rowpanel, x3_dma, news_tail, news_tail_bwd, user_fork)", name);
+            "news_aa_planes, wgrad_2step, wgrad_ws, rowpanel, x3_dma, news_tail, news_tail_bwd, user_fork, news_fork, news_qkv_planes, "
+            "news_pad_share)", name);
   return NRL_E_INVALID;
 }
 
@@ -209,6 +210,15 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     a.qkv_save = (save_for_backward && !opt(O_NEWS_FUSED_BWD)) ? w.qkv : nullptr;   // else recomputed in the backward
     a.qkv_head_major = opt(O_NEWS_ATTN_MFMA) ? 1 : 0;
     a.lse = save_for_backward ? w.lse : nullptr;
+    // evaluation (nothing saved, no dropout): the run of padding tokens from token 15 on is ONE row -- partition the news into
+    // short / long (list + counts in the log-sum-exp buffer, dead in an evaluation call) and let both kernels share the row
+    const bool share = !save_for_backward && p_drop == 0.0 && opt(O_NEWS_PAD_SHARE) && seq_len >= 17 && sf.od_planes &&
+                       news_tail_on(sf, seq_len, w) && n_news < (1LL << 31);
+    if (share) {
+      int32_t* hdr = reinterpret_cast<int32_t*>(w.lse);
+      NRL_TRY(launch_news_classify(ids, n_news, seq_len, hdr, hdr + 2, st));
+      a.n_short = hdr; a.perm = hdr + 2;
+    }
     {
       ProfScope prof(st, 2.0 * (double)s.M * 3.0 * s.D * s.D + 4.0 * (double)s.M * seq_len * s.D);
       NRL_TRY(launch_news_fused_fwd(a, st));
@@ -219,6 +229,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
       t.o_planes = a.o_planes; t.img_o = bp.rp.tail_o.img; t.img_a = bp.rp.tail_a.img; t.q_a = p->att_query;
       t.n_news = n_news; t.L = seq_len; t.D = s.D; t.Q = s.Q; t.drop2 = d2; t.out = out;
       t.y_planes = nullptr; t.t = nullptr; t.w = nullptr;
+      t.perm = a.perm; t.n_short = a.n_short;
       if (save_for_backward) {
         t.y_planes = reinterpret_cast<unsigned char*>(w.yp); t.w = w.w;
         t.t = news_tail_bwd_on(sf, seq_len, w) ? nullptr : w.t;     // the fused backward recomputes the tanh output

@@ -132,9 +132,13 @@ static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 //   news_qkv_planes NRL_NEWS_QKV_PLANES=0  token-attention backward builds every operand fragment from its fp32 image
 //                                          (news_attn_bwd_kernel) instead of splitting q|k|v / d_o once into LDS planes
 //                                          and reading fragments (news_attn_bwd_p_kernel; bit-identical output)
+//   news_pad_share  NRL_NEWS_PAD_SHARE=0   evaluation forward of the fused news path computes every token row of every news,
+//                                          instead of ONE row for the run of padding tokens from token 15 on (no dropout:
+//                                          identical rows; news_classify_kernel + the SHARE shapes of news_fused_fwd_kernel /
+//                                          news_tail_fwd_kernel; bit-identical output)
 enum {
   O_NEWS_FUSED = 0, O_NEWS_FUSED_BWD, O_NEWS_ATTN_MFMA, O_NEWS_PLANES, O_NEWS_OD_PLANES, O_NEWS_AA_PLANES, O_WGRAD_2STEP,
-  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_NEWS_QKV_PLANES, O_COUNT
+  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_NEWS_QKV_PLANES, O_NEWS_PAD_SHARE, O_COUNT
 };
 extern std::atomic<uint32_t> g_opt_default;  // (nrl_api.hip)
 extern thread_local int64_t t_opts;

@@ -22,6 +22,8 @@
 // images.  Sync: one barrier per 16 KB chunk (slot reuse) + one `vmcnt(0)` per head; the DMA of head h + 1's
 // chunk c is issued right after chunk c of head h has been consumed, so it has the rest of the head to land.
 #pragma once
+#include <type_traits>
+
 #include "nrl_rowpanel.h"
 
 namespace nrl {
@@ -57,7 +59,55 @@ struct NewsFusedArgs {
   int qkv_head_major;
   float* lse;               // (n_news * heads, L) or null
   int full_wgs;             // workgroups [0, full_wgs) own 8 news each, the rest 4 (set by the launcher: tail balancing)
+  // Evaluation only (no saves, no dropout): pad-row sharing.  `perm` lists the news with the SHORT ones first, `n_short` (device
+  // scalar) says how many: a short news has token 15 and every later token equal to the padding id 0 (news_classify_kernel), so
+  // without dropout its token rows 15 .. L - 1 are ONE row: identical embedding row -> identical q|k|v -> identical attention
+  // output.  A wave that owns a short news computes row block 0 only and fills the keys / values of block 1 with copies of
+  // row 15; `o` is written for rows 0 .. 15 only (the tail kernel, given the same lists, never reads the rest).  Both null: off.
+  const int32_t* perm = nullptr;
+  const int32_t* n_short = nullptr;
 };
+
+// One launch that partitions the news of an evaluation call into short (token 15 and everything after it is the padding id;
+// L >= 17) and long ones: perm[0 .. n_short) = the short news, perm[n_short .. n_news) = the long ones (filled from the back),
+// hdr[0] = n_short, hdr[1] = n_long (both zeroed by the caller).  The order inside a class depends on the atomics' arrival
+// order -- irrelevant: a news vector does not depend on which wave computes it.  One returning atomic per workgroup and class.
+static __global__ void __launch_bounds__(1024) news_classify_kernel(const int64_t* __restrict__ ids, int64_t n_news, int L,
+                                                              int32_t* __restrict__ hdr, int32_t* __restrict__ perm) {
+  __shared__ int cnt[16][2];
+  __shared__ int base[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 1024 + tid;
+  bool is_short = false;
+  if (n < n_news && L >= 17) {
+    const int64_t* row = ids + n * L;
+    int64_t acc = 0;
+    for (int t = 15; t < L; ++t) acc |= row[t];
+    is_short = acc == 0;
+  }
+  const bool valid = n < n_news;
+  const unsigned long long bs = __ballot(valid && is_short), bl = __ballot(valid && !is_short);
+  if (lane == 0) { cnt[wave][0] = __popcll(bs); cnt[wave][1] = __popcll(bl); }
+  __syncthreads();
+  if (tid < 2) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) { const int c = cnt[w][tid]; cnt[w][tid] = tot; tot += c; }
+    base[tid] = tot > 0 ? atomicAdd(hdr + tid, tot) : 0;
+  }
+  __syncthreads();
+  if (valid) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (is_short) perm[base[0] + cnt[wave][0] + __popcll(bs & below)] = (int32_t)n;
+    else perm[n_news - 1 - (base[1] + cnt[wave][1] + __popcll(bl & below))] = (int32_t)n;
+  }
+}
+static inline int launch_news_classify(const int64_t* ids, int64_t n_news, int L, int32_t* hdr, int32_t* perm, hipStream_t st) {
+  NRL_REQUIRE(n_news < (1LL << 31), "news_classify: too many news");
+  NRL_HIP(hipMemsetAsync(hdr, 0, 2 * sizeof(int32_t), st));
+  hipLaunchKernelGGL(news_classify_kernel, dim3((unsigned)ceil_div(n_news, 1024)), dim3(1024), 0, st, ids, n_news, L, hdr, perm);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
 
 __device__ __forceinline__ float nf_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 // lane ^ 16 / lane ^ 32 exchanges on the gfx950 row / half swaps: one VALU op + a select instead of a ds_bpermute
@@ -114,9 +164,10 @@ typedef uint4 __attribute__((may_alias)) nap_u4a;
 // 64 = counted head-top wait (vmcnt(8): the q|k|v slab stores stay in flight), 128 = every slab store of a wave lands on
 // the same 7.5 KB (cache-resident: the stores are issued, nothing drains to HBM), 256 = slab stores in front of the attention phase instead of after the score MFMAs,
 // 512 = half of them there, half after the P V MFMAs
-template <int DH, bool SAVE, int ABL = 0>
+template <int DH, bool SAVE, int ABL = 0, bool SHARE = false>
 __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
   static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
+  static_assert(!(SHARE && SAVE), "pad-row sharing is for evaluation forwards (no dropout, nothing saved)");
   // plain (write-allocate) stores: this kernel is not store-bound and the L2 merges the 80-byte `o` pieces; streaming
   // saves measured slower (train 0.62-0.65 vs 0.60 ms, tools/nf_probe.hip).  ABL 16 / 32 select the streaming forms.
   constexpr int NT = (ABL & 16) ? 1 : 0;
@@ -136,10 +187,20 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
   // partly filled round of 8-news workgroups (7040 news = 3.44 rounds of 256) is replaced by 4-news workgroups whose
   // waves have a SIMD to themselves; their other four waves only keep the barrier / DMA protocol going.
   const bool half_wg = (int)blockIdx.x >= P.full_wgs;
-  const int64_t news = half_wg ? (int64_t)P.full_wgs * NF_WAVES + (int64_t)((int)blockIdx.x - P.full_wgs) * 4 + wave
-                               : (int64_t)blockIdx.x * NF_WAVES + wave;
+  const int64_t news_v = half_wg ? (int64_t)P.full_wgs * NF_WAVES + (int64_t)((int)blockIdx.x - P.full_wgs) * 4 + wave
+                                 : (int64_t)blockIdx.x * NF_WAVES + wave;
   const bool wave_active = !half_wg || wave < 4;
-  const bool news_ok = wave_active && news < P.n_news;
+  const bool news_ok = wave_active && news_v < P.n_news;
+  // SHARE: the wave's news comes from the short-first list; position < n_short <=> a short news (wave-uniform)
+  int64_t news = news_v;
+  bool short_w = false;
+  if constexpr (SHARE) {
+    if (news_ok) {
+      news = __builtin_amdgcn_readfirstlane(P.perm[news_v]);
+      short_w = news_v < (int64_t)__builtin_amdgcn_readfirstlane(*P.n_short);
+    }
+  }
+  const int Lw = short_w ? 16 : L;                      // token rows this wave computes and writes
   const int64_t row0 = (news_ok ? news : 0) * L;        // first token row of this wave's news
 
   // ---- weight DMA: chunk c of head h = k-blocks 2c, 2c + 1 x column blocks 4h .. 4h + 3 x (hi, lo): 16 pieces of
@@ -186,6 +247,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       const int t = rb * 16 + l15;
       okr[rb] = news_ok && t < L;
       growr[rb] = row0 + (okr[rb] ? t : 0);
+      if (SHARE && rb == 1 && short_w) continue;          // (row block 1 of a short news is never computed)
       const float* rowp = P.table + P.ids[growr[rb]] * (int64_t)D;
 #pragma unroll
       for (int kb = 0; kb < NF_KB; ++kb) {
@@ -199,6 +261,11 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
     }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
+      if (SHARE && rb == 1 && short_w) {
+#pragma unroll
+        for (int kb = 0; kb < NF_KB; ++kb) ah[1][kb] = al[1][kb] = bf16x8{};
+        continue;
+      }
       const uint32_t idx0 = (uint32_t)growr[rb] * (uint32_t)D;
       const float live = okr[rb] ? 1.0f : 0.0f;
 #pragma unroll
@@ -253,7 +320,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
         rp_split8(*reinterpret_cast<const float4*>(image + row * NF_IMG_LD + half * 8),
                   *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + half * 8 + 4), hi, lo);
         unsigned char* dst = P.o_planes + (((m >> 4) * 19 + hp) * 2) * 512 + (m & 15) * 32 + half * 16;
-        if (row < L) {
+        if (row < Lw) {
           *reinterpret_cast<bf16x8*>(dst) = hi;
           *reinterpret_cast<bf16x8*>(dst + 512) = lo;
         }
@@ -267,7 +334,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
         split_pair(v.x, v.y, h0, l0);
         split_pair(v.z, v.w, h1, l1);
         unsigned char* blk = P.o_planes + (((m >> 4) * 19 + heads + (hp >> 2)) * 2) * 512 + (m & 15) * 32;
-        if (row < L) {
+        if (row < Lw) {
           if (ln < 32) {
             *reinterpret_cast<uint2*>(blk + (hp & 3) * 8) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(blk + 512 + (hp & 3) * 8) = make_uint2(l0, l1);
@@ -290,7 +357,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       for (int pass = 0; pass < 3; ++pass) {               // 32 rows x 5 float4 = 160 slots
         const int slot_i = pass * 64 + ln;
         const int row = slot_i / 5, c4 = slot_i - row * 5;
-        if (slot_i < 160 && row < L)
+        if (slot_i < 160 && row < Lw)
           store4(o_out + (row * D + hp * DH + 4 * c4), *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * c4), NT_O);
       }
     }
@@ -303,205 +370,228 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
   //  0.643 vs 0.645 ms, bit-identical output -- the stores' latency is not what the kernel waits for; its 1.49 GB of output
   //  drain at the ~3 TB/s a larger-than-cache write stream gets (profiles/r01_store_probe.txt).  Product code waits vmcnt(0).)
   const bool slab_tail = (ABL & 64) && SAVE && !(ABL & 8) && P.qkv_save != nullptr && P.qkv_head_major && news_ok && L >= 29;
-  for (int h = 0; h < heads; ++h) {
-    // every chunk of head h was issued while head h - 1 ran: landed for this wave, then (barrier) for all
-    if (h > 0 && slab_tail) wait_vmcnt<8>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int hn = h + 1 < heads ? h + 1 : h;            // last head: re-issue its own chunks (uniform control flow)
-    // 20 steps per head = (chunk c, k-block kbi, column-block pair np); the B fragments of step t + 1 are fetched
-    // before the 12 MFMAs of step t (two named fragment sets -- hipcc alone fetches each pair right before its
-    // first MFMA and waits lgkmcnt(0) there, exposing the LDS latency every 2-4 MFMAs).  Reading ahead across a
-    // chunk boundary is safe: the barrier there only guards the REFILL of the slot just finished.
-    auto read_step = [&](int t, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) {
-      const int c = t >> 2, kbi = (t >> 1) & 1, np = t & 1;
-      const unsigned char* slot = smem + c * 16384 + lane * 16;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        bh[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2) * 1024);
-        bl[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2 + 1) * 1024);
+  // The head loop exists in two compile-time shapes: NI = 2 row blocks (every training wave, the long news of an evaluation
+  // call) and NI = 1 (SHARE: a short news -- half the in-projection MFMAs, half the score / P V MFMAs, one softmax block).
+  // Both execute the same barriers, so waves of either shape can share a workgroup (the short-first list makes that rare).
+  auto run_heads = [&](auto sh_c) {
+    constexpr bool SH = decltype(sh_c)::value;
+    constexpr int NI = SH ? 1 : 2;
+    for (int h = 0; h < heads; ++h) {
+      // every chunk of head h was issued while head h - 1 ran: landed for this wave, then (barrier) for all
+      if (h > 0 && slab_tail) wait_vmcnt<8>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      f32x4 acc[2][4];
+  #pragma unroll
+      for (int i = 0; i < 2; ++i)
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int hn = h + 1 < heads ? h + 1 : h;            // last head: re-issue its own chunks (uniform control flow)
+      // 20 steps per head = (chunk c, k-block kbi, column-block pair np); the B fragments of step t + 1 are fetched
+      // before the 12 MFMAs of step t (two named fragment sets -- hipcc alone fetches each pair right before its
+      // first MFMA and waits lgkmcnt(0) there, exposing the LDS latency every 2-4 MFMAs).  Reading ahead across a
+      // chunk boundary is safe: the barrier there only guards the REFILL of the slot just finished.
+      auto read_step = [&](int t, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) {
+        const int c = t >> 2, kbi = (t >> 1) & 1, np = t & 1;
+        const unsigned char* slot = smem + c * 16384 + lane * 16;
+  #pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          bh[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2) * 1024);
+          bl[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2 + 1) * 1024);
+        }
+      };
+      auto mfma_step = [&](int t, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
+        const int kb = t >> 1, np = t & 1;
+        if constexpr (ABL & 2) {
+  #pragma unroll
+          for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(bh[jj]), "v"(bl[jj]));
+          return;
+        }
+  #pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+  #pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+  #pragma unroll
+            for (int i = 0; i < NI; ++i)
+              acc[i][2 * np + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  pass == 1 ? al[i][kb] : ah[i][kb], pass == 0 ? bl[jj] : bh[jj], acc[i][2 * np + jj], 0, 0, 0);
+      };
+      bf16x8 bh0[2], bl0[2], bh1[2], bl1[2];
+      read_step(0, bh0, bl0);
+  #pragma unroll
+      for (int t = 0; t < 20; t += 2) {
+        read_step(t + 1, bh1, bl1);
+        mfma_step(t, bh0, bl0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NI, 0);
+        if (t + 2 < 20) read_step(t + 2, bh0, bl0);
+        mfma_step(t + 1, bh1, bl1);
+        if (t + 2 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NI, 0);
+        if ((t & 3) == 2) {
+          // steps 4c .. 4c + 3 done: all waves are finished with slot c -> refill it with chunk c of the next head
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          if constexpr (!(ABL & 4)) issue_chunk(hn, t >> 2);
+          if (t == 2 && h > 0) flush_o(h - 1);              // the previous head's O, under this head's MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-    };
-    auto mfma_step = [&](int t, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
-      const int kb = t >> 1, np = t & 1;
-      if constexpr (ABL & 2) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(bh[jj]), "v"(bl[jj]));
-        return;
-      }
-#pragma unroll
-      for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[i][2 * np + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                pass == 1 ? al[i][kb] : ah[i][kb], pass == 0 ? bl[jj] : bh[jj], acc[i][2 * np + jj], 0, 0, 0);
-    };
-    bf16x8 bh0[2], bl0[2], bh1[2], bl1[2];
-    read_step(0, bh0, bl0);
-#pragma unroll
-    for (int t = 0; t < 20; t += 2) {
-      read_step(t + 1, bh1, bl1);
-      mfma_step(t, bh0, bl0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-      if (t + 2 < 20) read_step(t + 2, bh0, bl0);
-      mfma_step(t + 1, bh1, bl1);
-      if (t + 2 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-      if ((t & 3) == 2) {
-        // steps 4c .. 4c + 3 done: all waves are finished with slot c -> refill it with chunk c of the next head
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        if constexpr (!(ABL & 4)) issue_chunk(hn, t >> 2);
-        if (t == 2 && h > 0) flush_o(h - 1);              // the previous head's O, under this head's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
 
-    // ---- accumulators -> private image [token][q 20 | k 20 | v 20 | 0 4] -----------------------------
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) image[(i * 16 + 4 * g + r) * NF_IMG_LD + nb * 16 + l15] = acc[i][nb][r];
+      // ---- accumulators -> private image [token][q 20 | k 20 | v 20 | 0 4] -----------------------------
+  #pragma unroll
+      for (int i = 0; i < NI; ++i)
+  #pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) image[(i * 16 + 4 * g + r) * NF_IMG_LD + nb * 16 + l15] = acc[i][nb][r];
+      if constexpr (SH) {
+        // short news: token rows 16 .. L - 1 are the row 15 (all of them the padding id, no dropout): its q|k|v -- held by the
+        // lanes g = 3 as element 3 -- are copied into the image rows of block 1, where the keys / values of the attention read them
+  #pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const float v15 = __shfl(acc[0][nb][3], 48 + l15, 64);
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) image[(16 + 4 * g + r) * NF_IMG_LD + nb * 16 + l15] = v15;
+        }
+      }
 
-    auto save_qkv = [&](int pass_lo, int pass_hi) {
-    // ---- save q|k|v for the backward kernels: (row, 3D) layout, q at head*dh, k at D + .., v at 2D + .. ---
-      // (the output base pointers are made opaque per head: hipcc otherwise hoists the per-pass store addresses out
-      //  of the head loop and spills them)
-      // wave-uniform bases + 32-bit lane offsets (scalar-base addressing)
-      float* qkv_out = P.qkv_save + row0 * (int64_t)(3 * D);
-      if (P.qkv_head_major) qkv_out = P.qkv_save + ((news_ok ? news : 0) * heads + h) * (int64_t)L * 64;
-      if constexpr (ABL & 128) qkv_out = P.qkv_save + ((int64_t)(blockIdx.x & 255) * NF_WAVES + wave) * (int64_t)L * 64;
-      asm volatile("" : "+s"(qkv_out));
-      if (SAVE && P.qkv_save != nullptr && news_ok && !(ABL & 8)) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        if (P.qkv_head_major) {
-          // whole image rows: 1 KiB per pass, every 128-byte line written in full (the packed-row form below writes
-          // 80-byte pieces at a 3.6 KB stride)
-#pragma unroll
-          for (int pass = 0; pass < 8; ++pass) {
-            if (pass < pass_lo || pass >= pass_hi) continue;
-            const int slot_i = pass * 64 + ln;
-            const int row = slot_i >> 4, ch = slot_i & 15;
-            if (row < L)
-              store4(qkv_out + 4 * slot_i, *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * ch), NT);
-          }
-        } else {
-#pragma unroll
-          for (int pass = 0; pass < 8; ++pass) {            // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
-            if (pass < pass_lo || pass >= pass_hi) continue;
-            const int slot_i = pass * 64 + ln;
-            const int row = slot_i >> 4, ch = slot_i & 15;
-            if (ch < 15 && row < L) {
-              const int part = ch / 5, c4 = ch - part * 5;
-              const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + part * DH + 4 * c4);
-              *reinterpret_cast<float4*>(qkv_out + (row * 3 * D + part * D + h * DH + 4 * c4)) = v;
+      auto save_qkv = [&](int pass_lo, int pass_hi) {
+      // ---- save q|k|v for the backward kernels: (row, 3D) layout, q at head*dh, k at D + .., v at 2D + .. ---
+        // (the output base pointers are made opaque per head: hipcc otherwise hoists the per-pass store addresses out
+        //  of the head loop and spills them)
+        // wave-uniform bases + 32-bit lane offsets (scalar-base addressing)
+        float* qkv_out = P.qkv_save + row0 * (int64_t)(3 * D);
+        if (P.qkv_head_major) qkv_out = P.qkv_save + ((news_ok ? news : 0) * heads + h) * (int64_t)L * 64;
+        if constexpr (ABL & 128) qkv_out = P.qkv_save + ((int64_t)(blockIdx.x & 255) * NF_WAVES + wave) * (int64_t)L * 64;
+        asm volatile("" : "+s"(qkv_out));
+        if (SAVE && P.qkv_save != nullptr && news_ok && !(ABL & 8)) {
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          if (P.qkv_head_major) {
+            // whole image rows: 1 KiB per pass, every 128-byte line written in full (the packed-row form below writes
+            // 80-byte pieces at a 3.6 KB stride)
+  #pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+              if (pass < pass_lo || pass >= pass_hi) continue;
+              const int slot_i = pass * 64 + ln;
+              const int row = slot_i >> 4, ch = slot_i & 15;
+              if (row < L)
+                store4(qkv_out + 4 * slot_i, *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 4 * ch), NT);
+            }
+          } else {
+  #pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {            // 32 rows x 15 float4 (3 parts x 5) -> 480 of 512 slots
+              if (pass < pass_lo || pass >= pass_hi) continue;
+              const int slot_i = pass * 64 + ln;
+              const int row = slot_i >> 4, ch = slot_i & 15;
+              if (ch < 15 && row < L) {
+                const int part = ch / 5, c4 = ch - part * 5;
+                const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + part * DH + 4 * c4);
+                *reinterpret_cast<float4*>(qkv_out + (row * 3 * D + part * D + h * DH + 4 * c4)) = v;
+              }
             }
           }
         }
-      }
-    };
-    if constexpr (ABL & 256) save_qkv(0, 8);                 // (probe: the stores in front of the attention phase)
+      };
+      if constexpr (ABL & 256) save_qkv(0, 8);                 // (probe: the stores in front of the attention phase)
 
-    if constexpr (ABL & 1) continue;
-    // ---- S^T = K Q^T on the matrix cores ---------------------------------------------------------------
-    bf16x8 kh[2], kl[2], qh[2], ql[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      nf_frag8(image + (b * 16 + l15) * NF_IMG_LD + DH, g, 1.0f, kh[b], kl[b]);
-      nf_frag8(image + (b * 16 + l15) * NF_IMG_LD, g, P.scale, qh[b], ql[b]);
-    }
-    f32x4 s[2][2];                                         // [key block][query block]
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) s[jb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
-          s[jb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? kl[jb] : kh[jb], pass == 0 ? ql[ib] : qh[ib],
-                                                              s[jb][ib], 0, 0, 0);
-    // the slab stores go out under the latency of the score MFMAs (in front of the attention phase they cost 8-15 us more per
-    // launch at B = 128, tools/nf_probe.hip; the q columns are overwritten by O only at the end of the phase)
-    if constexpr (!(ABL & (256 | 512))) save_qkv(0, 8);
-    if constexpr (ABL & 512) save_qkv(0, 4);                // (probe: half here, half under the P V MFMAs)
-    // lane (query = ib * 16 + l15, g) holds keys jb * 16 + 4g + r: softmax over all L keys of the query
-    bf16x8 ph[2], pl[2];
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      float e[8];
-      float m = -INFINITY;
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = jb * 16 + 4 * g + r;
-          e[jb * 4 + r] = key < L ? s[jb][ib][r] : -INFINITY;
-          m = fmaxf(m, e[jb * 4 + r]);
-        }
-      m = fmaxf(m, nf_xor16(m, lane));
-      m = fmaxf(m, nf_xor32(m, lane));
-      // exp(s - m) as one fma + v_exp_f32 (2^x, 1 ulp): |s - m| stays far below the 2^-24 |x| the pre-scaling adds
-      constexpr float LOG2E = 1.4426950408889634f;
-      const float m2 = m * LOG2E;
-      float sum = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        e[q] = __builtin_amdgcn_exp2f(fmaf(e[q], LOG2E, -m2));   // masked keys: 2^(-inf) = 0
-        sum += e[q];
+      if constexpr (ABL & 1) continue;
+      // ---- S^T = K Q^T on the matrix cores ---------------------------------------------------------------
+      bf16x8 kh[2], kl[2], qh[2], ql[2];
+  #pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        nf_frag8(image + (b * 16 + l15) * NF_IMG_LD + DH, g, 1.0f, kh[b], kl[b]);
+        if (b < NI) nf_frag8(image + (b * 16 + l15) * NF_IMG_LD, g, P.scale, qh[b], ql[b]);   // (short: the queries of block 0 only)
       }
-      sum += nf_xor16(sum, lane);
-      sum += nf_xor32(sum, lane);
-      const float inv = __builtin_amdgcn_rcpf(sum);
-      if (SAVE && g == 0) image[(ib * 16 + l15) * NF_IMG_LD + 60] = m + logf(sum);   // -> flush_o of the next head
-      // A fragment of P V: slot e of lane group g <-> key kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4)
-      rp_split8(make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv),
-                make_float4(e[4] * inv, e[5] * inv, e[6] * inv, e[7] * inv), ph[ib], pl[ib]);
-    }
-    // B fragments of V under the same key permutation: lane (d = db * 16 + l15, g) <- V[kappa(g, e)][d]
-    bf16x8 vh[2], vl[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const int d = db * 16 + l15;
-      nf_kfrag(image + 2 * DH + d, NF_IMG_LD, g, d < DH ? 1.0f : 0.f, vh[db], vl[db]);
-    }
-    f32x4 oacc[2][2];                                      // [query block][feature block]
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-      for (int db = 0; db < 2; ++db) oacc[ib][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
+      f32x4 s[2][2];                                         // [key block][query block]
+  #pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+  #pragma unroll
+        for (int ib = 0; ib < 2; ++ib) s[jb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+  #pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+  #pragma unroll
+          for (int ib = 0; ib < NI; ++ib)
+            s[jb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? kl[jb] : kh[jb], pass == 0 ? ql[ib] : qh[ib],
+                                                                s[jb][ib], 0, 0, 0);
+      // the slab stores go out under the latency of the score MFMAs (in front of the attention phase they cost 8-15 us more per
+      // launch at B = 128, tools/nf_probe.hip; the q columns are overwritten by O only at the end of the phase)
+      if constexpr (!(ABL & (256 | 512))) save_qkv(0, 8);
+      if constexpr (ABL & 512) save_qkv(0, 4);                // (probe: half here, half under the P V MFMAs)
+      // lane (query = ib * 16 + l15, g) holds keys jb * 16 + 4g + r: softmax over all L keys of the query
+      bf16x8 ph[2], pl[2];
+  #pragma unroll
+      for (int ib = 0; ib < NI; ++ib) {
+        float e[8];
+        float m = -INFINITY;
+  #pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = jb * 16 + 4 * g + r;
+            e[jb * 4 + r] = key < L ? s[jb][ib][r] : -INFINITY;
+            m = fmaxf(m, e[jb * 4 + r]);
+          }
+        m = fmaxf(m, nf_xor16(m, lane));
+        m = fmaxf(m, nf_xor32(m, lane));
+        // exp(s - m) as one fma + v_exp_f32 (2^x, 1 ulp): |s - m| stays far below the 2^-24 |x| the pre-scaling adds
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float m2 = m * LOG2E;
+        float sum = 0.f;
+  #pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          e[q] = __builtin_amdgcn_exp2f(fmaf(e[q], LOG2E, -m2));   // masked keys: 2^(-inf) = 0
+          sum += e[q];
+        }
+        sum += nf_xor16(sum, lane);
+        sum += nf_xor32(sum, lane);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        if (SAVE && g == 0) image[(ib * 16 + l15) * NF_IMG_LD + 60] = m + logf(sum);   // -> flush_o of the next head
+        // A fragment of P V: slot e of lane group g <-> key kappa(g, e) = (e < 4 ? 4g + e : 16 + 4g + e - 4)
+        rp_split8(make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv),
+                  make_float4(e[4] * inv, e[5] * inv, e[6] * inv, e[7] * inv), ph[ib], pl[ib]);
+      }
+      // B fragments of V under the same key permutation: lane (d = db * 16 + l15, g) <- V[kappa(g, e)][d]
+      bf16x8 vh[2], vl[2];
+  #pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int d = db * 16 + l15;
+        nf_kfrag(image + 2 * DH + d, NF_IMG_LD, g, d < DH ? 1.0f : 0.f, vh[db], vl[db]);
+      }
+      f32x4 oacc[2][2];                                      // [query block][feature block]
+  #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
+  #pragma unroll
+        for (int db = 0; db < 2; ++db) oacc[ib][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+  #pragma unroll
+        for (int ib = 0; ib < NI; ++ib)
+  #pragma unroll
+          for (int db = 0; db < 2; ++db)
+            oacc[ib][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? pl[ib] : ph[ib], pass == 0 ? vl[db] : vh[db],
+                                                                   oacc[ib][db], 0, 0, 0);
+      if constexpr (ABL & 512) save_qkv(4, 8);
+      // O -> image (over the q columns, dead by now) -> 16-byte row stores into o[:, head * dh ..]
+  #pragma unroll
+      for (int ib = 0; ib < NI; ++ib)
+  #pragma unroll
         for (int db = 0; db < 2; ++db)
-          oacc[ib][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? pl[ib] : ph[ib], pass == 0 ? vl[db] : vh[db],
-                                                                 oacc[ib][db], 0, 0, 0);
-    if constexpr (ABL & 512) save_qkv(4, 8);
-    // O -> image (over the q columns, dead by now) -> 16-byte row stores into o[:, head * dh ..]
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (db * 16 + l15 < DH) image[(ib * 16 + 4 * g + r) * NF_IMG_LD + db * 16 + l15] = oacc[ib][db][r];
-    // (the global stores of O / lse are issued by `flush_o` during the NEXT head's MFMA phase: the head-top
-    //  vmcnt(0) that the weight DMA needs would otherwise also wait out these stores' full latency -- 0.15 ms of
-    //  0.64 at B = 128, tools/nf_probe.hip)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (db * 16 + l15 < DH) image[(ib * 16 + 4 * g + r) * NF_IMG_LD + db * 16 + l15] = oacc[ib][db][r];
+      // (the global stores of O / lse are issued by `flush_o` during the NEXT head's MFMA phase: the head-top
+      //  vmcnt(0) that the weight DMA needs would otherwise also wait out these stores' full latency -- 0.15 ms of
+      //  0.64 at B = 128, tools/nf_probe.hip)
+    }
+  };
+  if constexpr (SHARE) {
+    if (short_w) run_heads(std::true_type{});
+    else run_heads(std::false_type{});
+  } else {
+    run_heads(std::false_type{});
   }
   flush_o(heads - 1);
   // outstanding re-issued DMA of the last head must not outlive the workgroup's LDS allocation
@@ -532,11 +622,17 @@ static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t s
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   NRL_REQUIRE(a.x_planes == nullptr || NF_KB == 10, "x planes assume 20 column blocks");
   if ((a.x_save != nullptr || a.x_planes != nullptr) && a.lse != nullptr) {   // training: x + lse (+ q|k|v unless recomputed)
+    NRL_REQUIRE(a.perm == nullptr, "fused news encoder: pad-row sharing is for evaluation forwards");
     hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
   } else {
     NRL_REQUIRE(a.x_save == nullptr && a.x_planes == nullptr && a.qkv_save == nullptr && a.lse == nullptr,
                 "fused news encoder: save x and lse (and optionally q|k|v), or nothing");
-    hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+    if (a.perm != nullptr) {
+      NRL_REQUIRE(a.n_short != nullptr && a.drop1.thresh == 0u, "fused news encoder: pad-row sharing needs the short-first list and no dropout");
+      hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+    }
   }
   NRL_LAUNCH_CHECK();
   return NRL_OK;

@@ -22,6 +22,11 @@ struct NewsTailArgs {
   float* t;                       // training, optional: tanh output (n_news * L, Q) for pool_bwd_pre; null when the backward
                                   // recomputes it (news_tail_bwd_kernel)
   float* w;                       // training: pooling weights (n_news * L), or null
+  // evaluation only: the short-first news list of the fused front half (NewsFusedArgs::perm / n_short, nrl_news_fused.h).  A
+  // short news has ONE distinct token row from token 15 on, so its wave computes token block 0 only and takes the logit and
+  // the y values of tokens 16 .. L - 1 from token 15.  Both null: off.
+  const int32_t* perm = nullptr;
+  const int32_t* n_short = nullptr;
 };
 
 struct NewsTailBwdArgs {

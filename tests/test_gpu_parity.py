@@ -330,6 +330,62 @@ def test_news_path_format_switches_agree(N, L, option):
         assert _maxerr(g0, res[1][1][k]) <= 1e-4 * scale, (option, k)
 
 
+@pytest.mark.parametrize("N,L", [(37, 30), (8, 17), (19, 32), (260, 30), (5, 16), (3, 9)])
+def test_eval_pad_row_sharing_is_bit_identical(N, L):
+    """Evaluation forward of the fused news path (`news_pad_share`): a news whose tokens 15 .. L - 1 are all
+    the padding id is computed on its first 16 token rows only -- with no dropout the pad rows are ONE row, and every output row
+    of the projections depends on its own input row only, so the result must be BIT-identical to computing every row
+    (text.py:224-236 has no mask: the pad tokens still take part in both softmaxes, through the shared row).  Cases: mixed
+    short / long news, a zero id in the MIDDLE of a long title (not a trailing pad), titles of exactly 15 / 16 / 17 real tokens,
+    all-pad news, every news short / every news long, L = 17 (one shared row), L = 32 (no padding to 32), L <= 16 (sharing off),
+    more news than one 1024-thread classification block per class."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.news_encoder import MHSAAddAtt
+    _lib.set_gemm_engine("bf16x3")
+    params = _news_params(vocab=97, seed=N + L)
+    gen = torch.Generator().manual_seed(N * 31 + L)
+    ids = torch.randint(1, 97, (N, L), generator=gen)
+    lens = torch.randint(1, L + 1, (N,), generator=gen)
+    fixed = [0, 1, 14, 15, 16, 17, L]                       # real-token counts of the first news (0 = all padding)
+    for i, n in enumerate(fixed):
+        if i < N:
+            lens[i] = min(n, L)
+    ids[torch.arange(L)[None, :] >= lens[:, None]] = 0
+    if N > 10 and L > 20:
+        ids[8, 5] = 0                                       # a zero in the middle of a long title: an ordinary token row
+        lens[8] = L
+        ids[8, 6:] = torch.randint(1, 97, (L - 6,), generator=gen)
+        ids[9, 16:] = 0                                     # exactly 16 real tokens: token 15 is real -> long
+        ids[9, :16] = torch.randint(1, 97, (16,), generator=gen)
+    variants = [ids]
+    if (N, L) == (37, 30):
+        allshort = ids.clone(); allshort[:, 10:] = 0
+        alllong = torch.randint(1, 97, (N, L), generator=gen)
+        variants += [allshort, alllong]
+    was = bool((_lib.load().nrl_get_options() >> _lib.OPTION_NAMES.index("news_pad_share")) & 1)
+    assert was, "news_pad_share must be on by default"
+    enc = MHSAAddAtt(params[O.EMB_KEY], 300, 15, 200, 0.2)
+    enc.load_state_dict({k[len(O.NEWS_PREFIX):]: v for k, v in params.items() if k.startswith(O.NEWS_PREFIX)})
+    enc = enc.to(DEV).eval()
+    for v in variants:
+        outs = []
+        for on in (True, False, True):
+            _lib.set_option("news_pad_share", on)
+            try:
+                with torch.no_grad():
+                    outs.append(enc(v.to(DEV)).cpu())
+            finally:
+                _lib.set_option("news_pad_share", was)
+        assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+        assert torch.equal(outs[0], outs[2])
+        assert torch.isfinite(outs[0]).all()
+    # and against the oracle (eval mode), so a row that is shared WRONGLY on both sides cannot hide
+    with torch.no_grad():
+        got = enc(ids.to(DEV)).cpu()
+    ref = O.news_encoder_fwd(ids, params, 15)
+    assert _maxerr(got, ref) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_switches_travel_with_the_call():
     """The kernel-selection switches select private workspace formats.  They are per call (NrlBlockParams.options): the
     autograd forward captures the word and hands it to its backward, so (a) a backward still reads the workspace in the

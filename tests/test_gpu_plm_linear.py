@@ -149,9 +149,23 @@ def test_frozen_linear_keeps_its_weight_images_and_rebuilds_them_when_the_weight
     # a trainable weight: no cache (the fused Adam changes it through raw pointers, which no version counter sees)
     lin.weight.requires_grad_(True)
     lin.bias.requires_grad_(True)
-    before = dict(nl._images._key)
     nl(x).sum().backward()
-    assert nl._images._key == before
+    assert nl._images._key == {}, "a weight seen trainable must drop its cached images (it may be frozen again later)"
+    # ... trained through a path no version counter sees (what the fused Adam's raw-pointer writes look like), frozen again:
+    # the next frozen call must rebuild, not meet the image of the old values
+    lin.weight.data.mul_(0.5)
+    lin.weight.requires_grad_(False)
+    lin.bias.requires_grad_(False)
+    y3, _ = run()
+    ref3 = torch.nn.functional.linear(x.detach(), lin.weight, lin.bias)
+    assert float((y3 - ref3).abs().max()) <= 1e-4 * float(ref3.abs().max())
+    # explicit invalidation after a `.data` write on a frozen weight (ops_blocks.invalidate_frozen_images / FrozenImages.invalidate)
+    from newsreclib_amd import ops_blocks
+    lin.weight.data.mul_(3.0)
+    ops_blocks.invalidate_frozen_images()
+    y4, _ = run()
+    ref4 = torch.nn.functional.linear(x.detach(), lin.weight, lin.bias)
+    assert float((y4 - ref4).abs().max()) <= 1e-4 * float(ref4.abs().max())
 
 
 def _sdpa_reference(q, k, v, keep, scale, mult=None):
