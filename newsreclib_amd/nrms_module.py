@@ -64,10 +64,14 @@ def text_vocab(module) -> Optional[int]:
     return None
 
 
-def prepare_batch(batch: Dict, vocab: Optional[int] = None) -> Dict:
+def prepare_batch(batch: Dict, vocab: Optional[int] = None, need_order: Optional[bool] = None) -> Dict:
     """``attach_layout`` + the per-step device work on the token ids: history and candidate ids as the single
     encoder call sees them, and their id-sorted visiting order for the embedding gradient (the sort the reference
-    pays inside ``embedding_dense_backward``).  No host sync; part of the train step (bench.py times it)."""
+    pays inside ``embedding_dense_backward``).  No host sync; part of the train step (bench.py times it).
+    ``need_order`` (default: whether gradients are enabled): the visiting order serves the backward only, so a forward
+    under ``torch.no_grad()`` does not sort."""
+    if need_order is None:
+        need_order = torch.is_grad_enabled()
     out = attach_layout(batch)
     if "x_all" in out:
         return out
@@ -85,7 +89,7 @@ def prepare_batch(batch: Dict, vocab: Optional[int] = None) -> Dict:
                 # NRL_SORT_ASYNC=2: not here at all -- the news encoder's forward issues it on the side stream AFTER its own launches,
                 # so it runs beside the user encoder's few-row launches instead of beside the fused forward
                 mode = os.environ.get("NRL_SORT_ASYNC", "1")
-                if mode != "2":
+                if mode != "2" and need_order:
                     sort = ops.sort_positions_async if mode == "1" else ops.sort_positions
                     out["x_all"][attr + "_order"] = sort(ids, vocab)
             # (PLM tokenizer output -- a dict of (N, L) tensors, rec_dataset.py:180-190 -- is NOT merged: the

@@ -8,12 +8,12 @@ import torch
 
 from . import _lib
 from ._lib import NrlAddAttGrads, NrlAddAttParams
-from .ops import _chk, _grad_targets, _stream
+from .ops import GradAwareFunction, _chk, _grad_targets, _stream, saving
 
 ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2}
 
 
-class AdditiveAttentionFn(torch.autograd.Function):
+class AdditiveAttentionFn(GradAwareFunction):
     """``AdditiveAttention.forward`` (reference layers/attention.py:24-42): (G, S, D) -> (G, D)."""
 
     @staticmethod
@@ -31,7 +31,7 @@ class AdditiveAttentionFn(torch.autograd.Function):
         ws = torch.empty(max(lib.nrl_additive_attention_workspace_bytes(G, S, D, Q), 256), dtype=torch.uint8,
                          device=y.device)
         out = torch.empty((G, D), dtype=torch.float32, device=y.device)
-        save = any(ctx.needs_input_grad)
+        save = saving(ctx)
         _lib.check(lib.nrl_additive_attention_fwd(ctypes.byref(ap), y.data_ptr(), G, S, int(save), out.data_ptr(),
                                                   ws.data_ptr(), ws.numel(), _stream()), "nrl_additive_attention_fwd")
         if save:
@@ -59,7 +59,7 @@ class AdditiveAttentionFn(torch.autograd.Function):
         return (d_y, *rets, None)
 
 
-class LinearActFn(torch.autograd.Function):
+class LinearActFn(GradAwareFunction):
     """``act(nn.Linear(x))``, act in {none, tanh, relu}: (M, K) -> (M, N)."""
 
     @staticmethod
@@ -75,7 +75,7 @@ class LinearActFn(torch.autograd.Function):
         c = torch.empty((M, N), dtype=torch.float32, device=a.device)
         _lib.check(lib.nrl_linear_act_fwd(a.data_ptr(), w.data_ptr(), bias.data_ptr(), M, N, K, code, c.data_ptr(),
                                           ws.data_ptr(), ws.numel(), _stream()), "nrl_linear_act_fwd")
-        if any(ctx.needs_input_grad):
+        if saving(ctx):
             ctx.save_for_backward(a, w, bias, c)
             ctx.ws, ctx.code, ctx.grad_bufs, ctx.engine = ws, code, grad_bufs, _lib.engine_code()
             ctx.options = _lib.options_mask()
@@ -100,7 +100,7 @@ class LinearActFn(torch.autograd.Function):
         return (d_a, rets[0], rets[1], None, None)
 
 
-class LinearFn(torch.autograd.Function):
+class LinearFn(GradAwareFunction):
     """``nn.Linear`` on this library's projection engines (bf16x3 / exact fp32 matrix cores): (..., K) -> (..., N).
     The weight gradient is skipped for a frozen weight (the PLM body: layers 0-7 frozen while their inputs still need
     gradients, reference text.py:69-73); the bf16 weight planes are rebuilt by the backward (10 us) rather than kept
@@ -124,7 +124,7 @@ class LinearFn(torch.autograd.Function):
                                           ws.numel(), ready, _stream()), "nrl_linear_fwd")
         if key is not None:
             images.commit("fwd", key)
-        if any(ctx.needs_input_grad):
+        if saving(ctx):
             need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             ctx.save_for_backward(a2 if need_w else None, w, bias)
             ctx.grad_bufs, ctx.engine, ctx.in_shape = grad_bufs, _lib.engine_code(), tuple(a.shape)
@@ -158,7 +158,7 @@ class LinearFn(torch.autograd.Function):
         return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None, None)
 
 
-class SdpaFn(torch.autograd.Function):
+class SdpaFn(GradAwareFunction):
     """``F.scaled_dot_product_attention`` of a transformer body on the bf16x3 matrix-core kernels (``nrl_sdpa_fwd`` / ``_bwd``):
     q, k, v (N, L, H, dh) -- the projections' outputs viewed per head, NOT transposed -- -> (N, L, H, dh).  ``keep`` (N, L) uint8
     or None: the key-padding mask (1 = attend).  Attention-probability dropout ``p_drop`` under the library's counter-based
@@ -175,7 +175,7 @@ class SdpaFn(torch.autograd.Function):
             keep = _chk(keep, torch.uint8, "key mask")
             if tuple(keep.shape) != (N, L):
                 raise ValueError("newsreclib_amd: sdpa key mask must be (batch, seq)")
-        save = any(ctx.needs_input_grad[:3])
+        save = saving(ctx, slice(0, 3))
         out = torch.empty_like(q)
         lse = torch.empty((N * H, L), dtype=torch.float32, device=q.device) if save else None
         _lib.check(lib.nrl_sdpa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), keep.data_ptr() if keep is not None else None,
@@ -254,7 +254,7 @@ class FrozenImages:
             self._key[which] = key
 
 
-class MhaFn(torch.autograd.Function):
+class MhaFn(GradAwareFunction):
     """``nn.MultiheadAttention(x, x, x)[0]`` with ``batch_first=False``: x (S, Bt, D) -> (S, Bt, D), attention over
     S.  ``scale`` = the factor applied to q (None: 1/sqrt(D / heads))."""
 
@@ -275,7 +275,7 @@ class MhaFn(torch.autograd.Function):
         mp = NrlMhaParams(*[p.data_ptr() for p in params], D, int(heads), float(scale or 0.0), engine)
         ws = torch.empty(max(lib.nrl_mha_workspace_bytes(S, Bt, D, int(heads)), 256), dtype=torch.uint8, device=x.device)
         out = torch.empty_like(x)
-        save = any(ctx.needs_input_grad)
+        save = saving(ctx)
         _lib.check(lib.nrl_mha_fwd(ctypes.byref(mp), x.data_ptr(), S, Bt, int(save), out.data_ptr(), ws.data_ptr(),
                                    ws.numel(), _stream()), "nrl_mha_fwd")
         if save:

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import NrlCnnGrads, NrlCnnParams, NrlGruGrads, NrlGruParams
-from .ops import _chk, _grad_targets, _stream
+from .ops import GradAwareFunction, _chk, _grad_targets, _stream, saving
 from .ops import sort_positions as _sort_positions
 
 
@@ -25,7 +25,7 @@ def _cnn_params(tensors: Sequence[torch.Tensor], embed_dim: int) -> NrlCnnParams
     return NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), w_a.data_ptr(), b_a.data_ptr(), q_a.data_ptr(), D, F, W, Q)
 
 
-class CnnEncoderFn(torch.autograd.Function):
+class CnnEncoderFn(GradAwareFunction):
     """``CNNAddAtt.forward`` (reference text.py:163-176): ids (N, L) -> (N, F)."""
 
     @staticmethod
@@ -41,7 +41,7 @@ class CnnEncoderFn(torch.autograd.Function):
         N, L = ids.shape
         V, D = emb.shape
         cp = _cnn_params(params[1:], D)
-        save = any(ctx.needs_input_grad)
+        save = saving(ctx)
         ws_bytes = lib.nrl_cnn_encoder_workspace_bytes(N, L, D, cp.num_filters, cp.window, cp.query_dim)
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=ids.device)
         out = torch.empty((N, cp.num_filters), dtype=torch.float32, device=ids.device)
@@ -84,7 +84,7 @@ class CnnEncoderFn(torch.autograd.Function):
         return (None, *rets, None, None, None, None, None)
 
 
-class EmbeddingRowsFn(torch.autograd.Function):
+class EmbeddingRowsFn(GradAwareFunction):
     """``nn.Embedding(padding_idx=0)`` lookup + row mask: category encoder (category.py:72-73, p_row = 0) and
     the masked long-term user vector (user/lstur.py:70-71, ``nn.Dropout2d`` over whole users)."""
 
@@ -116,7 +116,7 @@ class EmbeddingRowsFn(torch.autograd.Function):
         return (None, rets[0], None, None, None, None)
 
 
-class GruFn(torch.autograd.Function):
+class GruFn(GradAwareFunction):
     """``nn.GRU`` over a packed batch-first sequence, last hidden state (user/lstur.py:74-83):
     hist (B, T, Din), lengths (B) int64, h0 (B, Hd) or None -> (B, Hd)."""
 
@@ -142,7 +142,7 @@ class GruFn(torch.autograd.Function):
         ws_bytes = lib.nrl_gru_workspace_bytes(B, T, Din, Hd)
         ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=hist.device)
         out = torch.empty((B, Hd), dtype=torch.float32, device=hist.device)
-        save = any(ctx.needs_input_grad)
+        save = saving(ctx)
         _lib.check(lib.nrl_gru_fwd(ctypes.byref(gp), hist.data_ptr(), lengths.data_ptr(),
                                    h0.data_ptr() if h0 is not None else None, B, T, int(save), out.data_ptr(),
                                    ws.data_ptr(), ws.numel(), _stream()), "nrl_gru_fwd")
@@ -174,7 +174,7 @@ class GruFn(torch.autograd.Function):
         return (d_hist, None, d_h0, *rets, None)
 
 
-class CnnMhsaEncoderFn(torch.autograd.Function):
+class CnnMhsaEncoderFn(GradAwareFunction):
     """``CNNMHSAAddAtt.forward`` (reference text.py:291-309): ids (N, L) -> (N, F).  ``w_c`` in the
     (F, 1, W, D) layout of ``CnnEncoderFn`` (the module permutes its ``nn.Conv1d`` weight (F, D, W))."""
 
@@ -194,7 +194,7 @@ class CnnMhsaEncoderFn(torch.autograd.Function):
         options = _lib.options_word()
         bp = _block_params(params[3:], heads, engine, options)
         cp = NrlCnnParams(w_c.data_ptr(), b_c.data_ptr(), None, None, None, D, F_, W, bp.query_dim)
-        save = any(ctx.needs_input_grad)
+        save = saving(ctx)
         ws = torch.empty(max(lib.nrl_cnn_mhsa_encoder_workspace_bytes(N, L, D, F_, W, heads, bp.query_dim), 256),
                          dtype=torch.uint8, device=ids.device)
         out = torch.empty((N, F_), dtype=torch.float32, device=ids.device)
