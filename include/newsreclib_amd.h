@@ -258,6 +258,24 @@ int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   double lr, double beta1, double beta2, double eps, int64_t step, float grad_scale,
                   int32_t zero_grad, void* stream);
 
+/* ---- optimizer, lazy form for the embedding table (ABI v13).  Same arithmetic, same bits as nrl_adam_step: a row whose
+ * gradient is zero evolves by a deterministic fp32 recurrence in (p, m, v, step), so its update may be applied later -- before
+ * the row is next gathered, when it next receives a gradient, or when the state is exported.  `last_step[rows]` (int32, zeros
+ * at step 0) records how far each row has been advanced; `mark[rows]` (int32) names the rows a step touches; `status[1]` is set
+ * to 1 if a row was found more than 127 steps behind (the window of bias corrections a call carries) -- the caller's rolling
+ * flush must keep every lag below that.
+ *   nrl_adam_rows_mark     mark[id] = step for every id of the step's batch (ids outside [0, rows) are ignored)
+ *   nrl_adam_rows_advance  candidate rows r = offset + j * stride (< rows); with `mark`: only those with mark[r] == upto_step + 1.
+ *                          Each is advanced from last_step[r] to upto_step with zero gradients; with_grad != 0: then step
+ *                          upto_step + 1 is applied with its gradient row (times grad_scale), the gradient row is cleared and
+ *                          last_step[r] = upto_step + 1.  (catch-up before a forward: mark, upto_step = t - 1, with_grad 0;
+ *                          update after the backward: mark, upto_step = t - 1, with_grad 1; flush: mark NULL, with_grad 0.) */
+int nrl_adam_rows_mark(const int64_t* ids, int64_t n_ids, int64_t rows, int32_t* mark, int64_t step, void* stream);
+int nrl_adam_rows_advance(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t rows, int32_t dim,
+                          int32_t* last_step, const int32_t* mark, int32_t* status, int64_t stride, int64_t offset,
+                          int64_t upto_step, int32_t with_grad, double lr, double beta1, double beta2, double eps,
+                          float grad_scale, void* stream);
+
 /* =================================================================================================
  * LSTUR path (BASELINE config 5): CNN text encoder, row-masked embedding
  * lookups (category / long-term user vector) and the GRU user encoder.

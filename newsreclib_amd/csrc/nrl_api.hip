@@ -487,6 +487,19 @@ int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                    (hipStream_t)stream);
 }
 
+int nrl_adam_rows_mark(const int64_t* ids, int64_t n_ids, int64_t rows, int32_t* mark, int64_t step, void* stream) {
+  NRL_REQUIRE((ids || n_ids == 0) && mark && n_ids >= 0 && rows > 0, "adam_rows_mark: bad arguments");
+  return adam_rows_mark(ids, n_ids, rows, mark, step, (hipStream_t)stream);
+}
+
+int nrl_adam_rows_advance(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t rows, int32_t dim,
+                          int32_t* last_step, const int32_t* mark, int32_t* status, int64_t stride, int64_t offset,
+                          int64_t upto_step, int32_t with_grad, double lr, double beta1, double beta2, double eps,
+                          float grad_scale, void* stream) {
+  return adam_rows_advance(param, grad, exp_avg, exp_avg_sq, rows, dim, last_step, mark, status, stride, offset, upto_step,
+                           with_grad, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+}
+
 int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,
                          float* out, void* stream) {
   NRL_REQUIRE(table && ids && out && n_ids >= 0 && dim > 0, "embedding_gather: bad arguments");

@@ -69,6 +69,12 @@ int ce_loss_fwd_bwd(const float* scores, const float* y, int64_t B, int64_t C, f
 
 int adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
               double eps, int64_t step, float grad_scale, int zero_grad, hipStream_t stream);
+// lazy row-wise Adam of a (rows, dim) table (nrl_kernels.hip): mark the rows a step touches; advance marked rows / a slice /
+// all rows to step `upto0` with zero gradients and, with_grad, apply step upto0 + 1 with their gradient rows
+int adam_rows_mark(const int64_t* ids, int64_t n, int64_t rows, int32_t* mark, int64_t step, hipStream_t stream);
+int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int dim, int32_t* last, const int32_t* mark,
+                      int32_t* status, int64_t stride, int64_t offset, int64_t upto0, int with_grad, double lr, double b1,
+                      double b2, double eps, float grad_scale, hipStream_t stream);
 
 int embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int D, float* out,
                      hipStream_t stream);

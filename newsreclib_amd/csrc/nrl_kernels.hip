@@ -1021,6 +1021,139 @@ int adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr, doub
 }
 
 // =============================================================================================
+// Lazy dense Adam for a (rows, dim) table whose gradient is zero outside the rows a step touched
+// =============================================================================================
+// Dense Adam moves EVERY row every step (abstract_recommender.py:96: torch.optim.Adam over all parameters; a row with a zero
+// gradient still drifts through its decaying moments).  For a row with g = 0 that update is a deterministic fp32 recurrence
+// in (p, m, v, step), so it can be applied LATER -- when the row is next read (the forward's gather) or written (a non-zero
+// gradient), or when its state is exported -- with the same instruction sequence (adam_elem with g = 0) and therefore the same
+// bits.  `last[r]` = the step up to which row r has been advanced.  One kernel, three uses:
+//   catch-up  rows with mark[r] == tag -> advanced to step upto0 = t - 1 (g = 0), before the forward of step t reads them;
+//   update    the same rows -> (advanced to t - 1 if another rank touched them, then) step t with their gradient row, which is
+//             cleared; last = t;
+//   flush     a slice (rows r = offset + j * stride: the rolling flush that bounds every row's lag) or all rows -> upto0.
+// The bias corrections of the 128 steps up to the current one travel as kernel arguments (computed on the host exactly as
+// adam_step computes them), indexed step & 127: a row may lag by at most 127 steps (status[0] is set if one lags further --
+// the trainer's rolling flush keeps every lag <= its period).
+constexpr int ADAM_WIN = 128;
+struct AdamRowsArgs {
+  float *p, *g, *m, *v;
+  int32_t* last;
+  const int32_t* mark;     // or null: every candidate row
+  int32_t* status;
+  int64_t n_cand, stride, offset;
+  int32_t tag, upto0, with_grad, D;
+  AdamConst base;          // b1, b2, 1 - b1, 1 - b2, eps, grad_scale (step_size / inv_sqrt_bc2 come from the window)
+  float step_size[ADAM_WIN], inv_sqrt_bc2[ADAM_WIN];
+};
+
+__global__ void __launch_bounds__(256) adam_rows_kernel(const AdamRowsArgs A) {
+  __shared__ int s_rows[64];
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  if (tid < 64) {
+    const int64_t j = (int64_t)blockIdx.x * 64 + tid;
+    bool take = false;
+    int64_t r = 0;
+    if (j < A.n_cand) {
+      r = A.offset + j * A.stride;
+      take = (A.mark == nullptr || A.mark[r] == A.tag) && (A.with_grad || A.last[r] < A.upto0);
+    }
+    const unsigned long long b = __ballot(take);
+    if (take) s_rows[__popcll(b & ((1ull << lane) - 1ull))] = (int)(j - (int64_t)blockIdx.x * 64);
+    if (lane == 0) s_n = __popcll(b);
+  }
+  __syncthreads();
+  const int n = s_n;
+  const int D4 = A.D >> 2;
+  for (int i = wave; i < n; i += 4) {
+    const int64_t r = A.offset + ((int64_t)blockIdx.x * 64 + s_rows[i]) * A.stride;
+    const int from = A.last[r];
+    if (A.upto0 - from >= ADAM_WIN && lane == 0) A.status[0] = 1;
+    float4* p4 = reinterpret_cast<float4*>(A.p + r * A.D);
+    float4* m4 = reinterpret_cast<float4*>(A.m + r * A.D);
+    float4* v4 = reinterpret_cast<float4*>(A.v + r * A.D);
+    float4* g4 = reinterpret_cast<float4*>(A.g + r * A.D);
+    for (int c = lane; c < D4; c += 64) {
+      float4 pp = p4[c], mm = m4[c], vv = v4[c];
+      AdamConst k = A.base;
+      for (int s = from + 1; s <= A.upto0; ++s) {
+        k.step_size = A.step_size[s & (ADAM_WIN - 1)];
+        k.inv_sqrt_bc2 = A.inv_sqrt_bc2[s & (ADAM_WIN - 1)];
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;      // the row's gradient at a missed step
+        adam_elem(pp.x, z0, mm.x, vv.x, k);
+        adam_elem(pp.y, z1, mm.y, vv.y, k);
+        adam_elem(pp.z, z2, mm.z, vv.z, k);
+        adam_elem(pp.w, z3, mm.w, vv.w, k);
+      }
+      if (A.with_grad) {
+        const int s = A.upto0 + 1;
+        k.step_size = A.step_size[s & (ADAM_WIN - 1)];
+        k.inv_sqrt_bc2 = A.inv_sqrt_bc2[s & (ADAM_WIN - 1)];
+        float4 gg = g4[c];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, k);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, k);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, k);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, k);
+        g4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      p4[c] = pp; m4[c] = mm; v4[c] = vv;
+    }
+    if (lane == 0) A.last[r] = A.upto0 + (A.with_grad ? 1 : 0);
+  }
+}
+
+__global__ void __launch_bounds__(256) adam_mark_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t rows,
+                                                         int32_t* __restrict__ mark, int32_t tag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = ids[i];
+    // (plain stores of one value: racing writers agree; a load first keeps the hot ids' lines clean)
+    if (id >= 0 && id < rows && mark[id] != tag) mark[id] = tag;
+  }
+}
+
+int adam_rows_mark(const int64_t* ids, int64_t n, int64_t rows, int32_t* mark, int64_t step, hipStream_t stream) {
+  if (n == 0) return NRL_OK;
+  NRL_REQUIRE(step >= 1 && step < (1LL << 31), "adam_rows_mark: step out of range");
+  hipLaunchKernelGGL(adam_mark_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, ids, n, rows, mark, (int32_t)step);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int dim, int32_t* last, const int32_t* mark,
+                      int32_t* status, int64_t stride, int64_t offset, int64_t upto0, int with_grad, double lr, double b1,
+                      double b2, double eps, float grad_scale, hipStream_t stream) {
+  NRL_REQUIRE(p && g && m && v && last && status && rows >= 0 && dim > 0 && dim % 4 == 0, "adam_rows: bad arguments");
+  NRL_REQUIRE(stride >= 1 && offset >= 0 && upto0 >= 0 && upto0 + 1 < (1LL << 31), "adam_rows: bad slice / step");
+  NRL_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (dim * sizeof(float)) % 16 == 0,
+              "adam_rows: buffers must be 16-byte aligned");
+  if (offset >= rows) return NRL_OK;
+  AdamRowsArgs A;
+  A.p = p; A.g = g; A.m = m; A.v = v; A.last = last; A.mark = mark; A.status = status;
+  A.n_cand = (rows - offset + stride - 1) / stride; A.stride = stride; A.offset = offset;
+  A.tag = (int32_t)(upto0 + 1);      // the step the marks were written for: catch-up and update both run during step upto0 + 1
+  A.upto0 = (int32_t)upto0; A.with_grad = with_grad ? 1 : 0; A.D = dim;
+  A.base.b1 = (float)b1; A.base.b2 = (float)b2; A.base.one_m_b1 = (float)(1.0 - b1); A.base.one_m_b2 = (float)(1.0 - b2);
+  A.base.eps = (float)eps; A.base.grad_scale = grad_scale; A.base.step_size = 0.f; A.base.inv_sqrt_bc2 = 0.f;
+  const int64_t hi = upto0 + 1;
+  for (int64_t s = hi; s > hi - ADAM_WIN; --s) {
+    float ss = 0.f, ib = 0.f;
+    if (s >= 1) {
+      const double bc1 = 1.0 - pow(b1, (double)s), bc2 = 1.0 - pow(b2, (double)s);     // (exactly adam_step's constants)
+      ss = (float)(lr / bc1);
+      ib = (float)(1.0 / sqrt(bc2));
+    }
+    A.step_size[s & (ADAM_WIN - 1)] = ss;
+    A.inv_sqrt_bc2[s & (ADAM_WIN - 1)] = ib;
+  }
+  hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((A.n_cand + 63) / 64)), dim3(256), 0, stream, A);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+// =============================================================================================
 // embedding gather (bit-exact copy of table rows) and the dropout-mask probe
 // =============================================================================================
 __global__ void gather_kernel(const float4* __restrict__ table, const int64_t* __restrict__ ids,

@@ -484,6 +484,30 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
                                  int(step), float(grad_scale), int(zero_grad), _stream()), "nrl_adam_step")
 
 
+def adam_rows_mark_(ids: torch.Tensor, mark: torch.Tensor, step: int) -> None:
+    """mark[id] = step for the ids of a step's batch (``nrl_adam_rows_mark``; lazy table Adam, trainer.LazyTableAdam)."""
+    lib = _lib.load()
+    ids = _chk(ids, torch.int64, "ids").reshape(-1)
+    _lib.check(lib.nrl_adam_rows_mark(ids.data_ptr(), ids.numel(), mark.numel(), mark.data_ptr(), int(step), _stream()),
+               "nrl_adam_rows_mark")
+
+
+def adam_rows_advance_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                       last_step: torch.Tensor, mark: Optional[torch.Tensor], status: torch.Tensor, upto_step: int,
+                       with_grad: bool, lr: float, betas: Tuple[float, float], eps: float, grad_scale: float = 1.0,
+                       stride: int = 1, offset: int = 0) -> None:
+    """``nrl_adam_rows_advance`` over a (rows, dim) table and its flat gradient / moment views (see include/newsreclib_amd.h)."""
+    lib = _lib.load()
+    rows, dim = param.shape
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == (rows, dim)):
+            raise ValueError("newsreclib_amd.adam_rows_advance_: contiguous float32 GPU tensors of one (rows, dim) shape required")
+    _lib.check(lib.nrl_adam_rows_advance(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), rows, dim,
+                                         last_step.data_ptr(), mark.data_ptr() if mark is not None else None,
+                                         status.data_ptr(), int(stride), int(offset), int(upto_step), int(bool(with_grad)),
+                                         lr, betas[0], betas[1], eps, float(grad_scale), _stream()), "nrl_adam_rows_advance")
+
+
 def sort_positions(ids: torch.Tensor, vocab: Optional[int] = None) -> torch.Tensor:
     """Positions of the flat id vector grouped by ascending id: the visiting order of the embedding-table gradient
     (what ``embedding_dense_backward`` gets from its own sort).  With ``vocab`` (exclusive upper bound of the ids) a

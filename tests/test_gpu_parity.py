@@ -386,6 +386,111 @@ def test_eval_pad_row_sharing_is_bit_identical(N, L):
     assert _maxerr(got, ref) <= 1e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("period", [64, 7])
+def test_lazy_table_adam_is_bit_identical_to_dense_adam(period):
+    """trainer.LazyTableAdam (dense-Adam semantics of abstract_recommender.py:96): over 200 steps with
+    ragged, Zipf-like touched-row sets (the padding row almost every step, most rows untouched for long stretches, steps that
+    touch a single row), identical gradients fed to the dense kernel and to the lazy optimizer: (a) the rows a step is about to
+    gather equal the dense table's rows BEFORE the forward (bitwise), (b) after `flush` the parameters and both moment
+    buffers equal the dense kernel's over the WHOLE flat buffer (bitwise), (c) the gradient buffer is clean, (d) no row ever
+    lagged beyond the bias-correction window (rolling flush: period 64 as shipped, 7 to cycle it many times)."""
+    from newsreclib_amd.trainer import FlatParams, FusedAdam, LazyTableAdam
+    V, D = 1000, 300
+    gen = torch.Generator().manual_seed(11)
+
+    def make():
+        torch.manual_seed(5)
+        ps = [torch.nn.Parameter(torch.randn(V, D, device=DEV)), torch.nn.Parameter(torch.randn(70, 33, device=DEV)),
+              torch.nn.Parameter(torch.randn(129, device=DEV))]
+        flat = FlatParams(ps)
+        return ps, flat, FusedAdam(flat, lr=1e-3)
+
+    pa, fa, oa = make()
+    pb, fb, ob = make()
+    lazy = LazyTableAdam(fb, ob, pb[0], period=period)
+    side = torch.cuda.Stream()
+    zipf = (1.0 / torch.arange(1, V + 1, dtype=torch.float64)) ** 1.1
+    for t in range(1, 201):
+        n = int(torch.randint(1, 400, (1,), generator=gen)) if t % 17 else 1
+        ids = torch.multinomial(zipf, n, replacement=True, generator=gen)
+        if t % 5:
+            ids = torch.cat([ids, torch.zeros(30, dtype=torch.int64)])          # padding positions
+        ids = ids.to(DEV)
+        uniq = torch.unique(ids)
+        scale = 1.0 if t % 3 else 0.5
+        g_rows = torch.randn(uniq.numel(), D, generator=gen).to(DEV)
+        g_rest = torch.randn(fa.numel - V * D, generator=gen).to(DEV)
+        before = pa[0].detach()[uniq].clone()
+        lazy.begin(ids.reshape(-1, 1), side if t % 2 else None)
+        assert torch.equal(pb[0].detach()[uniq], before), f"step {t}: gathered rows differ from dense Adam's"
+        for f in (fa, fb):
+            f.grad[: V * D].view(V, D)[uniq] = g_rows
+            f.grad[V * D:] = g_rest
+        oa.step(grad_scale=scale, zero_grad=True)
+        torch.cuda.current_stream().wait_stream(side)
+        lazy.finish(scale)
+        assert oa.step_count == ob.step_count == t
+    assert lazy.pending
+    lazy.flush()
+    assert not lazy.pending
+    assert torch.equal(fb.flat, fa.flat) and torch.equal(ob.exp_avg, oa.exp_avg) and torch.equal(ob.exp_avg_sq, oa.exp_avg_sq)
+    assert float(fb.grad.abs().max()) == 0.0 and float(fa.grad.abs().max()) == 0.0
+    assert int(lazy.last.min()) == int(lazy.last.max()) == 200
+    lazy.check()
+    # a step whose table gradient is dense (all-reduce fallback) goes through `finish_dense`
+    g = torch.randn(fa.numel, generator=gen).to(DEV)
+    fa.grad.copy_(g); fb.grad.copy_(g)
+    oa.step(grad_scale=1.0, zero_grad=True)
+    lazy.finish_dense(1.0)
+    assert torch.equal(fb.flat, fa.flat) and torch.equal(ob.exp_avg_sq, oa.exp_avg_sq)
+
+
+def test_trainer_with_lazy_table_adam_tracks_the_dense_trainer():
+    """NRMSTrainer with the lazy table optimizer (default on one GPU) against NRMSTrainer(lazy_adam=False) on the same ragged
+    batches and dropout seeds: the loss sequences agree to rounding (the backward's atomics are order-dependent at 1e-7, so
+    bitwise equality is the optimizer-level test's job), an evaluation forward between steps and `state_dict()` see flushed
+    tables (forward pre-hook / state-dict pre-hook), and a saved optimizer state resumes."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.nrms_module import prepare_batch
+    from newsreclib_amd.synthetic import make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    _lib.set_gemm_engine("bf16x3")
+    vocab = 400
+    params = O.make_params(vocab, seed=3)
+    mods, trs = [], []
+    for lazy in (True, False):
+        mod = build_module(params, p_drop=0.2, device=DEV)
+        te = mod.news_encoder.text_encoders["title"]
+        orig = te.forward
+        te.forward = (lambda o: (lambda text, seed=None, **kw: o(text, seed=77, **kw)))(orig)
+        mods.append(mod)
+        trs.append(NRMSTrainer(mod, lr=1e-3, lazy_adam=lazy))
+    assert trs[0].lazy is not None and trs[1].lazy is None
+    batches = [batch_to(make_batch(5 + i % 3, vocab, "ragged", seed=50 + i), DEV) for i in range(12)]
+    for i, b in enumerate(batches):
+        la, lb = float(trs[0].step(prepare_batch(dict(b)))), float(trs[1].step(prepare_batch(dict(b))))
+        assert abs(la - lb) <= 2e-5 * max(1.0, abs(lb)), (i, la, lb)
+        if i == 5:
+            assert trs[0].lazy.pending
+            with torch.no_grad():
+                ea = mods[0].eval()(dict(b)).cpu()
+                eb = mods[1].eval()(dict(b)).cpu()
+            assert not trs[0].lazy.pending, "an evaluation forward must see a flushed table"
+            assert _maxerr(ea, eb) <= 1e-4
+    sd = mods[0].state_dict()
+    assert not trs[0].lazy.pending
+    wa = sd["news_encoder.text_encoders.title.embedding_layer.weight"].cpu()
+    wb = mods[1].state_dict()["news_encoder.text_encoders.title.embedding_layer.weight"].cpu()
+    # Adam turns a rounding-level gradient difference into a +-lr step for a few elements: bound the bulk tightly, the rest by 2 lr per step
+    d = (wa - wb).abs()
+    assert float(d.max()) <= 12 * 2.1e-3 and float((d > 2e-5).float().mean()) <= 0.02, (float(d.max()), float((d > 2e-5).float().mean()))
+    state = trs[0].state_dict()
+    trs[0].load_state_dict(state)
+    assert int(trs[0].lazy.last.min()) == trs[0].opt.step_count == 12
+    float(trs[0].step(prepare_batch(dict(batches[0]))))
+    trs[0].lazy.check()
+
+
 def test_switches_travel_with_the_call():
     """The kernel-selection switches select private workspace formats.  They are per call (NrlBlockParams.options): the
     autograd forward captures the word and hands it to its backward, so (a) a backward still reads the workspace in the
