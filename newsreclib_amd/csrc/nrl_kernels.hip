@@ -962,18 +962,22 @@ int ce_loss_fwd_bwd(const float* scores, const float* y, int64_t B, int64_t C, f
 }
 
 // =============================================================================================
-// dense Adam (torch _single_tensor_adam arithmetic), HBM-bound: 4 reads + 4 writes per element
+// dense Adam (the update rule of torch _single_tensor_adam; see adam_elem for the arithmetic), HBM-bound: 4 reads + 4 writes per element
 // =============================================================================================
 struct AdamConst {
   float b1, b2, one_m_b1, one_m_b2, step_size, inv_sqrt_bc2, eps, grad_scale;
 };
 
+// One element, one step.  Every operation is spelled out (no contraction left to the compiler), so the dense kernel and the
+// lazy row kernel below execute the SAME instruction sequence and a replayed zero-gradient step reproduces the dense one
+// bit for bit.  sqrt and the reciprocal are the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32: the relative error they add to an
+// update of size <= lr is ~2e-7 (the IEEE sequences cost ~20 instructions per element, which is what a replayed step pays).
 __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, const AdamConst& k) {
-  const float gg = g * k.grad_scale;
-  m = m * k.b1 + k.one_m_b1 * gg;
-  v = v * k.b2 + k.one_m_b2 * gg * gg;
-  const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
-  p = p - k.step_size * (m / denom);
+  const float gg = __fmul_rn(g, k.grad_scale);
+  m = __fmaf_rn(k.one_m_b1, gg, __fmul_rn(m, k.b1));
+  v = __fmaf_rn(__fmul_rn(k.one_m_b2, gg), gg, __fmul_rn(v, k.b2));
+  const float denom = __fmaf_rn(__builtin_amdgcn_sqrtf(v), k.inv_sqrt_bc2, k.eps);
+  p = __fmaf_rn(-k.step_size, __fmul_rn(m, __builtin_amdgcn_rcpf(denom)), p);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1047,59 +1051,72 @@ struct AdamRowsArgs {
   float step_size[ADAM_WIN], inv_sqrt_bc2[ADAM_WIN];
 };
 
+// CAND candidate rows per 256-thread workgroup: 32 where a mark selects a sparse subset (several rows per wave), 4 for the
+// flushes (one row per wave: a flushed row replays up to `period` steps, a long dependent chain).  A lane owns one float4 and
+// one single float of every 320-float chunk of the row (D = 300: 5 elements per lane, one pass).
+template <int CAND>
 __global__ void __launch_bounds__(256) adam_rows_kernel(const AdamRowsArgs A) {
-  __shared__ int s_rows[64];
+  __shared__ int s_rows[CAND];
   __shared__ int s_n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_n = 0;
-  __syncthreads();
   if (tid < 64) {
-    const int64_t j = (int64_t)blockIdx.x * 64 + tid;
+    const int64_t j = (int64_t)blockIdx.x * CAND + tid;
     bool take = false;
-    int64_t r = 0;
-    if (j < A.n_cand) {
-      r = A.offset + j * A.stride;
+    if (tid < CAND && j < A.n_cand) {
+      const int64_t r = A.offset + j * A.stride;
       take = (A.mark == nullptr || A.mark[r] == A.tag) && (A.with_grad || A.last[r] < A.upto0);
     }
     const unsigned long long b = __ballot(take);
-    if (take) s_rows[__popcll(b & ((1ull << lane) - 1ull))] = (int)(j - (int64_t)blockIdx.x * 64);
+    if (take) s_rows[__popcll(b & ((1ull << lane) - 1ull))] = tid;
     if (lane == 0) s_n = __popcll(b);
   }
   __syncthreads();
   const int n = s_n;
-  const int D4 = A.D >> 2;
+  const int D = A.D;
   for (int i = wave; i < n; i += 4) {
-    const int64_t r = A.offset + ((int64_t)blockIdx.x * 64 + s_rows[i]) * A.stride;
-    const int from = A.last[r];
+    const int64_t r = A.offset + ((int64_t)blockIdx.x * CAND + s_rows[i]) * A.stride;
+    const int from = __builtin_amdgcn_readfirstlane(A.last[r]);
     if (A.upto0 - from >= ADAM_WIN && lane == 0) A.status[0] = 1;
-    float4* p4 = reinterpret_cast<float4*>(A.p + r * A.D);
-    float4* m4 = reinterpret_cast<float4*>(A.m + r * A.D);
-    float4* v4 = reinterpret_cast<float4*>(A.v + r * A.D);
-    float4* g4 = reinterpret_cast<float4*>(A.g + r * A.D);
-    for (int c = lane; c < D4; c += 64) {
-      float4 pp = p4[c], mm = m4[c], vv = v4[c];
+    float* const pr = A.p + r * D;
+    float* const mr = A.m + r * D;
+    float* const vr = A.v + r * D;
+    float* const gr = A.g + r * D;
+    for (int base = 0; base < D; base += 320) {
+      const int q = base + 4 * lane;                       // this lane's float4 ...
+      const bool has4 = q + 3 < D && q < base + 256;
+      const int e = base + 256 + lane;                     // ... and its single float of the chunk
+      const bool has1 = e < D && e < base + 320;
+      float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp;
+      float p1 = 0.f, m1 = 0.f, v1 = 0.f;
+      if (has4) { pp = *reinterpret_cast<const float4*>(pr + q); mm = *reinterpret_cast<const float4*>(mr + q); vv = *reinterpret_cast<const float4*>(vr + q); }
+      if (has1) { p1 = pr[e]; m1 = mr[e]; v1 = vr[e]; }
       AdamConst k = A.base;
       for (int s = from + 1; s <= A.upto0; ++s) {
         k.step_size = A.step_size[s & (ADAM_WIN - 1)];
         k.inv_sqrt_bc2 = A.inv_sqrt_bc2[s & (ADAM_WIN - 1)];
-        float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;      // the row's gradient at a missed step
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, z4 = 0.f;   // the row's gradient at a missed step
         adam_elem(pp.x, z0, mm.x, vv.x, k);
         adam_elem(pp.y, z1, mm.y, vv.y, k);
         adam_elem(pp.z, z2, mm.z, vv.z, k);
         adam_elem(pp.w, z3, mm.w, vv.w, k);
+        adam_elem(p1, z4, m1, v1, k);
       }
       if (A.with_grad) {
         const int s = A.upto0 + 1;
         k.step_size = A.step_size[s & (ADAM_WIN - 1)];
         k.inv_sqrt_bc2 = A.inv_sqrt_bc2[s & (ADAM_WIN - 1)];
-        float4 gg = g4[c];
+        float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+        float g1 = 0.f;
+        if (has4) { gg = *reinterpret_cast<const float4*>(gr + q); *reinterpret_cast<float4*>(gr + q) = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (has1) { g1 = gr[e]; gr[e] = 0.f; }
         adam_elem(pp.x, gg.x, mm.x, vv.x, k);
         adam_elem(pp.y, gg.y, mm.y, vv.y, k);
         adam_elem(pp.z, gg.z, mm.z, vv.z, k);
         adam_elem(pp.w, gg.w, mm.w, vv.w, k);
-        g4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        adam_elem(p1, g1, m1, v1, k);
       }
-      p4[c] = pp; m4[c] = mm; v4[c] = vv;
+      if (has4) { *reinterpret_cast<float4*>(pr + q) = pp; *reinterpret_cast<float4*>(mr + q) = mm; *reinterpret_cast<float4*>(vr + q) = vv; }
+      if (has1) { pr[e] = p1; mr[e] = m1; vr[e] = v1; }
     }
     if (lane == 0) A.last[r] = A.upto0 + (A.with_grad ? 1 : 0);
   }
@@ -1148,7 +1165,8 @@ int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int 
     A.step_size[s & (ADAM_WIN - 1)] = ss;
     A.inv_sqrt_bc2[s & (ADAM_WIN - 1)] = ib;
   }
-  hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((A.n_cand + 63) / 64)), dim3(256), 0, stream, A);
+  if (mark != nullptr) hipLaunchKernelGGL(adam_rows_kernel<32>, dim3((unsigned)((A.n_cand + 31) / 32)), dim3(256), 0, stream, A);
+  else hipLaunchKernelGGL(adam_rows_kernel<4>, dim3((unsigned)((A.n_cand + 3) / 4)), dim3(256), 0, stream, A);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
