@@ -1060,7 +1060,9 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(const AdamRowsArgs A) {
   __shared__ int s_n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 64) {
-    const int64_t j = (int64_t)blockIdx.x * CAND + tid;
+    // candidates are dealt round-robin over the workgroups: the token ids of a batch crowd the low rows (Zipf), and contiguous
+    // blocks of candidates would hand a few workgroups 32 marked rows and most of them none
+    const int64_t j = (int64_t)blockIdx.x + (int64_t)tid * gridDim.x;
     bool take = false;
     if (tid < CAND && j < A.n_cand) {
       const int64_t r = A.offset + j * A.stride;
@@ -1074,7 +1076,7 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(const AdamRowsArgs A) {
   const int n = s_n;
   const int D = A.D;
   for (int i = wave; i < n; i += 4) {
-    const int64_t r = A.offset + ((int64_t)blockIdx.x * CAND + s_rows[i]) * A.stride;
+    const int64_t r = A.offset + ((int64_t)blockIdx.x + (int64_t)s_rows[i] * gridDim.x) * A.stride;
     const int from = __builtin_amdgcn_readfirstlane(A.last[r]);
     if (A.upto0 - from >= ADAM_WIN && lane == 0) A.status[0] = 1;
     float* const pr = A.p + r * D;
