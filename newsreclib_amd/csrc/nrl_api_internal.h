@@ -136,9 +136,11 @@ static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 //                                          instead of ONE row for the run of padding tokens from token 15 on (no dropout:
 //                                          identical rows; news_classify_kernel + the SHARE shapes of news_fused_fwd_kernel /
 //                                          news_tail_fwd_kernel; bit-identical output)
+//   news_tail_od    NRL_NEWS_TAIL_OD=0     the out-projection's activation gradient d_o = dy W_o as its own row-panel launch
+//                                          instead of phase D of the fused tail backward (nrl_news_tail.h)
 enum {
   O_NEWS_FUSED = 0, O_NEWS_FUSED_BWD, O_NEWS_ATTN_MFMA, O_NEWS_PLANES, O_NEWS_OD_PLANES, O_NEWS_AA_PLANES, O_WGRAD_2STEP,
-  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_NEWS_QKV_PLANES, O_NEWS_PAD_SHARE, O_COUNT
+  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_NEWS_QKV_PLANES, O_NEWS_PAD_SHARE, O_NEWS_TAIL_OD, O_COUNT
 };
 extern std::atomic<uint32_t> g_opt_default;  // (nrl_api.hip)
 extern thread_local int64_t t_opts;
@@ -622,6 +624,9 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
     b.y_planes = reinterpret_cast<const unsigned char*>(w.yp); b.w = w.w; b.d_out = d_out; b.img_a = bp.rp.tail_a.img;
     b.img_ad = bp.rp.tail_ad.img; b.q_a = P->att_query; b.n_news = s.pool_groups; b.L = s.pool_len; b.D = D; b.Q = Q;
     b.drop2 = drop2; b.dpre_planes = tpl; b.dy_planes = dyp; b.dq_a = G->att_query;
+    // d_o = dy W_o inside the same launch (phase D) when the dgrad image has the tail's geometry
+    const bool od_fused = opt(O_NEWS_TAIL_OD) && bp.rp.out_d.nblk == NT_FB && bp.rp.out_d.kblocks == NT_KB;
+    if (od_fused) { b.img_od = bp.rp.out_d.img; b.d_o = w.d_o; }
     NRL_TRY(news_tail_bwd(b, st));
     if (side != nullptr && side->s != nullptr && news_fork_on(s)) {
       NRL_HIP(hipEventRecord(side->fork, st));
@@ -630,7 +635,7 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
       NRL_HIP(hipEventRecord(side->join, side->s));      // the caller makes `st` wait for it at the end of phase 1
     }
     // d_o = dy W_o
-    NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
+    if (!od_fused) NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
     if (!attention_elsewhere) {
     if (block_attn_x3(s)) NRL_TRY(attn_bwd_x3(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
     else NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));

@@ -114,15 +114,19 @@ __device__ __forceinline__ float nt_tanh(float x) {
 // 8 = no phase-1 MFMAs, 16 = no phase-2 MFMAs, 32 = no pooling reduction
 // SAVE: 0 = evaluation (nothing but `out`), 1 = training (y planes + w; the fused backward recomputes tanh), 2 = training with
 // the tanh output t as well (backward through pool_bwd_pre)
-template <int SAVE, int WAVES, int ABL = 0, bool SHARE = false>
-__global__ void __launch_bounds__(WAVES * 64, 2) news_tail_fwd_kernel(const NewsTailArgs P) {
-  static_assert(!(SHARE && SAVE), "pad-row sharing is for evaluation forwards");
+// The kernel's work for one wave's news in two compile-time shapes: NTB = 2 token blocks, and (SH: pad-row sharing, a short
+// news of an evaluation call) NTB = 1.  Both execute the same barriers and the same share of the weight DMA, so waves of
+// either shape can share a workgroup.  (A function template rather than a lambda inside the kernel: as a nested closure the
+// evaluation shapes kept 40-odd captured values in scratch.)
+template <int SAVE, int WAVES, int ABL, bool SH>
+__device__ __forceinline__ void news_tail_fwd_body(const NewsTailArgs& P, unsigned char* const smem, const int64_t news,
+                                                   const bool news_ok) {
   using Cfg = NtCfg<WAVES>;
   constexpr int NT_SLOT = Cfg::SLOT, NT_SLOTS = Cfg::SLOTS, LOOK = Cfg::LOOK, KPARTS = Cfg::KPARTS;
   constexpr int NT_NCHUNK = NT_KB + 4 * KPARTS;       // phase 2: 4 query groups x KPARTS parts of the reduction
   constexpr int PPW = (40 + WAVES - 1) / WAVES;       // DMA pieces per wave and chunk (<= 40 pieces per chunk)
   constexpr int STREAM = (ABL & 64) ? 0 : 1;          // y planes: streaming stores (probe: ABL 64 = plain)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NT_SLOTS * NT_SLOT + 1024];
+  constexpr int NTB = SH ? 1 : 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,16 +138,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_fwd_kernel(const News
   __syncthreads();
 
   const int L = P.L, D = P.D, Q = P.Q;
-  const int64_t news_raw = (int64_t)blockIdx.x * WAVES + wave;
-  const bool news_ok = news_raw < P.n_news;
-  int64_t news = news_ok ? news_raw : 0;            // idle waves of the last workgroup recompute news 0 and store nothing
-  bool short_w = false;                             // SHARE: position in the short-first list < n_short (wave-uniform)
-  if constexpr (SHARE) {
-    if (news_ok) {
-      news = __builtin_amdgcn_readfirstlane(P.perm[news_raw]);
-      short_w = news_raw < (int64_t)__builtin_amdgcn_readfirstlane(*P.n_short);
-    }
-  }
   const int64_t row0 = news * L;
 
   // ---- weight DMA: chunk c < NT_KB = k-block c of the W_o image (38 pieces of 1 KiB); chunk NT_KB + KPARTS grp + part =
@@ -188,330 +182,341 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_fwd_kernel(const News
     mrow[tb] = row0 + (tok_ok[tb] ? t : L - 1);
     orow[tb] = P.o_planes + ((mrow[tb] >> 4) * NT_FB + (g >> 1)) * 1024 + (mrow[tb] & 15) * 32 + (g & 1) * 16;
   }
-  // Everything from here on exists in two compile-time shapes: NTB = 2 token blocks, and (SHARE, a short news) NTB = 1.  Both
-  // execute the same barriers and the same share of the weight DMA.
-  auto body = [&](auto sh_c) {
-    constexpr bool SH = decltype(sh_c)::value;
-    constexpr int NTB = SH ? 1 : 2;
-    auto load_o = [&](int kb, bf16x8 (&oh)[2], bf16x8 (&ol)[2]) {
-      // block column 19 (k-block 9, g >= 2) does not exist: read a valid address, zero the fragment
-      const bool dead = kb == NT_KB - 1 && g >= 2;
-  #pragma unroll
-      for (int tb = 0; tb < NTB; ++tb) {
-        const unsigned char* p = orow[tb] + (dead ? 0 : kb * 2048);
-        uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + 512);
-        if (dead) { h = make_uint4(0u, 0u, 0u, 0u); l = h; }
-        oh[tb] = __builtin_bit_cast(bf16x8, h);
-        ol[tb] = __builtin_bit_cast(bf16x8, l);
-      }
-    };
+  auto load_o = [&](int kb, bf16x8 (&oh)[2], bf16x8 (&ol)[2]) {
+    // block column 19 (k-block 9, g >= 2) does not exist: read a valid address, zero the fragment
+    const bool dead = kb == NT_KB - 1 && g >= 2;
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      const unsigned char* p = orow[tb] + (dead ? 0 : kb * 2048);
+      uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + 512);
+      if (dead) { h = make_uint4(0u, 0u, 0u, 0u); l = h; }
+      oh[tb] = __builtin_bit_cast(bf16x8, h);
+      ol[tb] = __builtin_bit_cast(bf16x8, l);
+    }
+  };
 
-    // =============================== phase 1: y^T = W_o o^T ===============================================
-    f32x4 acc[NT_FB][2];
-  #pragma unroll
-    for (int fb = 0; fb < NT_FB; ++fb)
-  #pragma unroll
-      for (int tb = 0; tb < 2; ++tb) acc[fb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // =============================== phase 1: y^T = W_o o^T ===============================================
+  f32x4 acc[NT_FB][2];
+#pragma unroll
+  for (int fb = 0; fb < NT_FB; ++fb)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) acc[fb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int P1_PAIRS = (NT_FB + 1) / 2;
-    auto p1_read = [&](const unsigned char* base, int p, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
-  #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int fb = 2 * p + jj < NT_FB ? 2 * p + jj : NT_FB - 1;
-        wh[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048);
-        wl[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048 + 1024);
+  constexpr int P1_PAIRS = (NT_FB + 1) / 2;
+  auto p1_read = [&](const unsigned char* base, int p, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int fb = 2 * p + jj < NT_FB ? 2 * p + jj : NT_FB - 1;
+      wh[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048);
+      wl[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048 + 1024);
+    }
+  };
+  auto p1_mfma = [&](int p, const bf16x8 (&wh)[2], const bf16x8 (&wl)[2], const bf16x8 (&oh)[2], const bf16x8 (&ol)[2]) {
+    if constexpr (ABL & 8) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(wh[jj]), "v"(wl[jj]));
+      return;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        if (2 * p + jj < NT_FB)
+#pragma unroll
+          for (int tb = 0; tb < NTB; ++tb)
+            acc[2 * p + jj][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj], pass == 0 ? ol[tb] : oh[tb],
+                                                                          acc[2 * p + jj][tb], 0, 0, 0);
+  };
+  auto p1_chunk = [&](int slot, const bf16x8 (&oh)[2], const bf16x8 (&ol)[2]) {
+    const unsigned char* base = smem + slot * NT_SLOT + lane * 16;
+    bf16x8 wh0[2], wl0[2], wh1[2], wl1[2];
+    p1_read(base, 0, wh0, wl0);
+#pragma unroll
+    for (int p = 0; p < P1_PAIRS; p += 2) {
+      if (p + 1 < P1_PAIRS) p1_read(base, p + 1, wh1, wl1);
+      p1_mfma(p, wh0, wl0, oh, ol);
+      if (p + 1 < P1_PAIRS) {
+        if (p + 2 < P1_PAIRS) p1_read(base, p + 2, wh0, wl0);
+        p1_mfma(p + 1, wh1, wl1, oh, ol);
       }
-    };
-    auto p1_mfma = [&](int p, const bf16x8 (&wh)[2], const bf16x8 (&wl)[2], const bf16x8 (&oh)[2], const bf16x8 (&ol)[2]) {
-      if constexpr (ABL & 8) {
-  #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(wh[jj]), "v"(wl[jj]));
-        return;
-      }
-  #pragma unroll
-      for (int pass = 0; pass < 3; ++pass)
-  #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-          if (2 * p + jj < NT_FB)
-  #pragma unroll
-            for (int tb = 0; tb < NTB; ++tb)
-              acc[2 * p + jj][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj], pass == 0 ? ol[tb] : oh[tb],
-                                                                            acc[2 * p + jj][tb], 0, 0, 0);
-    };
-    auto p1_chunk = [&](int slot, const bf16x8 (&oh)[2], const bf16x8 (&ol)[2]) {
-      const unsigned char* base = smem + slot * NT_SLOT + lane * 16;
-      bf16x8 wh0[2], wl0[2], wh1[2], wl1[2];
-      p1_read(base, 0, wh0, wl0);
-  #pragma unroll
-      for (int p = 0; p < P1_PAIRS; p += 2) {
-        if (p + 1 < P1_PAIRS) p1_read(base, p + 1, wh1, wl1);
-        p1_mfma(p, wh0, wl0, oh, ol);
-        if (p + 1 < P1_PAIRS) {
-          if (p + 2 < P1_PAIRS) p1_read(base, p + 2, wh0, wl0);
-          p1_mfma(p + 1, wh1, wl1, oh, ol);
+    }
+    if constexpr (!(ABL & 8)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int p = 0; p < P1_PAIRS; ++p) {
+        if (p + 1 < P1_PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        if (2 * p + 1 < NT_FB) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTB, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTB, 0);
         }
       }
-      if constexpr (!(ABL & 8)) {
+    }
+  };
+
+#pragma unroll
+  for (int c = 0; c < LOOK; ++c) issue_chunk(c);
+  {
+    bf16x8 oha[2], ola[2], ohb[2], olb[2];
+    load_o(0, oha, ola);
+    auto step = [&](int kb, const bf16x8 (&ch)[2], const bf16x8 (&cl)[2], bf16x8 (&nh)[2], bf16x8 (&nl)[2]) {
+      wait_vmcnt<0>();                     // chunk kb has landed for this wave (issued LOOK chunks ago) ...
+      __builtin_amdgcn_s_barrier();        // ... and for all; everyone is done with the slot chunk kb + LOOK goes to
+      issue_chunk(kb + LOOK);
+      load_o(kb + 1 < NT_KB ? kb + 1 : kb, nh, nl);
+      __builtin_amdgcn_sched_barrier(0);
+      p1_chunk(kb % NT_SLOTS, ch, cl);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kb = 0; kb < NT_KB; kb += 2) {
+      step(kb, oha, ola, ohb, olb);
+      step(kb + 1, ohb, olb, oha, ola);
+    }
+  }
+
+  // =============================== epilogue 1: dropout, split, (training) y planes =======================
+  bf16x8 yh[NT_KS][2], yl[NT_KS][2];
+#pragma unroll
+  for (int tb = 0; tb < NTB; ++tb) {
+    const uint32_t idx_row = (uint32_t)mrow[tb] * (uint32_t)D;
+#pragma unroll
+    for (int s = 0; s < NT_KS; ++s) {
+      f32x4 v0 = acc[2 * s][tb];
+      f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (2 * s + 1 < NT_FB) v1 = acc[2 * s + 1][tb];
+      const int f0 = 32 * s + 4 * g;
+      if (!(ABL & 1) && P.drop2.thresh != 0u) {
+        const uint32_t i0 = idx_row + (uint32_t)f0, i1 = i0 + 16u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v0[r] *= P.drop2.mult(i0 + r);
+          if (2 * s + 1 < NT_FB) v1[r] *= P.drop2.mult(i1 + r);
+        }
+      }
+      // ones column at feature D (block 18, row 12): the bias row of the W_a image / the bias gradient's operand
+      if (2 * s == NT_FB - 1) {
+        if (f0 == D) v0[0] = 1.0f;
+      }
+      rp_split8(make_float4(v0[0], v0[1], v0[2], v0[3]), make_float4(v1[0], v1[1], v1[2], v1[3]), yh[s][tb], yl[s][tb]);
+    }
+  }
+  // y planes of k-step s: block columns 2s, 2s + 1, 8 bytes per lane and plane
+  auto store_y = [&](int s) {
+    if (!SAVE || (ABL & 2) || !news_ok) return;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      // (no token mask: the pad columns hold a bit-identical copy of the last token and store it to the same address;
+      //  opaque row: hipcc otherwise hoists the 80 store addresses out of phase 2 and spills them)
+      int64_t m = mrow[tb];
+      asm volatile("" : "+v"(m));
+      unsigned char* dst = P.y_planes + ((m >> 4) * NT_FB + 2 * s) * 1024 + (m & 15) * 32 + 8 * g;
+      const uint4 h = __builtin_bit_cast(uint4, yh[s][tb]), l = __builtin_bit_cast(uint4, yl[s][tb]);
+      nt_store8<STREAM>(dst, h.x, h.y);
+      nt_store8<STREAM>(dst + 512, l.x, l.y);
+      if (2 * s + 1 < NT_FB) {
+        nt_store8<STREAM>(dst + 1024, h.z, h.w);
+        nt_store8<STREAM>(dst + 1536, l.z, l.w);
+      }
+    }
+  };
+
+  // =============================== phase 2: pre^T = W_a y^T, tanh, . q_a =================================
+  float apart[2] = {0.f, 0.f};
+  nt_static_for<4>([&](auto grp_c) {
+    constexpr int grp = decltype(grp_c)::value;
+    constexpr int nb0 = grp == 0 ? 0 : 1 + 3 * grp, nbs = grp == 0 ? 4 : 3;
+    f32x4 pacc[4][2];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) pacc[nb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    nt_static_for<KPARTS>([&](auto part_c) {
+      constexpr int part = decltype(part_c)::value;
+      constexpr int c = NT_KB + KPARTS * grp + part;
+      constexpr int ks0 = nt_kp0(KPARTS, part), nks = nt_kp0(KPARTS, part + 1) - ks0;
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      issue_chunk(c + LOOK);
+      // training stores under this chunk's MFMAs: k-step j of the y planes in the j-th chunk of phase 2 (the first chunks
+      // take the k-steps that are left over when there are fewer chunks than k-steps)
+      {
+        constexpr int j = c - NT_KB, nch = 4 * KPARTS;
+        if constexpr (j < NT_KS) store_y(j);
+        if constexpr (nch + j < NT_KS) store_y(nch + j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* base = smem + (c % NT_SLOTS) * NT_SLOT + lane * 16;
+      constexpr int nsteps = nks * nbs;              // step i = (k-step ks0 + i / nbs, query block nb0 + i % nbs)
+      constexpr int npairs = (nsteps + 1) / 2;
+      auto p2_read = [&](int p, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int i = 2 * p + jj < nsteps ? 2 * p + jj : nsteps - 1;
+          wh[jj] = *reinterpret_cast<const bf16x8*>(base + i * 2048);
+          wl[jj] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + 1024);
+        }
+      };
+      auto p2_mfma = [&](int p, const bf16x8 (&wh)[2], const bf16x8 (&wl)[2]) {
+        if constexpr (ABL & 16) {
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(wh[jj]), "v"(wl[jj]));
+          return;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int i = 2 * p + jj;
+            if (i < nsteps) {
+              const int s = ks0 + i / nbs, nb = i % nbs;
+#pragma unroll
+              for (int tb = 0; tb < NTB; ++tb)
+                pacc[nb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj],
+                                                                       pass == 0 ? yl[s][tb] : yh[s][tb], pacc[nb][tb], 0, 0, 0);
+            }
+          }
+      };
+      bf16x8 wh0[2], wl0[2], wh1[2], wl1[2];
+      p2_read(0, wh0, wl0);
+#pragma unroll
+      for (int p = 0; p < npairs; p += 2) {
+        if (p + 1 < npairs) p2_read(p + 1, wh1, wl1);
+        p2_mfma(p, wh0, wl0);
+        if (p + 1 < npairs) {
+          if (p + 2 < npairs) p2_read(p + 2, wh0, wl0);
+          p2_mfma(p + 1, wh1, wl1);
+        }
+      }
+      if constexpr (!(ABL & 16)) {
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-  #pragma unroll
-        for (int p = 0; p < P1_PAIRS; ++p) {
-          if (p + 1 < P1_PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-          if (2 * p + 1 < NT_FB) {
+#pragma unroll
+        for (int p = 0; p < npairs; ++p) {
+          if (p + 1 < npairs) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          if (2 * p + 1 < nsteps) {
             __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTB, 0);
           } else {
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTB, 0);
           }
         }
       }
-    };
-
-  #pragma unroll
-    for (int c = 0; c < LOOK; ++c) issue_chunk(c);
-    {
-      bf16x8 oha[2], ola[2], ohb[2], olb[2];
-      load_o(0, oha, ola);
-      auto step = [&](int kb, const bf16x8 (&ch)[2], const bf16x8 (&cl)[2], bf16x8 (&nh)[2], bf16x8 (&nl)[2]) {
-        wait_vmcnt<0>();                     // chunk kb has landed for this wave (issued LOOK chunks ago) ...
-        __builtin_amdgcn_s_barrier();        // ... and for all; everyone is done with the slot chunk kb + LOOK goes to
-        issue_chunk(kb + LOOK);
-        load_o(kb + 1 < NT_KB ? kb + 1 : kb, nh, nl);
-        __builtin_amdgcn_sched_barrier(0);
-        p1_chunk(kb % NT_SLOTS, ch, cl);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      for (int kb = 0; kb < NT_KB; kb += 2) {
-        step(kb, oha, ola, ohb, olb);
-        step(kb + 1, ohb, olb, oha, ola);
-      }
-    }
-
-    // =============================== epilogue 1: dropout, split, (training) y planes =======================
-    bf16x8 yh[NT_KS][2], yl[NT_KS][2];
-  #pragma unroll
-    for (int tb = 0; tb < NTB; ++tb) {
-      const uint32_t idx_row = (uint32_t)mrow[tb] * (uint32_t)D;
-  #pragma unroll
-      for (int s = 0; s < NT_KS; ++s) {
-        f32x4 v0 = acc[2 * s][tb];
-        f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (2 * s + 1 < NT_FB) v1 = acc[2 * s + 1][tb];
-        const int f0 = 32 * s + 4 * g;
-        if (!(ABL & 1) && P.drop2.thresh != 0u) {
-          const uint32_t i0 = idx_row + (uint32_t)f0, i1 = i0 + 16u;
-  #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v0[r] *= P.drop2.mult(i0 + r);
-            if (2 * s + 1 < NT_FB) v1[r] *= P.drop2.mult(i1 + r);
-          }
-        }
-        // ones column at feature D (block 18, row 12): the bias row of the W_a image / the bias gradient's operand
-        if (2 * s == NT_FB - 1) {
-          if (f0 == D) v0[0] = 1.0f;
-        }
-        rp_split8(make_float4(v0[0], v0[1], v0[2], v0[3]), make_float4(v1[0], v1[1], v1[2], v1[3]), yh[s][tb], yl[s][tb]);
-      }
-    }
-    // y planes of k-step s: block columns 2s, 2s + 1, 8 bytes per lane and plane
-    auto store_y = [&](int s) {
-      if (!SAVE || (ABL & 2) || !news_ok) return;
-  #pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        // (no token mask: the pad columns hold a bit-identical copy of the last token and store it to the same address;
-        //  opaque row: hipcc otherwise hoists the 80 store addresses out of phase 2 and spills them)
-        int64_t m = mrow[tb];
-        asm volatile("" : "+v"(m));
-        unsigned char* dst = P.y_planes + ((m >> 4) * NT_FB + 2 * s) * 1024 + (m & 15) * 32 + 8 * g;
-        const uint4 h = __builtin_bit_cast(uint4, yh[s][tb]), l = __builtin_bit_cast(uint4, yl[s][tb]);
-        nt_store8<STREAM>(dst, h.x, h.y);
-        nt_store8<STREAM>(dst + 512, l.x, l.y);
-        if (2 * s + 1 < NT_FB) {
-          nt_store8<STREAM>(dst + 1024, h.z, h.w);
-          nt_store8<STREAM>(dst + 1536, l.z, l.w);
-        }
-      }
-    };
-
-    // =============================== phase 2: pre^T = W_a y^T, tanh, . q_a =================================
-    float apart[2] = {0.f, 0.f};
-    nt_static_for<4>([&](auto grp_c) {
-      constexpr int grp = decltype(grp_c)::value;
-      constexpr int nb0 = grp == 0 ? 0 : 1 + 3 * grp, nbs = grp == 0 ? 4 : 3;
-      f32x4 pacc[4][2];
-  #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-  #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) pacc[nb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      nt_static_for<KPARTS>([&](auto part_c) {
-        constexpr int part = decltype(part_c)::value;
-        constexpr int c = NT_KB + KPARTS * grp + part;
-        constexpr int ks0 = nt_kp0(KPARTS, part), nks = nt_kp0(KPARTS, part + 1) - ks0;
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        issue_chunk(c + LOOK);
-        // training stores under this chunk's MFMAs: k-step j of the y planes in the j-th chunk of phase 2 (the first chunks
-        // take the k-steps that are left over when there are fewer chunks than k-steps)
-        {
-          constexpr int j = c - NT_KB, nch = 4 * KPARTS;
-          if constexpr (j < NT_KS) store_y(j);
-          if constexpr (nch + j < NT_KS) store_y(nch + j);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* base = smem + (c % NT_SLOTS) * NT_SLOT + lane * 16;
-        constexpr int nsteps = nks * nbs;              // step i = (k-step ks0 + i / nbs, query block nb0 + i % nbs)
-        constexpr int npairs = (nsteps + 1) / 2;
-        auto p2_read = [&](int p, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
-  #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int i = 2 * p + jj < nsteps ? 2 * p + jj : nsteps - 1;
-            wh[jj] = *reinterpret_cast<const bf16x8*>(base + i * 2048);
-            wl[jj] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + 1024);
-          }
-        };
-        auto p2_mfma = [&](int p, const bf16x8 (&wh)[2], const bf16x8 (&wl)[2]) {
-          if constexpr (ABL & 16) {
-  #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) asm volatile("" ::"v"(wh[jj]), "v"(wl[jj]));
-            return;
-          }
-  #pragma unroll
-          for (int pass = 0; pass < 3; ++pass)
-  #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-              const int i = 2 * p + jj;
-              if (i < nsteps) {
-                const int s = ks0 + i / nbs, nb = i % nbs;
-  #pragma unroll
-                for (int tb = 0; tb < NTB; ++tb)
-                  pacc[nb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj],
-                                                                         pass == 0 ? yl[s][tb] : yh[s][tb], pacc[nb][tb], 0, 0, 0);
-              }
-            }
-        };
-        bf16x8 wh0[2], wl0[2], wh1[2], wl1[2];
-        p2_read(0, wh0, wl0);
-  #pragma unroll
-        for (int p = 0; p < npairs; p += 2) {
-          if (p + 1 < npairs) p2_read(p + 1, wh1, wl1);
-          p2_mfma(p, wh0, wl0);
-          if (p + 1 < npairs) {
-            if (p + 2 < npairs) p2_read(p + 2, wh0, wl0);
-            p2_mfma(p + 1, wh1, wl1);
-          }
-        }
-        if constexpr (!(ABL & 16)) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-  #pragma unroll
-          for (int p = 0; p < npairs; ++p) {
-            if (p + 1 < npairs) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            if (2 * p + 1 < nsteps) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTB, 0);
-            } else {
-              __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTB, 0);
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      // group epilogue: t = tanh(pre) (b_a came in through the ones feature), a += t . q_a over this lane's 4 queries
-  #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        if (nb >= nbs) continue;
-        const int q0 = 16 * (nb0 + nb) + 4 * g;
-        const float4 qv = *reinterpret_cast<const float4*>(qa_s + q0);
-  #pragma unroll
-        for (int tb = 0; tb < NTB; ++tb) {
-          const f32x4 pv = pacc[nb][tb];
-          const float4 tv = make_float4(nt_tanh(pv[0]), nt_tanh(pv[1]), nt_tanh(pv[2]), nt_tanh(pv[3]));
-          apart[tb] = fmaf(tv.x, qv.x, apart[tb]);
-          apart[tb] = fmaf(tv.y, qv.y, apart[tb]);
-          apart[tb] = fmaf(tv.z, qv.z, apart[tb]);
-          apart[tb] = fmaf(tv.w, qv.w, apart[tb]);
-          if (SAVE == 2 && !(ABL & 2) && news_ok && q0 < Q) {   // (pad columns: same value, same address)
-            int64_t m = mrow[tb];
-            asm volatile("" : "+v"(m));
-            *reinterpret_cast<float4*>(P.t + m * Q + q0) = tv;
-          }
-        }
-        // (pinned: the conditional stores split this epilogue into basic blocks, and hipcc sinks the dot products -- whose
-        //  result is only read after the last group -- down to the pooling, keeping every tanh value and q_a alive: spills)
-        asm volatile("" : "+v"(apart[0]), "+v"(apart[1]));
-      }
+      __builtin_amdgcn_sched_barrier(0);
     });
-
-    // =============================== softmax over the tokens, pooled sum ====================================
-    float wt[2];
-    {
-      float a[2];
-  #pragma unroll
+    // group epilogue: t = tanh(pre) (b_a came in through the ones feature), a += t . q_a over this lane's 4 queries
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      if (nb >= nbs) continue;
+      const int q0 = 16 * (nb0 + nb) + 4 * g;
+      const float4 qv = *reinterpret_cast<const float4*>(qa_s + q0);
+#pragma unroll
       for (int tb = 0; tb < NTB; ++tb) {
-        float v = apart[tb];
-        v += nf_xor16(v, lane);
-        v += nf_xor32(v, lane);
-        a[tb] = tok_ok[tb] ? v : -INFINITY;
+        const f32x4 pv = pacc[nb][tb];
+        const float4 tv = make_float4(nt_tanh(pv[0]), nt_tanh(pv[1]), nt_tanh(pv[2]), nt_tanh(pv[3]));
+        apart[tb] = fmaf(tv.x, qv.x, apart[tb]);
+        apart[tb] = fmaf(tv.y, qv.y, apart[tb]);
+        apart[tb] = fmaf(tv.z, qv.z, apart[tb]);
+        apart[tb] = fmaf(tv.w, qv.w, apart[tb]);
+        if (SAVE == 2 && !(ABL & 2) && news_ok && q0 < Q) {   // (pad columns: same value, same address)
+          int64_t m = mrow[tb];
+          asm volatile("" : "+v"(m));
+          *reinterpret_cast<float4*>(P.t + m * Q + q0) = tv;
+        }
       }
+      // (pinned: the conditional stores split this epilogue into basic blocks, and hipcc sinks the dot products -- whose
+      //  result is only read after the last group -- down to the pooling, keeping every tanh value and q_a alive: spills)
+      asm volatile("" : "+v"(apart[0]), "+v"(apart[1]));
+    }
+  });
+
+  // =============================== softmax over the tokens, pooled sum ====================================
+  float wt[2];
+  {
+    float a[2];
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+      float v = apart[tb];
+      v += nf_xor16(v, lane);
+      v += nf_xor32(v, lane);
+      a[tb] = tok_ok[tb] ? v : -INFINITY;
+    }
+    if constexpr (SH) {
+      // tokens 16 .. L - 1 of a short news ARE token 15 (same o row -> same y -> same logit): the value the lanes l15 == 15 hold
+      const float a15 = __shfl(a[0], lane | 15, 64);
+      a[1] = tok_ok[1] ? a15 : -INFINITY;
+    }
+    const float mx = nt_row_max(fmaxf(a[0], a[1]));
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float e0 = __builtin_amdgcn_exp2f((a[0] - mx) * LOG2E), e1 = __builtin_amdgcn_exp2f((a[1] - mx) * LOG2E);
+    const float inv = 1.0f / nt_row_sum(e0 + e1);
+    wt[0] = e0 * inv;
+    wt[1] = e1 * inv;
+    if (SAVE && !(ABL & 2) && news_ok && g == 0) {
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+        if (tok_ok[tb]) P.w[mrow[tb]] = wt[tb];
+    }
+  }
+  // out[f] = sum_t w_t y[t][f], y = hi + lo; feature 16 fb + 4g + r sits in k-step fb / 2, elements 4 (fb & 1) + r
+  float* const outp = P.out + news * D;
+#pragma unroll
+  for (int fb = 0; fb < NT_FB; ++fb) {
+    const int s = fb >> 1, wsel = (fb & 1) * 2;
+    float pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pr[r] = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const uint4 h = __builtin_bit_cast(uint4, yh[s][SH ? 0 : tb]), l = __builtin_bit_cast(uint4, yl[s][SH ? 0 : tb]);
+      uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
       if constexpr (SH) {
-        // tokens 16 .. L - 1 of a short news ARE token 15 (same o row -> same y -> same logit): the value the lanes l15 == 15 hold
-        const float a15 = __shfl(a[0], lane | 15, 64);
-        a[1] = tok_ok[1] ? a15 : -INFINITY;
-      }
-      const float mx = nt_row_max(fmaxf(a[0], a[1]));
-      constexpr float LOG2E = 1.4426950408889634f;
-      const float e0 = __builtin_amdgcn_exp2f((a[0] - mx) * LOG2E), e1 = __builtin_amdgcn_exp2f((a[1] - mx) * LOG2E);
-      const float inv = 1.0f / nt_row_sum(e0 + e1);
-      wt[0] = e0 * inv;
-      wt[1] = e1 * inv;
-      if (SAVE && !(ABL & 2) && news_ok && g == 0) {
-  #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-          if (tok_ok[tb]) P.w[mrow[tb]] = wt[tb];
-      }
-    }
-    // out[f] = sum_t w_t y[t][f], y = hi + lo; feature 16 fb + 4g + r sits in k-step fb / 2, elements 4 (fb & 1) + r
-    float* const outp = P.out + news * D;
-  #pragma unroll
-    for (int fb = 0; fb < NT_FB; ++fb) {
-      const int s = fb >> 1, wsel = (fb & 1) * 2;
-      float pr[4];
-  #pragma unroll
-      for (int r = 0; r < 4; ++r) pr[r] = 0.f;
-  #pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const uint4 h = __builtin_bit_cast(uint4, yh[s][SH ? 0 : tb]), l = __builtin_bit_cast(uint4, yl[s][SH ? 0 : tb]);
-        uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
-        if constexpr (SH) {
-          if (tb == 1) {   // y of tokens 16 .. L - 1 = y of token 15: this lane's features as the lane (l15 = 15, same g) holds them
-            hw[wsel] = __shfl(hw[wsel], lane | 15, 64);
-            hw[wsel + 1] = __shfl(hw[wsel + 1], lane | 15, 64);
-            lw[wsel] = __shfl(lw[wsel], lane | 15, 64);
-            lw[wsel + 1] = __shfl(lw[wsel + 1], lane | 15, 64);
-          }
-        }
-        // (opaque: hipcc otherwise recognises `word << 16` as the hi half the split already computed and keeps ~90 unpacked
-        //  floats alive -- spilled -- across all of phase 2)
-        asm volatile("" : "+v"(hw[wsel]), "+v"(hw[wsel + 1]), "+v"(lw[wsel]), "+v"(lw[wsel + 1]));
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t hv = hw[wsel + (r >> 1)], lv = lw[wsel + (r >> 1)];
-          const float yv = __builtin_bit_cast(float, (r & 1) ? (hv & 0xFFFF0000u) : (hv << 16)) +
-                           __builtin_bit_cast(float, (r & 1) ? (lv & 0xFFFF0000u) : (lv << 16));
-          pr[r] = fmaf(wt[tb], yv, pr[r]);
+        if (tb == 1) {   // y of tokens 16 .. L - 1 = y of token 15: this lane's features as the lane (l15 = 15, same g) holds them
+          hw[wsel] = __shfl(hw[wsel], lane | 15, 64);
+          hw[wsel + 1] = __shfl(hw[wsel + 1], lane | 15, 64);
+          lw[wsel] = __shfl(lw[wsel], lane | 15, 64);
+          lw[wsel + 1] = __shfl(lw[wsel + 1], lane | 15, 64);
         }
       }
-      if constexpr (!(ABL & 32)) {
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) pr[r] = nt_row_sum(pr[r]);
+      // (opaque: hipcc otherwise recognises `word << 16` as the hi half the split already computed and keeps ~90 unpacked
+      //  floats alive -- spilled -- across all of phase 2)
+      asm volatile("" : "+v"(hw[wsel]), "+v"(hw[wsel + 1]), "+v"(lw[wsel]), "+v"(lw[wsel + 1]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t hv = hw[wsel + (r >> 1)], lv = lw[wsel + (r >> 1)];
+        const float yv = __builtin_bit_cast(float, (r & 1) ? (hv & 0xFFFF0000u) : (hv << 16)) +
+                         __builtin_bit_cast(float, (r & 1) ? (lv & 0xFFFF0000u) : (lv << 16));
+        pr[r] = fmaf(wt[tb], yv, pr[r]);
       }
-      const int f0 = 16 * fb + 4 * g;
-      if (news_ok && l15 == 0 && f0 < D) *reinterpret_cast<float4*>(outp + f0) = make_float4(pr[0], pr[1], pr[2], pr[3]);
     }
-    // (every DMA issued has been waited for: the last chunk's wait covers chunks up to NT_NCHUNK - 1, none is issued later)
-    static_assert(2 * 5 * 4 <= NT_SLOT / 1024 || KPARTS == 3, "phase-2 chunk must fit a ring slot");
-  };
+    if constexpr (!(ABL & 32)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[r] = nt_row_sum(pr[r]);
+    }
+    const int f0 = 16 * fb + 4 * g;
+    if (news_ok && l15 == 0 && f0 < D) *reinterpret_cast<float4*>(outp + f0) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+  }
+  // (every DMA issued has been waited for: the last chunk's wait covers chunks up to NT_NCHUNK - 1, none is issued later)
+  static_assert(2 * 5 * 4 <= NT_SLOT / 1024 || KPARTS == 3, "phase-2 chunk must fit a ring slot");
+}
+
+template <int SAVE, int WAVES, int ABL = 0, bool SHARE = false>
+__global__ void __launch_bounds__(WAVES * 64, 2) news_tail_fwd_kernel(const NewsTailArgs P) {
+  static_assert(!(SHARE && SAVE), "pad-row sharing is for evaluation forwards");
+  using Cfg = NtCfg<WAVES>;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[Cfg::SLOTS * Cfg::SLOT + 1024];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int64_t news_raw = (int64_t)blockIdx.x * WAVES + wave;
+  const bool news_ok = news_raw < P.n_news;
+  int64_t news = news_ok ? news_raw : 0;            // idle waves of the last workgroup recompute news 0 and store nothing
   if constexpr (SHARE) {
-    if (short_w) body(std::true_type{});
-    else body(std::false_type{});
+    // the wave's news comes from the short-first list; position < n_short <=> a short news (wave-uniform)
+    bool short_w = false;
+    if (news_ok) {
+      news = __builtin_amdgcn_readfirstlane(P.perm[news_raw]);
+      short_w = news_raw < (int64_t)__builtin_amdgcn_readfirstlane(*P.n_short);
+    }
+    if (short_w) news_tail_fwd_body<SAVE, WAVES, ABL, true>(P, smem, news, news_ok);
+    else news_tail_fwd_body<SAVE, WAVES, ABL, false>(P, smem, news, news_ok);
   } else {
-    body(std::false_type{});
+    news_tail_fwd_body<SAVE, WAVES, ABL, false>(P, smem, news, news_ok);
   }
 }
 
@@ -555,16 +560,25 @@ static inline int launch_news_tail_fwd(const NewsTailArgs& a, hipStream_t st) {
 //                                                  order) * d_pre^T (B: the accumulators of phase A, split once), two halves
 // Outputs: d_pre and dy as (hi, lo) planes over the real rows (operands of the two weight gradients and of the
 // out-projection's activation gradient), dq_a through LDS + one atomic per query and workgroup.
-template <int WAVES, int ABL = 0>
+// OD (round 4): the out-projection's activation gradient in the same kernel,
+//   d_o = dy W_o                                  phase D: d_o^T (o features x tokens) = W_o^T (A: the row-panel dgrad image
+//                                                  `out_d`, natural k order, half a k-block per ring slot) * dy^T (B: the dy
+//                                                  planes this wave has just written, read back as fragments -- its own rows)
+// so the launch `rp_gemm<KCPlanesG, EpiStore>` (135 us at B = 128: 0.26 GB of dy planes read from HBM) disappears; d_o leaves as
+// the fp32 rows the token-attention backward reads.
+template <int WAVES, int ABL = 0, bool OD = false>
 __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const NewsTailBwdArgs P) {
   using Cfg = NtCfg<WAVES>;
   constexpr int NT_SLOT = Cfg::BSLOT, NT_SLOTS = Cfg::SLOTS, LOOK = Cfg::LOOK, KPC = Cfg::KPC;
   constexpr int NPC = (NT_QS + KPC - 1) / KPC;         // phase-C chunks per half of the features
-  constexpr int NT_NCHUNK = NT_KS + 2 * NPC;
+  constexpr int NT_NCHUNK_C = NT_KS + 2 * NPC;         // chunks of phases A and C
+  constexpr int NT_NCHUNK = NT_NCHUNK_C + (OD ? 2 * NT_KB : 0);   // + phase D: (k-block, half of the feature blocks)
+  static_assert(!OD || 2 * 10 * 1024 <= NT_SLOT, "phase-D chunk must fit a ring slot");
   constexpr int PPW = (2 * KPC * 10 + WAVES - 1) / WAVES > (2 * NT_QB + WAVES - 1) / WAVES ? (2 * KPC * 10 + WAVES - 1) / WAVES
                                                                                              : (2 * NT_QB + WAVES - 1) / WAVES;
   static_assert(2 * NT_QB * 1024 <= NT_SLOT && 2 * KPC * 10 * 1024 <= NT_SLOT, "chunk must fit a ring slot");
   constexpr int STREAM = (ABL & 64) ? 0 : 1;          // d_pre / dy planes: streaming stores (probe: ABL 64 = plain)
+  constexpr int STREAM_DY = OD ? 0 : STREAM;          // (phase D reads the dy planes back: keep them in the cache hierarchy)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NT_SLOTS * NT_SLOT + 2048 + WAVES * NT_DROW * 4];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -603,7 +617,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const News
         piece = piece < 2 * NT_QB ? piece : 2 * NT_QB - 1;
         glds16_saddr(src + piece * 1024, lane_off, dst + (uint32_t)piece * 1024u);
       }
-    } else if (c < NT_NCHUNK) {
+    } else if (c < NT_NCHUNK_C) {
       const int j = c - NT_KS, half = j / NPC, p = j - half * NPC;
       const int fb0 = half ? 10 : 0, nfb = half ? 9 : 10;
       const int nks = (p + 1) * KPC <= NT_QS ? KPC : NT_QS - p * KPC;
@@ -615,6 +629,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const News
         piece = piece < pieces ? piece : pieces - 1;
         const int ks = piece / (2 * nfb), rem = piece - ks * 2 * nfb;      // rem = fb * 2 + plane
         glds16_saddr(src + ((size_t)((KPC * p + ks) * NT_FB + fb0) * 2 + rem) * 1024, lane_off, dst + (uint32_t)piece * 1024u);
+      }
+    } else if (OD && c < NT_NCHUNK) {
+      // phase D: k-block kb of the out-projection dgrad image, feature blocks of the half (10 or 9) x (hi, lo): one contiguous run
+      const int j = c - NT_NCHUNK_C, kb = j >> 1, half = j & 1;
+      const int fb0 = half ? 10 : 0, pieces = (half ? 9 : 10) * 2;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_od) + (size_t)(kb * NT_FB + fb0) * 2048;
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) {
+        int piece = wave + q * WAVES;
+        piece = piece < pieces ? piece : pieces - 1;
+        glds16_saddr(src + piece * 1024, lane_off, dst + (uint32_t)piece * 1024u);
       }
     }
   };
@@ -883,14 +908,113 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const News
         split_pair(v[2], v[3], h1, l1);
         if (!(ABL & 2) && news_ok && tok_ok[tb]) {
           unsigned char* dst = P.dy_planes + ((m >> 4) * NT_FB + fb0 + fb) * 1024 + (m & 15) * 32 + 8 * g;
-          nt_store8<STREAM>(dst, h0, h1);
-          nt_store8<STREAM>(dst + 512, l0, l1);
+          nt_store8<STREAM_DY>(dst, h0, h1);
+          nt_store8<STREAM_DY>(dst + 512, l0, l1);
         }
       }
     }
   };
   phase_c(std::integral_constant<int, 0>{});
   phase_c(std::integral_constant<int, 1>{});
+
+  // =============================== phase D: d_o^T = W_o^T dy^T ============================================
+  if constexpr (OD) {
+    // B fragments: the 8 consecutive features 32 kb + 8g .. + 7 of this lane's token, from the dy planes written above (this
+    // wave's own rows; every chunk top's vmcnt(0) has long retired those stores) -- the loader of the forward's phase 1
+    const unsigned char* drow[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+      drow[tb] = P.dy_planes + ((mrow[tb] >> 4) * NT_FB + (g >> 1)) * 1024 + (mrow[tb] & 15) * 32 + (g & 1) * 16;
+    auto load_dy = [&](int kb, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
+      const bool dead = kb == NT_KB - 1 && g >= 2;     // block column 19 does not exist
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        const unsigned char* p = drow[tb] + (dead ? 0 : kb * 2048);
+        uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + 512);
+        if (dead) { h = make_uint4(0u, 0u, 0u, 0u); l = h; }
+        dh[tb] = __builtin_bit_cast(bf16x8, h);
+        dl[tb] = __builtin_bit_cast(bf16x8, l);
+      }
+    };
+    f32x4 oacc[NT_FB][2];
+#pragma unroll
+    for (int fb = 0; fb < NT_FB; ++fb)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) oacc[fb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one half-chunk: feature blocks fb0 .. fb0 + nfb - 1 (pairs of blocks, fragments fetched one pair ahead)
+    auto pd_half = [&](auto half_c, int slot, const bf16x8 (&dh)[2], const bf16x8 (&dl)[2]) {
+      constexpr int half = decltype(half_c)::value;
+      constexpr int fb0 = half ? 10 : 0, nfb = half ? 9 : 10, npairs = (nfb + 1) / 2;
+      const unsigned char* base = smem + slot * NT_SLOT + lane * 16;
+      auto rd = [&](int p, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int fb = 2 * p + jj < nfb ? 2 * p + jj : nfb - 1;
+          wh[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048);
+          wl[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048 + 1024);
+        }
+      };
+      auto mm = [&](int p, const bf16x8 (&wh)[2], const bf16x8 (&wl)[2]) {
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+            if (2 * p + jj < nfb)
+#pragma unroll
+              for (int tb = 0; tb < 2; ++tb)
+                oacc[fb0 + 2 * p + jj][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj], pass == 0 ? dl[tb] : dh[tb],
+                                                                                     oacc[fb0 + 2 * p + jj][tb], 0, 0, 0);
+      };
+      bf16x8 wh0[2], wl0[2], wh1[2], wl1[2];
+      rd(0, wh0, wl0);
+#pragma unroll
+      for (int p = 0; p < npairs; p += 2) {
+        if (p + 1 < npairs) rd(p + 1, wh1, wl1);
+        mm(p, wh0, wl0);
+        if (p + 1 < npairs) {
+          if (p + 2 < npairs) rd(p + 2, wh0, wl0);
+          mm(p + 1, wh1, wl1);
+        }
+      }
+    };
+    bf16x8 dha[2], dla[2], dhb[2], dlb[2];
+    auto kstep = [&](int kb, const bf16x8 (&ch)[2], const bf16x8 (&cl)[2], bf16x8 (&nh)[2], bf16x8 (&nl)[2]) {
+      const int c = NT_NCHUNK_C + 2 * kb;
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      issue_chunk(c + LOOK);
+      load_dy(kb + 1 < NT_KB ? kb + 1 : kb, nh, nl);
+      __builtin_amdgcn_sched_barrier(0);
+      pd_half(std::integral_constant<int, 0>{}, c % NT_SLOTS, ch, cl);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      issue_chunk(c + 1 + LOOK);
+      __builtin_amdgcn_sched_barrier(0);
+      pd_half(std::integral_constant<int, 1>{}, (c + 1) % NT_SLOTS, ch, cl);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // (phase C's last chunk top has waited vmcnt(0) after the first half's dy stores; the second half's stores are waited
+    //  for by the first kstep's vmcnt(0) -- but the FIRST fragment load must not overtake them: wait here)
+    wait_vmcnt<0>();
+    load_dy(0, dha, dla);
+    for (int kb = 0; kb < NT_KB; kb += 2) {
+      kstep(kb, dha, dla, dhb, dlb);
+      kstep(kb + 1, dhb, dlb, dha, dla);
+    }
+    // d_o rows: lane (l15, g) holds features 16 fb + 4g .. + 3 of token 16 tb + l15 -> one 16-byte store each
+#pragma unroll
+    for (int fb = 0; fb < NT_FB; ++fb) {
+      const int f0 = 16 * fb + 4 * g;
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        int64_t m = mrow[tb];
+        asm volatile("" : "+v"(m));
+        if (!(ABL & 2) && news_ok && tok_ok[tb] && f0 < D)
+          *reinterpret_cast<float4*>(P.d_o + m * D + f0) = make_float4(oacc[fb][tb][0], oacc[fb][tb][1], oacc[fb][tb][2], oacc[fb][tb][3]);
+      }
+    }
+  }
   // dq_a: the workgroup's sums -> one atomic per query
   __syncthreads();
   if (tid < Q) atomicAdd(P.dq_a + tid, dq_s[tid]);
@@ -903,7 +1027,12 @@ static inline int launch_news_tail_bwd(const NewsTailBwdArgs& a, hipStream_t st)
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   NRL_REQUIRE(a.D == 300 && a.Q < 16 * NT_QB && a.Q % 4 == 0 && a.L >= 1 && a.L <= 32, "fused news tail backward: unsupported geometry");
   NRL_REQUIRE((((uintptr_t)a.d_out | (uintptr_t)a.q_a) & 15) == 0, "fused news tail backward: 16-byte alignment");
-  hipLaunchKernelGGL((news_tail_bwd_kernel<WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
+  if (a.d_o != nullptr) {
+    NRL_REQUIRE(a.img_od != nullptr && ((uintptr_t)a.d_o & 15) == 0, "fused news tail backward: the out-projection dgrad needs its image and an aligned d_o");
+    hipLaunchKernelGGL((news_tail_bwd_kernel<WAVES, ABL, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((news_tail_bwd_kernel<WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
+  }
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

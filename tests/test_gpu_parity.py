@@ -296,7 +296,7 @@ def test_fused_news_tail_query_widths(Q, N, L, p_drop, engine):
 
 
 @pytest.mark.parametrize("option", ["news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes", "news_tail", "news_tail_bwd",
-                                    "news_qkv_planes", "news_fork"])
+                                    "news_qkv_planes", "news_fork", "news_tail_od"])
 @pytest.mark.parametrize("N,L", [(9, 17), (70, 30)])
 def test_news_path_format_switches_agree(N, L, option):
     """The measurement switches of the fused news path select private workspace formats (head-major q|k|v slabs, bf16
