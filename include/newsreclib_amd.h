@@ -122,8 +122,8 @@ int nrl_get_gemm_engine(void);
  *  15 "news_pad_share"  (ABI v13) evaluation forward of the fused news path (nothing saved, p_drop == 0): the run of padding tokens
  *                       from token 15 on is ONE row (identical embedding row, no dropout), so a news whose tokens 15 .. L - 1 are
  *                       all the padding id is computed on its first 16 token rows only; bit-identical to computing every row
- *  16 "news_tail_od"    (ABI v13) the out-projection's activation gradient of the fused news path inside the fused tail backward
- *                       (d_o never needs the dy planes re-read from HBM; one launch fewer)
+ *  16 "news_tail_od"    (ABI v13, default OFF: measured slower) the out-projection's activation gradient of the fused news path
+ *                       inside the fused tail backward (the dy planes are read back by the wave that wrote them; one launch fewer)
  * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
  * must see the same defaults (newsreclib_amd/ops*.py compare nrl_get_options() at both). */
 int nrl_set_option(const char* name, int32_t value);

@@ -32,7 +32,9 @@ static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_B
 std::atomic<uint32_t> g_opt_default{[] {
   uint32_t m = 0;
   for (int i = 0; i < O_COUNT; ++i) {
-    const bool dflt = i != O_NEWS_FUSED_BWD && i != O_USER_FORK && i != O_NEWS_FORK;   // (off: the measured losers; news_fork: A/B pending)
+    // (off: the measured losers -- news_tail_od, round 4: the fused tail backward grows 337 -> 488 us, the launch it replaces
+    //  took 135: step 2.92 vs 2.89 ms, two alternating pairs)
+    const bool dflt = i != O_NEWS_FUSED_BWD && i != O_USER_FORK && i != O_NEWS_FORK && i != O_NEWS_TAIL_OD;
     const char* e = getenv(kOptEnv[i]);
     const bool v = e == nullptr ? dflt : (dflt ? e[0] != '0' : e[0] == '1');
     m |= v ? (1u << i) : 0u;

@@ -347,7 +347,12 @@ class LazyTableAdam:
     def __init__(self, flat: FlatParams, opt: FusedAdam, table: torch.Tensor, period: int = 64):
         self.flat, self.opt = flat, opt
         self.rows, self.dim = int(table.shape[0]), int(table.shape[1])
-        self.head = self.rows * self.dim
+        idx = [i for i, p in enumerate(flat.params) if p is table]
+        if len(idx) != 1 or table.dim() != 2 or self.dim % 4:
+            raise ValueError("LazyTableAdam: the table must be one 2-D parameter of the flat buffer with dim % 4 == 0")
+        self.offset = int(flat.offsets[idx[0]])
+        self.numel = self.rows * self.dim
+        self.head = self.offset + self.numel       # (end of the table in the flat buffer)
         dev = flat.flat.device
         self.last = torch.zeros(self.rows, dtype=torch.int32, device=dev)
         self.mark = torch.zeros(self.rows, dtype=torch.int32, device=dev)
@@ -357,7 +362,7 @@ class LazyTableAdam:
         self.flushed_upto = 0          # every row is at least this far (== opt.step_count: nothing pending)
 
     def _views(self):
-        v = lambda t: t[: self.head].view(self.rows, self.dim)
+        v = lambda t: t[self.offset: self.head].view(self.rows, self.dim)
         return v(self.flat.flat), v(self.flat.grad), v(self.opt.exp_avg), v(self.opt.exp_avg_sq)
 
     def _advance(self, mark, upto, with_grad, grad_scale=1.0, stride=1, offset=0):
@@ -385,23 +390,32 @@ class LazyTableAdam:
         """Rows other ranks touched this step (touched-row exchange): same tag as ``begin``."""
         ops.adam_rows_mark_(ids, self.mark, self.opt.step_count + 1)
 
+    def update(self, grad_scale: float) -> None:
+        """After the backward (and the gradient exchange), BEFORE ``opt.begin_step()``: step t for the marked rows with their
+        gradient rows (cleared)."""
+        self._advance(self.mark, self.opt.step_count, True, grad_scale)
+
     def finish(self, grad_scale: float) -> None:
-        """After the backward (and the gradient exchange): step t for the marked rows with their gradient rows (cleared), and
-        the dense kernel over the non-table parameters."""
-        t = self.opt.step_count + 1
-        self._advance(self.mark, t - 1, True, grad_scale)
+        """``update`` + the dense kernel over everything else of the flat buffer (the single-table case)."""
+        self.update(grad_scale)
         self.opt.begin_step()
+        self.opt.step_range(0, self.offset, grad_scale, zero_grad=True)
         self.opt.step_range(self.head, self.flat.numel, grad_scale, zero_grad=True)
 
+    def advance_all_before_dense(self) -> None:
+        """A step whose table gradient may be non-zero ANYWHERE (a dense all-reduce fallback): every row to t - 1; the caller
+        then runs the dense kernel over the whole flat buffer and calls ``mark_all_current``."""
+        self._advance(None, self.opt.step_count, False)
+
+    def mark_all_current(self) -> None:
+        self.last.fill_(self.opt.step_count)
+        self.flushed_upto = self.opt.step_count
+
     def finish_dense(self, grad_scale: float) -> None:
-        """A step whose table gradient may be non-zero ANYWHERE (a dense all-reduce fallback): every row to t - 1, then the
-        dense kernel over the whole flat buffer."""
-        t = self.opt.step_count + 1
-        self._advance(None, t - 1, False)
+        self.advance_all_before_dense()
         self.opt.begin_step()
         self.opt.step_range(0, self.flat.numel, grad_scale, zero_grad=True)
-        self.last.fill_(t)
-        self.flushed_upto = t
+        self.mark_all_current()
 
     def flush(self) -> None:
         """Every row to the current step: after this the flat buffers hold exactly what dense Adam would."""
@@ -456,17 +470,61 @@ class NRMSTrainer:
             self._side = torch.cuda.Stream(device=dev)
         # lazy dense Adam for the embedding table (bit-identical to the dense kernel after a flush): on one GPU, and under the
         # touched-row exchange (every rank then knows every touched row); the dense all-reduce leaves any row possibly non-zero
-        self.lazy = None
+        self.lazy = None               # the word-embedding table's lazy optimizer (first of `lazy_tables`), or None
+        self.lazy_tables = []          # [(LazyTableAdam, ids_of_batch)]
+        self._dense_ranges = [(0, self.flat.numel)]
         self._in_step = False
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if lazy_adam is None:
             lazy_adam = os.environ.get("NRL_LAZY_ADAM", "1") not in ("", "0")
-        if lazy_adam and head > 0 and dev.type == "cuda" and (world == 1 or grad_exchange == "rows"):
-            self.lazy = LazyTableAdam(self.flat, self.opt, te.embedding_layer.weight)
-            # anything that reads the table outside a step (an evaluation forward, a checkpoint) sees dense-Adam values
-            te.register_forward_pre_hook(lambda _m, _a: self._table_read())
+        if lazy_adam and dev.type == "cuda" and (world == 1 or (grad_exchange == "rows" and head > 0)):
+            self._find_lazy_tables(module, enc, single=world > 1)
+        if self.lazy_tables:
+            self.lazy = self.lazy_tables[0][0]
+            cuts = sorted((t.offset, t.head) for t, _ in self.lazy_tables)
+            self._dense_ranges, lo = [], 0
+            for a, b in cuts:
+                if a > lo:
+                    self._dense_ranges.append((lo, a))
+                lo = b
+            if lo < self.flat.numel:
+                self._dense_ranges.append((lo, self.flat.numel))
             if hasattr(module, "register_state_dict_pre_hook"):
                 module.register_state_dict_pre_hook(lambda *_a, **_k: self._table_read())
+
+    def _find_lazy_tables(self, module, enc, single: bool) -> None:
+        """Embedding tables whose gradient is zero outside the rows a step's batch names: the word table of every text encoder
+        (ids: the token ids of the attributes it encodes, ``batch['x_all']``) and the LSTUR user encoder's long-term user table
+        (ids: ``batch['user_idx']``).  Anything that reads such a table outside a step sees dense-Adam values (forward pre-hooks)."""
+        in_flat = {id(p) for p in self.flat.params}
+        seen = set()
+        if enc is not None and hasattr(enc, "text_encoders"):
+            for name, te in enc.text_encoders.items():
+                emb = getattr(te, "embedding_layer", None)
+                w = getattr(emb, "weight", None)
+                if w is None or id(w) not in in_flat or w.dim() != 2 or w.shape[1] % 4 or not w.requires_grad:
+                    continue
+                attrs = [n for n, t2 in enc.text_encoders.items() if t2 is te]
+                if id(w) in seen:
+                    continue
+                seen.add(id(w))
+
+                def ids_of(batch, _attrs=tuple(attrs)):
+                    xa = batch.get("x_all", {})
+                    parts = [xa[a].reshape(-1) for a in _attrs if torch.is_tensor(xa.get(a))]
+                    if len(parts) != len(_attrs):
+                        raise RuntimeError("NRMSTrainer: the lazy table optimizer needs the step's token ids (batch['x_all'])")
+                    return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+                self.lazy_tables.append((LazyTableAdam(self.flat, self.opt, w), ids_of))
+                te.register_forward_pre_hook(lambda _m, _a: self._table_read())
+                if single:
+                    return
+        ue = getattr(module, "user_encoder", None)
+        w = getattr(getattr(ue, "long_term_user_embedding", None), "weight", None)
+        if not single and w is not None and id(w) in in_flat and w.dim() == 2 and w.shape[1] % 4 == 0 and w.requires_grad:
+            self.lazy_tables.append((LazyTableAdam(self.flat, self.opt, w), lambda batch: batch["user_idx"].reshape(-1)))
+            ue.register_forward_pre_hook(lambda _m, _a: self._table_read())
 
     LOSS_FOLD = 256
 
@@ -498,7 +556,8 @@ class NRMSTrainer:
         moment buffers (flat, in ``FlatParams`` order -- ``layout`` names the slices), plus the hyper-parameters they were
         built under.  (Lightning checkpoints ``optimizer.state_dict()`` next to the module; this is that half for the flat
         optimizer of the bench / test loop.)"""
-        getattr(self, "flush", lambda: None)() if getattr(self, "lazy", None) is not None else None   # moments of EVERY row at step_count
+        if getattr(self, "lazy_tables", None):
+            self.flush()                                   # moments of EVERY row at step_count
         names = {id(p): n for n, p in self.module.named_parameters()}
         layout = [(names.get(id(p), f"param{i}"), int(o), int(p.numel())) for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets))]
         return {"step_count": int(self.opt.step_count), "exp_avg": self.opt.exp_avg.detach().clone(),
@@ -514,19 +573,17 @@ class NRMSTrainer:
         self.opt.exp_avg.copy_(state["exp_avg"])
         self.opt.exp_avg_sq.copy_(state["exp_avg_sq"])
         self.opt.lr, self.opt.betas, self.opt.eps = float(state["lr"]), tuple(state["betas"]), float(state["eps"])
-        lazy = getattr(self, "lazy", None)
-        if lazy is not None:            # a saved state is a flushed state: every row stands at step_count
-            lazy.last.fill_(self.opt.step_count)
-            lazy.flushed_upto = self.opt.step_count
+        for tab, _ in getattr(self, "lazy_tables", []):      # a saved state is a flushed state: every row stands at step_count
+            tab.mark_all_current()
 
     def _table_read(self) -> None:
-        if self.lazy is not None and not self._in_step:
-            self.lazy.flush()
+        if not self._in_step:
+            self.flush()
 
     def flush(self) -> None:
         """Brings every lazily updated table row to the current step (no-op without the lazy table optimizer)."""
-        if self.lazy is not None:
-            self.lazy.flush()
+        for tab, _ in self.lazy_tables:
+            tab.flush()
 
     def exchange_info(self) -> Dict:
         """What the data-parallel gradient exchange ships per rank and step (bench.py prints it for N > 1)."""
@@ -535,20 +592,17 @@ class NRMSTrainer:
     def step(self, batch: Dict) -> torch.Tensor:
         self.module.train()
         rows_mode = hasattr(self.reduce, "prepare") and self.reduce._active()
-        if rows_mode or self.lazy is not None:
+        if rows_mode or self.lazy_tables:
             # the step's token ids exist now.  Touched-row exchange: unique ids + the async exchange of their counts go out before
             # the forward, so the backward's hook finds the sizes on the host without draining the launch queue.  Lazy table
             # Adam: the rows the forward gathers are brought up to date first.
-            from .nrms_module import prepare_batch, text_vocab
-            batch = prepare_batch(batch, text_vocab(self.module))
-            xa = batch.get("x_all", {})
-            ids = xa.get("title") if torch.is_tensor(xa.get("title")) else None
-            if rows_mode and ids is not None:
-                self.reduce.prepare(ids, xa.get("title_order"))
-            if self.lazy is not None:
-                if ids is None:
-                    raise RuntimeError("NRMSTrainer: the lazy table optimizer needs the step's token ids (batch['x_all']['title'])")
-                self.lazy.begin(ids, self._side)
+            batch = self.module._prepare(batch) if hasattr(self.module, "_prepare") else batch
+            if rows_mode:
+                xa = batch.get("x_all", {})
+                if torch.is_tensor(xa.get("title")):
+                    self.reduce.prepare(xa["title"], xa.get("title_order"))
+            for tab, ids_of in self.lazy_tables:
+                tab.begin(ids_of(batch), self._side)
         self._in_step = True
         try:
             # model_step directly: training_step would append preds / targets to training_step_outputs every step, and
@@ -572,16 +626,29 @@ class NRMSTrainer:
             if p.grad is not None:
                 p.main_grad.add_(p.grad)
                 p.grad = None
-        if self.lazy is not None:
+        if self.lazy_tables:
             scale = self.reduce.finish()
+            dense_step = False
             if rows_mode:
                 gathered = getattr(self.reduce, "last_gathered", None)
                 if gathered is None:                       # the exchange fell back to a dense all-reduce this step
-                    self.lazy.finish_dense(scale)
-                    return loss.detach()
-                for ids_r in gathered:
-                    self.lazy.mark_more(ids_r)
-            self.lazy.finish(scale)
+                    dense_step = True
+                else:
+                    for ids_r in gathered:
+                        self.lazy.mark_more(ids_r)
+            if dense_step:
+                for tab, _ in self.lazy_tables:
+                    tab.advance_all_before_dense()
+                self.opt.begin_step()
+                self.opt.step_range(0, self.flat.numel, scale, zero_grad=True)
+                for tab, _ in self.lazy_tables:
+                    tab.mark_all_current()
+            else:
+                for tab, _ in self.lazy_tables:
+                    tab.update(scale)
+                self.opt.begin_step()
+                for lo, hi in self._dense_ranges:
+                    self.opt.step_range(lo, hi, scale, zero_grad=True)
         elif hasattr(self.reduce, "finish_pipelined"):
             # dense exchange: Adam over each slice of the flat buffer as soon as its all-reduce has landed
             self.opt.begin_step()
