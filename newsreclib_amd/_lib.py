@@ -236,7 +236,7 @@ def get_gemm_engine() -> str:
 # bit order of the switch mask (include/newsreclib_amd.h, nrl_set_option)
 OPTION_NAMES = ("news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes", "news_aa_planes",
                 "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail", "news_tail_bwd", "user_fork", "news_fork",
-                "news_qkv_planes", "news_pad_share", "news_tail_od")
+                "news_qkv_planes", "news_pad_share", "news_tail_od", "user_proj")
 
 
 def set_option(name: str, value: bool) -> None:

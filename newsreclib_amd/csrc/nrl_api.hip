@@ -24,11 +24,11 @@ thread_local int64_t t_opts = -1;
 
 static const char* const kOptName[O_COUNT] = {"news_fused", "news_fused_bwd", "news_attn_mfma", "news_planes", "news_od_planes",
                                               "news_aa_planes", "wgrad_2step", "wgrad_ws", "rowpanel", "x3_dma", "news_tail",
-                                              "news_tail_bwd", "user_fork", "news_fork", "news_qkv_planes", "news_pad_share", "news_tail_od"};
+                                              "news_tail_bwd", "user_fork", "news_fork", "news_qkv_planes", "news_pad_share", "news_tail_od", "user_proj"};
 static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_BWD", "NRL_NEWS_ATTN_MFMA", "NRL_NEWS_PLANES",
                                              "NRL_NEWS_OD_PLANES", "NRL_NEWS_AA_PLANES", "NRL_WGRAD_2STEP", "NRL_WGRAD_WS",
                                              "NRL_ROWPANEL", "NRL_X3_DMA", "NRL_NEWS_TAIL", "NRL_NEWS_TAIL_BWD", "NRL_USER_FORK",
-                                             "NRL_NEWS_FORK", "NRL_NEWS_QKV_PLANES", "NRL_NEWS_PAD_SHARE", "NRL_NEWS_TAIL_OD"};
+                                             "NRL_NEWS_FORK", "NRL_NEWS_QKV_PLANES", "NRL_NEWS_PAD_SHARE", "NRL_NEWS_TAIL_OD", "NRL_USER_PROJ"};
 std::atomic<uint32_t> g_opt_default{[] {
   uint32_t m = 0;
   for (int i = 0; i < O_COUNT; ++i) {
@@ -149,7 +149,7 @@ int nrl_set_option(const char* name, int32_t value) {
     }
   set_error("set_option: unknown option '%s' (news_fused, news_fused_bwd, news_attn_mfma, news_planes, news_od_planes, "
             "news_aa_planes, wgrad_2step, wgrad_ws, rowpanel, x3_dma, news_tail, news_tail_bwd, user_fork, news_fork, news_qkv_planes, "
-            "news_pad_share, news_tail_od)", name);
+            "news_pad_share, news_tail_od, user_proj)", name);
   return NRL_E_INVALID;
 }
 

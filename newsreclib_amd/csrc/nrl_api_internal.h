@@ -139,9 +139,11 @@ static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 //   news_tail_od    NRL_NEWS_TAIL_OD=1     (default OFF) the out-projection's activation gradient d_o = dy W_o as phase D of the
 //                                          fused tail backward (nrl_news_tail.h) instead of its own row-panel launch --
 //                                          measured slower: 337 -> 488 us for the kernel against the 135 us launch it replaces
+//   user_proj       NRL_USER_PROJ=0        the user encoder's in-projection as its own tiled GEMM launch (+ the weight split in
+//                                          front of it) instead of inside the across-users attention kernel (ua_fwd_proj_kernel)
 enum {
   O_NEWS_FUSED = 0, O_NEWS_FUSED_BWD, O_NEWS_ATTN_MFMA, O_NEWS_PLANES, O_NEWS_OD_PLANES, O_NEWS_AA_PLANES, O_WGRAD_2STEP,
-  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_NEWS_QKV_PLANES, O_NEWS_PAD_SHARE, O_NEWS_TAIL_OD, O_COUNT
+  O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_NEWS_QKV_PLANES, O_NEWS_PAD_SHARE, O_NEWS_TAIL_OD, O_USER_PROJ, O_COUNT
 };
 extern std::atomic<uint32_t> g_opt_default;  // (nrl_api.hip)
 extern thread_local int64_t t_opts;
@@ -304,7 +306,7 @@ struct BlockPlanes {
 
 // carve (and, in the forward, fill) the bf16 planes of the block's three weights
 static int block_planes(const NrlBlockParams* P, const BlockShape& s, const BlockWs& w, bool fill,
-                        BlockPlanes* bp, hipStream_t st, int fused_heads = 0) {
+                        BlockPlanes* bp, hipStream_t st, int fused_heads = 0, int proj_heads = 0) {
   const int D = s.D, Q = s.Q;
   uint16_t* p = w.planes;
   const float* ws[3] = {P->in_proj_weight, P->out_proj_weight, P->att_weight};
@@ -315,7 +317,8 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
   for (int i = 0; i < 3; ++i) {
     // planes nobody reads are not built: with the row-panel kernels on, the out-projection / additive-attention
     // planes; with the fused news encoder, the in-projection ones too (its dgrad runs on the row-panel image)
-    const bool needed = i == 0 ? !(fused_heads > 0 && bp->rp.on) : !bp->rp.on;
+    // (proj_heads: the user encoder's in-projection inside its attention kernel, ua_fwd_proj_kernel -- per-head image instead)
+    const bool needed = i == 0 ? !((fused_heads > 0 || proj_heads > 0) && bp->rp.on) : !bp->rp.on;
     if (fill && needed) {
       NRL_TRY(split_weight(ws[i], ns[i], D, p, outs[i], st));
     } else {
@@ -357,13 +360,17 @@ static int block_planes(const NrlBlockParams* P, const BlockShape& s, const Bloc
         if (fill) rp_jobs_add_kperm(&jobs, P->out_proj_weight, D, 1, D, fused_heads, q, NT_FB, P->out_proj_bias);
         q += rp_image_elems(NT_FB, NT_KB);
         bp->rp.tail_a.img = q; bp->rp.tail_a.nblk = NT_QB; bp->rp.tail_a.kblocks = NT_KS;
-        if (fill) rp_jobs_add_kappa(&jobs, P->att_weight, D, 1, Q, D, P->att_bias, q, NT_QB);
+        if (fill) rp_jobs_add_kappa(&jobs, P->att_weight, D, 1, Q, D, P->att_bias, q, NT_QB, NT_KS);
         q += rp_image_elems(NT_QB, NT_KS);
         // backward: dy^T = W_a^T d_pre^T, element (n = feature, k = query) = W_a[k][n], queries in kappa order
         bp->rp.tail_ad.img = q; bp->rp.tail_ad.nblk = NT_FB; bp->rp.tail_ad.kblocks = NT_QS;
-        if (fill && news_tail_bwd_geometry_ok(32, D, Q, fused_heads)) rp_jobs_add_kappa(&jobs, P->att_weight, 1, D, D, Q, nullptr, q, NT_FB);
+        if (fill && news_tail_bwd_geometry_ok(32, D, Q, fused_heads)) rp_jobs_add_kappa(&jobs, P->att_weight, 1, D, D, Q, nullptr, q, NT_FB, NT_QS);
         q += rp_image_elems(NT_FB, NT_QS);
       }
+    } else if (proj_heads > 0) {                                    // nrl_attn_x3.hip: ua_fwd_proj_kernel
+      bp->rp.in_heads.img = q; bp->rp.in_heads.nblk = proj_heads * 4; bp->rp.in_heads.kblocks = NF_KB;
+      if (fill) rp_jobs_add_qkv_heads(&jobs, P->in_proj_weight, D, P->in_proj_bias, q, proj_heads, D / proj_heads);
+      q += rp_image_elems(proj_heads * 4, NF_KB);
     }
     if (fill) NRL_TRY(rp_jobs_launch(jobs, st));
   }
@@ -503,7 +510,21 @@ static int block_fwd(const NrlBlockParams* P, const AOp& a_in, const BlockShape&
   const int D = s.D;
   const Dropout nodrop = make_dropout(0.0, 0, 0);
   BlockPlanes bp;
-  NRL_TRY(block_planes(P, s, w, cur_engine() == ENGINE_BF16X3, &bp, st));
+  // user_proj: the in-projection inside the across-users attention kernel (plain input rows, the x3 attention's geometry, the
+  // per-head image's k-blocks): no in-projection GEMM launch, no weight-split launch
+  bool proj = false;
+  if constexpr (std::is_same<AOp, KCPlain>::value) {
+    proj = opt(O_USER_PROJ) && cur_engine() == ENGINE_BF16X3 && block_rp_ok(D, s.Q) && block_attn_x3(s) && a_in.ld == D &&
+           D == s.heads * 20 && attn_x3_proj_ok(s.geom, s.heads * 4, NF_KB) && s.geom.q_outer % 3 == 0 && s.geom.q_seq % 3 == 0;
+  }
+  NRL_TRY(block_planes(P, s, w, cur_engine() == ENGINE_BF16X3, &bp, st, 0, proj ? s.heads : 0));
+  if constexpr (std::is_same<AOp, KCPlain>::value) {
+    if (proj) {
+      NRL_TRY(attn_fwd_x3_proj(a_in.p, s.geom.q_outer / 3, s.geom.q_seq / 3, bp.rp.in_heads.img, bp.rp.in_heads.nblk,
+                               save ? w.qkv : nullptr, w.o, save ? w.lse : nullptr, s.geom, st));
+      return block_fwd_tail(P, s, w, bp, drop2, out, st);
+    }
+  }
   // q|k|v = x W_in^T + b_in           (text.py:229 / user/nrms.py:34; torch in-projection)
   {
     ProfScope prof(st, prof_in_proj ? 2.0 * (double)s.M * 3.0 * D * D : 0.0);

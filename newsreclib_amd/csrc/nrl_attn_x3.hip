@@ -90,26 +90,13 @@ __device__ __forceinline__ void ua_col(uint32_t mat_lds, int t, int db, uint32_t
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);       \
   } while (0)
 
-__global__ void __launch_bounds__(UA_WAVES * 64)
-    ua_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse, const AttnGeom G) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * UA_MATB];
-  unsigned char* const Qs = smem;
-  unsigned char* const Ks = smem + UA_MATB;
-  const uint32_t Vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + 2u * UA_MATB;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// softmax(q k^T) v of one (slot, head) group from the staged (hi, lo) planes: wave w owns queries 16w .. 16w + 15
+__device__ __forceinline__ void ua_fwd_attend(const unsigned char* __restrict__ Qs, const unsigned char* __restrict__ Ks,
+                                              const uint32_t Vs_lds, float* __restrict__ o, float* __restrict__ lse,
+                                              const AttnGeom& G, const int64_t grp, const int64_t outer, const int head, const int S,
+                                              const int wave, const int lane) {
   const int l15 = lane & 15, g = lane >> 4;
   const uint32_t lane_off = (uint32_t)((4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8);
-  const int64_t grp = ua_item(G.groups);
-  if (grp < 0) return;
-  const int64_t outer = grp / G.heads;
-  const int head = (int)(grp % G.heads);
-  const int S = G.S;
-  const float* qb = qkv + outer * G.q_outer + head * UA_DH;
-  ua_stage(Qs, qb, G.q_seq, S, G.scale, tid);
-  ua_stage(Ks, qb + G.D, G.q_seq, S, 1.0f, tid);
-  ua_stage(smem + 2 * UA_MATB, qb + 2 * G.D, G.q_seq, S, 1.0f, tid);
-  __syncthreads();
   const int q0 = wave * 16;
   if (q0 >= S) return;
 
@@ -169,6 +156,141 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
       if (l15 < UA_DH - 16) orow[16 + l15] = oacc[1][r];
     }
   }
+}
+
+__global__ void __launch_bounds__(UA_WAVES * 64)
+    ua_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse, const AttnGeom G) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * UA_MATB];
+  unsigned char* const Qs = smem;
+  unsigned char* const Ks = smem + UA_MATB;
+  const uint32_t Vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + 2u * UA_MATB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const uint32_t lane_off = (uint32_t)((4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8);
+  const int64_t grp = ua_item(G.groups);
+  if (grp < 0) return;
+  const int64_t outer = grp / G.heads;
+  const int head = (int)(grp % G.heads);
+  const int S = G.S;
+  const float* qb = qkv + outer * G.q_outer + head * UA_DH;
+  ua_stage(Qs, qb, G.q_seq, S, G.scale, tid);
+  ua_stage(Ks, qb + G.D, G.q_seq, S, 1.0f, tid);
+  ua_stage(smem + 2 * UA_MATB, qb + 2 * G.D, G.q_seq, S, 1.0f, tid);
+  __syncthreads();
+  ua_fwd_attend(Qs, Ks, Vs_lds, o, lse, G, grp, outer, head, S, wave, lane);
+}
+
+// The same forward with the in-projection INSIDE (round 4; user/nrms.py:34: q|k|v = hist W_in^T + b_in): the group's 128 x 64
+// slice [q 20 | k 20 | v 20 | 0 4] of the projection is computed by the workgroup itself -- wave w: rows 16w .. 16w + 15, its input
+// rows read straight from global (all ten k-blocks in flight together) and split once, B operand = the head's 64 columns of the
+// per-head weight image of the fused news encoder (rp_jobs_add_qkv_heads: bias at k = D against a ones column on the A side), read
+// from global by every wave (the eight waves of a workgroup walk the same 80 KB: L1 / L2 hits) -- and goes accumulator -> (hi, lo)
+// planes in LDS (each wave fills its own row block) and, for a training forward, -> the packed q|k|v rows the backward reads.
+// Replaces the tiled in-projection GEMM launch (33 us at B = 128: one panel's k-loop latency for 3.5 GFLOP) and the weight
+// split launch in front of it.
+struct UaProjArgs {
+  const float* x;            // input rows: row (outer, r) at x + outer * x_outer + r * x_seq, D floats each
+  int64_t x_outer, x_seq;
+  const uint16_t* img;       // per-head q|k|v image: [k-block][head * 4 + nb][hi | lo][lane][8 bf16], 10 k-blocks
+  int nblk;                  // heads * 4
+  float* qkv;                // packed q|k|v rows (geometry G.q_outer / G.q_seq), or null: evaluation
+};
+
+__global__ void __launch_bounds__(UA_WAVES * 64)
+    ua_fwd_proj_kernel(const UaProjArgs A, float* __restrict__ o, float* __restrict__ lse, const AttnGeom G) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * UA_MATB];
+  const uint32_t Vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + 2u * UA_MATB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int64_t grp = ua_item(G.groups);
+  if (grp < 0) return;
+  const int64_t outer = grp / G.heads;
+  const int head = (int)(grp % G.heads);
+  const int S = G.S, D = G.D;
+  constexpr int KB = 10;                                 // k-blocks of 32: D + 1 (bias column) <= 320
+  // ---- A fragments: row min(16w + l15, S - 1), k = 32 kb + 8g .. + 7 (rows past S: copies of the last row) -------------
+  const int arow = 16 * wave + l15 < S ? 16 * wave + l15 : S - 1;
+  const float* xr = A.x + outer * A.x_outer + (int64_t)arow * A.x_seq;
+  float4 raw[KB][2];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const int k = kb * 32 + 8 * g;
+    const int k0 = (kb < KB - 1 || k < D) ? k : D - 4, k1 = (kb < KB - 1 || k + 4 < D) ? k + 4 : D - 4;
+    raw[kb][0] = *reinterpret_cast<const float4*>(xr + k0);
+    raw[kb][1] = *reinterpret_cast<const float4*>(xr + k1);
+  }
+  // this wave's row block of the three operand images: zero (features 20 .. 31 must read as 0), then the values below
+  {
+    unsigned char* zb = smem + wave * 1024 + lane * 16;   // row block w = bytes [w * 1024, (w + 1) * 1024) of every plane
+#pragma unroll
+    for (int m = 0; m < 6; ++m) *reinterpret_cast<uint4*>(zb + m * UA_PLANE) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(A.img) + (size_t)head * 4 * 2048 + lane * 16;
+  auto load_b = [&](int kb, bf16x8 (&bh)[4], bf16x8 (&bl)[4]) {
+    const unsigned char* p = wb + (size_t)kb * A.nblk * 2048;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      bh[nb] = *reinterpret_cast<const bf16x8*>(p + nb * 2048);
+      bl[nb] = *reinterpret_cast<const bf16x8*>(p + nb * 2048 + 1024);
+    }
+  };
+  bf16x8 bh0[4], bl0[4], bh1[4], bl1[4];
+  load_b(0, bh0, bl0);
+  auto kstep = [&](int kb, const bf16x8 (&bh)[4], const bf16x8 (&bl)[4]) {
+    const int k = kb * 32 + 8 * g;
+    float4 v0 = raw[kb][0], v1 = raw[kb][1];
+    if (kb == KB - 1) {
+      const bool in0 = k < D, in1 = k + 4 < D;
+      if (!in0) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!in1) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k == D) v0.x = 1.0f;                            // the ones column: the image's bias row is added by the matrix cores
+      if (k + 4 == D) v1.x = 1.0f;
+    }
+    bf16x8 ah, al;
+    rp_split8(v0, v1, ah, al);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) UA_MFMA3(acc[nb], ah, al, bh[nb], bl[nb]);
+  };
+#pragma unroll
+  for (int kb = 0; kb < KB; kb += 2) {
+    load_b(kb + 1, bh1, bl1);
+    kstep(kb, bh0, bl0);
+    if (kb + 2 < KB) load_b(kb + 2, bh0, bl0);
+    kstep(kb + 1, bh1, bl1);
+  }
+  // ---- accumulators -> the operand planes (and the packed rows): lane (l15, g) holds rows 16w + 4g + r of column 16 nb + l15 ----
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int c = 16 * nb + l15;
+    const int part = c / UA_DH, f = c - part * UA_DH;       // 0 q | 1 k | 2 v | 3 pad
+    if (part < 3) {
+      unsigned char* mat = smem + part * UA_MATB;
+      const float mul = part == 0 ? G.scale : 1.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const int row = 16 * wave + 4 * g + r;
+        uint32_t h, l;
+        split_pair(acc[nb][r] * mul, acc[nb][r + 1] * mul, h, l);
+        const int off = (wave * 2 + (f >> 4)) * 512 + (4 * g + r) * 32 + (f & 15) * 2;
+        *reinterpret_cast<uint16_t*>(mat + off) = (uint16_t)(h & 0xffffu);
+        *reinterpret_cast<uint16_t*>(mat + off + 32) = (uint16_t)(h >> 16);
+        *reinterpret_cast<uint16_t*>(mat + UA_PLANE + off) = (uint16_t)(l & 0xffffu);
+        *reinterpret_cast<uint16_t*>(mat + UA_PLANE + off + 32) = (uint16_t)(l >> 16);
+        if (A.qkv != nullptr) {
+          float* q0p = A.qkv + outer * G.q_outer + (int64_t)row * G.q_seq + part * D + head * UA_DH + f;
+          if (row < S) q0p[0] = acc[nb][r];
+          if (row + 1 < S) q0p[G.q_seq] = acc[nb][r + 1];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  ua_fwd_attend(smem, smem + UA_MATB, Vs_lds, o, lse, G, grp, outer, head, S, wave, lane);
 }
 
 __global__ void __launch_bounds__(UA_WAVES * 64)
@@ -337,6 +459,23 @@ int attn_fwd_x3(const float* qkv, float* o, float* lse, const AttnGeom& G, hipSt
   NRL_REQUIRE(G.groups + 7 < (1LL << 31), "attention grid too large");
   NRL_REQUIRE((((uintptr_t)qkv | (uintptr_t)o) & 15) == 0, "attn_fwd_x3: 16-byte alignment");
   hipLaunchKernelGGL(ua_fwd_kernel, dim3((unsigned)(8 * ((G.groups + 7) / 8))), dim3(UA_WAVES * 64), 0, stream, qkv, o, lse, G);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+bool attn_x3_proj_ok(const AttnGeom& G, int nblk, int kblocks) {
+  return attn_x3_ok(G) && G.dh == UA_DH && nblk == G.heads * 4 && kblocks == 10 && G.D % 4 == 0 && G.D >= 288 && G.D <= 316;
+}
+
+int attn_fwd_x3_proj(const float* x, int64_t x_outer, int64_t x_seq, const uint16_t* img, int nblk, float* qkv, float* o,
+                     float* lse, const AttnGeom& G, hipStream_t stream) {
+  if (G.groups == 0) return NRL_OK;
+  NRL_REQUIRE(attn_x3_ok(G) && nblk == G.heads * 4, "attn_fwd_x3_proj: unsupported geometry");
+  NRL_REQUIRE(G.groups + 7 < (1LL << 31), "attention grid too large");
+  NRL_REQUIRE((((uintptr_t)x | (uintptr_t)o | (uintptr_t)img) & 15) == 0 && x_outer % 4 == 0 && x_seq % 4 == 0,
+              "attn_fwd_x3_proj: 16-byte alignment");
+  UaProjArgs A{x, x_outer, x_seq, img, nblk, qkv};
+  hipLaunchKernelGGL(ua_fwd_proj_kernel, dim3((unsigned)(8 * ((G.groups + 7) / 8))), dim3(UA_WAVES * 64), 0, stream, A, o, lse, G);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -31,6 +31,11 @@ bool attn_x3_ok(const AttnGeom& G);
 int attn_fwd_x3(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream);
 int attn_bwd_x3(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, const AttnGeom& G,
                 hipStream_t stream);
+// attn_fwd_x3 with the in-projection inside: q|k|v of a group computed from its input rows (x + outer * x_outer + r * x_seq) and the
+// per-head weight image (rp_jobs_add_qkv_heads); `qkv` (packed rows for the backward) may be null
+bool attn_x3_proj_ok(const AttnGeom& G, int nblk, int kblocks);
+int attn_fwd_x3_proj(const float* x, int64_t x_outer, int64_t x_seq, const uint16_t* img, int nblk, float* qkv, float* o,
+                     float* lse, const AttnGeom& G, hipStream_t stream);
 // dqkv (rows, 3D) fully overwritten
 int attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
              const AttnGeom& G, hipStream_t stream);

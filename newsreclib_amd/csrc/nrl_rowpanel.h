@@ -179,10 +179,18 @@ static inline RpImageJob* rp_jobs_add_kperm(RpImageJobs* js, const float* src, i
   return J;
 }
 // image in kappa order (second projection of the fused news tail): bias at k = K against the ones feature of y
+// `kblocks` > 0: the number of k-blocks the CONSUMER streams (the fused tail kernels walk a fixed count whatever K is): the
+// blocks past K are written too, as zeros -- an image that stops at rp_kblocks(K) leaves them uninitialised, and a NaN bit
+// pattern there times a zero operand is still NaN (found in round 4 with a NaN-poisoned workspace at Q = 64: the W_a^T
+// image of the tail backward had 2 of its 7 k-blocks written)
 static inline RpImageJob* rp_jobs_add_kappa(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int K,
-                                            const float* bias, uint16_t* img, int nblk) {
+                                            const float* bias, uint16_t* img, int nblk, int kblocks = 0) {
   RpImageJob* J = rp_jobs_add(js, src, sn, sk, N, K, bias, img, nblk);
   J->kappa = 1;
+  if (kblocks > J->kblocks) {
+    J->kblocks = kblocks;
+    js->first_thread[js->count] = js->first_thread[js->count - 1] + (int64_t)J->kblocks * nblk * 64;
+  }
   return J;
 }
 static inline int rp_jobs_launch(const RpImageJobs& js, hipStream_t st) {
