@@ -205,7 +205,8 @@ def extra_plm(device, batch_size=8, steps=3):
                       "GEMM engine via news_encoder.NrlLinear, its self-attention on nrl_sdpa_fwd / _bwd via the HF attention "
                       "registry), d=768, 16 heads, L=96, B=8 (BASELINE.json configs[3])",
             "body_linears_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_linears),
-            "body_attention_on_this_library": bool(mod.news_encoder.text_encoders["title"].nrl_attention)}
+            "body_attention_on_this_library": bool(mod.news_encoder.text_encoders["title"].nrl_attention),
+            "body_output_blocks_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_output_blocks)}
 
 
 def self_launch(n_gpus: int) -> int:

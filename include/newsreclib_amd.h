@@ -280,6 +280,21 @@ int nrl_adam_rows_advance(float* param, float* grad, float* exp_avg, float* exp_
                           int64_t upto_step, int32_t with_grad, double lr, double beta1, double beta2, double eps,
                           float grad_scale, void* stream);
 
+/* ---- transformer-body glue (ABI v13; config 4, text.py:89-109: every layer of the PLM body ends its attention and its
+ * feed-forward block with LayerNorm(dropout(dense_out) + residual)).  One launch each way instead of dropout + add + layer norm:
+ *   fwd: z = x * keep / (1 - p) + residual;  y = (z - mean) * rstd * gamma + beta.  z_save / mean_save / rstd_save: all three
+ *        (training) or all NULL (evaluation).  The keep mask is the library's counter-based one over the element index
+ *        row * dim + col (seed, stream0), so the backward re-evaluates it instead of reading a stored mask.
+ *   bwd: d_residual = LayerNorm backward of d_y; d_x = d_residual * keep / (1 - p) (d_x may be NULL when p_drop == 0: the two
+ *        are equal); d_gamma / d_beta (both or neither; NULL for a frozen LayerNorm) are ACCUMULATED.
+ * dim % 4 == 0, dim <= 2048, rows * dim < 2^32. */
+int nrl_dropout_add_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, int64_t rows,
+                                  int32_t dim, float eps, double p_drop, uint64_t seed, uint32_t stream0, float* z_save,
+                                  float* mean_save, float* rstd_save, float* y, void* stream);
+int nrl_dropout_add_layernorm_bwd(const float* d_y, const float* z_saved, const float* gamma, const float* mean_saved,
+                                  const float* rstd_saved, int64_t rows, int32_t dim, double p_drop, uint64_t seed,
+                                  uint32_t stream0, float* d_x, float* d_residual, float* d_gamma, float* d_beta, void* stream);
+
 /* =================================================================================================
  * LSTUR path (BASELINE config 5): CNN text encoder, row-masked embedding
  * lookups (category / long-term user vector) and the GRU user encoder.

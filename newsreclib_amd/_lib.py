@@ -126,6 +126,10 @@ SIGNATURES = {
     "nrl_adam_rows_advance": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_int64, c_int64, c_int32, c_double, c_double, c_double, c_double, c_float,
                                         c_void_p]),
+    "nrl_dropout_add_layernorm_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_double,
+                                                c_uint64, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nrl_dropout_add_layernorm_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_double,
+                                                c_uint64, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nrl_cnn_encoder_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "nrl_cnn_encoder_fwd": (c_int32, [POINTER(NrlCnnParams), c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                       c_double, c_uint64, c_uint32, c_int32, c_void_p, c_void_p, c_size_t,

@@ -166,8 +166,6 @@ __global__ void __launch_bounds__(UA_WAVES * 64)
   const uint32_t Vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + 2u * UA_MATB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, g = lane >> 4;
-  const uint32_t lane_off = (uint32_t)((4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8);
   const int64_t grp = ua_item(G.groups);
   if (grp < 0) return;
   const int64_t outer = grp / G.heads;

@@ -223,9 +223,45 @@ def swap_linears(module: nn.Module) -> int:
     return n
 
 
+def _fused_output_forward(self, hidden_states: torch.Tensor, input_tensor: torch.Tensor) -> torch.Tensor:
+    """``LayerNorm(dropout(dense(hidden_states)) + input_tensor)`` of a BERT-family output block with the three elementwise
+    passes after the projection as ONE launch (``ops_blocks.DropoutAddLayerNormFn``)."""
+    h = self.dense(hidden_states)
+    ln = self.LayerNorm
+    if h.dtype != torch.float32 or not h.is_cuda or ln.weight is None or ln.bias is None or h.shape[-1] % 4 or h.shape[-1] > 2048 \
+            or h.numel() >= (1 << 32):
+        FALLBACK_CALLS["output_block_cuda" if h.is_cuda else "output_block_host"] += 1
+        return ln(self.dropout(h) + input_tensor)
+    p = float(self.dropout.p) if self.training else 0.0
+    params = (ln.weight, ln.bias)
+    return ops_blocks.DropoutAddLayerNormFn.apply(h.contiguous(), input_tensor.contiguous(), ln.weight, ln.bias, float(ln.eps), p,
+                                                  _draw_seed() if p > 0.0 else 0, _grad_bufs(params))
+
+
+def swap_output_blocks(module: nn.Module) -> int:
+    """Gives every ``dense -> dropout -> LayerNorm(. + residual)`` block below ``module`` (``RobertaSelfOutput`` /
+    ``RobertaOutput`` and their BERT-family namesakes: attributes ``dense``, ``dropout``, ``LayerNorm`` and a
+    ``forward(hidden_states, input_tensor)``) the fused forward above; returns how many.  Parameters, state-dict keys and
+    freezing are untouched (only ``forward`` of the block instance is rebound)."""
+    import inspect
+    import types
+    n = 0
+    for m in module.modules():
+        if isinstance(getattr(m, "LayerNorm", None), nn.LayerNorm) and isinstance(getattr(m, "dropout", None), nn.Dropout) \
+                and isinstance(getattr(m, "dense", None), nn.Module):
+            try:
+                names = list(inspect.signature(m.forward).parameters)
+            except (TypeError, ValueError):
+                continue
+            if names[:2] == ["hidden_states", "input_tensor"] and len(names) == 2:
+                m.forward = types.MethodType(_fused_output_forward, m)
+                n += 1
+    return n
+
+
 NRL_ATTENTION = "nrl_x3"
 # calls of the PLM body that did NOT run on this library's kernels (framework fallbacks), by kind; `reset_fallback_calls()` zeroes
-FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0}
+FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0, "output_block_cuda": 0, "output_block_host": 0}
 
 
 def reset_fallback_calls() -> None:
@@ -321,6 +357,11 @@ class PLM(nn.Module):
         self.nrl_linears = 0
         if os.environ.get("NRL_PLM_LINEAR", "1") != "0" and hasattr(self.plm_model, "encoder"):
             self.nrl_linears = swap_linears(self.plm_model.encoder)
+        # ... the dropout + residual + LayerNorm that ends both halves of every layer as one launch each way
+        # (nrl_dropout_add_layernorm_fwd / _bwd); NRL_PLM_GLUE=0 keeps the three framework kernels (A/B)
+        self.nrl_output_blocks = 0
+        if os.environ.get("NRL_PLM_GLUE", "1") != "0" and hasattr(self.plm_model, "encoder"):
+            self.nrl_output_blocks = swap_output_blocks(self.plm_model.encoder)
         # ... and its self-attention on this library's bf16x3 kernels (nrl_sdpa_fwd / _bwd: heads of 64 over <= 128 tokens; other
         # shapes fall through to the framework's SDPA inside the interface); NRL_PLM_ATTENTION=0 keeps the HF path (A/B)
         self.nrl_attention = False

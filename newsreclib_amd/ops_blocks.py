@@ -201,6 +201,56 @@ class SdpaFn(GradAwareFunction):
         return dq, dk, dv, None, None, None, None
 
 
+class DropoutAddLayerNormFn(GradAwareFunction):
+    """``LayerNorm(dropout(x) + residual)`` -- the line that ends both halves of every layer of a BERT-family encoder
+    (``RobertaSelfOutput`` / ``RobertaOutput``; the PLM body of text.py:89-109) -- as ONE launch each way
+    (``nrl_dropout_add_layernorm_fwd`` / ``_bwd``) instead of dropout + add + layer norm (7 passes over the activation forward,
+    8 backward -> 4 and 4).  x, residual (..., dim); gamma, beta (dim).  The dropout mask is the library's counter-based one."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps, p_drop, seed, grad_bufs):
+        lib = _lib.load()
+        x, residual = _chk(x, torch.float32, "input"), _chk(residual, torch.float32, "residual")
+        gamma, beta = _chk(gamma, torch.float32, "LayerNorm.weight"), _chk(beta, torch.float32, "LayerNorm.bias")
+        dim = x.shape[-1]
+        if residual.shape != x.shape or gamma.shape != (dim,) or beta.shape != (dim,):
+            raise ValueError("newsreclib_amd: dropout_add_layernorm expects x and residual of one shape and (dim,) parameters")
+        rows = x.numel() // dim
+        save = saving(ctx)
+        y = torch.empty_like(x)
+        z = torch.empty_like(x) if save else None
+        stats = torch.empty((2, rows), dtype=torch.float32, device=x.device) if save else None
+        _lib.check(lib.nrl_dropout_add_layernorm_fwd(
+            x.data_ptr(), residual.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, dim, float(eps), float(p_drop), int(seed), 0,
+            z.data_ptr() if save else None, stats[0].data_ptr() if save else None, stats[1].data_ptr() if save else None,
+            y.data_ptr(), _stream()), "nrl_dropout_add_layernorm_fwd")
+        if save:
+            ctx.save_for_backward(z, stats, gamma, beta)
+            ctx.cfg, ctx.grad_bufs = (float(p_drop), int(seed)), grad_bufs
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        z, stats, gamma, beta = ctx.saved_tensors
+        p_drop, seed = ctx.cfg
+        d_y = _chk(d_y, torch.float32, "d_out")
+        dim = z.shape[-1]
+        rows = z.numel() // dim
+        need_params = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        rets = [None, None]
+        dg = db = None
+        if need_params:
+            bufs, rets = _grad_targets([gamma, beta], ctx.grad_bufs)
+            dg, db = bufs[0].data_ptr(), bufs[1].data_ptr()
+        d_res = torch.empty_like(z)
+        d_x = torch.empty_like(z) if p_drop > 0.0 else None
+        _lib.check(lib.nrl_dropout_add_layernorm_bwd(
+            d_y.data_ptr(), z.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), rows, dim, p_drop, seed, 0,
+            d_x.data_ptr() if d_x is not None else None, d_res.data_ptr(), dg, db, _stream()), "nrl_dropout_add_layernorm_bwd")
+        return (d_x if d_x is not None else d_res, d_res, rets[0], rets[1], None, None, None, None)
+
+
 def sdpa_supported(n_batch: int, seq_len: int, heads: int, head_dim: int) -> bool:
     return bool(_lib.load().nrl_sdpa_supported(int(n_batch), int(seq_len), int(heads), int(head_dim)))
 

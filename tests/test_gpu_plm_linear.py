@@ -2,6 +2,8 @@
 (news_encoder.NrlLinear / swap_linears -> nrl_linear_fwd / nrl_linear_bwd) against the same HF layer on fp32 torch."""
 import copy
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -243,3 +245,94 @@ def test_plm_body_runs_its_attention_on_the_library_kernels(tmp_path):
     valid = am.bool()[:, :, None]
     err = float(((ours - ref) * valid).abs().max())
     assert err <= 2e-4 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,dim,p", [(300, 768, 0.1), (300, 768, 0.0), (37, 64, 0.3), (5, 2048, 0.1), (1000, 300, 0.1), (4099, 768, 0.1)])
+@pytest.mark.parametrize("trainable", [True, False])
+def test_dropout_add_layernorm_matches_torch(rows, dim, p, trainable):
+    """``nrl_dropout_add_layernorm_fwd`` / ``_bwd`` (the line that ends both halves of every PLM body layer: RobertaSelfOutput /
+    RobertaOutput, behind text.py:89-91) against fp64 torch: LayerNorm(x * keep / (1 - p) + residual) under the library's own
+    keep mask (exported by ``ops.dropout_mask`` for the call's seed), outputs and all four gradients; frozen LayerNorm
+    parameters get none; evaluation (no_grad) saves nothing and gives the same output as p = 0."""
+    from newsreclib_amd import ops, ops_blocks
+    gen = torch.Generator().manual_seed(rows + dim)
+    x = torch.randn(rows, dim, generator=gen).to(DEV).requires_grad_(True)
+    r = torch.randn(rows, dim, generator=gen).to(DEV).requires_grad_(True)
+    gamma = (1.0 + 0.3 * torch.randn(dim, generator=gen)).to(DEV).requires_grad_(trainable)
+    beta = (0.2 * torch.randn(dim, generator=gen)).to(DEV).requires_grad_(trainable)
+    dy = torch.randn(rows, dim, generator=gen).to(DEV)
+    seed = 1234
+    y = ops_blocks.DropoutAddLayerNormFn.apply(x, r, gamma, beta, 1e-5, p, seed, None)
+    y.backward(dy)
+    keep = ops.dropout_mask(rows * dim, p, seed, 0, DEV).view(rows, dim).double() if p > 0 else torch.ones(rows, dim, device=DEV, dtype=torch.float64)
+    xd, rd = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
+    gd, bd = gamma.detach().double().requires_grad_(True), beta.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd * keep / (1.0 - p) + rd, (dim,), gd, bd, 1e-5)
+    ref.backward(dy.double())
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    for got, want, name in ((x.grad, xd.grad, "d_x"), (r.grad, rd.grad, "d_residual")):
+        assert float((got.double() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), name
+    if trainable:
+        for got, want, name in ((gamma.grad, gd.grad, "d_gamma"), (beta.grad, bd.grad, "d_beta")):
+            assert float((got.double() - want).abs().max()) <= 2e-4 * max(1.0, float(want.abs().max())), name
+    else:
+        assert gamma.grad is None and beta.grad is None
+    with torch.no_grad():
+        ye = ops_blocks.DropoutAddLayerNormFn.apply(x, r, gamma, beta, 1e-5, 0.0, 0, None)
+    ref0 = torch.nn.functional.layer_norm(xd + rd, (dim,), gd, bd, 1e-5)
+    assert float((ye.double() - ref0).abs().max()) <= 2e-5 * max(1.0, float(ref0.abs().max()))
+    # gradients accumulated straight into caller-owned buffers (the flat-gradient trainer's `main_grad`)
+    if trainable:
+        bufs = (torch.ones(dim, device=DEV), torch.ones(dim, device=DEV))
+        x2 = x.detach().requires_grad_(True)
+        y2 = ops_blocks.DropoutAddLayerNormFn.apply(x2, r.detach(), gamma, beta, 1e-5, p, seed, bufs)
+        gamma.grad = None
+        y2.backward(dy)
+        assert gamma.grad is None
+        assert float((bufs[0].double() - 1.0 - gd.grad).abs().max()) <= 2e-4 * max(1.0, float(gd.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_plm_full_width_step_runs_on_this_library(tmp_path):
+    """BASELINE configs[3] at full width (roberta-base SHAPE, random init: d = 768, 12 layers, 12 body heads, L = 96, B = 8,
+    layers 0-7 frozen as the reference's experiment file has them; text.py:15-109): three train steps -- finite, decreasing loss --
+    with every body projection, self-attention and output block on this library's kernels: the framework-fallback counters of
+    the GPU path stay 0."""
+    from functools import partial
+
+    from transformers import RobertaConfig, RobertaModel
+
+    from newsreclib_amd import _lib
+    from newsreclib_amd import news_encoder as ne
+    from newsreclib_amd.nrms_module import NRMSModule, prepare_batch
+    from newsreclib_amd.synthetic import make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    _lib.set_gemm_engine("bf16x3")
+    torch.manual_seed(0)
+    cfg = RobertaConfig(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                        max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    RobertaModel(cfg, add_pooling_layer=False).save_pretrained(str(tmp_path))
+    mod = NRMSModule(
+        dataset_attributes=["title", "abstract", "category"], attributes2encode=["title"],
+        outputs={"train": [], "val": [], "test": []}, dual_loss_training=False, dual_loss_coef=None,
+        loss="cross_entropy_loss", late_fusion=False, temperature=None, use_plm=True, pretrained_embeddings_path=None,
+        plm_model=str(tmp_path), frozen_layers=list(range(8)), embed_dim=768, num_heads=16, query_dim=200,
+        dropout_probability=0.2, top_k_list=[5, 10], num_categ_classes=18, num_sent_classes=3, save_recs=False,
+        recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None).to(DEV)
+    te = mod.news_encoder.text_encoders["title"]
+    assert te.nrl_linears == 72 and te.nrl_attention and te.nrl_output_blocks == 24
+    trainer = NRMSTrainer(mod, lr=1e-4)
+    b = make_batch(8, vocab=50000, mode="fixed", seed=1, L=96, device=DEV)
+    for part in ("x_hist", "x_cand"):
+        ids = b[part]["title"].clamp_min(3)
+        am = torch.ones_like(ids)
+        am[:, 70:] = 0                                        # a padded tail: the body attention gets a key-padding mask
+        b[part]["title"] = {"input_ids": ids, "attention_mask": am}
+    pb = prepare_batch(b)
+    ne.reset_fallback_calls()
+    losses = [float(trainer.step(pb)) for _ in range(3)]
+    assert all(np.isfinite(l) for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    fb = dict(ne.FALLBACK_CALLS)
+    assert fb["linear_cuda"] == 0 and fb["attention"] == 0 and fb["output_block_cuda"] == 0, fb
