@@ -377,14 +377,22 @@ class LazyTableAdam:
         """Before the forward of step t = step_count + 1: the rows of `ids` are brought to step t - 1 (what the gather must
         read); then the step's slice of the rolling flush, on `side` if given (it only moves rows the catch-up left behind)."""
         t = self.opt.step_count + 1
+        self._join_side()                # the previous step's flush slice (side stream) before anything here moves a row
         ops.adam_rows_mark_(ids, self.mark, t)
         self._advance(self.mark, t - 1, False)
         if side is not None:
+            self._side = side
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._advance(None, t - 1, False, stride=self.period, offset=t % self.period)
         else:
             self._advance(None, t - 1, False, stride=self.period, offset=t % self.period)
+
+    def _join_side(self) -> None:
+        side = getattr(self, "_side", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            self._side = None
 
     def mark_more(self, ids: torch.Tensor) -> None:
         """Rows other ranks touched this step (touched-row exchange): same tag as ``begin``."""
@@ -405,6 +413,7 @@ class LazyTableAdam:
     def advance_all_before_dense(self) -> None:
         """A step whose table gradient may be non-zero ANYWHERE (a dense all-reduce fallback): every row to t - 1; the caller
         then runs the dense kernel over the whole flat buffer and calls ``mark_all_current``."""
+        self._join_side()
         self._advance(None, self.opt.step_count, False)
 
     def mark_all_current(self) -> None:
@@ -420,6 +429,7 @@ class LazyTableAdam:
     def flush(self) -> None:
         """Every row to the current step: after this the flat buffers hold exactly what dense Adam would."""
         if self.pending:
+            self._join_side()
             self._advance(None, self.opt.step_count, False)
             self.flushed_upto = self.opt.step_count
 

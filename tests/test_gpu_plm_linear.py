@@ -330,9 +330,21 @@ def test_plm_full_width_step_runs_on_this_library(tmp_path):
         am[:, 70:] = 0                                        # a padded tail: the body attention gets a key-padding mask
         b[part]["title"] = {"input_ids": ids, "attention_mask": am}
     pb = prepare_batch(b)
+
+    def eval_loss():
+        mod.eval()
+        with torch.no_grad():
+            return float(mod.model_step(pb)[0])
+
+    before = eval_loss()
     ne.reset_fallback_calls()
     losses = [float(trainer.step(pb)) for _ in range(3)]
     assert all(np.isfinite(l) for l in losses), losses
-    assert losses[-1] < losses[0], losses
+    fb_train = dict(ne.FALLBACK_CALLS)
+    # the train losses carry a fresh dropout draw each (noise of the same size as three steps' progress): "decreases" is judged
+    # on the dropout-free loss of the same batch before and after the three steps
+    after = eval_loss()
+    assert np.isfinite(before) and after < before, (before, after, losses)
+    ne.FALLBACK_CALLS.update(fb_train)
     fb = dict(ne.FALLBACK_CALLS)
     assert fb["linear_cuda"] == 0 and fb["attention"] == 0 and fb["output_block_cuda"] == 0, fb
