@@ -1167,7 +1167,11 @@ int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int 
     A.step_size[s & (ADAM_WIN - 1)] = ss;
     A.inv_sqrt_bc2[s & (ADAM_WIN - 1)] = ib;
   }
-  if (mark != nullptr) hipLaunchKernelGGL(adam_rows_kernel<32>, dim3((unsigned)((A.n_cand + 31) / 32)), dim3(256), 0, stream, A);
+  static const int cand = [] { const char* e = getenv("NRL_ADAM_ROWS_CAND"); return e ? atoi(e) : 32; }();   // (probe: 8 / 16 / 32 / 64)
+  if (mark != nullptr && cand == 8) hipLaunchKernelGGL(adam_rows_kernel<8>, dim3((unsigned)((A.n_cand + 7) / 8)), dim3(256), 0, stream, A);
+  else if (mark != nullptr && cand == 16) hipLaunchKernelGGL(adam_rows_kernel<16>, dim3((unsigned)((A.n_cand + 15) / 16)), dim3(256), 0, stream, A);
+  else if (mark != nullptr && cand == 64) hipLaunchKernelGGL(adam_rows_kernel<64>, dim3((unsigned)((A.n_cand + 63) / 64)), dim3(256), 0, stream, A);
+  else if (mark != nullptr) hipLaunchKernelGGL(adam_rows_kernel<32>, dim3((unsigned)((A.n_cand + 31) / 32)), dim3(256), 0, stream, A);
   else hipLaunchKernelGGL(adam_rows_kernel<4>, dim3((unsigned)((A.n_cand + 3) / 4)), dim3(256), 0, stream, A);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
