@@ -72,26 +72,33 @@ struct NewsFusedArgs {
 // L >= 17) and long ones: perm[0 .. n_short) = the short news, perm[n_short .. n_news) = the long ones (filled from the back),
 // hdr[0] = n_short, hdr[1] = n_long (both zeroed by the caller).  The order inside a class depends on the atomics' arrival
 // order -- irrelevant: a news vector does not depend on which wave computes it.  One returning atomic per workgroup and class.
-static __global__ void __launch_bounds__(1024) news_classify_kernel(const int64_t* __restrict__ ids, int64_t n_news, int L,
-                                                              int32_t* __restrict__ hdr, int32_t* __restrict__ perm) {
-  __shared__ int cnt[16][2];
+static __global__ void __launch_bounds__(256) news_classify_kernel(const int64_t* __restrict__ ids, int64_t n_news, int L,
+                                                                    int32_t* __restrict__ hdr, int32_t* __restrict__ perm) {
+  __shared__ int cnt[4][2];
   __shared__ int base[2];
+  __shared__ int longf[256];            // news of this workgroup with a real token at position >= 15
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 1024 + tid;
-  bool is_short = false;
-  if (n < n_news && L >= 17) {
-    const int64_t* row = ids + n * L;
-    int64_t acc = 0;
-    for (int t = 15; t < L; ++t) acc |= row[t];
-    is_short = acc == 0;
+  const int64_t n0 = (int64_t)blockIdx.x * 256;
+  longf[tid] = 0;
+  __syncthreads();
+  // the workgroup's 256 x L ids are one contiguous run: coalesced loads, flag = any non-zero id at a token position >= 15
+  const int64_t rows = n_news - n0 < 256 ? n_news - n0 : 256;
+  const int64_t total = rows * L;
+  const int64_t* src = ids + n0 * L;
+  for (int64_t e = tid; e < total; e += 256) {
+    const int nl = (int)(e / L), t = (int)(e - (int64_t)nl * L);
+    if (t >= 15 && src[e] != 0) longf[nl] = 1;          // (racing writers agree)
   }
+  __syncthreads();
+  const int64_t n = n0 + tid;
   const bool valid = n < n_news;
+  const bool is_short = valid && L >= 17 && longf[tid] == 0;
   const unsigned long long bs = __ballot(valid && is_short), bl = __ballot(valid && !is_short);
   if (lane == 0) { cnt[wave][0] = __popcll(bs); cnt[wave][1] = __popcll(bl); }
   __syncthreads();
   if (tid < 2) {
     int tot = 0;
-    for (int w = 0; w < 16; ++w) { const int c = cnt[w][tid]; cnt[w][tid] = tot; tot += c; }
+    for (int w = 0; w < 4; ++w) { const int c = cnt[w][tid]; cnt[w][tid] = tot; tot += c; }
     base[tid] = tot > 0 ? atomicAdd(hdr + tid, tot) : 0;
   }
   __syncthreads();
@@ -104,7 +111,7 @@ static __global__ void __launch_bounds__(1024) news_classify_kernel(const int64_
 static inline int launch_news_classify(const int64_t* ids, int64_t n_news, int L, int32_t* hdr, int32_t* perm, hipStream_t st) {
   NRL_REQUIRE(n_news < (1LL << 31), "news_classify: too many news");
   NRL_HIP(hipMemsetAsync(hdr, 0, 2 * sizeof(int32_t), st));
-  hipLaunchKernelGGL(news_classify_kernel, dim3((unsigned)ceil_div(n_news, 1024)), dim3(1024), 0, st, ids, n_news, L, hdr, perm);
+  hipLaunchKernelGGL(news_classify_kernel, dim3((unsigned)ceil_div(n_news, 256)), dim3(256), 0, st, ids, n_news, L, hdr, perm);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -338,7 +338,7 @@ def test_eval_pad_row_sharing_is_bit_identical(N, L):
     (text.py:224-236 has no mask: the pad tokens still take part in both softmaxes, through the shared row).  Cases: mixed
     short / long news, a zero id in the MIDDLE of a long title (not a trailing pad), titles of exactly 15 / 16 / 17 real tokens,
     all-pad news, every news short / every news long, L = 17 (one shared row), L = 32 (no padding to 32), L <= 16 (sharing off),
-    more news than one 1024-thread classification block per class."""
+    more news than one 256-thread classification block."""
     from newsreclib_amd import _lib
     from newsreclib_amd.news_encoder import MHSAAddAtt
     _lib.set_gemm_engine("bf16x3")
