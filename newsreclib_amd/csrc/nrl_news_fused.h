@@ -83,10 +83,13 @@ static __global__ void __launch_bounds__(256) news_classify_kernel(const int64_t
   __syncthreads();
   // the workgroup's 256 x L ids are one contiguous run: coalesced loads, flag = any non-zero id at a token position >= 15
   const int64_t rows = n_news - n0 < 256 ? n_news - n0 : 256;
-  const int64_t total = rows * L;
+  const int total = (int)rows * L;                        // <= 256 * 32
   const int64_t* src = ids + n0 * L;
-  for (int64_t e = tid; e < total; e += 256) {
-    const int nl = (int)(e / L), t = (int)(e - (int64_t)nl * L);
+  // 32-bit indices and a multiply-shift division by L (exact for L <= 32, e < 2^13 with the 2^18 reciprocal rounded up: checked
+  // exhaustively; a 64-bit e / L is a ~100-instruction software division per element)
+  const unsigned rcp = ((1u << 18) + (unsigned)L - 1u) / (unsigned)L;
+  for (int e = tid; e < total; e += 256) {
+    const int nl = (int)(((unsigned)e * rcp) >> 18), t = e - nl * L;
     if (t >= 15 && src[e] != 0) longf[nl] = 1;          // (racing writers agree)
   }
   __syncthreads();
