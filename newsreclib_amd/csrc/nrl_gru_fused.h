@@ -218,15 +218,15 @@ inline int gru_step_fused(const float* h_prev, const uint16_t* w_hi, int64_t ld,
 // = 66 k-tiles at Hd = 700, dealt to its 16 waves: <= GRU_BWD_MAXK each), so dh_{t-1} of its tile is final inside the kernel and
 // the gate backward of step t - 1 -- elementwise in (sequence, unit) -- runs in the epilogue: 51 launches instead of 100, no atomics.
 // B operand: the k-contiguous planes of W_hh^T (split_weight's transposed image), row = hidden unit.
-constexpr int GRU_BWD_WAVES = 16;
-constexpr int GRU_BWD_MAXK = 5;
+constexpr int GRU_BWD_KTILES = 80;     // k-tiles a workgroup covers at most: GRU_BWD_WAVES * GRU_BWD_MAXK for every shape below
 
-template <int TR>
+template <int TR, int GRU_BWD_WAVES>
 __global__ void __launch_bounds__(GRU_BWD_WAVES * 64)
     gru_step_bwd_fused_kernel(const float* __restrict__ dgh_t, const uint16_t* __restrict__ wt_hi, const int64_t ldt,
                               float* dhz, float* gates_prev, const float* __restrict__ ghn_prev, const float* __restrict__ hprev_prev,
                               float* __restrict__ dgh_prev, const int64_t* __restrict__ len, const int t_prev, const int B,
                               const int Hd) {
+  constexpr int GRU_BWD_MAXK = GRU_BWD_KTILES / GRU_BWD_WAVES;
   __shared__ float red[GRU_BWD_WAVES][TR][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
@@ -290,8 +290,8 @@ __global__ void __launch_bounds__(GRU_BWD_WAVES * 64)
     for (int r = 0; r < 4; ++r) red[wave][i][r][lane] = acc[i][r];
   __syncthreads();
   // thread (i, r, lane) of the first TR * 4 waves finishes sequence m0 + 16 i + 4 (lane >> 4) + r, unit u0 + (lane & 15)
-  if (tid < TR * 256) {
-    const int i = tid >> 8, r = (tid >> 6) & 3;
+  for (int o_ = tid; o_ < TR * 256; o_ += GRU_BWD_WAVES * 64) {
+    const int i = o_ >> 8, r = (o_ >> 6) & 3;      // (o_ & 63 == lane: the stride is a multiple of 64)
     float sum = 0.f;
 #pragma unroll
     for (int w = 0; w < GRU_BWD_WAVES; ++w) sum += red[w][i][r][lane];
@@ -325,8 +325,14 @@ __global__ void __launch_bounds__(GRU_BWD_WAVES * 64)
 }
 
 inline bool gru_step_bwd_fused_ok(int Hd) {
-  static const bool on = [] { const char* e = getenv("NRL_GRU_BWD_FUSED"); return !(e != nullptr && e[0] == '0'); }();
-  return on && Hd % 4 == 0 && (3 * Hd + 31) / 32 <= GRU_BWD_WAVES * GRU_BWD_MAXK;
+  // OFF by default (NRL_GRU_BWD_FUSED=1 enables): measured SLOWER -- 28.6 us per step against 15.5 + 5.1 us for the split-K product
+  // + gate launch (LSTUR step 9.31 vs 8.88 ms; GRU forward + backward 2.79-3.03 ms over 4 / 8 / 16 waves and 16 / 32 rows per
+  // workgroup against 2.40).  With the whole reduction in one workgroup a CU has to pull 400 KB of operands through its own
+  // outstanding-miss capacity (the forward kernel's ~1.6 us per k-tile, times 66 k-tiles); split-K spreads the same lines over
+  // 11x more CUs.  What would win is split-K with a last-arriver epilogue, whose cross-workgroup release is exactly what made
+  // the persistent forward slow on this multi-XCD part (gru_grid_barrier above).
+  static const bool on = [] { const char* e = getenv("NRL_GRU_BWD_FUSED"); return e != nullptr && e[0] == '1'; }();
+  return on && Hd % 4 == 0 && (3 * Hd + 31) / 32 <= GRU_BWD_KTILES;
 }
 
 // one BPTT step: dh_{t-1} into `dhz` (in place over dh_t * z_t), and -- t_prev >= 0 -- the gate backward of step t_prev = t - 1
@@ -334,15 +340,19 @@ inline int gru_step_bwd_fused(const float* dgh_t, const uint16_t* wt_hi, int64_t
                               const float* ghn_prev, const float* hprev_prev, float* dgh_prev, const int64_t* len, int t_prev,
                               int64_t B, int Hd, hipStream_t stream) {
   if (B == 0) return NRL_OK;
-  const int tr = Hd >= 512 ? 2 : 1;
-  const dim3 block(GRU_BWD_WAVES * 64);
-  if (tr == 2) {
-    hipLaunchKernelGGL(gru_step_bwd_fused_kernel<2>, dim3((unsigned)(ceil_div(B, 32) * ceil_div(Hd, 16))), block, 0, stream, dgh_t,
-                       wt_hi, ldt, dhz, gates_prev, ghn_prev, hprev_prev, dgh_prev, len, t_prev, (int)B, Hd);
-  } else {
-    hipLaunchKernelGGL(gru_step_bwd_fused_kernel<1>, dim3((unsigned)(ceil_div(B, 16) * ceil_div(Hd, 16))), block, 0, stream, dgh_t,
-                       wt_hi, ldt, dhz, gates_prev, ghn_prev, hprev_prev, dgh_prev, len, t_prev, (int)B, Hd);
-  }
+  static const int tr_env = [] { const char* e = getenv("NRL_GRU_BWD_TR"); return e ? atoi(e) : 0; }();
+  static const int wv_env = [] { const char* e = getenv("NRL_GRU_BWD_WAVES"); return e ? atoi(e) : 16; }();
+  const int tr = tr_env ? tr_env : (Hd >= 512 ? 2 : 1);
+#define NRL_GRU_BWD_LAUNCH(TRV, WV)                                                                                              \
+  hipLaunchKernelGGL((gru_step_bwd_fused_kernel<TRV, WV>), dim3((unsigned)(ceil_div(B, 16 * TRV) * ceil_div(Hd, 16))), dim3(WV * 64), \
+                     0, stream, dgh_t, wt_hi, ldt, dhz, gates_prev, ghn_prev, hprev_prev, dgh_prev, len, t_prev, (int)B, Hd)
+  if (tr == 2 && wv_env == 16) NRL_GRU_BWD_LAUNCH(2, 16);
+  else if (tr == 2 && wv_env == 8) NRL_GRU_BWD_LAUNCH(2, 8);
+  else if (tr == 2) NRL_GRU_BWD_LAUNCH(2, 4);
+  else if (wv_env == 16) NRL_GRU_BWD_LAUNCH(1, 16);
+  else if (wv_env == 8) NRL_GRU_BWD_LAUNCH(1, 8);
+  else NRL_GRU_BWD_LAUNCH(1, 4);
+#undef NRL_GRU_BWD_LAUNCH
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
