@@ -564,6 +564,42 @@ def test_user_encoder_fwd_and_bwd_vs_oracle(B, H):
         assert e <= 2e-4 * scale, k
 
 
+@pytest.mark.parametrize("B,H", [(128, 5), (77, 6), (64, 50)])
+def test_user_encoder_in_projection_inside_the_attention_kernel_matches_the_separate_launches(B, H):
+    """`user_proj` (user/nrms.py:34 inside ua_fwd_proj_kernel): forward output, evaluation output (no q|k|v save) and every
+    gradient against the path with the tiled in-projection GEMM + attention launch, to rounding -- the two paths accumulate the
+    K = 300 reduction in different orders -- and both against the oracle through test_user_encoder_fwd_and_bwd_vs_oracle."""
+    from newsreclib_amd import _lib
+    from newsreclib_amd.user_encoder import UserEncoder
+    _lib.set_gemm_engine("bf16x3")
+    params = _news_params()
+    gen = torch.Generator().manual_seed(B + H)
+    hist = torch.randn(B, H, 300, generator=gen)
+    d_out = torch.randn(B, 300, generator=gen)
+    was = bool((_lib.load().nrl_get_options() >> _lib.OPTION_NAMES.index("user_proj")) & 1)
+    assert was, "user_proj must be on by default"
+    res = []
+    for on in (True, False):
+        _lib.set_option("user_proj", on)
+        try:
+            enc = UserEncoder(300, 15, 200)
+            enc.load_state_dict({k[len(O.USER_PREFIX):]: v for k, v in params.items() if k.startswith(O.USER_PREFIX)})
+            enc = enc.to(DEV)
+            hg = hist.to(DEV).requires_grad_(True)
+            out = enc(hg)
+            out.backward(d_out.to(DEV))
+            with torch.no_grad():
+                ev = enc(hist.to(DEV))
+            res.append((out.detach().cpu(), ev.cpu(), hg.grad.cpu(), {k: p.grad.cpu() for k, p in enc.named_parameters()}))
+        finally:
+            _lib.set_option("user_proj", was)
+    assert _maxerr(res[0][0], res[1][0]) <= 2e-5 and _maxerr(res[0][1], res[1][1]) <= 2e-5
+    assert _maxerr(res[0][0], res[0][1]) <= 1e-6                      # (no dropout in this module: train == eval)
+    assert _maxerr(res[0][2], res[1][2]) <= 1e-4 * max(1.0, float(res[1][2].abs().max()))
+    for k, g0 in res[0][3].items():
+        assert _maxerr(g0, res[1][3][k]) <= 1e-4 * max(1.0, float(g0.abs().max())), k
+
+
 def test_to_dense_batch_scores_and_ce_vs_oracle():
     from newsreclib_amd.click_predictor import CrossEntropyLoss, DotProduct
     from newsreclib_amd.dense_batch import to_dense_batch
