@@ -273,7 +273,9 @@ int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  *                          Each is advanced from last_step[r] to upto_step with zero gradients; with_grad != 0: then step
  *                          upto_step + 1 is applied with its gradient row (times grad_scale), the gradient row is cleared and
  *                          last_step[r] = upto_step + 1.  (catch-up before a forward: mark, upto_step = t - 1, with_grad 0;
- *                          update after the backward: mark, upto_step = t - 1, with_grad 1; flush: mark NULL, with_grad 0.) */
+ *                          update after the backward: mark, upto_step = t - 1, with_grad 1; flush: mark NULL, with_grad 0;
+ *                          with_grad 2, mark NULL: "scan" -- every candidate row whose gradient row has a non-zero element is
+ *                          updated, all-zero rows stay lazy: the update after a DENSE all-reduce, which leaves no list of rows.) */
 int nrl_adam_rows_mark(const int64_t* ids, int64_t n_ids, int64_t rows, int32_t* mark, int64_t step, void* stream);
 int nrl_adam_rows_advance(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t rows, int32_t dim,
                           int32_t* last_step, const int32_t* mark, int32_t* status, int64_t stride, int64_t offset,

@@ -1047,6 +1047,8 @@ struct AdamRowsArgs {
   int32_t* status;
   int64_t n_cand, stride, offset;
   int32_t tag, upto0, with_grad, D;
+  int32_t scan;            // with_grad and no mark: a candidate row is updated iff its gradient row has a non-zero element (a dense
+                           // all-reduce leaves no list of touched rows; an all-zero row's update IS the replay it gets later)
   AdamConst base;          // b1, b2, 1 - b1, 1 - b2, eps, grad_scale (step_size / inv_sqrt_bc2 come from the window)
   float step_size[ADAM_WIN], inv_sqrt_bc2[ADAM_WIN];
 };
@@ -1066,7 +1068,7 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(const AdamRowsArgs A) {
     bool take = false;
     if (tid < CAND && j < A.n_cand) {
       const int64_t r = A.offset + j * A.stride;
-      take = (A.mark == nullptr || A.mark[r] == A.tag) && (A.with_grad || A.last[r] < A.upto0);
+      take = (A.mark == nullptr || A.mark[r] == A.tag) && (A.with_grad || A.last[r] < A.upto0);     // (scan: every candidate)
     }
     const unsigned long long b = __ballot(take);
     if (take) s_rows[__popcll(b & ((1ull << lane) - 1ull))] = tid;
@@ -1077,12 +1079,24 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(const AdamRowsArgs A) {
   const int D = A.D;
   for (int i = wave; i < n; i += 4) {
     const int64_t r = A.offset + ((int64_t)blockIdx.x + (int64_t)s_rows[i] * gridDim.x) * A.stride;
+    float* const gr = A.g + r * D;
+    if (A.scan) {
+      // any non-zero gradient element in this row?  (D <= 320 * 4 chunks is plenty for the tables this serves)
+      bool nz = false;
+      for (int base = 0; base < D; base += 256) {
+        const int q = base + 4 * lane;
+        if (q + 3 < D) {
+          const float4 gv = *reinterpret_cast<const float4*>(gr + q);
+          nz = nz || gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f;
+        }
+      }
+      if (__ballot(nz) == 0ull) continue;
+    }
     const int from = __builtin_amdgcn_readfirstlane(A.last[r]);
     if (A.upto0 - from >= ADAM_WIN && lane == 0) A.status[0] = 1;
     float* const pr = A.p + r * D;
     float* const mr = A.m + r * D;
     float* const vr = A.v + r * D;
-    float* const gr = A.g + r * D;
     for (int base = 0; base < D; base += 320) {
       const int q = base + 4 * lane;                       // this lane's float4 ...
       const bool has4 = q + 3 < D && q < base + 256;
@@ -1144,6 +1158,9 @@ int adam_rows_mark(const int64_t* ids, int64_t n, int64_t rows, int32_t* mark, i
 int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int dim, int32_t* last, const int32_t* mark,
                       int32_t* status, int64_t stride, int64_t offset, int64_t upto0, int with_grad, double lr, double b1,
                       double b2, double eps, float grad_scale, hipStream_t stream) {
+  // with_grad == 2: "scan" -- no mark; every candidate row whose gradient row is non-zero is updated (dense all-reduce)
+  const int scan = with_grad == 2 ? 1 : 0;
+  NRL_REQUIRE(!scan || mark == nullptr, "adam_rows: the scan update takes no mark");
   NRL_REQUIRE(p && g && m && v && last && status && rows >= 0 && dim > 0 && dim % 4 == 0, "adam_rows: bad arguments");
   NRL_REQUIRE(stride >= 1 && offset >= 0 && upto0 >= 0 && upto0 + 1 < (1LL << 31), "adam_rows: bad slice / step");
   NRL_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (dim * sizeof(float)) % 16 == 0,
@@ -1153,7 +1170,7 @@ int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int 
   A.p = p; A.g = g; A.m = m; A.v = v; A.last = last; A.mark = mark; A.status = status;
   A.n_cand = (rows - offset + stride - 1) / stride; A.stride = stride; A.offset = offset;
   A.tag = (int32_t)(upto0 + 1);      // the step the marks were written for: catch-up and update both run during step upto0 + 1
-  A.upto0 = (int32_t)upto0; A.with_grad = with_grad ? 1 : 0; A.D = dim;
+  A.upto0 = (int32_t)upto0; A.with_grad = with_grad ? 1 : 0; A.D = dim; A.scan = scan;
   A.base.b1 = (float)b1; A.base.b2 = (float)b2; A.base.one_m_b1 = (float)(1.0 - b1); A.base.one_m_b2 = (float)(1.0 - b2);
   A.base.eps = (float)eps; A.base.grad_scale = grad_scale; A.base.step_size = 0.f; A.base.inv_sqrt_bc2 = 0.f;
   const int64_t hi = upto0 + 1;
@@ -1171,7 +1188,7 @@ int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int 
   if (mark != nullptr && cand == 8) hipLaunchKernelGGL(adam_rows_kernel<8>, dim3((unsigned)((A.n_cand + 7) / 8)), dim3(256), 0, stream, A);
   else if (mark != nullptr && cand == 16) hipLaunchKernelGGL(adam_rows_kernel<16>, dim3((unsigned)((A.n_cand + 15) / 16)), dim3(256), 0, stream, A);
   else if (mark != nullptr && cand == 64) hipLaunchKernelGGL(adam_rows_kernel<64>, dim3((unsigned)((A.n_cand + 63) / 64)), dim3(256), 0, stream, A);
-  else if (mark != nullptr) hipLaunchKernelGGL(adam_rows_kernel<32>, dim3((unsigned)((A.n_cand + 31) / 32)), dim3(256), 0, stream, A);
+  else if (mark != nullptr || scan) hipLaunchKernelGGL(adam_rows_kernel<32>, dim3((unsigned)((A.n_cand + 31) / 32)), dim3(256), 0, stream, A);
   else hipLaunchKernelGGL(adam_rows_kernel<4>, dim3((unsigned)((A.n_cand + 3) / 4)), dim3(256), 0, stream, A);
   NRL_LAUNCH_CHECK();
   return NRL_OK;

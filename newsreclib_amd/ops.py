@@ -494,7 +494,7 @@ def adam_rows_mark_(ids: torch.Tensor, mark: torch.Tensor, step: int) -> None:
 
 def adam_rows_advance_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                        last_step: torch.Tensor, mark: Optional[torch.Tensor], status: torch.Tensor, upto_step: int,
-                       with_grad: bool, lr: float, betas: Tuple[float, float], eps: float, grad_scale: float = 1.0,
+                       with_grad, lr: float, betas: Tuple[float, float], eps: float, grad_scale: float = 1.0,
                        stride: int = 1, offset: int = 0) -> None:
     """``nrl_adam_rows_advance`` over a (rows, dim) table and its flat gradient / moment views (see include/newsreclib_amd.h)."""
     lib = _lib.load()
@@ -504,7 +504,7 @@ def adam_rows_advance_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.T
             raise ValueError("newsreclib_amd.adam_rows_advance_: contiguous float32 GPU tensors of one (rows, dim) shape required")
     _lib.check(lib.nrl_adam_rows_advance(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), rows, dim,
                                          last_step.data_ptr(), mark.data_ptr() if mark is not None else None,
-                                         status.data_ptr(), int(stride), int(offset), int(upto_step), int(bool(with_grad)),
+                                         status.data_ptr(), int(stride), int(offset), int(upto_step), int(with_grad),
                                          lr, betas[0], betas[1], eps, float(grad_scale), _stream()), "nrl_adam_rows_advance")
 
 

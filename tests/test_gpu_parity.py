@@ -418,17 +418,28 @@ def test_lazy_table_adam_is_bit_identical_to_dense_adam(period):
         ids = ids.to(DEV)
         uniq = torch.unique(ids)
         scale = 1.0 if t % 3 else 0.5
-        g_rows = torch.randn(uniq.numel(), D, generator=gen).to(DEV)
-        g_rest = torch.randn(fa.numel - V * D, generator=gen).to(DEV)
         before = pa[0].detach()[uniq].clone()
         lazy.begin(ids.reshape(-1, 1), side if t % 2 else None)
         assert torch.equal(pb[0].detach()[uniq], before), f"step {t}: gathered rows differ from dense Adam's"
+        scan = t % 4 == 0           # a data-parallel step under the dense all-reduce: OTHER ranks' rows carry gradients too, no list
+        if scan:
+            extra = torch.randint(0, V, (37,), generator=gen).to(DEV)
+            uniq = torch.unique(torch.cat([uniq, extra]))
+        g_rows = torch.randn(uniq.numel(), D, generator=gen).to(DEV)
+        if scan:
+            g_rows[::5] = 0.0       # (a touched row whose reduced gradient is exactly zero stays lazy: same result)
+        g_rest = torch.randn(fa.numel - V * D, generator=gen).to(DEV)
         for f in (fa, fb):
             f.grad[: V * D].view(V, D)[uniq] = g_rows
             f.grad[V * D:] = g_rest
         oa.step(grad_scale=scale, zero_grad=True)
         torch.cuda.current_stream().wait_stream(side)
-        lazy.finish(scale)
+        if scan:
+            lazy.update_scan(scale)
+            ob.begin_step()
+            ob.step_range(V * D, fb.numel, scale, zero_grad=True)
+        else:
+            lazy.finish(scale)
         assert oa.step_count == ob.step_count == t
     assert lazy.pending
     lazy.flush()
