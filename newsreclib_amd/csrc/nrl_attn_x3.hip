@@ -195,6 +195,8 @@ struct UaProjArgs {
   float* qkv;                // packed q|k|v rows (geometry G.q_outer / G.q_seq), or null: evaluation
 };
 
+// (hipcc keeps 76 registers here and sinks the row loads towards their use; pinning all twenty in flight -- sched_barrier, 146
+//  registers, one workgroup per CU instead of three -- measured SLOWER: 47 vs 39 us.  Three resident workgroups hide the latency.)
 __global__ void __launch_bounds__(UA_WAVES * 64)
     ua_fwd_proj_kernel(const UaProjArgs A, float* __restrict__ o, float* __restrict__ lse, const AttnGeom G) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * UA_MATB];
