@@ -125,7 +125,7 @@ int nrl_get_gemm_engine(void);
  *  16 "news_tail_od"    (ABI v13, default OFF: measured slower) the out-projection's activation gradient of the fused news path
  *                       inside the fused tail backward (the dy planes are read back by the wave that wrote them; one launch fewer)
  *  17 "user_proj"       (ABI v13) the NRMS user encoder's in-projection inside its across-users attention kernel (bf16x3 engine,
- *                       64 <= users <= 128 per call, D = 20 * heads in [288, 316]) instead of a separate GEMM launch
+ *                       32 <= users <= 128 per call, D = 20 * heads in [288, 316]) instead of a separate GEMM launch
  * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
  * must see the same defaults (newsreclib_amd/ops*.py compare nrl_get_options() at both). */
 int nrl_set_option(const char* name, int32_t value);

@@ -498,8 +498,10 @@ static int block_fwd_tail(const NrlBlockParams* P, const BlockShape& s, const Bl
 // user encoder at 64 .. 128 users per rank); everything else -- and the exact-fp32 engine -- on attn_fwd / attn_bwd.  Forward
 // and backward of a call agree on it: the engine travels with the call, the geometry is the call's.
 static inline bool block_attn_x3(const BlockShape& s) {
-  // (NRL_ATTN_X3_MIN_S: A/B runs of the lower edge; below it the vector-ALU kernels pack 4-8 groups into a workgroup)
-  static const int min_s = [] { const char* e = getenv("NRL_ATTN_X3_MIN_S"); return e ? atoi(e) : 64; }();
+  // (NRL_ATTN_X3_MIN_S: A/B runs of the lower edge; below it the vector-ALU kernels pack 4-8 groups into a workgroup.  32 since
+  //  round 4: with the in-projection inside the kernel (user_proj) the configs[0] step, S = B = 32, is 1.065 vs 1.093 ms; round 3,
+  //  without it: 1.18 vs 1.19 at a threshold of 17, not worth a routing rule then)
+  static const int min_s = [] { const char* e = getenv("NRL_ATTN_X3_MIN_S"); return e ? atoi(e) : 32; }();
   return cur_engine() == ENGINE_BF16X3 && s.geom.S >= min_s && attn_x3_ok(s.geom);
 }
 

@@ -25,7 +25,7 @@ int attn_fwd(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStrea
 int attn_fwd_mfma(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream);
 int attn_bwd_mfma(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                   const AttnGeom& G, hipStream_t stream);
-// the same pair for 64 <= S <= 128, dh = 20 on the bf16 matrix cores with (hi, lo) split operands (nrl_attn_x3.hip): the NRMS
+// the same pair for (by default) 32 <= S <= 128, dh = 20 on the bf16 matrix cores with (hi, lo) split operands (nrl_attn_x3.hip): the NRMS
 // user encoder's across-users attention under the bf16x3 engine (the exact-fp32 engine keeps the fp32 kernels)
 bool attn_x3_ok(const AttnGeom& G);
 int attn_fwd_x3(const float* qkv, float* o, float* lse, const AttnGeom& G, hipStream_t stream);
