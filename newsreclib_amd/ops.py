@@ -20,7 +20,16 @@ from . import _lib
 from ._lib import NrlBlockGrads, NrlBlockParams
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """Raw handle of the current HIP stream of the current device.  (Through the private fast path when this torch has it:
+    ``torch.cuda.current_stream()`` builds a Stream object per call, ~9 us, and every ctypes wrapper asks once -- 16 calls = 0.15 ms
+    of host time per train step, a sixth of the whole issue time at B = 32 where host and device are neck and neck.)"""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 

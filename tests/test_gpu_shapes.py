@@ -94,3 +94,16 @@ def test_user_encoder_shapes(shape, engine):
         scale = max(1.0, float(want.abs().max()))
         # (the key third of in_proj_bias has an exactly-zero true gradient: both sides are rounding noise)
         assert float((p.grad.cpu() - want).abs().max()) <= gtol * scale, k
+
+
+@pytest.mark.gpu
+def test_raw_stream_handle_follows_the_current_stream():
+    """ops._stream() (the handle every C-ABI call is issued on) through torch's private fast path == the public
+    ``torch.cuda.current_stream().cuda_stream``, on the default stream and inside ``torch.cuda.stream(side)``."""
+    import torch
+    from newsreclib_amd import ops
+    assert ops._stream() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert ops._stream() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert ops._stream() == torch.cuda.current_stream().cuda_stream
