@@ -93,6 +93,7 @@ class deferred_weight_grads:
 
     def __exit__(self, *exc):
         deferred_weight_grads._active = None
+        self.joined = bool(self.keep)      # (the caller's stream now waits for everything issued on `stream` so far)
         if self.keep:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.keep = []

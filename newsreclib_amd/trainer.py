@@ -647,8 +647,13 @@ class NRMSTrainer:
         root = self._one if self._unit_root and loss.dim() == 0 and loss.dtype == torch.float32 and loss.device == self._one.device else None
         if self._side is not None:
             # the user encoder's weight gradients on a side stream beside the news-encoder backward; joined on exit
-            with ops.deferred_weight_grads(self._side):
+            with ops.deferred_weight_grads(self._side) as deferred:
                 loss.backward(gradient=root)
+            if deferred.joined:
+                # that join also covers the lazy optimizer's flush slice (issued on the same side stream before the forward): one
+                # cross-stream wait per step instead of two (each is a barrier packet of ~6 us on the launch queue)
+                for tab, _ in self.lazy_tables:
+                    tab._side = None
         else:
             loss.backward(gradient=root)
         # parameters whose gradient came through ordinary autograd (``.grad``: a transformer body, a small
