@@ -302,11 +302,9 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
           if (k + 4 == D) v1.x = 1.0f;
         }
         rp_split8(v0, v1, ah[rb][kb], al[rb][kb]);
-        if constexpr (SAVE && !(ABL & 1024)) {
-          // (ABL 1024, the probe's old form: the 40 plane stores of a lane here, in the gather phase, where nothing overlaps their
-          //  issue; the product stores k-block h under head h's MFMAs -- store_x below)
-        } else if constexpr (SAVE) {
+        if constexpr (SAVE) {
           if (P.x_planes != nullptr && news_ok) {
+            // block (mb = 2 news + rb, cb = 2 kb + (g >> 1)): row l15, columns 8 (g & 1) .. + 7 (pad rows: zeros + the ones column)
             unsigned char* dst = P.x_planes + (((news * 2 + rb) * 20 + 2 * kb + (g >> 1)) * 2) * 512 + l15 * 32 + (g & 1) * 16;
             *reinterpret_cast<bf16x8*>(dst) = ah[rb][kb];
             *reinterpret_cast<bf16x8*>(dst + 512) = al[rb][kb];
@@ -315,38 +313,6 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       }
     }
   }
-
-  // x planes of k-block kb (both row blocks): the fragments this wave holds for all heads, so they can leave at any time -- k-block h
-  // goes out under head h's MFMAs (four 16-byte stores per lane and head instead of forty in the un-overlapped gather phase).
-  // block (mb = 2 news + rb, cb = 2 kb + (g >> 1)): row l15, columns 8 (g & 1) .. + 7 (pad rows: zeros + the ones column)
-  auto store_x_kb = [&](auto kb_c) {
-    constexpr int kb = decltype(kb_c)::value;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      int ln15 = l15;
-      asm volatile("" : "+v"(ln15));         // (opaque: keeps the per-k-block addresses out of the head loop's live ranges)
-      unsigned char* dst = P.x_planes + (((news * 2 + rb) * 20 + 2 * kb + (g >> 1)) * 2) * 512 + ln15 * 32 + (g & 1) * 16;
-      *reinterpret_cast<bf16x8*>(dst) = ah[rb][kb];
-      *reinterpret_cast<bf16x8*>(dst + 512) = al[rb][kb];
-    }
-  };
-  auto store_x = [&](int h) {
-    if constexpr (!SAVE || (ABL & 1024)) return;
-    if (P.x_planes == nullptr || !news_ok) return;
-    switch (h) {                              // (h is wave-uniform; the register arrays need compile-time indices)
-      case 0: store_x_kb(std::integral_constant<int, 0>{}); break;
-      case 1: store_x_kb(std::integral_constant<int, 1>{}); break;
-      case 2: store_x_kb(std::integral_constant<int, 2>{}); break;
-      case 3: store_x_kb(std::integral_constant<int, 3>{}); break;
-      case 4: store_x_kb(std::integral_constant<int, 4>{}); break;
-      case 5: store_x_kb(std::integral_constant<int, 5>{}); break;
-      case 6: store_x_kb(std::integral_constant<int, 6>{}); break;
-      case 7: store_x_kb(std::integral_constant<int, 7>{}); break;
-      case 8: store_x_kb(std::integral_constant<int, 8>{}); break;
-      case 9: store_x_kb(std::integral_constant<int, 9>{}); break;
-      default: break;
-    }
-  };
 
   // image (q columns = O, column 60 = log-sum-exp of the query) of head `hp` -> global, 16-byte row stores
   auto flush_o = [&](int hp) {
@@ -477,7 +443,6 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
           __builtin_amdgcn_s_barrier();
           if constexpr (!(ABL & 4)) issue_chunk(hn, t >> 2);
           if (t == 2 && h > 0) flush_o(h - 1);              // the previous head's O, under this head's MFMAs
-          if (t == 6) store_x(h);                            // ... and k-block h of the x planes (heads 0 .. 9)
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -666,7 +631,6 @@ static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t s
   }
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   NRL_REQUIRE(a.x_planes == nullptr || NF_KB == 10, "x planes assume 20 column blocks");
-  NRL_REQUIRE(a.x_planes == nullptr || a.heads >= NF_KB, "x planes leave one k-block per head: heads >= 10");
   if ((a.x_save != nullptr || a.x_planes != nullptr) && a.lse != nullptr) {   // training: x + lse (+ q|k|v unless recomputed)
     NRL_REQUIRE(a.perm == nullptr, "fused news encoder: pad-row sharing is for evaluation forwards");
     hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
