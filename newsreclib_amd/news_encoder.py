@@ -185,12 +185,17 @@ class NrlLinear(nn.Module):
         self.weight, self.bias = linear.weight, linear.bias
         # a frozen weight's matrix-core images are built once, not twice per step (NRL_PLM_IMAGE_CACHE=0: every call, A/B)
         self._images = ops_blocks.FrozenImages() if os.environ.get("NRL_PLM_IMAGE_CACHE", "1") != "0" else None
+        # ... and a trainable weight's within one optimizer step (two encoder calls per step; NRL_PLM_STEP_IMAGES=0: rebuilt per call)
+        self._step_images = ops_blocks.FrozenImages(allow_trainable=True) \
+            if os.environ.get("NRL_PLM_STEP_IMAGES", "1") != "0" and self._images is not None else None
 
     def _load_from_state_dict(self, *args, **kwargs):
         # load_state_dict copies into the Parameter under no_grad (the version counter moves) -- but a caller may also have
         # swapped storage behind it; a load is rare and an image build is 10 us, so drop the cached images outright
         if self._images is not None:
             self._images.invalidate()
+        if self._step_images is not None:
+            self._step_images.invalidate()
         return super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -203,7 +208,7 @@ class NrlLinear(nn.Module):
         trainable = self.weight.requires_grad or self.bias.requires_grad
         if trainable and self._images is not None:
             self._images.invalidate()        # trained now, maybe frozen again later: never meet an image of the old values
-        images = self._images if not trainable else None
+        images = self._images if not trainable else self._step_images
         return ops_blocks.LinearFn.apply(x.contiguous(), self.weight, self.bias, _grad_bufs(params), images)
 
     def extra_repr(self) -> str:

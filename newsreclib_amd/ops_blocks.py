@@ -128,7 +128,7 @@ class LinearFn(GradAwareFunction):
             need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             ctx.save_for_backward(a2 if need_w else None, w, bias)
             ctx.grad_bufs, ctx.engine, ctx.in_shape = grad_bufs, _lib.engine_code(), tuple(a.shape)
-            ctx.images = images if not need_w else None
+            ctx.images = images          # (a FrozenImages decides per weight whether it may keep an image)
         return c.view(*a.shape[:-1], N)
 
     @staticmethod
@@ -256,6 +256,12 @@ def sdpa_supported(n_batch: int, seq_len: int, heads: int, head_dim: int) -> boo
 
 
 _IMAGE_GENERATION = [0]
+_STEP_GENERATION = [0]      # bumped by an optimizer that writes parameters through raw pointers (trainer.FusedAdam.begin_step)
+
+
+def next_optimizer_step() -> None:
+    """Tells the per-step weight-image caches (``FrozenImages(allow_trainable=True)``) that trainable weights are about to change."""
+    _STEP_GENERATION[0] += 1
 
 
 def invalidate_frozen_images() -> None:
@@ -275,20 +281,25 @@ class FrozenImages:
     (the PLM body's frozen layers, text.py:69-73: two thirds of a config-4 step's image builds).
     A buffer is marked ready only by ``commit`` AFTER the C call that built its image returned NRL_OK."""
 
-    def __init__(self):
+    def __init__(self, allow_trainable: bool = False):
+        # allow_trainable: images of a TRAINABLE weight, valid within one optimizer step (the PLM encoder is called twice per
+        # step -- history, candidates -- and every trainable projection rebuilt its forward and its backward image in both
+        # calls).  Sound only because every writer of such a weight moves the key: torch.optim's in-place updates bump the
+        # tensor's version counter, this library's FusedAdam bumps the module-wide generation (``begin_step``).
         self._buf = {}
         self._key = {}
+        self._allow_trainable = bool(allow_trainable)
 
     def invalidate(self) -> None:
         self._key = {}
 
     def buffer(self, which: str, w: torch.Tensor, lib, device):
         """-> (buffer, ready flag, key to ``commit`` once the call succeeded); (None, 0, None) for a trainable weight."""
-        if w.requires_grad:
+        if w.requires_grad and not self._allow_trainable:
             self.invalidate()
             return None, 0, None
         key = (w.data_ptr(), w._version, tuple(w.shape), _lib.engine_code(), _lib.options_word(), str(device),
-               _IMAGE_GENERATION[0])
+               _IMAGE_GENERATION[0], _STEP_GENERATION[0] if self._allow_trainable else 0, bool(w.requires_grad))
         buf = self._buf.get(which)
         if buf is None or buf.device != device:
             N, K = w.shape

@@ -67,6 +67,10 @@ class FusedAdam:
 
     def begin_step(self) -> None:
         self.step_count += 1
+        # this optimizer writes parameters through raw pointers, which no tensor version counter sees: the within-step image
+        # caches of trainable weights (ops_blocks.FrozenImages(allow_trainable=True)) are keyed on this generation
+        from . import ops_blocks
+        ops_blocks.next_optimizer_step()
 
     def step_range(self, lo: int, hi: int, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         """The Adam update of elements [lo, hi) of the flat buffer (after ``begin_step``): lets the trainer update a slice

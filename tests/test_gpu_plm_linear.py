@@ -348,3 +348,45 @@ def test_plm_full_width_step_runs_on_this_library(tmp_path):
     ne.FALLBACK_CALLS.update(fb_train)
     fb = dict(ne.FALLBACK_CALLS)
     assert fb["linear_cuda"] == 0 and fb["attention"] == 0 and fb["output_block_cuda"] == 0, fb
+
+
+@pytest.mark.gpu
+def test_trainable_linear_keeps_its_images_within_an_optimizer_step_only():
+    """``NrlLinear`` over a TRAINABLE weight (layers 8-11 of the PLM body, two encoder calls per step): the forward / backward
+    images are built once per optimizer step and rebuilt after ``FusedAdam.begin_step`` (raw-pointer writes: generation) and
+    after an in-place update (torch.optim: version counter) -- outputs and gradients always those of the CURRENT weights."""
+    from newsreclib_amd import ops_blocks
+    from newsreclib_amd.news_encoder import NrlLinear
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(768, 768).to(DEV)
+    nl = NrlLinear(lin)
+    assert nl._step_images is not None
+    x = torch.randn(200, 768, device=DEV, requires_grad=True)
+    g = torch.randn(200, 768, device=DEV)
+
+    def run():
+        x.grad = None
+        lin.weight.grad = None
+        y = nl(x)
+        y.backward(g)
+        return y.detach().clone(), x.grad.clone(), lin.weight.grad.clone()
+
+    def check(y, dx, dw):
+        ref = torch.nn.functional.linear(x.detach(), lin.weight, lin.bias)
+        assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        assert float((dx - g @ lin.weight.detach()).abs().max()) <= 1e-4 * float(dx.abs().max())
+        assert float((dw - g.t() @ x.detach()).abs().max()) <= 1e-4 * float(dw.abs().max())
+
+    y0, dx0, dw0 = run()
+    check(y0, dx0, dw0)
+    k0 = dict(nl._step_images._key)
+    assert k0.get("fwd") is not None and k0.get("bwd") is not None
+    y1, dx1, _ = run()                                  # second encoder call of the step: same images
+    assert nl._step_images._key == k0 and torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    lin.weight.data.mul_(1.5)                           # a raw write, as the fused Adam does ...
+    ops_blocks.next_optimizer_step()                    # ... announced by its begin_step
+    check(*run())
+    assert nl._step_images._key != k0
+    with torch.no_grad():
+        lin.weight.mul_(0.5)                            # torch.optim-style in-place update: the version counter moves
+    check(*run())
