@@ -43,14 +43,14 @@ def ranking_metrics(preds: torch.Tensor, targets: torch.Tensor, cand_news_size: 
     pos, neg = preds[targets > 0], preds[targets <= 0]
     if pos.numel() and neg.numel():
         allv = torch.cat([pos, neg])
-        r = torch.empty_like(allv)
+        r = torch.empty(allv.shape, dtype=torch.float64, device=allv.device)
         srt, idx = torch.sort(allv)
-        # average ranks for ties
+        # average ranks for ties; rank sums in float64 (an epoch holds millions of pairs: float32 ranks stop being integers at 2^24)
         uniq, inv, cnt = torch.unique_consecutive(srt, return_inverse=True, return_counts=True)
-        ends = torch.cumsum(cnt, 0).float()
-        avg_rank = ends - (cnt.float() - 1) / 2
+        ends = torch.cumsum(cnt, 0).double()
+        avg_rank = ends - (cnt.double() - 1) / 2
         r[idx] = avg_rank[inv]
-        auc = (r[: pos.numel()].sum() - pos.numel() * (pos.numel() + 1) / 2) / (pos.numel() * neg.numel())
+        auc = (r[: pos.numel()].sum() - pos.numel() * (pos.numel() + 1) / 2) / (float(pos.numel()) * neg.numel())
         out["auc"] = float(auc)
     else:
         out["auc"] = 0.0

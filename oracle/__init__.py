@@ -15,7 +15,8 @@ container, and the reference holds no test or fixture for them), each stated aga
 * ``input_oracle.py`` (the host collate): ``rec_dataset.py`` -> ``mind_dataframe.py`` needs
   ``omegaconf`` -- restatement checked by hand-made known answers only: **parity unpinned**.
 * ``metrics_oracle.py`` (row f.3, the aspect-metric half of the evaluation path): ``metrics/functional.py`` imports
-  ``torchmetrics`` -- **parity unpinned**.  (The scoring half of row f.3 IS pinned: cached == uncached == nrms_oracle.)
+  ``torchmetrics`` -- **parity unpinned**.  (The scoring half of row f.3 IS pinned: cached == uncached == nrms_oracle; the
+  AUC / MRR / nDCG half is cross-checked against scikit-learn, an independent implementation of the same definitions.)
 * ``losses_oracle.py`` (the SupCon half of row f.4): ``pytorch-metric-learning==2.2.0`` is absent and un-vendored -- its
   published ``GenericPairLoss`` / ``AvgNonZeroReducer`` arithmetic is restated: **parity unpinned** for that half.
 * ``to_dense_batch`` (row a8): third-party ``torch_geometric==2.3.0``, absent -- pinned by known answers.

@@ -126,6 +126,42 @@ def test_ranking_metrics_known_answers():
     assert abs(m["auc"] - 6.0 / 8.0) < 1e-6
 
 
+def test_ranking_metrics_agree_with_scikit_learn_on_ragged_impressions():
+    """torchmetrics (the reference's metric library, nrms_module.py:182-195) is not installed here; scikit-learn is, and
+    implements the same published definitions independently: binary AUROC with tie-averaged ranks (`roc_auc_score`), nDCG@k
+    with the log2 discount (`ndcg_score`; it ranks ties by AVERAGING, so the scores below are tie-free per impression), and
+    the reciprocal rank of the first positive.  Impressions without a positive count 0 (empty_target_action="neg")."""
+    from sklearn.metrics import ndcg_score, roc_auc_score
+    from newsreclib_amd.metrics import ranking_metrics
+    rng = np.random.default_rng(7)
+    sizes = rng.integers(2, 40, size=200)
+    preds, targets = [], []
+    for i, n in enumerate(sizes):
+        preds.append(rng.permutation(n).astype(np.float32) / 64.0 + rng.integers(0, 3))     # tie-free inside, ties across impressions
+        t = (rng.random(n) < 0.15).astype(np.float32)
+        if i % 17 == 0:
+            t[:] = 0.0                                                                       # an impression without a click
+        targets.append(t)
+    p, t = np.concatenate(preds), np.concatenate(targets)
+    m = ranking_metrics(torch.from_numpy(p), torch.from_numpy(t), torch.from_numpy(sizes), [5, 10])
+    assert abs(m["auc"] - roc_auc_score(t, p)) < 1e-6
+    for k in (5, 10):
+        want = np.mean([ndcg_score(tt[None], pp[None], k=k) if tt.sum() > 0 else 0.0 for pp, tt in zip(preds, targets)])
+        assert abs(m[f"ndcg@{k}"] - want) < 1e-6, (k, m[f"ndcg@{k}"], want)
+    rr = []
+    for pp, tt in zip(preds, targets):
+        order = np.argsort(-pp, kind="stable")
+        hit = np.nonzero(tt[order] > 0)[0]
+        rr.append(1.0 / (hit[0] + 1) if hit.size else 0.0)
+    assert abs(m["mrr"] - np.mean(rr)) < 1e-6
+    # an epoch's worth of pairs with heavy ties: the rank sums exceed 2^24 many times over
+    n = 3_000_000
+    p = (rng.integers(0, 4096, size=n) / 4096.0).astype(np.float32)
+    t = (rng.random(n) < 0.2 + 0.1 * p).astype(np.float32)
+    m = ranking_metrics(torch.from_numpy(p), torch.from_numpy(t), torch.full((n // 5,), 5), [5])
+    assert abs(m["auc"] - roc_auc_score(t, p)) < 1e-9
+
+
 _OVERLAP_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["REPO"])
