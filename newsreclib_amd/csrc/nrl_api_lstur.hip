@@ -34,7 +34,23 @@ struct CnnWs {
   float *x, *c, *t, *w, *dc, *dx;
   uint16_t *planes_conv, *planes_att, *planes_conv_t;
   uint16_t* rp;  // row-panel weight images (nrl_rowpanel.h)
+  unsigned char *xpl, *dpl;   // x / dc as fragment-block planes over 32 padded rows per news (conv weight gradient), or null
+  float* wsc;                 // its split-K partial tiles
 };
+
+// The convolution weight gradient from planes (wgrad_planes_conv_kernel, nrl_wgrad_planes.h): window 3, a news inside one
+// 32-row k-tile with at least one zero row after it.  NRL_CONV_WGRAD_PLANES=0 keeps the fp32-fed kernel.
+static int cnn_conv_planes_splits() {
+  static const int sp = [] { const char* e = getenv("NRL_CONV_WGRAD_SPLITS"); const int v = e ? atoi(e) : 24; return v < 1 ? 1 : (v > 512 ? 512 : v); }();
+  return sp;
+}
+static bool cnn_conv_planes_ok(const CnnShape& s) {
+  static const bool on = [] { const char* e = getenv("NRL_CONV_WGRAD_PLANES"); return !(e != nullptr && e[0] == '0'); }();
+  return on && s.W == 3 && s.L <= 63 && s.N < (1LL << 31);
+}
+static int cnn_conv_kt(const CnnShape& s) { return s.L <= 31 ? 1 : 2; }   // k-tiles of 32 padded rows per news
+static int cnn_ncb_x(const CnnShape& s) { return (s.D + 16) / 16; }     // + the ones column
+static int cnn_ncb_dc(const CnnShape& s) { return (s.F + 15) / 16; }
 
 // conv forward / dgrad and additive-attention forward / dgrad on the row-panel kernel (bf16x3, widths <= 320)
 struct CnnRp {
@@ -89,6 +105,10 @@ static size_t cnn_ws_floats(const CnnShape& s) {
   n += al((split_weight_elems(s.Q, s.F) + 1) / 2);
   n += al((conv_t_plane_elems(s.D, s.F, s.W) + 1) / 2);
   n += al((cnn_rp_elems(s) + 1) / 2);
+  if (cnn_conv_planes_ok(s)) {
+    n += al(planes_from_rows_bytes(s.N, cnn_ncb_x(s), 2 * cnn_conv_kt(s)) / 4) + al(planes_from_rows_bytes(s.N, cnn_ncb_dc(s), 2 * cnn_conv_kt(s)) / 4);
+    n += al(wgrad_planes_conv_scratch_floats(5, 2, cnn_ncb_dc(s), cnn_ncb_x(s), cnn_conv_planes_splits()));
+  }
   return n;
 }
 
@@ -111,6 +131,13 @@ static int cnn_carve(void* ws, size_t ws_bytes, const CnnShape& s, CnnWs* o) {
   o->planes_att = reinterpret_cast<uint16_t*>(take((split_weight_elems(s.Q, s.F) + 1) / 2));
   o->planes_conv_t = reinterpret_cast<uint16_t*>(take((conv_t_plane_elems(s.D, s.F, s.W) + 1) / 2));
   o->rp = reinterpret_cast<uint16_t*>(take((cnn_rp_elems(s) + 1) / 2));
+  o->xpl = o->dpl = nullptr;
+  o->wsc = nullptr;
+  if (cnn_conv_planes_ok(s)) {
+    o->xpl = reinterpret_cast<unsigned char*>(take(planes_from_rows_bytes(s.N, cnn_ncb_x(s), 2 * cnn_conv_kt(s)) / 4));
+    o->dpl = reinterpret_cast<unsigned char*>(take(planes_from_rows_bytes(s.N, cnn_ncb_dc(s), 2 * cnn_conv_kt(s)) / 4));
+    o->wsc = take(wgrad_planes_conv_scratch_floats(5, 2, cnn_ncb_dc(s), cnn_ncb_x(s), cnn_conv_planes_splits()));
+  }
   return NRL_OK;
 }
 
@@ -166,6 +193,24 @@ static int gemm_wgrad_any(const float* dy, int I, const BOp& b, int J, float* dW
     return launch_gemm_bf16x3<X3_TILE_W>(a, b, epi, I, J + 1, M, splits(64), st);
   }
   return launch_gemm<NRL_TILE_W>(a, b, epi, I, J + 1, M, wgrad_splits(I, J + 1, M, 64, 160), st);
+}
+
+// dWc[f, t*D + d] += sum_m dc[m, f] x[m + t - pad, d] ; db_c += colsum(dc)
+static int cnn_conv_wgrad(const CnnShape& s, const CnnWs& w, const float* dc, const float* x, int F, float* d_weight,
+                          float* d_bias, hipStream_t st) {
+  const int KD = s.W * s.D;
+  if (w.xpl != nullptr && cur_engine() == ENGINE_BF16X3) {
+    const int ncb_x = cnn_ncb_x(s), ncb_dc = cnn_ncb_dc(s);
+    const int kt = cnn_conv_kt(s);
+    NRL_TRY(launch_planes_from_rows(x, s.D, s.N, s.L, s.D, ncb_x, 2 * kt, true, w.xpl, st));
+    NRL_TRY(launch_planes_from_rows(dc, F, s.N, s.L, F, ncb_dc, 2 * kt, false, w.dpl, st));
+    if (kt == 1)
+      return launch_wgrad_planes_conv<5, 2, 1>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 32, F, s.D, d_weight, d_bias,
+                                               cnn_conv_planes_splits(), st, w.wsc);
+    return launch_wgrad_planes_conv<5, 2, 2>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 64, F, s.D, d_weight, d_bias,
+                                             cnn_conv_planes_splits(), st, w.wsc);
+  }
+  return gemm_wgrad_any(dc, F, rc_window(x, s.D, s.L, s.pad, 1, (int64_t)KD), KD, d_weight, d_bias, s.M, st);
 }
 
 // Small-M GEMM of one GRU step, C += A B with split-K partial sums added atomically: with M = batch
@@ -313,7 +358,7 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
   NRL_TRY(cnn_carve(ws, ws_bytes, s, &w));
   hipStream_t st = (hipStream_t)stream;
   const Dropout drop1 = make_dropout(p_drop, seed, stream0), drop2 = make_dropout(p_drop, seed, stream0 + 1);
-  const int KD = s.W * s.D, KF = s.W * s.F;
+  const int KF = s.W * s.F;
   const SplitWeight sa = planes_view(w.planes_att, s.Q, s.F);
   CnnRp rp;
   NRL_TRY(cnn_rp_images(p, s, w, false, &rp, st));        // built by the forward; weights unchanged since
@@ -324,9 +369,7 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
                      rp.on ? &rp.att_d : nullptr));
   // dW_a += d_pre^T c ; db_a += colsum(d_pre)
   NRL_TRY(gemm_wgrad(w.t, s.Q, w.c, s.F, g->att_weight, g->att_bias, s.M, st));
-  // dWc[f, t*D + d] += sum_m dc[m, f] x[m + t - pad, d] ; db_c += colsum(dc)
-  NRL_TRY(gemm_wgrad_any(w.dc, s.F, rc_window(w.x, s.D, s.L, s.pad, 1, (int64_t)KD), KD, g->conv_weight,
-                         g->conv_bias, s.M, st));
+  NRL_TRY(cnn_conv_wgrad(s, w, w.dc, w.x, s.F, g->conv_weight, g->conv_bias, st));
   // dx[m, d] = dropout1 * sum_{t', f} dc[m + t' - pad', f] Wc[f, (W-1-t')*D + d]
   {
     const KCWindow a{w.dc, s.M, s.F, s.L, s.W, s.W - 1 - s.pad};
@@ -444,7 +487,7 @@ int nrl_cnn_mhsa_encoder_bwd(const NrlCnnParams* cp, const NrlCnnGrads* cg, cons
   hipStream_t st = (hipStream_t)stream;
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1),
                 d3 = make_dropout(p_drop, seed, stream0 + 2);
-  const int KD = cs.W * cs.D, KF = cs.W * cs.F, F = cs.F;
+  const int KF = cs.W * cs.F, F = cs.F;
   BlockPlanes planes;
   NRL_TRY(block_planes(bp, bs, bw, false, &planes, st));
   NRL_TRY(block_bwd_phase1(bp, bg, bs, bw, planes, d3, d_out, st));
@@ -453,8 +496,7 @@ int nrl_cnn_mhsa_encoder_bwd(const NrlCnnParams* cp, const NrlCnnGrads* cg, cons
                      F, st));
   NRL_TRY(block_bwd_phase2(bg, cw.c, bs, bw, st));
   // conv weight / bias gradient, conv dgrad -> dx -> table gradient (as nrl_cnn_encoder_bwd)
-  NRL_TRY(gemm_wgrad_any(cw.dc, F, rc_window(cw.x, cs.D, cs.L, cs.pad, 1, (int64_t)KD), KD, cg->conv_weight,
-                         cg->conv_bias, cs.M, st));
+  NRL_TRY(cnn_conv_wgrad(cs, cw, cw.dc, cw.x, F, cg->conv_weight, cg->conv_bias, st));
   {
     const KCWindow a{cw.dc, cs.M, F, cs.L, cs.W, cs.W - 1 - cs.pad};
     const RCConvT b_rc{cp->conv_weight, F, cs.D, cs.W, (int64_t)cs.D};

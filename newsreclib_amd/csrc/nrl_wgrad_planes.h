@@ -422,4 +422,289 @@ static inline int launch_wgrad_planes_g(const void* a_planes, int ncb_a, const v
   return NRL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Convolution weight gradient (Conv1d over the tokens of a news, window 3; CNNAddAtt text.py:169, LSTUR / NAML):
+//
+//     dWc[f][w * D + d] += sum over token rows m of  dc[m][f] * x[m + w - 1][d]       (x zero outside its news)
+//     db_c[f]           += sum over m of dc[m][f]
+//
+// Both operands as fragment-block planes over PADDED rows: one news = 32 rows = one k-tile, rows L .. 31 zero on both
+// sides (planes_from_rows_kernel below).  Then the three taps are three ROTATIONS of the k-tile's rows on the x side:
+// the lane that fetches token row r for the A operand fetches row (r + w - 1) & 31 for the B operand -- row -1 is row
+// 31 (zero), row L is zero, and whatever a zero dc row meets is finite.  `ds_read_b64_tr_b16` takes an address per
+// lane, so a rotation is three precomputed lane offsets and nothing else: no halo, no masks, no VALU in the loop.
+// One staged x block column feeds three output column groups (the taps): tile = (2 TM x 16) filters x (2 TN x 16)
+// features x 3 taps; 4 waves (2 x 2), three LDS stages, split-K over news with the two-step reduction.
+// The fp32-fed kernel it replaces (gemm_bf16x3_dma_tn<RCPlain, RCWindow>) re-split every operand element once per tile
+// that used it and ran at 0.07 of the dense bf16 peak (2 x 0.97 ms per LSTUR step, profiles/r04_lstur_kernel_stats.txt).
+struct EpiConvWB {
+  float* dw;       // (F, W * D) row-major, tap-major columns (the C ABI's conv_weight layout)
+  int64_t ldc;
+  float* db;       // may be null
+  int D;
+  int tn16;        // 16 TN: feature columns of one wave and tap
+  int center;      // tap whose ones column is the bias gradient
+  struct Row {
+    float* out;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{dw + m * ldc}; }
+  // tile column c = (wave column wn) * 3 tn16 + tap * tn16 + feature-in-wave
+  __device__ __forceinline__ void operator()(const Row& r, int64_t m, int n, float v) const {
+    const int tw = 6 * tn16;
+    const int tile = n / tw, c = n - tile * tw;
+    const int wn = c / (3 * tn16), rem = c - wn * 3 * tn16;
+    const int tap = rem / tn16;
+    const int col = tile * 2 * tn16 + wn * tn16 + (rem - tap * tn16);
+    if (col < D)
+      atomicAdd(r.out + tap * D + col, v);
+    else if (col == D && tap == center && db != nullptr)
+      atomicAdd(db + m, v);
+  }
+};
+
+// KT = k-tiles of 32 rows per news (1: L <= 31, three LDS stages of one news each; 2: L <= 63, two stages -- the same bytes
+// in flight); the rotation is modulo 32 KT.
+template <int TM, int TN, int KT, class Epi>
+__global__ void __launch_bounds__(256, 1) wgrad_planes_conv_kernel(const WgradPlanesGArgs P, const Epi epi) {
+  constexpr int NS = 3, TNS = NS * TN;
+  constexpr int A_ST = 4 * TM * KT * 1024, B_ST = 4 * TN * KT * 1024, STAGE = A_ST + B_ST;
+  constexpr int STAGES = KT == 1 ? 3 : 2, PD = STAGES - 1;     // news in flight ahead of the one being multiplied
+  constexpr int NPA = TM * KT, NPB = TN * KT, NP = NPA + NPB;  // one-KiB pieces per wave and news
+  constexpr int PER_STEP = (NP + TM * KT - 1) / (TM * KT);
+  constexpr int ROWS = 32 * KT;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char wp_smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wp_smem;
+
+  const int tiles_total = P.tiles_m * P.tiles_n;
+  const int64_t bid = blockIdx.x;
+  const int64_t xcd = bid % 8, local = bid / 8;
+  const int t = (int)(local % tiles_total);
+  const int64_t split = (local / tiles_total) * 8 + xcd;
+  if (split >= P.nsplit) return;
+  const int tm = t / P.tiles_n, tn = t % P.tiles_n;
+  const int64_t kt_all = P.n_mb / (2 * KT);                  // news
+  const int64_t kt0 = split * P.kt_per_split;
+  const int64_t kt1 = kt0 + P.kt_per_split < kt_all ? kt0 + P.kt_per_split : kt_all;
+  if (kt0 >= kt1) return;
+  const int nkt = (int)(kt1 - kt0);
+
+  // piece pa = 4 q + wave of an operand = (block column cbi = pa / (2 KT), row block mbi = pa % (2 KT)): LDS [cbi][mbi][p][512]
+  const unsigned char* base_a[NPA];
+  const unsigned char* base_b[NPB];
+#pragma unroll
+  for (int q = 0; q < NPA; ++q) {
+    const int pa = 4 * q + wave;
+    int cb = 2 * TM * tm + pa / (2 * KT);
+    cb = cb < P.ncb_a ? cb : P.ncb_a - 1;
+    base_a[q] = P.a + ((2 * KT * kt0 + pa % (2 * KT)) * P.ncb_a + cb) * 1024;
+  }
+#pragma unroll
+  for (int q = 0; q < NPB; ++q) {
+    const int pb = 4 * q + wave;
+    int cb = 2 * TN * tn + pb / (2 * KT);
+    cb = cb < P.ncb_b ? cb : P.ncb_b - 1;                  // block columns past the matrix: dropped by the epilogue (col > D)
+    base_b[q] = P.b + ((2 * KT * kt0 + pb % (2 * KT)) * P.ncb_b + cb) * 1024;
+  }
+  const int64_t step_a = 2 * KT * (int64_t)P.ncb_a * 1024, step_b = 2 * KT * (int64_t)P.ncb_b * 1024;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto issue = [&](int rel, int stage, int c0, int c1) {
+    const uint32_t sbase = smem_base + (uint32_t)stage * STAGE + (uint32_t)wave * 1024u;
+#pragma unroll
+    for (int c = c0; c < c1; ++c) {
+      if (c < NPA) glds16_saddr(base_a[c] + rel * step_a, lane16, sbase + (uint32_t)c * 4096u);
+      else if (c < NP) glds16_saddr(base_b[c - NPA] + rel * step_b, lane16, sbase + (uint32_t)A_ST + (uint32_t)(c - NPA) * 4096u);
+    }
+  };
+
+  f32x4 acc[TM][TNS];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TNS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // token row r of a news sits at (r >> 4) * 1024 + (r & 15) * 32 of a (block column, plane); this lane's row of the first
+  // half of k-tile u is 32 u + 4 g + (l15 >> 2), of the second half 16 more; tap w reads the row w - 1 further on, modulo ROWS
+  const int r0 = 4 * g + (l15 >> 2);
+  const uint32_t colb = (uint32_t)(l15 & 3) * 8u;
+  auto row_addr = [&](int r) -> uint32_t { r &= ROWS - 1; return (uint32_t)((r >> 4) * 1024 + (r & 15) * 32) + colb; };
+  uint32_t off[KT][NS][2];
+#pragma unroll
+  for (int u = 0; u < KT; ++u)
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+      off[u][w][0] = row_addr(32 * u + r0 + w - 1);
+      off[u][w][1] = row_addr(32 * u + r0 + 16 + w - 1);
+    }
+  auto frag2 = [&](uint32_t a0, uint32_t a1) -> bf16x8 {
+    typedef __attribute__((address_space(3))) wp_v4i16* lds_v4;
+    const wp_v4i16 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)a0);
+    const wp_v4i16 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)a1);
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, (v8i16)__builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  constexpr uint32_t CBS = 2048u * KT;                       // one block column of a stage: 2 KT row blocks x (hi, lo)
+
+#pragma unroll
+  for (int p = 0; p < PD; ++p) issue(p < nkt ? p : nkt - 1, p, 0, NP);
+  int stage = 0;
+  for (int it = 0; it < nkt; ++it) {
+    wait_vmcnt<(PD - 1) * NP>();                           // news `it` landed for this wave (PD - 1 later ones may be in flight)
+    __builtin_amdgcn_s_barrier();
+    const int nx = it + PD < nkt ? it + PD : nkt - 1;
+    const int st2 = stage + PD >= STAGES ? stage + PD - STAGES : stage + PD;
+    const uint32_t sa = smem_base + (uint32_t)stage * STAGE;
+    const uint32_t sb = sa + A_ST;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      bf16x8 bh[TNS], bl[TNS];
+#pragma unroll
+      for (int w = 0; w < NS; ++w)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const uint32_t c0 = sb + (uint32_t)(wn * TN + j) * CBS;
+          bh[w * TN + j] = frag2(c0 + off[u][w][0], c0 + off[u][w][1]);
+          bl[w * TN + j] = frag2(c0 + 512u + off[u][w][0], c0 + 512u + off[u][w][1]);
+        }
+      bf16x8 ah[2], al[2];
+      {
+        const uint32_t a0 = sa + (uint32_t)(wm * TM) * CBS;
+        ah[0] = frag2(a0 + off[u][1][0], a0 + off[u][1][1]);
+        al[0] = frag2(a0 + 512u + off[u][1][0], a0 + 512u + off[u][1][1]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i + 1 < TM) {
+          const uint32_t a0 = sa + (uint32_t)(wm * TM + i + 1) * CBS;
+          ah[(i + 1) & 1] = frag2(a0 + off[u][1][0], a0 + off[u][1][1]);
+          al[(i + 1) & 1] = frag2(a0 + 512u + off[u][1][0], a0 + 512u + off[u][1][1]);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+          for (int j = 0; j < TNS; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i & 1] : ah[i & 1], pass == 0 ? bl[j] : bh[j],
+                                                               acc[i][j], 0, 0, 0);
+        if (i + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TNS, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(nx, st2, (u * TM + i) * PER_STEP, (u * TM + i + 1) * PER_STEP);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    stage = stage + 1 == STAGES ? 0 : stage + 1;
+  }
+  wait_vmcnt<0>();
+
+  if (P.scratch != nullptr) {
+    const EpiStore part{P.scratch + ((int64_t)split * tiles_total + t) * (32 * TM * 32 * TNS), 32 * TNS};
+    store_accumulators<TM, TNS>(part, acc, 0, 0, wm, wn, l15, g, 32 * TM, 32 * TNS);
+  } else {
+    store_accumulators<TM, TNS>(epi, acc, (int64_t)tm * (32 * TM), tn * (32 * TNS), wm, wn, l15, g, P.M, P.N);
+  }
+}
+
+static inline size_t wgrad_planes_conv_scratch_floats(int TM, int TN, int ncb_a, int ncb_b, int nsplit) {
+  return (size_t)nsplit * ((ncb_a + 2 * TM - 1) / (2 * TM)) * ((ncb_b + 2 * TN - 1) / (2 * TN)) * (32 * TM) * (96 * TN);
+}
+// a: dc planes (ncb_a block columns, F = m_valid filters), b: x planes (ncb_b block columns holding D features + the ones
+// column); rows = padded rows (32 per news).  dw (F, 3 D), db (F).
+template <int TM, int TN, int KT>
+static inline int launch_wgrad_planes_conv(const void* a_planes, int ncb_a, const void* b_planes, int ncb_b, int64_t rows,
+                                           int64_t m_valid, int D, float* dw, float* db, int nsplit, hipStream_t st,
+                                           float* scratch = nullptr) {
+  if (rows <= 0) return NRL_OK;
+  NRL_REQUIRE(a_planes && b_planes && ncb_a > 0 && ncb_b > 0 && rows % (32 * KT) == 0 && ncb_b * 16 > D,
+              "wgrad_planes_conv: bad arguments (whole news of 32 KT rows, a ones column after the features)");
+  typedef EpiConvWB Epi;
+  constexpr int LDS = (KT == 1 ? 3 : 2) * 4 * (TM + TN) * KT * 1024;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  WgradPlanesGArgs P;
+  P.a = (const unsigned char*)a_planes; P.b = (const unsigned char*)b_planes;
+  P.n_mb = rows / 16; P.ncb_a = ncb_a; P.ncb_b = ncb_b;
+  P.tiles_m = (ncb_a + 2 * TM - 1) / (2 * TM); P.tiles_n = (ncb_b + 2 * TN - 1) / (2 * TN);
+  const int64_t kt = rows / (32 * KT);                       // news
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > kt) nsplit = (int)kt;
+  P.kt_per_split = ceil_div(kt, nsplit);
+  P.nsplit = (int)ceil_div(kt, P.kt_per_split);
+  P.M = m_valid; P.N = P.tiles_n * 96 * TN;
+  const Epi epi{dw, (int64_t)3 * D, db, D, 16 * TN, 1};
+  const int64_t blocks = (int64_t)P.tiles_m * P.tiles_n * ceil_div(P.nsplit, 8) * 8;
+  NRL_REQUIRE(blocks < (1LL << 31), "wgrad_planes_conv: grid too large");
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  NRL_HIP(hipGetDevice(&dev));
+  if (!((attr_done.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
+    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_conv_kernel<TM, TN, KT, Epi>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+  }
+  P.scratch = P.nsplit > 1 ? scratch : nullptr;
+  hipLaunchKernelGGL((wgrad_planes_conv_kernel<TM, TN, KT, Epi>), dim3((unsigned)blocks), dim3(256), LDS, st, P, epi);
+  NRL_LAUNCH_CHECK();
+  if (P.scratch != nullptr) {
+    const int tiles = P.tiles_m * P.tiles_n;
+    const int64_t threads = (int64_t)tiles * (32 * TM) * (96 * TN) / 4;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<32 * TM, 96 * TN, Epi>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st,
+                       P.scratch, P.nsplit, P.tiles_n, tiles, P.M, P.N, epi);
+    NRL_LAUNCH_CHECK();
+  }
+  return NRL_OK;
+}
+
+// fp32 rows (n_news * L of them, `ld` floats apart, `ncols` valid columns, ncols % 4 == 0) -> (hi, lo) fragment-block planes
+// over 16 nrb padded rows per news: block (mb = nrb * news + row / 16, cb) at (mb * ncb + cb) * 1024, hi plane first; rows >= L and
+// columns >= ncols zero, except column `ncols` of the real rows when `ones` (the bias gradient's ones column).
+struct PlanesFromRowsArgs {
+  const float* src;
+  int64_t ld, n_news;
+  int L, ncols, ncb, ones;
+  int nrb;                   // row blocks per news (2: 32 padded rows, 4: 64)
+  unsigned char* dst;
+};
+static __global__ void __launch_bounds__(256) planes_from_rows_kernel(const PlanesFromRowsArgs P) {
+  const int64_t news = blockIdx.x;
+  const int items = P.nrb * P.ncb * 32;                      // (row block, block column, row, half row of 8 features)
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int half = it & 1, r16 = (it >> 1) & 15, rest = it >> 5;
+    const int mbi = rest / P.ncb, cb = rest - mbi * P.ncb;
+    const int r = 16 * mbi + r16, col0 = 16 * cb + 8 * half;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (r < P.L) {
+      const float* row = P.src + (news * P.L + r) * P.ld + col0;
+      if (col0 < P.ncols) v0 = *reinterpret_cast<const float4*>(row);
+      if (col0 + 4 < P.ncols) v1 = *reinterpret_cast<const float4*>(row + 4);
+      if (P.ones) {
+        if (col0 == P.ncols) v0.x = 1.0f;
+        if (col0 + 4 == P.ncols) v1.x = 1.0f;
+      }
+    }
+    uint32_t h[4], l[4];
+    split_pair(v0.x, v0.y, h[0], l[0]);
+    split_pair(v0.z, v0.w, h[1], l[1]);
+    split_pair(v1.x, v1.y, h[2], l[2]);
+    split_pair(v1.z, v1.w, h[3], l[3]);
+    unsigned char* dst = P.dst + ((P.nrb * news + mbi) * P.ncb + cb) * 1024 + r16 * 32 + half * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(dst + 512) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+}
+static inline size_t planes_from_rows_bytes(int64_t n_news, int ncb, int nrb) { return (size_t)n_news * nrb * ncb * 1024; }
+static inline int launch_planes_from_rows(const float* src, int64_t ld, int64_t n_news, int L, int ncols, int ncb, int nrb, bool ones,
+                                          void* dst, hipStream_t st) {
+  if (n_news <= 0) return NRL_OK;
+  NRL_REQUIRE(src && dst && L > 0 && L <= 16 * nrb && ncols % 4 == 0 && ncb * 16 >= ncols + (ones ? 1 : 0) && (ld & 3) == 0 &&
+                  ((uintptr_t)src & 15) == 0 && n_news < (1LL << 31),
+              "planes_from_rows: bad arguments");
+  const PlanesFromRowsArgs P{src, ld, n_news, L, ncols, ncb, ones ? 1 : 0, nrb, (unsigned char*)dst};
+  hipLaunchKernelGGL(planes_from_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, st, P);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
 }  // namespace nrl

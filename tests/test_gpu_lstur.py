@@ -32,7 +32,7 @@ def _cnn_params(rng, V, D, F, W, Q):
 
 
 @pytest.mark.parametrize("shape", [(37, 12, 64, 48, 3, 32), (5, 30, 300, 300, 3, 200), (130, 9, 32, 64, 5, 16),
-                                   (3, 4, 16, 16, 1, 8)])
+                                   (3, 4, 16, 16, 1, 8), (1, 31, 20, 36, 3, 8), (9, 32, 16, 16, 3, 8), (4, 63, 24, 20, 3, 8)])
 @pytest.mark.parametrize("p_drop", [0.0, 0.2])
 def test_cnn_encoder_matches_oracle(shape, p_drop, engine):
     from newsreclib_amd.ops_lstur import CnnEncoderFn
@@ -203,3 +203,56 @@ def test_gru_persistent_cooperative_launch_matches_oracle():
     env = dict(os.environ, NRL_GRU_PERSISTENT="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", _PERSISTENT_GRU_SCRIPT], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "PERSISTENT_GRU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_CONV_WGRAD_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from newsreclib_amd import _lib
+from newsreclib_amd.ops_lstur import CnnEncoderFn
+_lib.set_gemm_engine("bf16x3")
+N, L, D, F, W, Q = (int(v) for v in sys.argv[3:9])
+rng = np.random.default_rng(N + L)
+V = 500
+t = lambda *s, scale: torch.from_numpy((rng.standard_normal(s) * scale).astype(np.float32))
+params = [t(V, D, scale=0.3), t(F, 1, W, D, scale=(W * D) ** -0.5), t(F, scale=0.05), t(Q, F, scale=F ** -0.5), t(Q, scale=0.05),
+          t(Q, scale=0.1)]
+ids = torch.from_numpy(rng.integers(0, V, (N, L)))
+ids[::3, L - 3:] = 0
+d_out = torch.from_numpy(rng.standard_normal((N, F)).astype(np.float32))
+dev = [p.cuda().requires_grad_(True) for p in params]
+out = CnnEncoderFn.apply(ids.cuda(), *dev, 0.2, 11, 2, None, torch.argsort(ids.reshape(-1)).cuda())
+out.backward(d_out.cuda())
+np.savez(sys.argv[2], out=out.detach().cpu().numpy(), **{"g%d" % i: p.grad.cpu().numpy() for i, p in enumerate(dev)})
+"""
+
+
+@pytest.mark.parametrize("shape", [(700, 30, 300, 300, 3, 200), (260, 50, 300, 300, 3, 200), (33, 31, 64, 48, 3, 32),
+                                   (40, 63, 20, 36, 3, 8), (1100, 7, 32, 16, 3, 8)])
+def test_conv_weight_gradient_from_planes_equals_the_fp32_fed_kernel(shape, tmp_path, engine):
+    """The planes form of the convolution weight gradient (wgrad_planes_conv_kernel: padded 32 / 64-row news, the taps as row
+    rotations; x planes from the lookup kernel, dc planes from the attention-backward epilogue) against the fp32-fed kernel it
+    replaces, same inputs, one process each (the switch is read once per process): every other output bit for bit -- the
+    planes are extra outputs -- and the convolution's weight / bias gradients to summation order."""
+    import os
+    import subprocess
+    import sys
+    if engine != "bf16x3":
+        pytest.skip("bf16x3 path")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        f = str(tmp_path / ("g%s.npz" % flag))
+        env = dict(os.environ, NRL_CONV_WGRAD_PLANES=flag)
+        subprocess.run([sys.executable, "-c", _CONV_WGRAD_SCRIPT, root, f] + [str(v) for v in shape], check=True, env=env,
+                       timeout=600)
+        res[flag] = np.load(f)
+    a, b = res["0"], res["1"]
+    assert np.array_equal(a["out"], b["out"])
+    assert np.array_equal(a["g0"], b["g0"])                                  # table gradient: sorted segments, fixed order
+    for k in ("g1", "g2"):                                                   # conv weight (F, 1, W, D), conv bias
+        scale = max(1.0, float(np.abs(a[k]).max()))
+        assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
+    for k in ("g3", "g4", "g5"):                                             # attention parameters: atomics in both runs
+        scale = max(1.0, float(np.abs(a[k]).max()))
+        assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * scale, k
