@@ -1220,7 +1220,9 @@ def test_long_sequence_attention_on_matrix_cores(S, H, D, heads, engine):
 def test_sibling_modules_with_plm_text_encoder(tmp_path, model):
     """``use_plm=True`` through every sibling mirror: the PLM text encoder (pinned against the reference ``PLM`` by
     plm_tiny.npz) is wired as in the reference -- TWO encoder calls, widths following the text vector -- and the
-    module's scores equal the composition of its own sub-modules called the reference's way; backward runs."""
+    module's scores equal the composition of its own sub-modules called the reference's way; backward runs.  (Wiring only: the
+    parity evidence for ``use_plm=True`` in a sibling is tests/test_gpu_naml.py::test_naml_module_with_plm_text_encoder_matches_
+    reference_golden, against the reference's own components.)"""
     from functools import partial
 
     from tests.helpers import PLM_HEADS, PLM_Q, make_tiny_roberta
