@@ -443,6 +443,31 @@ struct EpiPoolBwd {
     return v;
   }
   __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const { store4(r.out + n, apply4(r, n, v), stream); }
+  // The two operand loads of a 4-column piece, issued AHEAD of the arithmetic by the output stage (kPrefetch): as written above
+  // every piece waits for its own loads -- 38 dependent HBM round trips per wave behind a 7-k-block product (K = query_dim),
+  // which is what the launch then costs (MFMA-busy 0.14 at 2.9 TB/s, profiles/r04_plm_lstur_pmc.txt).
+  static constexpr bool kPrefetch = true;
+  struct Pre {
+    float4 g, s;
+  };
+  __device__ __forceinline__ Pre prefetch(const Row& r, int n) const {
+    Pre p;
+    p.g = *reinterpret_cast<const float4*>(r.g + n);
+    p.s = r.src != nullptr ? *reinterpret_cast<const float4*>(r.src + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    return p;
+  }
+  __device__ __forceinline__ void vec4_pre(const Row& r, int64_t, int n, float4 v, const Pre& p) const {
+    v.x = fmaf(r.wm, p.g.x, v.x); v.y = fmaf(r.wm, p.g.y, v.y); v.z = fmaf(r.wm, p.g.z, v.z); v.w = fmaf(r.wm, p.g.w, v.w);
+    if (drop.thresh != 0u) {
+      const uint32_t idx = r.idx0 + (uint32_t)n;
+      v.x *= drop.mult(idx); v.y *= drop.mult(idx + 1); v.z *= drop.mult(idx + 2); v.w *= drop.mult(idx + 3);
+    }
+    if (r.src != nullptr) {
+      v.x = p.s.x > 0.f ? v.x : 0.f; v.y = p.s.y > 0.f ? v.y : 0.f;
+      v.z = p.s.z > 0.f ? v.z : 0.f; v.w = p.s.w > 0.f ? v.w : 0.f;
+    }
+    store4(r.out + n, v, stream);
+  }
 };
 
 // out += v with atomics: split-K partial sums of the small per-step GRU GEMMs (the k-loop of a 128-row
@@ -556,6 +581,11 @@ template <class Epi, class = void>
 struct EpiHasVec4 : std::false_type {};
 template <class Epi>
 struct EpiHasVec4<Epi, std::enable_if_t<Epi::kVec4>> : std::true_type {};
+// epilogues whose pieces read operands of their own (EpiPoolBwd): prefetch(row, n) / vec4_pre(row, m, n, v, pre)
+template <class Epi, class = void>
+struct EpiHasPrefetch : std::false_type {};
+template <class Epi>
+struct EpiHasPrefetch<Epi, std::enable_if_t<Epi::kPrefetch>> : std::true_type {};
 
 // Output rows of a GEMM over PADDED token rows (32 per news, KCPlanes) mapped back to the real rows news * L + t;
 // the pad rows t >= L produce nothing.
@@ -620,6 +650,34 @@ __device__ __forceinline__ void store_accumulators(const Epi& epi, f32x4 (&acc)[
   if constexpr (EpiHasVec4<Epi>::value) {
     if ((N & 3) == 0 && epi.vec_ok()) {
       const int t = l15 & 3, q4 = l15 & ~3;
+      if constexpr (EpiHasPrefetch<Epi>::value) {
+        constexpr int CH = 7;                           // pieces whose operand loads are in flight together (14 x 16 B per lane)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + t;
+          const bool mok = m < M;
+          const typename Epi::Row rs = epi.row(mok ? m : 0);
+#pragma unroll
+          for (int j0 = 0; j0 < TN; j0 += CH) {
+            typename Epi::Pre pre[CH];
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+              const int n = n0 + (wn * TN + j0 + jj) * 16 + q4;
+              if (j0 + jj < TN && mok && n < N) pre[jj] = epi.prefetch(rs, n);
+            }
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+              if (j0 + jj < TN) {
+                float a[4] = {acc[i][j0 + jj][0], acc[i][j0 + jj][1], acc[i][j0 + jj][2], acc[i][j0 + jj][3]};
+                quad_transpose(a, t);
+                const int n = n0 + (wn * TN + j0 + jj) * 16 + q4;
+                if (mok && n < N) epi.vec4_pre(rs, m, n, make_float4(a[0], a[1], a[2], a[3]), pre[jj]);
+              }
+            }
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int64_t m = m0 + (wm * TM + i) * 16 + 4 * g + t;
