@@ -46,7 +46,9 @@ static int cnn_conv_planes_splits() {
 }
 static bool cnn_conv_planes_ok(const CnnShape& s) {
   static const bool on = [] { const char* e = getenv("NRL_CONV_WGRAD_PLANES"); return !(e != nullptr && e[0] == '0'); }();
-  return on && s.W == 3 && s.L <= 63 && s.N < (1LL << 31);
+  // (F <= 320: two 160-filter tiles.  At 400 filters -- NAML, CenNewsRec -- a third, 20 % empty tile and the wider dc conversion
+  //  make the planes form the slower one: NAML step 9.53 vs 9.16 ms, profiles/r04_ab.txt)
+  return on && s.W == 3 && s.L <= 63 && s.F <= 320 && s.N < (1LL << 31);
 }
 static int cnn_conv_kt(const CnnShape& s) { return s.L <= 31 ? 1 : 2; }   // k-tiles of 32 padded rows per news
 static int cnn_ncb_x(const CnnShape& s) { return (s.D + 16) / 16; }     // + the ones column
