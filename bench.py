@@ -6,7 +6,10 @@
 
 One "step" = one full train step of the hot path over one synthetic MIND-shaped batch that is
 already resident in HBM: forward (history + candidate news encode, user encode, score), CE loss,
-backward, (N > 1: RCCL all-reduce of the flat gradient), dense Adam -- dropout active, fp32.
+backward, (N > 1: gradient exchange over RCCL), Adam with the reference's dense semantics -- dropout active, fp32.
+The optimizer is `trainer.LazyTableAdam` + the dense kernel for the 0.84 M non-table parameters: rows of the embedding
+table with a zero gradient are advanced lazily (bit-identical to dense Adam after a flush; a rolling flush bounds every
+row's lag by 64 steps), so a timed region ends with rows whose update is pending -- `config.optimizer` says so.
 Workload at every N (weak scaling): BASELINE.json configs[1], B = 128 impressions per GPU,
 H = 50 clicks, C = 5 candidates, L = 30 tokens, V = 70,000, D = 300, 15 heads, Q = 200.
 Rank 0 prints ONE JSON line.
@@ -258,9 +261,11 @@ def main():
                     help="projection-GEMM engine: exact fp32 MFMA, or fp32 via 3 bf16 MFMAs per product")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mindsmall",
                     help="mindsmall = BASELINE.json configs[1] (headline); mind32 = configs[0] (B=32); mindlarge = configs[2]'s per-rank shape (V=150k, B=64/GPU)")
-    ap.add_argument("--grad-exchange", choices=["dense", "rows", "auto"], default="dense",
-                    help="N > 1: all-reduce of the whole flat gradient, all-gather of the touched table rows + dense rest, or "
-                         "auto = per step whichever ships fewer bytes (rows when unique_rows * (8 + 4 D) * world < 0.5 * 4 V D)")
+    ap.add_argument("--grad-exchange", choices=["dense", "rows", "owners", "auto"], default="dense",
+                    help="N > 1: dense = all-reduce of the whole flat gradient; rows = all-gather of the touched table rows + "
+                         "dense rest; owners = touched rows reduced by their owner rank (id %% world), then all-gathered; "
+                         "auto = per step whichever of the three trainer.predicted_wire_ms prices lowest (dense stays the default: it is the "
+                         "one exchange whose RCCL calls have run on hardware, at world size 1)")
     args = ap.parse_args()
     B_PER_GPU, VOCAB = WORKLOADS[args.workload]["batch"], WORKLOADS[args.workload]["vocab"]
     M_ROWS = B_PER_GPU * (H + C) * L
@@ -407,7 +412,9 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.engine == "f32" else "f32 (projections: 3xbf16 split MFMA)",
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload]["name"],
-                       "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "gemm_engine": args.engine},
+                       "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "gemm_engine": args.engine,
+                       "optimizer": ("lazy-dense table Adam (bit-identical to dense Adam after flush), rolling flush period 64; "
+                                     "dense Adam kernel for the non-table parameters") if trainer.lazy_tables else "dense Adam"},
             "build_id": build_id, "git_head": git_head(),
             "roofline": roof,
         }

@@ -208,7 +208,8 @@ class NrlLinear(nn.Module):
         trainable = self.weight.requires_grad or self.bias.requires_grad
         if trainable and self._images is not None:
             self._images.invalidate()        # trained now, maybe frozen again later: never meet an image of the old values
-        images = self._images if not trainable else self._step_images
+        # (a trainable weight's images survive a call only when this library's optimizer drives the step: ops_blocks.step_images_allowed)
+        images = self._images if not trainable else (self._step_images if ops_blocks.step_images_allowed() else None)
         return ops_blocks.LinearFn.apply(x.contiguous(), self.weight, self.bias, _grad_bufs(params), images)
 
     def extra_repr(self) -> str:

@@ -259,9 +259,26 @@ _IMAGE_GENERATION = [0]
 _STEP_GENERATION = [0]      # bumped by an optimizer that writes parameters through raw pointers (trainer.FusedAdam.begin_step)
 
 
+_STEP_DRIVERS = [0]         # optimizers of THIS library alive in the process (trainer.FusedAdam registers itself)
+
+
 def next_optimizer_step() -> None:
     """Tells the per-step weight-image caches (``FrozenImages(allow_trainable=True)``) that trainable weights are about to change."""
     _STEP_GENERATION[0] += 1
+
+
+def register_step_driver() -> None:
+    """Called by an optimizer that promises ``next_optimizer_step()`` before every parameter write (trainer.FusedAdam)."""
+    _STEP_DRIVERS[0] += 1
+
+
+def step_images_allowed() -> bool:
+    """Whether images of TRAINABLE weights may be kept within an optimizer step.  Only under this library's own optimizer:
+    a foreign writer that updates through ``p.data`` (apex, legacy AdamW forks, EMA weight swaps, manual ``.data.copy_``)
+    moves neither the parameter's version counter nor the step generation, and the kernels would keep multiplying by the
+    old weights (round-4 advisor finding).  Outside ``trainer.NRMSTrainer`` -- the Lightning / Hydra drop-in path, whose
+    optimizer comes from the config -- a trainable weight's images are rebuilt on every call."""
+    return _STEP_DRIVERS[0] > 0
 
 
 def invalidate_frozen_images() -> None:

@@ -60,6 +60,8 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = 0
+        from . import ops_blocks
+        ops_blocks.register_step_driver()      # this optimizer announces every parameter write (begin_step): per-step weight images are safe
 
     def step(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         self.begin_step()
@@ -166,9 +168,11 @@ class OverlappedGradReduce:
 XGMI_LINK_GBPS = 153.0      # MI355X: 7 point-to-point xGMI links per GPU, ~153 GB/s each (MI355X_MICROARCH.md)
 
 
-def predicted_wire_ms(mode: str, payload_bytes: float, world: int) -> Dict[str, float]:
+def predicted_wire_ms(mode: str, payload_bytes: float, world: int, gather_bytes: float = 0.0) -> Dict[str, float]:
     """Back-of-envelope wire time of one gradient exchange over xGMI (no RCCL protocol overhead):
-    dense = sum all-reduce of `payload_bytes`; rows = all-gather where every rank contributes `payload_bytes`.
+    dense = sum all-reduce of `payload_bytes`; rows = all-gather where every rank contributes `payload_bytes`; owners =
+    all-to-all in which every rank sends `payload_bytes` in total (point-to-point pieces of 1/world each, so both models price
+    it the same) followed by an all-gather where every rank contributes `gather_bytes`.
     `ring`: every byte crosses one link per hop; `direct`: reduce-scatter + all-gather (or the all-gather) spread over all
     world - 1 links of the fully connected node."""
     if world <= 1:
@@ -177,10 +181,20 @@ def predicted_wire_ms(mode: str, payload_bytes: float, world: int) -> Dict[str, 
     if mode == "dense":
         ring = 2.0 * (world - 1) / world * payload_bytes / bw
         direct = 2.0 * (payload_bytes / world) / bw
+    elif mode == "owners":
+        a2a = payload_bytes / world / bw
+        ring = a2a + (world - 1) * gather_bytes / bw
+        direct = a2a + gather_bytes / bw
     else:
         ring = (world - 1) * payload_bytes / bw
         direct = payload_bytes / bw
     return {"ring": round(ring * 1e3, 6), "direct": round(direct * 1e3, 6)}
+
+
+def wire_model() -> str:
+    """Which column of ``predicted_wire_ms`` the `auto` exchange decides by: "ring" (RCCL's ring algorithms, the conservative
+    default) or "direct" (NRL_WIRE_MODEL=direct)."""
+    return "direct" if os.environ.get("NRL_WIRE_MODEL", "ring") == "direct" else "ring"
 
 
 class TouchedRowsExchange:
@@ -201,8 +215,11 @@ class TouchedRowsExchange:
     and with two ranks the result is bit-identical to the dense all-reduce (a + b == b + a).  Dense Adam is unchanged (rows
     nobody touched carry a zero gradient).
 
-    ``auto=True`` (``--grad-exchange auto``): per step, from the gathered counts (identical on every rank, so every rank takes
-    the same branch): rows when ``max_count * (8 + 4 D) * world < 0.5 * 4 V D``, else the dense all-reduce of the head."""
+    ``auto=True``: per step, from the gathered counts (identical on every rank, so every rank takes the same branch):
+    whichever of {rows, dense} ``predicted_wire_ms`` prices lower under ``wire_model()`` -- an all-gather moves
+    (w - 1) * payload per rank on a ring, a ring all-reduce 2 (w - 1) / w * S, so the break-even is payload * world < 2 S
+    (round 4 shipped ``< 0.5 S``, which sent the configs[2] rank shape to the dense all-reduce its own predictor priced 4x
+    slower).  ``--grad-exchange auto`` itself is ``OwnerRowsExchange(mode="auto")``, which also has the owner-partitioned form."""
 
     def __init__(self, flat: "FlatParams", head_numel: int, table: torch.Tensor, group=None, auto: bool = False):
         self.flat, self.head, self.group, self.auto = flat, int(head_numel), group, bool(auto)
@@ -274,12 +291,17 @@ class TouchedRowsExchange:
         g = self._table_grad()
         rows_bytes = cap * (8 + 4 * self.dim)
         self._last = {"choice": "rows", "max_unique_rows": cap}
-        if self.auto and rows_bytes * world >= 0.5 * 4 * self.rows * self.dim:
+        m = wire_model()
+        if self.auto and predicted_wire_ms("rows", rows_bytes, world)[m] >= predicted_wire_ms("dense", 4 * self.head, world)[m]:
             self._last["choice"] = "dense"
             self._dense_work = dist.all_reduce(self.flat.grad[: self.head], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._payload = 4 * self.flat.numel
             return
-        ids_pad = uniq[:cap].contiguous()                         # entries past the rank's own count: id 0, never added
+        # padded to the LARGEST rank's count: `uniq` has one slot per token of THIS rank's batch, which a ragged / partial
+        # batch can leave shorter than another rank's unique count (entries past the rank's own count: id 0, never added)
+        ids_pad = torch.zeros(cap, dtype=uniq.dtype, device=uniq.device)
+        k = min(int(uniq.numel()), cap)
+        ids_pad[:k] = uniq[:k]
         rows_pad = g.index_select(0, ids_pad)
         ids_all = [torch.empty_like(ids_pad) for _ in range(world)]
         rows_all = [torch.empty_like(rows_pad) for _ in range(world)]
@@ -328,12 +350,325 @@ class TouchedRowsExchange:
         return {"mode": "auto" if self.auto else "rows", "last_step_choice": self._last["choice"],
                 "max_unique_rows_per_rank": self._last["max_unique_rows"],
                 "payload_bytes_per_rank": int(self._payload), "dense_payload_bytes_per_rank": dense,
-                "rule": "rows when max_unique_rows * (8 + 4 D) * world < 0.5 * 4 V D" if self.auto else None,
+                "rule": f"whichever of rows / dense predicted_wire_ms prices lower ({wire_model()} model)" if self.auto else None,
                 "predicted_wire_ms": {"dense": predicted_wire_ms("dense", dense, world),
                                       "rows": predicted_wire_ms("rows", rows, world),
                                       "link_GBps": XGMI_LINK_GBPS, "unmeasured": True},
                 "note": "all-gather of (unique ids, their table-gradient rows) padded to the largest rank + dense all-reduce of "
                         "the non-table gradient; last step's sizes; no host sync beyond one early event"}
+
+
+def _sorted_unique_ids(ids: torch.Tensor, order: Optional[torch.Tensor] = None):
+    """-> (uniq, count): the ascending unique ids of `ids` at the front of an n-slot buffer (zeros behind) and their number
+    as a (1,) device tensor -- device arithmetic only (flags of the id-sorted positions, prefix sum, scatter): no
+    ``torch.unique``, no read-back.  ``order``: the id-sorted visiting order if the caller has it (``ops.sort_positions``)."""
+    flat_ids = ids.reshape(-1)
+    n = flat_ids.numel()
+    dev = flat_ids.device
+    if order is not None:
+        ev = getattr(order, "_nrl_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream(dev).wait_event(ev)
+        sorted_ids = flat_ids.index_select(0, order[:n])
+    else:
+        sorted_ids = torch.sort(flat_ids).values
+    first = torch.ones(n, dtype=torch.bool, device=dev)
+    if n > 1:
+        first[1:] = sorted_ids[1:] != sorted_ids[:-1]
+    slot = torch.cumsum(first, 0) - 1
+    uniq = torch.zeros(n, dtype=torch.int64, device=dev)
+    uniq.scatter_(0, slot, sorted_ids)                      # (equal ids write equal values: deterministic)
+    count = (slot[-1:] + 1) if n > 0 else torch.zeros(1, dtype=torch.int64, device=dev)
+    return uniq, count
+
+
+class OwnerRowsExchange:
+    """Owner-partitioned exchange of the touched embedding-table rows (``--grad-exchange owners`` / ``auto``; DESIGN section 6;
+    reference leg: ``configs/trainer/ddp.yaml:4``, whose DDP all-reduces the dense (V, D) gradient).
+
+    Rank r OWNS the table rows with ``id % world == r``.  Per step:
+
+    ``prepare`` (before the forward, on the exchange's own stream): the rank's sorted unique ids go out in ONE all-gather of a
+    fixed-capacity message ``[count | ids ...]`` (``id_capacity`` slots: every rank must post the same size without asking
+    anyone).  From it every rank derives -- identically, on the device -- the per-owner UNION of touched ids (the canonical
+    order of the reduced rows), the all-to-all split matrix and, for itself as an owner, the slot of every row it will
+    receive.  The three small integer tables the host needs (counts, union sizes, splits) are copied to pinned memory behind
+    one event.  No ids travel after this point.
+
+    ``start_head`` (from inside the backward, after the table gradient is complete): the host reads those tables (an event of
+    the step's first microseconds), gathers the rank's gradient rows in (owner, id) order and posts ONE async all-to-all:
+    each row goes to its owner, under the weight-gradient GEMMs.
+
+    ``finish``: the owner sums what it received IN RANK ORDER into its union slots (one ``index_add_`` per source, unique
+    slots each: a fixed order, so a rerun gives the same bits), all-gathers the reduced rows (padded to the largest owner's
+    union, no ids), and every replica copies them into its table gradient -- every replica receives the SAME bytes, so the
+    replicas stay bit-identical at any world size, and at two ranks the result is bit-identical to the dense all-reduce
+    (0 + a + b).  Rows nobody touched keep their zero gradient.  ``last_gathered`` = the union (the lazy table optimizer's marks).
+
+    Against the all-gather of (ids, rows) of ``TouchedRowsExchange`` the second leg carries each touched row ONCE (the
+    Zipf head of a news vocabulary is touched by every rank), and the summation work is split eight ways.
+
+    ``mode="auto"``: per step, from the gathered counts: whichever of {owners, rows, dense} ``predicted_wire_ms`` prices
+    lowest under ``wire_model()``; the ``rows`` branch here needs no id traffic either.  A step in which some rank has more
+    unique ids than ``id_capacity`` takes the dense all-reduce (every rank sees every count, so all take the same branch)."""
+
+    def __init__(self, flat: "FlatParams", head_numel: int, table: torch.Tensor, group=None, mode: str = "owners",
+                 id_capacity: int = 32768):
+        if mode not in ("owners", "auto"):
+            raise ValueError("OwnerRowsExchange: mode must be 'owners' or 'auto'")
+        self.flat, self.head, self.group, self.mode = flat, int(head_numel), group, mode
+        self.rows, self.dim = int(table.shape[0]), int(table.shape[1])
+        self.capacity = int(id_capacity)
+        self._prepared = None
+        self._pending = None
+        self._payload = 0
+        self._stream = None
+        self.last_gathered = None
+        self._last = {"choice": mode, "max_unique_rows": 0, "union_rows": 0}
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _table_grad(self) -> torch.Tensor:
+        return self.flat.grad[: self.rows * self.dim].view(self.rows, self.dim)
+
+    def prepare(self, ids: torch.Tensor, order: Optional[torch.Tensor] = None) -> None:
+        if not self._active() or self.head <= 0 or ids is None:
+            self._prepared = None
+            return
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        dev = ids.device
+        cuda = dev.type == "cuda"
+        main = torch.cuda.current_stream(dev) if cuda else None
+        if cuda and self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        if cuda:
+            self._stream.wait_stream(main)                     # the ids (and a side-stream sort's event) come from there
+        with (torch.cuda.stream(self._stream) if cuda else _NullCtx()):
+            V, cap0 = self.rows, self.capacity
+            uniq, count = _sorted_unique_ids(ids, order)
+            msg = torch.zeros(cap0 + 1, dtype=torch.int64, device=dev)
+            msg[:1] = count
+            k = min(int(uniq.numel()), cap0)
+            msg[1:1 + k] = uniq[:k]
+            allmsg = torch.empty(world, cap0 + 1, dtype=torch.int64, device=dev)
+            _all_gather_rows(allmsg, msg, self.group)
+            counts = allmsg[:, 0]
+            ids_mat = allmsg[:, 1:]
+            valid = torch.arange(cap0, device=dev)[None, :] < counts[:, None]
+            owner = ids_mat % world
+            sentinel = world * V
+            key = torch.where(valid, owner * V + ids_mat, torch.full_like(ids_mat, sentinel))     # (owner, id) order
+            ks = torch.sort(key.reshape(-1)).values
+            first = torch.ones_like(ks, dtype=torch.bool)
+            first[1:] = ks[1:] != ks[:-1]
+            first &= ks < sentinel
+            upos = torch.cumsum(first, 0) - 1
+            union_keys = torch.full((ks.numel() + 1,), sentinel, dtype=torch.int64, device=dev)
+            union_keys.scatter_(0, torch.where(first, upos, torch.full_like(upos, ks.numel())), ks)
+            union_keys = union_keys[:-1]                       # ascending (owner, id) keys of every touched row, sentinels behind
+            own_of = torch.where(first, ks // V, torch.full_like(ks, world))
+            U = torch.bincount(own_of, minlength=world + 1)[:world]               # union size per owner
+            ustart = torch.cumsum(U, 0) - U
+            pair = torch.arange(world, device=dev)[:, None] * (world + 1) + torch.where(valid, owner, torch.full_like(owner, world))
+            C = torch.bincount(pair.reshape(-1), minlength=world * (world + 1)).view(world, world + 1)[:, :world]
+            # this rank as a SOURCE: its ids in (owner, id) order
+            my_key = key[rank]
+            send_ids = torch.sort(my_key).values % V           # (sentinels -> id 0 behind the real ones)
+            # this rank as an OWNER: for every (source, entry) it receives, in (source, id) order, the slot in its union list
+            slot_glob = torch.searchsorted(union_keys, key.reshape(-1))
+            mine = valid & (owner == rank)
+            pick = torch.where(mine, torch.arange(world * cap0, device=dev).view(world, cap0), torch.full_like(ids_mat, world * cap0))
+            pick = torch.sort(pick.reshape(-1)).values         # the first sum(C[:, rank]) entries are the received rows' (source, entry)
+            recv_slots = slot_glob[pick.clamp_max(world * cap0 - 1)] - ustart[rank]
+            stats = torch.cat([counts, U, C.reshape(-1)])
+            if cuda:
+                host = torch.empty(stats.numel(), dtype=torch.int64, pin_memory=True)
+                host.copy_(stats, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+            else:
+                host, ev = stats, None
+        keep = (uniq, allmsg, union_keys, ustart, send_ids, recv_slots, stats)
+        if cuda:
+            for t in keep:
+                t.record_stream(main)                          # allocator: read on the launch stream later in the step
+        self._prepared = (host, ev, ids_mat, union_keys, ustart, send_ids, recv_slots, keep)
+
+    def _decide(self, counts, U, C, world, rank) -> str:
+        cap = max(max(counts), 1)
+        row_b = 4 * self.dim
+        rows_bytes = cap * row_b
+        own = counts[rank]
+        a2a = max(counts) * row_b                              # the largest sender bounds the all-to-all
+        ag = max(max(U), 1) * row_b
+        m = wire_model()
+        price = {"dense": predicted_wire_ms("dense", 4 * self.head, world)[m],
+                 "rows": predicted_wire_ms("rows", rows_bytes, world)[m],
+                 "owners": predicted_wire_ms("owners", a2a, world, ag)[m]}
+        self._last = {"choice": self.mode, "max_unique_rows": cap, "union_rows": int(sum(U)), "priced_ms": price,
+                      "own_rows": int(own)}
+        if max(counts) > self.capacity:
+            return "dense (a rank's unique ids exceed id_capacity)"
+        if self.mode == "owners":
+            return "owners"
+        return min(("owners", "rows", "dense"), key=lambda k: price[k])
+
+    def start_head(self, _grad=None, ids=None) -> None:
+        if not self._active() or self.head <= 0:
+            return
+        if self._prepared is None:
+            if ids is None:
+                return
+            self.prepare(ids)
+        host, ev, ids_mat, union_keys, ustart, send_ids, recv_slots, keep = self._prepared
+        self._prepared = None
+        if ev is not None:
+            ev.synchronize()                                   # an event of the step's first microseconds: no drain
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        st = [int(x) for x in host.tolist()]
+        counts, U = st[:world], st[world:2 * world]
+        C = [st[2 * world + s * world: 2 * world + (s + 1) * world] for s in range(world)]
+        choice = self._decide(counts, U, C, world, rank)
+        self._last["choice"] = choice
+        g = self._table_grad()
+        D = self.dim
+        if choice.startswith("dense"):
+            work = dist.all_reduce(self.flat.grad[: self.head], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending = ("dense", work)
+            self._payload = 4 * self.flat.numel
+            return
+        if choice == "rows":
+            cap = max(max(counts), 1)
+            ids_pad = ids_mat[rank, :cap]
+            rows_pad = g.index_select(0, ids_pad)
+            rows_all = torch.empty(world, cap, D, dtype=g.dtype, device=g.device)
+            work = _all_gather_rows(rows_all, rows_pad, self.group, async_op=True)
+            self._pending = ("rows", work, counts, ids_mat, rows_all, keep)
+            self._payload = cap * 4 * D + 8 * (self.capacity + 1) + 4 * (self.flat.numel - self.head)
+            return
+        own = counts[rank]
+        send_splits, recv_splits = C[rank], [C[s][rank] for s in range(world)]
+        rows_send = g.index_select(0, send_ids[:own])
+        rows_recv = torch.empty(sum(recv_splits), D, dtype=g.dtype, device=g.device)
+        work = _all_to_all_rows(rows_recv, rows_send, recv_splits, send_splits, self.group)
+        self._pending = ("owners", work, U, recv_splits, rows_recv, rows_send, recv_slots, union_keys, ustart, keep)
+        self._payload = (own - C[rank][rank]) * 4 * D + max(max(U), 1) * 4 * D + 8 * (self.capacity + 1) + \
+            4 * (self.flat.numel - self.head)
+
+    def finish(self) -> float:
+        self.last_gathered = None
+        if not self._active():
+            return 1.0
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        pend, self._pending = self._pending, None
+        if pend is None:                                        # the hook did not fire (or carried no ids): dense fallback
+            self._prepared = None
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._payload = 4 * self.flat.numel
+            self._last = dict(self._last, choice="dense (hook did not fire)")
+            return 1.0 / world
+        if self.head < self.flat.numel:
+            dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
+        g = self._table_grad()
+        D = self.dim
+        if pend[0] == "dense":
+            pend[1].wait()
+            return 1.0 / world
+        if pend[0] == "rows":
+            _, work, counts, ids_mat, rows_all, _keep = pend
+            work.wait()
+            self.last_gathered = [ids_mat[r, : counts[r]] for r in range(world) if counts[r] > 0]
+            g.index_fill_(0, ids_mat[rank, : counts[rank]], 0.0)     # own rows out, then every rank's rows in, in rank order
+            for r in range(world):
+                # one launch per source ON PURPOSE: within a source the ids are unique, and the sources are added in a fixed
+                # order -- one concatenated index_add_ would leave the order of the (up to `world`) additions into a shared
+                # row to the atomics, and replicas that round differently drift apart
+                if counts[r] > 0:
+                    g.index_add_(0, ids_mat[r, : counts[r]], rows_all[r, : counts[r]])
+            return 1.0 / world
+        _, work, U, recv_splits, rows_recv, _rows_send, recv_slots, union_keys, ustart, _keep = pend
+        work.wait()
+        Umax, total = max(max(U), 1), sum(U)
+        acc = torch.zeros(Umax, D, dtype=g.dtype, device=g.device)
+        off = 0
+        for s in range(world):                                  # the owner's sum, in rank order (unique slots per source)
+            n_s = recv_splits[s]
+            if n_s:
+                acc.index_add_(0, recv_slots[off: off + n_s], rows_recv[off: off + n_s])
+                off += n_s
+        rows_all = torch.empty(world, Umax, D, dtype=g.dtype, device=g.device)
+        _all_gather_rows(rows_all, acc, self.group)
+        if total > 0:
+            ukeys = union_keys[:total]
+            own_of = ukeys // self.rows
+            pos = own_of * Umax + (torch.arange(total, device=g.device) - ustart.index_select(0, own_of))
+            union_ids = ukeys % self.rows
+            g.index_copy_(0, union_ids, rows_all.view(-1, D).index_select(0, pos))     # unique ids: every row written once
+            self.last_gathered = [union_ids]
+        return 1.0 / world
+
+    def info(self) -> Dict:
+        world = dist.get_world_size(self.group) if self._active() else 1
+        dense = 4 * self.flat.numel
+        row_b = 4 * self.dim
+        cap, uni = self._last.get("max_unique_rows", 0), self._last.get("union_rows", 0)
+        return {"mode": self.mode, "last_step_choice": self._last["choice"], "max_unique_rows_per_rank": cap,
+                "union_rows": uni, "id_capacity": self.capacity,
+                "payload_bytes_per_rank": int(self._payload), "dense_payload_bytes_per_rank": dense,
+                "rule": f"min over predicted_wire_ms of owners / rows / dense ({wire_model()} model)" if self.mode == "auto" else None,
+                "predicted_wire_ms": {"dense": predicted_wire_ms("dense", dense, world),
+                                      "rows": predicted_wire_ms("rows", cap * row_b, world),
+                                      "owners": predicted_wire_ms("owners", cap * row_b, world, -(-uni // max(world, 1)) * row_b),
+                                      "link_GBps": XGMI_LINK_GBPS, "unmeasured": True},
+                "note": "rank r owns the table rows id % world == r: one early all-gather of the unique ids (fixed capacity), "
+                        "all-to-all of the touched gradient rows to their owners, sum in rank order, all-gather of the reduced "
+                        "rows (each touched row once, no ids); dense all-reduce of the non-table gradient; last step's sizes"}
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+def _is_rccl(group=None) -> bool:
+    try:
+        return str(dist.get_backend(group)).lower() == "nccl"
+    except Exception:
+        return False
+
+
+def _all_gather_rows(out: torch.Tensor, piece: torch.Tensor, group=None, async_op: bool = False):
+    """all-gather of equally sized pieces into the leading axis of `out`: ``all_gather_into_tensor`` over RCCL, the list
+    form otherwise (gloo: the CPU tests of the orchestration, and the two-ranks-on-one-GPU test)."""
+    piece = piece.contiguous()
+    if out.is_cuda and _is_rccl(group):
+        return dist.all_gather_into_tensor(out, piece, group=group, async_op=async_op)
+    parts = [torch.empty_like(piece) for _ in range(out.shape[0])]
+    dist.all_gather(parts, piece, group=group)
+    for r, part in enumerate(parts):
+        out[r].copy_(part)
+    return _DoneWork() if async_op else None
+
+
+def _all_to_all_rows(recv: torch.Tensor, send: torch.Tensor, recv_splits, send_splits, group=None):
+    """async ``all_to_all_single`` (RCCL, or gloo over CPU tensors); gloo has no all-to-all for GPU tensors, so the
+    two-ranks-on-one-GPU test stages through the host."""
+    send = send.contiguous()
+    if send.is_cuda and not _is_rccl(group):
+        r_cpu = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r_cpu, send.cpu(), recv_splits, send_splits, group=group)
+        recv.copy_(r_cpu)
+        return _DoneWork()
+    return dist.all_to_all_single(recv, send, recv_splits, send_splits, group=group, async_op=True)
 
 
 class LazyTableAdam:
@@ -411,7 +746,13 @@ class LazyTableAdam:
     def update(self, grad_scale: float) -> None:
         """After the backward (and the gradient exchange), BEFORE ``opt.begin_step()``: step t for the marked rows with their
         gradient rows (cleared)."""
+        # (rows another rank touched -- mark_more -- were not advanced by begin(): the replay they get here must not race the
+        #  rolling-flush slice of the side stream over the same rows; a no-op when the trainer's join already covered it)
+        self._join_side()
         self._advance(self.mark, self.opt.step_count, True, grad_scale)
+        self._run_pending_slice()
+
+    def _run_pending_slice(self) -> None:
         t = getattr(self, "_slice_pending", None)
         if t is not None:                # the flush slice on the launch stream, after the update: rows nobody marked, to step t - 1
             self._slice_pending = None
@@ -423,6 +764,7 @@ class LazyTableAdam:
         IS the replay they get later.  Reads the whole table gradient once (84 MB at V = 70k) instead of 0.70 GB of Adam state."""
         self._join_side()
         self._advance(None, self.opt.step_count, 2, grad_scale)
+        self._run_pending_slice()          # (NRL_LAZY_FLUSH=end: the rolling flush must run under the dense exchange too)
 
     def finish(self, grad_scale: float) -> None:
         """``update`` + the dense kernel over everything else of the flat buffer (the single-table case)."""
@@ -464,10 +806,12 @@ class NRMSTrainer:
     """forward -> CE loss -> backward (table-gradient all-reduce overlapped) -> fused Adam."""
 
     def __init__(self, module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, group=None,
-                 grad_exchange: str = "dense", head_chunks: int = 4, lazy_adam: Optional[bool] = None):
-        if grad_exchange not in ("dense", "rows", "auto"):
-            raise ValueError("grad_exchange must be 'dense' (all-reduce of the flat gradient), 'rows' (touched table rows) or "
-                             "'auto' (per step, whichever ships fewer bytes)")
+                 grad_exchange: str = "dense", head_chunks: int = 4, lazy_adam: Optional[bool] = None,
+                 id_capacity: int = 32768):
+        if grad_exchange not in ("dense", "rows", "owners", "auto"):
+            raise ValueError("grad_exchange must be 'dense' (all-reduce of the flat gradient), 'rows' (all-gather of the touched "
+                             "table rows), 'owners' (touched rows reduced by their owner rank, then all-gathered) or 'auto' (per "
+                             "step, whichever of the three the wire model prices lowest)")
         self.module = module
         self.flat = FlatParams(module.parameters())
         self.opt = FusedAdam(self.flat, lr, betas, eps)
@@ -485,8 +829,11 @@ class NRMSTrainer:
         if te is not None and hasattr(te, "table_grad_hook") and len(enc.text_encoders) == 1 \
                 and self.flat.params[0] is te.embedding_layer.weight:
             head = self.flat.offsets[1] if len(self.flat.offsets) > 1 else self.flat.numel
-        if grad_exchange in ("rows", "auto") and head > 0:
-            self.reduce = TouchedRowsExchange(self.flat, head, te.embedding_layer.weight, group, auto=grad_exchange == "auto")
+        if grad_exchange in ("owners", "auto") and head > 0:
+            self.reduce = OwnerRowsExchange(self.flat, head, te.embedding_layer.weight, group, mode=grad_exchange,
+                                            id_capacity=id_capacity)
+        elif grad_exchange == "rows" and head > 0:
+            self.reduce = TouchedRowsExchange(self.flat, head, te.embedding_layer.weight, group)
         else:
             self.reduce = OverlappedGradReduce(self.flat, head, group, chunks=head_chunks)
         if head > 0:
@@ -525,6 +872,11 @@ class NRMSTrainer:
                 self._dense_ranges.append((lo, self.flat.numel))
             if hasattr(module, "register_state_dict_pre_hook"):
                 module.register_state_dict_pre_hook(lambda *_a, **_k: self._table_read())
+            # load_state_dict on a live trainer (restoring the best weights): every row is brought to the current step FIRST, so
+            # the loaded values are not followed by a replay of zero-gradient steps the old values had missed
+            reg = getattr(module, "register_load_state_dict_pre_hook", None) or getattr(module, "_register_load_state_dict_pre_hook", None)
+            if reg is not None:
+                reg(lambda *_a, **_k: self._table_read())
 
     def _find_lazy_tables(self, module, enc, single: bool) -> None:
         """Embedding tables whose gradient is zero outside the rows a step's batch names: the word table of every text encoder
@@ -617,15 +969,24 @@ class NRMSTrainer:
     def flush(self) -> None:
         """Brings every lazily updated table row to the current step (no-op without the lazy table optimizer)."""
         for tab, _ in self.lazy_tables:
+            pending = tab.pending
             tab.flush()
+            if pending:
+                tab.check()        # (one scalar read-back, outside the step: a row that ever lagged past the window raises here)
 
     def exchange_info(self) -> Dict:
         """What the data-parallel gradient exchange ships per rank and step (bench.py prints it for N > 1)."""
         return self.reduce.info()
 
     def step(self, batch: Dict) -> torch.Tensor:
-        if not self.module.training:        # (nn.Module.train() walks every submodule: 80 us of host time per step when called blindly)
+        # (nn.Module.train() walks every submodule and rebinds the flag: 80 us of host time per step when called blindly; the
+        #  cached list makes the check a few microseconds and still catches a submodule somebody left in eval())
+        mods = getattr(self, "_mods", None)
+        if mods is None:
+            mods = self._mods = list(self.module.modules())
+        if not all(m.training for m in mods):
             self.module.train()
+            self._mods = None
         rows_mode = hasattr(self.reduce, "prepare") and self.reduce._active()
         if rows_mode or self.lazy_tables:
             # the step's token ids exist now.  Touched-row exchange: unique ids + the async exchange of their counts go out before

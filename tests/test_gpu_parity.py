@@ -1119,12 +1119,13 @@ print("OK", rank)
 """
 
 
-@pytest.mark.parametrize("grad_exchange", ["dense", "rows"])
+@pytest.mark.parametrize("grad_exchange", ["dense", "rows", "owners", "auto"])
 def test_two_rank_data_parallel_steps_share_one_gpu(tmp_path, grad_exchange):
     """N>1 path with REAL kernels: two ranks (gloo, both on cuda:0 -- RCCL needs one GPU per rank, the
     box has one) take two train steps on different impressions; the table-gradient hook fires from
-    inside backward, the replicas stay bit-identical, and the result differs from training alone.  Both gradient
-    exchanges: the dense all-reduce and the touched-row all-gather (trainer.TouchedRowsExchange)."""
+    inside backward, the replicas stay bit-identical, and the result differs from training alone.  Every gradient
+    exchange: the dense all-reduce, the touched-row all-gather (trainer.TouchedRowsExchange), the owner-partitioned
+    exchange (trainer.OwnerRowsExchange) and `auto` (min over the wire model, per step)."""
     import os
     import subprocess
     import sys

@@ -377,6 +377,18 @@ def test_trainable_linear_keeps_its_images_within_an_optimizer_step_only():
         assert float((dx - g @ lin.weight.detach()).abs().max()) <= 1e-4 * float(dx.abs().max())
         assert float((dw - g.t() @ x.detach()).abs().max()) <= 1e-4 * float(dw.abs().max())
 
+    # without this library's optimizer in the process nothing of a trainable weight is kept: a writer through `p.data` (apex, EMA
+    # swaps) moves neither the version counter nor the generation, and must still meet its own values (advisor, round 4)
+    drivers = ops_blocks._STEP_DRIVERS[0]
+    ops_blocks._STEP_DRIVERS[0] = 0
+    try:
+        check(*run())
+        assert not nl._step_images._key
+        lin.weight.data.mul_(0.75)                      # unannounced raw write
+        check(*run())
+    finally:
+        ops_blocks._STEP_DRIVERS[0] = drivers
+    ops_blocks.register_step_driver()                   # (what trainer.FusedAdam.__init__ does)
     y0, dx0, dw0 = run()
     check(y0, dx0, dw0)
     k0 = dict(nl._step_images._key)
