@@ -310,14 +310,16 @@ def main():
 
     # ---- the timed region: EXACTLY `steps` steps.  No profiling hook inside (nrl_prof stays off); the only additions are the
     # per-step event records the median is computed from (one ~1 us host call each, nothing on the device) ----
+    # the loop knows its next batch (a prefetching loader does): the trainer runs that step's id bookkeeping -- id concatenation,
+    # counting sort, lazy-optimizer marks + catch-up -- on its side stream beside the current step (trainer._prefetch)
     for i in range(args.warmup):
-        trainer.step(batches[i % N_BATCHES])
+        trainer.step(batches[i % N_BATCHES], batches[(i + 1) % N_BATCHES])
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        trainer.step(batches[i % N_BATCHES])
+        trainer.step(batches[(args.warmup + i) % N_BATCHES], batches[(args.warmup + i + 1) % N_BATCHES])
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -327,7 +329,7 @@ def main():
     # (nrl_prof, recorded on the launch stream) ----
     lib.nrl_prof_enable(1)
     for i in range(args.steps):
-        trainer.step(batches[i % N_BATCHES])
+        trainer.step(batches[i % N_BATCHES], batches[(i + 1) % N_BATCHES])
     barrier()
     tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     lib.nrl_prof_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(flops))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 13
+#define NRL_ABI_VERSION 14
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -275,12 +275,16 @@ int nrl_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  *                          last_step[r] = upto_step + 1.  (catch-up before a forward: mark, upto_step = t - 1, with_grad 0;
  *                          update after the backward: mark, upto_step = t - 1, with_grad 1; flush: mark NULL, with_grad 0;
  *                          with_grad 2, mark NULL: "scan" -- every candidate row whose gradient row has a non-zero element is
- *                          updated, all-zero rows stay lazy: the update after a DENSE all-reduce, which leaves no list of rows.) */
+ *                          updated, all-zero rows stay lazy: the update after a DENSE all-reduce, which leaves no list of rows.)
+ *                          exclude_mark (ABI v14; NULL: none): rows with exclude_mark[r] == exclude_tag are skipped -- the EARLY
+ *                          catch-up of step t + 1 (mark = the next batch's marks, upto_step = t, with_grad 0) issued on another
+ *                          stream while step t runs must leave alone the rows step t owns (exclude_mark = step t's marks,
+ *                          exclude_tag = t).  One rank only: a row outside step t's batch has a zero gradient at step t. */
 int nrl_adam_rows_mark(const int64_t* ids, int64_t n_ids, int64_t rows, int32_t* mark, int64_t step, void* stream);
 int nrl_adam_rows_advance(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t rows, int32_t dim,
                           int32_t* last_step, const int32_t* mark, int32_t* status, int64_t stride, int64_t offset,
                           int64_t upto_step, int32_t with_grad, double lr, double beta1, double beta2, double eps,
-                          float grad_scale, void* stream);
+                          float grad_scale, const int32_t* exclude_mark, int32_t exclude_tag, void* stream);
 
 /* ---- transformer-body glue (ABI v13; config 4, text.py:89-109: every layer of the PLM body ends its attention and its
  * feed-forward block with LayerNorm(dropout(dense_out) + residual)).  One launch each way instead of dropout + add + layer norm:

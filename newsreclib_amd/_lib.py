@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -125,7 +125,7 @@ SIGNATURES = {
     "nrl_adam_rows_mark": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "nrl_adam_rows_advance": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_int64, c_int64, c_int32, c_double, c_double, c_double, c_double, c_float,
-                                        c_void_p]),
+                                        c_void_p, c_int32, c_void_p]),
     "nrl_dropout_add_layernorm_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_double,
                                                 c_uint64, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nrl_dropout_add_layernorm_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_double,

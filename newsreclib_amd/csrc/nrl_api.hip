@@ -497,9 +497,9 @@ int nrl_adam_rows_mark(const int64_t* ids, int64_t n_ids, int64_t rows, int32_t*
 int nrl_adam_rows_advance(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t rows, int32_t dim,
                           int32_t* last_step, const int32_t* mark, int32_t* status, int64_t stride, int64_t offset,
                           int64_t upto_step, int32_t with_grad, double lr, double beta1, double beta2, double eps,
-                          float grad_scale, void* stream) {
+                          float grad_scale, const int32_t* exclude_mark, int32_t exclude_tag, void* stream) {
   return adam_rows_advance(param, grad, exp_avg, exp_avg_sq, rows, dim, last_step, mark, status, stride, offset, upto_step,
-                           with_grad, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+                           with_grad, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream, exclude_mark, exclude_tag);
 }
 
 int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,

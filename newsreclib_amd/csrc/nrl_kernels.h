@@ -79,7 +79,8 @@ int adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr, doub
 int adam_rows_mark(const int64_t* ids, int64_t n, int64_t rows, int32_t* mark, int64_t step, hipStream_t stream);
 int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int dim, int32_t* last, const int32_t* mark,
                       int32_t* status, int64_t stride, int64_t offset, int64_t upto0, int with_grad, double lr, double b1,
-                      double b2, double eps, float grad_scale, hipStream_t stream);
+                      double b2, double eps, float grad_scale, hipStream_t stream, const int32_t* excl = nullptr,
+                      int32_t excl_tag = 0);
 
 int embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int D, float* out,
                      hipStream_t stream);

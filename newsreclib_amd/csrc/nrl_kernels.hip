@@ -1036,6 +1036,10 @@ int adam_step(float* p, float* g, float* m, float* v, int64_t n, double lr, doub
 //   update    the same rows -> (advanced to t - 1 if another rank touched them, then) step t with their gradient row, which is
 //             cleared; last = t;
 //   flush     a slice (rows r = offset + j * stride: the rolling flush that bounds every row's lag) or all rows -> upto0.
+//   early catch-up (round 5)  the catch-up of step t + 1, issued on a side stream WHILE step t runs, for a caller that knows
+//             the next batch's ids: rows marked for t + 1 (a second mark array) are advanced to step t -- except the rows step t
+//             itself owns (excl[r] == t: its update brings them to t anyway, and must not be raced).  Sound on one rank only: a
+//             row outside the running step's batch has a zero gradient at that step.
 // The bias corrections of the 128 steps up to the current one travel as kernel arguments (computed on the host exactly as
 // adam_step computes them), indexed step & 127: a row may lag by at most 127 steps (status[0] is set if one lags further --
 // the trainer's rolling flush keeps every lag <= its period).
@@ -1044,6 +1048,8 @@ struct AdamRowsArgs {
   float *p, *g, *m, *v;
   int32_t* last;
   const int32_t* mark;     // or null: every candidate row
+  const int32_t* excl;     // or null; else rows with excl[r] == excl_tag are skipped (the rows the RUNNING step owns, see below)
+  int32_t excl_tag;
   int32_t* status;
   int64_t n_cand, stride, offset;
   int32_t tag, upto0, with_grad, D;
@@ -1069,6 +1075,7 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(const AdamRowsArgs A) {
     if (tid < CAND && j < A.n_cand) {
       const int64_t r = A.offset + j * A.stride;
       take = (A.mark == nullptr || A.mark[r] == A.tag) && (A.with_grad || A.last[r] < A.upto0);     // (scan: every candidate)
+      if (A.excl != nullptr && A.excl[r] == A.excl_tag) take = false;
     }
     const unsigned long long b = __ballot(take);
     if (take) s_rows[__popcll(b & ((1ull << lane) - 1ull))] = tid;
@@ -1157,7 +1164,7 @@ int adam_rows_mark(const int64_t* ids, int64_t n, int64_t rows, int32_t* mark, i
 
 int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int dim, int32_t* last, const int32_t* mark,
                       int32_t* status, int64_t stride, int64_t offset, int64_t upto0, int with_grad, double lr, double b1,
-                      double b2, double eps, float grad_scale, hipStream_t stream) {
+                      double b2, double eps, float grad_scale, hipStream_t stream, const int32_t* excl, int32_t excl_tag) {
   // with_grad == 2: "scan" -- no mark; every candidate row whose gradient row is non-zero is updated (dense all-reduce)
   const int scan = with_grad == 2 ? 1 : 0;
   NRL_REQUIRE(!scan || mark == nullptr, "adam_rows: the scan update takes no mark");
@@ -1167,7 +1174,8 @@ int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int 
               "adam_rows: buffers must be 16-byte aligned");
   if (offset >= rows) return NRL_OK;
   AdamRowsArgs A;
-  A.p = p; A.g = g; A.m = m; A.v = v; A.last = last; A.mark = mark; A.status = status;
+  NRL_REQUIRE(excl == nullptr || (mark != nullptr && !with_grad), "adam_rows: an exclusion mark goes with a marked catch-up only");
+  A.p = p; A.g = g; A.m = m; A.v = v; A.last = last; A.mark = mark; A.status = status; A.excl = excl; A.excl_tag = excl_tag;
   A.n_cand = (rows - offset + stride - 1) / stride; A.stride = stride; A.offset = offset;
   A.tag = (int32_t)(upto0 + 1);      // the step the marks were written for: catch-up and update both run during step upto0 + 1
   A.upto0 = (int32_t)upto0; A.with_grad = with_grad ? 1 : 0; A.D = dim; A.scan = scan;

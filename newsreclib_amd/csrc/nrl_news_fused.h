@@ -174,31 +174,38 @@ typedef uint4 __attribute__((may_alias)) nap_u4a;
 // 64 = counted head-top wait (vmcnt(8): the q|k|v slab stores stay in flight), 128 = every slab store of a wave lands on
 // the same 7.5 KB (cache-resident: the stores are issued, nothing drains to HBM), 256 = slab stores in front of the attention phase instead of after the score MFMAs,
 // 512 = half of them there, half after the P V MFMAs
-template <int DH, bool SAVE, int ABL = 0, bool SHARE = false>
-__global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
+// WV (round 5): waves = news per workgroup.  8: one workgroup per CU, the whole head's image (5 chunks, 80 KB) resident one head
+// ahead.  4: TWO workgroups per CU (2 x 16 KB ring + 4 images = 66 KB each), chunks one ahead -- the two waves of a SIMD then
+// belong to different workgroups and share no barrier, so one's softmax / store phase runs under the other's MFMAs (what took the
+// tail kernels from 0.25 to 0.20 ms, nrl_news_tail.h); every weight byte is streamed L2 -> LDS once per 4 news instead of once per 8.
+template <int DH, bool SAVE, int ABL = 0, bool SHARE = false, int WV = NF_WAVES>
+__global__ void __launch_bounds__(WV * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
   static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
+  static_assert(WV == 8 || WV == 4, "8 waves (whole-head ring) or 4 waves (two-slot ring)");
+  constexpr int RING = WV == 8 ? NF_RING : 2 * 16384;
+  constexpr int PPW = 16 / WV;                          // 1 KiB DMA pieces per wave and chunk
   static_assert(!(SHARE && SAVE), "pad-row sharing is for evaluation forwards (no dropout, nothing saved)");
   // plain (write-allocate) stores: this kernel is not store-bound and the L2 merges the 80-byte `o` pieces; streaming
   // saves measured slower (train 0.62-0.65 vs 0.60 ms, tools/nf_probe.hip).  ABL 16 / 32 select the streaming forms.
   constexpr int NT = (ABL & 16) ? 1 : 0;
   constexpr int NT_O = (ABL & 32) ? 1 : 0;
   // (+ 16 bytes: the masked lanes of the last wave's V-fragment reads run 3 floats past its image)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NF_RING + NF_WAVES * NF_IMG_FLOATS * 4 + 16];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + WV * NF_IMG_FLOATS * 4 + 16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  float* const image = reinterpret_cast<float*>(smem + NF_RING) + wave * NF_IMG_FLOATS;
+  float* const image = reinterpret_cast<float*>(smem + RING) + wave * NF_IMG_FLOATS;
 
   const int L = P.L, D = P.D, heads = P.heads;
   const int nblk = heads * 4;
   // Tail balancing: a workgroup costs the same with 1 or 8 news (every wave streams all the weights), so the last,
   // partly filled round of 8-news workgroups (7040 news = 3.44 rounds of 256) is replaced by 4-news workgroups whose
   // waves have a SIMD to themselves; their other four waves only keep the barrier / DMA protocol going.
-  const bool half_wg = (int)blockIdx.x >= P.full_wgs;
+  const bool half_wg = WV == 8 && (int)blockIdx.x >= P.full_wgs;
   const int64_t news_v = half_wg ? (int64_t)P.full_wgs * NF_WAVES + (int64_t)((int)blockIdx.x - P.full_wgs) * 4 + wave
-                                 : (int64_t)blockIdx.x * NF_WAVES + wave;
+                                 : (int64_t)blockIdx.x * WV + wave;
   const bool wave_active = !half_wg || wave < 4;
   const bool news_ok = wave_active && news_v < P.n_news;
   // SHARE: the wave's news comes from the short-first list; position < n_short <=> a short news (wave-uniform)
@@ -215,21 +222,23 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
 
   // ---- weight DMA: chunk c of head h = k-blocks 2c, 2c + 1 x column blocks 4h .. 4h + 3 x (hi, lo): 16 pieces of
   // 1 KiB, two per wave.  LDS slot c holds [kbi][nb][plane][lane * 16].
-  auto issue_chunk = [&](int h, int c) {
+  // (WV == 8: chunk c lives in slot c; WV == 4: chunk c of head h lives in slot (h + c) & 1 -- five chunks per head)
+  auto issue_chunk = [&](int h, int c, int slot_i = -1) {
+    const uint32_t slot = slot_i >= 0 ? (uint32_t)slot_i : (WV == 8 ? (uint32_t)c : (uint32_t)((h + c) & 1));
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int piece = wave * 2 + q;                    // 0..15 = (kbi, nb, plane)
+    for (int q = 0; q < PPW; ++q) {
+      const int piece = wave * PPW + q;                  // 0..15 = (kbi, nb, plane)
       const int kbi = piece >> 3, nb = (piece >> 1) & 3, plane = piece & 1;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img) +
                                  ((size_t)(((2 * c + kbi) * nblk + h * 4 + nb) * 2 + plane)) * 1024 + lane * 16;
-      glds16_asm(src, smem_base + (uint32_t)c * 16384u + (uint32_t)piece * 1024u);
+      glds16_asm(src, smem_base + slot * 16384u + (uint32_t)piece * 1024u);
     }
   };
   if constexpr (!(ABL & 4)) {
 #pragma unroll
-    for (int c = 0; c < 5; ++c) issue_chunk(0, c);
+    for (int c = 0; c < (WV == 8 ? 5 : 2); ++c) issue_chunk(0, c);
   }
-  if (!wave_active) {
+  if (WV == 8 && !wave_active) {
     // idle wave of a 4-news workgroup: same barriers, same share of the weight DMA, nothing else
     for (int h = 0; h < heads; ++h) {
       wait_vmcnt<0>();
@@ -388,8 +397,13 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
     constexpr int NI = SH ? 1 : 2;
     for (int h = 0; h < heads; ++h) {
       // every chunk of head h was issued while head h - 1 ran: landed for this wave, then (barrier) for all
-      if (h > 0 && slab_tail) wait_vmcnt<8>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      // (WV == 4: chunk 0 of this head was waited for at the last chunk boundary of the previous head; only head 0 waits here)
+      if (WV == 8 || h == 0) {
+        if (h > 0 && slab_tail) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+      const unsigned char* const slot_even = smem + (WV == 8 ? 0 : (h & 1) * 16384);        // WV == 4: chunks 0, 2, 4 of this head
+      const unsigned char* const slot_odd = smem + (WV == 8 ? 0 : ((h & 1) ^ 1) * 16384);   //          chunks 1, 3
       f32x4 acc[2][4];
   #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -402,7 +416,7 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
       // chunk boundary is safe: the barrier there only guards the REFILL of the slot just finished.
       auto read_step = [&](int t, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) {
         const int c = t >> 2, kbi = (t >> 1) & 1, np = t & 1;
-        const unsigned char* slot = smem + c * 16384 + lane * 16;
+        const unsigned char* slot = WV == 8 ? smem + c * 16384 + lane * 16 : ((c & 1) ? slot_odd : slot_even) + lane * 16;
   #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           bh[jj] = *reinterpret_cast<const bf16x8*>(slot + ((kbi * 4 + 2 * np + jj) * 2) * 1024);
@@ -433,15 +447,32 @@ __global__ void __launch_bounds__(NF_WAVES * 64, 2) news_fused_fwd_kernel(const 
         mfma_step(t, bh0, bl0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * NI, 0);
-        if (t + 2 < 20) read_step(t + 2, bh0, bl0);
+        // (WV == 4: the next chunk may still be in flight at a chunk boundary -- its fragments are read after the boundary's wait)
+        const bool ahead = t + 2 < 20 && (WV == 8 || (t & 3) != 2);
+        if (ahead) read_step(t + 2, bh0, bl0);
         mfma_step(t + 1, bh1, bl1);
-        if (t + 2 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        if (ahead) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * NI, 0);
         if ((t & 3) == 2) {
-          // steps 4c .. 4c + 3 done: all waves are finished with slot c -> refill it with chunk c of the next head
           __builtin_amdgcn_sched_barrier(0);
-          __builtin_amdgcn_s_barrier();
-          if constexpr (!(ABL & 4)) issue_chunk(hn, t >> 2);
+          if constexpr (WV == 8) {
+            // steps 4c .. 4c + 3 done: all waves are finished with slot c -> refill it with chunk c of the next head
+            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 4)) issue_chunk(hn, t >> 2);
+          } else {
+            // two-slot ring: chunk c + 1 (chunk 0 of the next head after c = 4) was issued one chunk ago into the other slot: this
+            // wave's pieces have landed (vmcnt), then -- barrier -- everybody's, and everybody is done with chunk c's slot, which
+            // takes chunk c + 2 (of the next head past the end of this one; last head: its own chunks again, uniform control flow)
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const int c2 = (t >> 2) + 2;
+            if constexpr (!(ABL & 4)) {
+              // (the slot is the one chunk c just left, whichever head the refill belongs to: (h + c) & 1)
+              if (c2 < 5) issue_chunk(h, c2, (h + c2) & 1);
+              else issue_chunk(hn, c2 - 5, (h + c2) & 1);
+            }
+            if (t + 2 < 20) read_step(t + 2, bh0, bl0);
+          }
           if (t == 2 && h > 0) flush_o(h - 1);              // the previous head's O, under this head's MFMAs
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -613,16 +644,31 @@ static inline bool news_fused_ok(int L, int D, int heads) {
   return L >= 1 && L <= 32 && D % 4 == 0 && rp_kblocks(D, true) == NF_KB && heads > 0 && D == heads * 20;
 }
 
-template <int ABL = 0>
-static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t st) {
+// Workgroup shape (tools/nf4_probe.hip, profiles/r05_ab.txt; outputs bit-identical): 8 waves / one workgroup per CU for TRAINING
+// forwards (0.536 vs 0.556 ms at B = 128: with a two-slot ring every chunk boundary is a vmcnt(0), which also waits out the slab /
+// plane stores of the saves), 4 waves / two workgroups per CU for EVALUATION forwards (0.394 -> 0.386 ms, 0.473 -> 0.449 at 8192
+// news: nothing is stored between the chunk boundaries but `o`).  NRL_NF_WAVES=4|8 forces one shape for the evaluation kernels;
+// ALL = true (probes) also instantiates the 4-wave training kernel.
+static inline int news_fused_eval_waves() {
+  static const int wv = [] { const char* e = getenv("NRL_NF_WAVES"); return e != nullptr && atoi(e) == 8 ? 8 : 4; }();
+  return wv;
+}
+template <int ABL = 0, bool ALL = false>
+static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t st, int wv = 0) {
   if (a_in.n_news <= 0) return NRL_OK;
   NewsFusedArgs a = a_in;
+  const bool training = (a.x_save != nullptr || a.x_planes != nullptr) && a.lse != nullptr;
+  if (wv != 4 && wv != 8) wv = training ? 8 : news_fused_eval_waves();
+  if (training && !ALL) wv = 8;
   // full rounds of 8-news workgroups over the 256 CUs; what is left goes to 4-news workgroups if that fits one round
   constexpr int64_t CUS = 256;
   const int64_t full = (a.n_news / NF_WAVES) / CUS * CUS;
   const int64_t rem = a.n_news - full * NF_WAVES;
   int64_t blocks;
-  if (rem > 0 && rem <= 4 * CUS) {
+  if (wv == 4) {
+    blocks = ceil_div(a.n_news, 4);
+    a.full_wgs = (int)blocks;
+  } else if (rem > 0 && rem <= 4 * CUS) {
     a.full_wgs = (int)full;
     blocks = full + ceil_div(rem, 4);
   } else {
@@ -631,17 +677,25 @@ static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t s
   }
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   NRL_REQUIRE(a.x_planes == nullptr || NF_KB == 10, "x planes assume 20 column blocks");
-  if ((a.x_save != nullptr || a.x_planes != nullptr) && a.lse != nullptr) {   // training: x + lse (+ q|k|v unless recomputed)
+  const dim3 grid((unsigned)blocks), blk((unsigned)(wv * 64));
+  if (training) {   // x + lse (+ q|k|v unless recomputed)
     NRL_REQUIRE(a.perm == nullptr, "fused news encoder: pad-row sharing is for evaluation forwards");
-    hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+    if constexpr (ALL) {
+      if (wv == 4) hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL, false, 4>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), grid, blk, 0, st, a);
+    } else {
+      hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, ABL>), grid, blk, 0, st, a);
+    }
   } else {
     NRL_REQUIRE(a.x_save == nullptr && a.x_planes == nullptr && a.qkv_save == nullptr && a.lse == nullptr,
                 "fused news encoder: save x and lse (and optionally q|k|v), or nothing");
     if (a.perm != nullptr) {
       NRL_REQUIRE(a.n_short != nullptr && a.drop1.thresh == 0u, "fused news encoder: pad-row sharing needs the short-first list and no dropout");
-      hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+      if (wv == 4) hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true, 4>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true>), grid, blk, 0, st, a);
     } else {
-      hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+      if (wv == 4) hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, false, 4>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), grid, blk, 0, st, a);
     }
   }
   NRL_LAUNCH_CHECK();

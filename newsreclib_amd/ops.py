@@ -505,7 +505,7 @@ def adam_rows_mark_(ids: torch.Tensor, mark: torch.Tensor, step: int) -> None:
 def adam_rows_advance_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                        last_step: torch.Tensor, mark: Optional[torch.Tensor], status: torch.Tensor, upto_step: int,
                        with_grad, lr: float, betas: Tuple[float, float], eps: float, grad_scale: float = 1.0,
-                       stride: int = 1, offset: int = 0) -> None:
+                       stride: int = 1, offset: int = 0, exclude_mark: Optional[torch.Tensor] = None, exclude_tag: int = 0) -> None:
     """``nrl_adam_rows_advance`` over a (rows, dim) table and its flat gradient / moment views (see include/newsreclib_amd.h)."""
     lib = _lib.load()
     rows, dim = param.shape
@@ -515,7 +515,9 @@ def adam_rows_advance_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.T
     _lib.check(lib.nrl_adam_rows_advance(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), rows, dim,
                                          last_step.data_ptr(), mark.data_ptr() if mark is not None else None,
                                          status.data_ptr(), int(stride), int(offset), int(upto_step), int(with_grad),
-                                         lr, betas[0], betas[1], eps, float(grad_scale), _stream()), "nrl_adam_rows_advance")
+                                         lr, betas[0], betas[1], eps, float(grad_scale),
+                                         exclude_mark.data_ptr() if exclude_mark is not None else None, int(exclude_tag),
+                                         _stream()), "nrl_adam_rows_advance")
 
 
 def sort_positions(ids: torch.Tensor, vocab: Optional[int] = None) -> torch.Tensor:

@@ -694,7 +694,10 @@ class LazyTableAdam:
         self.head = self.offset + self.numel       # (end of the table in the flat buffer)
         dev = flat.flat.device
         self.last = torch.zeros(self.rows, dtype=torch.int32, device=dev)
-        self.mark = torch.zeros(self.rows, dtype=torch.int32, device=dev)
+        # marks of step t live in marks[t & 1]: the EARLY catch-up of step t + 1 (``hint``) writes the other array while step t's
+        # marks are still in use
+        self.marks = [torch.zeros(self.rows, dtype=torch.int32, device=dev) for _ in range(2)]
+        self._hinted = 0               # the step whose marks + catch-up were issued early (0: none)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.period = int(period)
         assert 1 <= self.period < 127
@@ -707,9 +710,14 @@ class LazyTableAdam:
             cached = self._view_cache = (v(self.flat.flat), v(self.flat.grad), v(self.opt.exp_avg), v(self.opt.exp_avg_sq))
         return cached
 
-    def _advance(self, mark, upto, with_grad, grad_scale=1.0, stride=1, offset=0):
+    def _advance(self, mark, upto, with_grad, grad_scale=1.0, stride=1, offset=0, exclude=None, exclude_tag=0):
         ops.adam_rows_advance_(*self._views(), self.last, mark, self.status, upto, with_grad, self.opt.lr, self.opt.betas,
-                               self.opt.eps, grad_scale, stride, offset)
+                               self.opt.eps, grad_scale, stride, offset, exclude, exclude_tag)
+
+    @property
+    def mark(self) -> torch.Tensor:
+        """The marks of the step in flight (t = step_count + 1)."""
+        return self.marks[(self.opt.step_count + 1) & 1]
 
     @property
     def pending(self) -> bool:
@@ -720,8 +728,14 @@ class LazyTableAdam:
         read); then the step's slice of the rolling flush, on `side` if given (it only moves rows the catch-up left behind)."""
         t = self.opt.step_count + 1
         self._join_side()                # the previous step's flush slice (side stream) before anything here moves a row
-        ops.adam_rows_mark_(ids, self.mark, t)
-        self._advance(self.mark, t - 1, False)
+        h = getattr(self, "_hint_ids", None)
+        hinted = self._hinted == t and h is not None and h.data_ptr() == ids.data_ptr() and h.numel() == ids.numel()
+        self._hinted, self._hint_ids = 0, None
+        if not hinted:
+            # (a hint for other ids than the ones that came: its rows were advanced to t - 1 and carry this step's tag -- their
+            #  update at the end of the step is a zero-gradient step, i.e. the replay they would get later: harmless)
+            ops.adam_rows_mark_(ids, self.mark, t)
+            self._advance(self.mark, t - 1, False)
         mode = os.environ.get("NRL_LAZY_FLUSH", "side")        # (A/B: "side" | "main" = right here | "end" = after the update)
         if mode == "end":
             self._slice_pending = t
@@ -732,6 +746,20 @@ class LazyTableAdam:
                 self._advance(None, t - 1, False, stride=self.period, offset=t % self.period)
         else:
             self._advance(None, t - 1, False, stride=self.period, offset=t % self.period)
+
+    def hint(self, next_ids: torch.Tensor, side) -> None:
+        """The mark + catch-up of step t + 1, issued on `side` WHILE step t runs (call after ``begin`` of step t): the rows of
+        `next_ids` that step t does not own are advanced to step t -- a row outside step t's batch has a zero gradient at step
+        t ON ONE RANK, so the replay is already determined -- and the rows both steps touch are brought to t by step t's own
+        update.  The next ``begin`` then launches nothing on the caller's stream (41 us of 2.8 ms at B = 128).  The caller joins
+        `side` before the next forward (the trainer's end-of-backward join covers it)."""
+        t = self.opt.step_count + 1
+        nxt = self.marks[(t + 1) & 1]
+        self._side = side
+        with torch.cuda.stream(side):
+            ops.adam_rows_mark_(next_ids, nxt, t + 1)
+            self._advance(nxt, t, False, exclude=self.marks[t & 1], exclude_tag=t)
+        self._hinted, self._hint_ids = t + 1, next_ids
 
     def _join_side(self) -> None:
         side = getattr(self, "_side", None)
@@ -978,7 +1006,43 @@ class NRMSTrainer:
         """What the data-parallel gradient exchange ships per rank and step (bench.py prints it for N > 1)."""
         return self.reduce.info()
 
-    def step(self, batch: Dict) -> torch.Tensor:
+    def _prefetch(self, next_batch: Dict) -> None:
+        """The id work of the NEXT step, issued on the side stream while this one runs: concatenating its history / candidate
+        ids, their counting sort (for its embedding gradient) and -- one rank, lazy table optimizer -- the mark + catch-up of
+        the table rows it will gather (``LazyTableAdam.hint``).  ~50 us of small launches leave the launch stream; the
+        end-of-backward join covers them."""
+        if next_batch is None or self._side is None or not hasattr(self.module, "_prepare"):
+            self._next = None
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)           # (this step's begin(): marks written, rows caught up; last step's update)
+        with torch.cuda.stream(self._side):
+            nb = self.module._prepare(next_batch)
+            for t in (nb.get("x_all") or {}).values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)      # allocated under the side stream, read on the launch stream next step
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            for tab, ids_of in self.lazy_tables:
+                tab.hint(ids_of(nb), self._side)
+        self._next = (next_batch, nb)
+
+    def _prefetch_pending(self) -> None:
+        nb, self._pending_next = getattr(self, "_pending_next", None), None
+        if nb is not None:
+            self._prefetch(nb)
+
+    def step(self, batch: Dict, next_batch: Optional[Dict] = None) -> torch.Tensor:
+        """One train step.  ``next_batch`` (optional): the batch the NEXT call will be given -- a loader that prefetches has it --
+        lets the trainer run that step's id bookkeeping beside this step (``_prefetch``); the result is bit-identical."""
+        nxt = getattr(self, "_next", None)
+        if nxt is not None:
+            if not getattr(self, "_side_joined", False) and self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)     # (no end-of-backward join happened: join here)
+            if nxt[0] is batch:
+                batch = nxt[1]
+        self._next = None
+        self._side_joined = False
         # (nn.Module.train() walks every submodule and rebinds the flag: 80 us of host time per step when called blindly; the
         #  cached list makes the check a few microseconds and still catches a submodule somebody left in eval())
         mods = getattr(self, "_mods", None)
@@ -999,6 +1063,19 @@ class NRMSTrainer:
                     self.reduce.prepare(xa["title"], xa.get("title_order"))
             for tab, ids_of in self.lazy_tables:
                 tab.begin(ids_of(batch), self._side)
+        # the next step's id work goes out from a forward hook of the news encoder: right AFTER the chip-filling kernels of the news
+        # forward, so that it runs beside the user encoder's few-row launches (issued at the top of the step it ran beside the
+        # fused forward and cost it what it saved: 0.545 -> 0.606 ms per launch, profiles/r05_ab.txt)
+        self._pending_next = next_batch if os.environ.get("NRL_PREFETCH_IDS", "1") not in ("", "0") else None
+        if self._pending_next is not None and not getattr(self, "_hooked", False):
+            enc = getattr(self.module, "news_encoder", None)
+            if enc is not None and os.environ.get("NRL_PREFETCH_AT", "hook") == "hook":
+                enc.register_forward_hook(lambda *_a, **_k: self._prefetch_pending())
+            self._hooked = True
+            if enc is None or os.environ.get("NRL_PREFETCH_AT", "hook") == "top":
+                self._prefetch_pending()
+        elif self._pending_next is not None and os.environ.get("NRL_PREFETCH_AT", "hook") == "top":
+            self._prefetch_pending()
         self._in_step = True
         try:
             # model_step directly: training_step would append preds / targets to training_step_outputs every step, and
@@ -1006,6 +1083,7 @@ class NRMSTrainer:
             loss = self.module.model_step(batch)[0]
         finally:
             self._in_step = False
+        self._prefetch_pending()               # (a module whose news encoder never ran through the hook)
         self._losses.append(loss.detach())
         if len(self._losses) >= self.LOSS_FOLD:
             self._fold_losses()
@@ -1015,6 +1093,7 @@ class NRMSTrainer:
             with ops.deferred_weight_grads(self._side) as deferred:
                 loss.backward(gradient=root)
             if deferred.joined:
+                self._side_joined = True
                 # that join also covers the lazy optimizer's flush slice (issued on the same side stream before the forward): one
                 # cross-stream wait per step instead of two (each is a barrier packet of ~6 us on the launch queue)
                 for tab, _ in self.lazy_tables:
