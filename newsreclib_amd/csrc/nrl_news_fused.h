@@ -644,22 +644,17 @@ static inline bool news_fused_ok(int L, int D, int heads) {
   return L >= 1 && L <= 32 && D % 4 == 0 && rp_kblocks(D, true) == NF_KB && heads > 0 && D == heads * 20;
 }
 
-// Workgroup shape (tools/nf4_probe.hip, profiles/r05_ab.txt; outputs bit-identical): 8 waves / one workgroup per CU for TRAINING
-// forwards (0.536 vs 0.556 ms at B = 128: with a two-slot ring every chunk boundary is a vmcnt(0), which also waits out the slab /
-// plane stores of the saves), 4 waves / two workgroups per CU for EVALUATION forwards (0.394 -> 0.386 ms, 0.473 -> 0.449 at 8192
-// news: nothing is stored between the chunk boundaries but `o`).  NRL_NF_WAVES=4|8 forces one shape for the evaluation kernels;
-// ALL = true (probes) also instantiates the 4-wave training kernel.
-static inline int news_fused_eval_waves() {
-  static const int wv = [] { const char* e = getenv("NRL_NF_WAVES"); return e != nullptr && atoi(e) == 8 ? 8 : 4; }();
-  return wv;
-}
+// Workgroup shape: 8 waves / one workgroup per CU.  The 4-wave / two-per-CU shape (WV = 4: two-slot weight ring, chunks one ahead,
+// bit-identical output) is instantiated for probes only (ALL = true, tools/nf4_probe.hip): measured in round 5 it loses 3 % on
+// training forwards (every chunk boundary is a vmcnt(0) that also waits out the saves' stores) and, although the bare evaluation
+// kernel gains 2-5 % in the probe, the evaluation forward of the step with pad-row sharing is slower with it (0.554 vs 0.547 ms;
+// profiles/r05_ab.txt).
 template <int ABL = 0, bool ALL = false>
 static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t st, int wv = 0) {
   if (a_in.n_news <= 0) return NRL_OK;
   NewsFusedArgs a = a_in;
   const bool training = (a.x_save != nullptr || a.x_planes != nullptr) && a.lse != nullptr;
-  if (wv != 4 && wv != 8) wv = training ? 8 : news_fused_eval_waves();
-  if (training && !ALL) wv = 8;
+  if (!ALL || wv != 4) wv = 8;
   // full rounds of 8-news workgroups over the 256 CUs; what is left goes to 4-news workgroups if that fits one round
   constexpr int64_t CUS = 256;
   const int64_t full = (a.n_news / NF_WAVES) / CUS * CUS;
@@ -691,11 +686,15 @@ static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t s
                 "fused news encoder: save x and lse (and optionally q|k|v), or nothing");
     if (a.perm != nullptr) {
       NRL_REQUIRE(a.n_short != nullptr && a.drop1.thresh == 0u, "fused news encoder: pad-row sharing needs the short-first list and no dropout");
-      if (wv == 4) hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true, 4>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true>), grid, blk, 0, st, a);
+      if constexpr (ALL) {
+        if (wv == 4) { hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true, 4>), grid, blk, 0, st, a); NRL_LAUNCH_CHECK(); return NRL_OK; }
+      }
+      hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, true>), grid, blk, 0, st, a);
     } else {
-      if (wv == 4) hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, false, 4>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), grid, blk, 0, st, a);
+      if constexpr (ALL) {
+        if (wv == 4) { hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL, false, 4>), grid, blk, 0, st, a); NRL_LAUNCH_CHECK(); return NRL_OK; }
+      }
+      hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), grid, blk, 0, st, a);
     }
   }
   NRL_LAUNCH_CHECK();
