@@ -212,6 +212,32 @@ def extra_plm(device, batch_size=8, steps=3):
             "body_output_blocks_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_output_blocks)}
 
 
+def predict_multi_gpu(step_ms: float, world: int = 8):
+    """UNMEASURED (no multi-GPU node has been available in any round): what `world` ranks of this workload would take per step
+    under trainer.predicted_wire_ms -- compute = this run's one-GPU step; the exchange overlaps the weight-gradient phase of the
+    news-encoder backward (22 % of the step in profiles/r04_x3_kernel_stats.csv) and its exposed rest adds to the step.  The
+    unique / union row counts are those of the `world` synthetic rank batches (seeds 1234 + rank)."""
+    from newsreclib_amd.synthetic import make_batch
+    from newsreclib_amd.trainer import predicted_wire_ms
+    ids = [torch.cat([b["x_hist"]["title"].reshape(-1), b["x_cand"]["title"].reshape(-1)])
+           for b in (make_batch(B_PER_GPU, VOCAB, "fixed", seed=1234 + r) for r in range(world))]
+    uniq = [int(torch.unique(i).numel()) for i in ids]
+    union = torch.unique(torch.cat(ids))
+    owners = [int((union % world == r).sum()) for r in range(world)]
+    row_b, head = 4 * D, 4.0 * VOCAB * D
+    wire = {"dense": predicted_wire_ms("dense", head + 4 * 843_200, world),
+            "rows": predicted_wire_ms("rows", max(uniq) * (row_b + 8), world),
+            "owners": predicted_wire_ms("owners", max(uniq) * row_b, world, max(owners) * row_b)}
+    overlap = 0.22 * step_ms
+    out = {"world": world, "unmeasured": True, "compute_ms": round(step_ms, 4), "overlap_window_ms": round(overlap, 4),
+           "unique_rows_per_rank_max": max(uniq), "union_rows": int(union.numel()), "predicted_wire_ms": wire, "modes": {}}
+    for mode, w in wire.items():
+        for model in ("ring", "direct"):
+            step = step_ms + max(0.0, w[model] - overlap) + (0.03 if mode != "dense" else 0.0)
+            out["modes"][f"{mode}/{model}"] = {"step_ms": round(step, 4), "speedup_over_1gpu": round(world * step_ms / step, 2)}
+    return out
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (reference multi-GPU leg:
     configs/trainer/ddp.yaml:4 `strategy: ddp`, one process per device)."""
@@ -261,12 +287,17 @@ def main():
                     help="projection-GEMM engine: exact fp32 MFMA, or fp32 via 3 bf16 MFMAs per product")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mindsmall",
                     help="mindsmall = BASELINE.json configs[1] (headline); mind32 = configs[0] (B=32); mindlarge = configs[2]'s per-rank shape (V=150k, B=64/GPU)")
-    ap.add_argument("--grad-exchange", choices=["dense", "rows", "owners", "auto"], default="dense",
+    ap.add_argument("--grad-exchange", choices=["dense", "rows", "owners", "auto"], default=None,
                     help="N > 1: dense = all-reduce of the whole flat gradient; rows = all-gather of the touched table rows + "
                          "dense rest; owners = touched rows reduced by their owner rank (id %% world), then all-gathered; "
                          "auto = per step whichever of the three trainer.predicted_wire_ms prices lowest (dense stays the default: it is the "
                          "one exchange whose RCCL calls have run on hardware, at world size 1)")
     args = ap.parse_args()
+    if args.grad_exchange is None:
+        # configs[1] (B = 128 per GPU): the dense all-reduce hides under the weight gradients even on a ring (predicted 7.0x at 8
+        # GPUs) and is the one exchange whose RCCL calls have run on hardware; configs[2] (B = 64 per GPU, V = 150k): its 183 MB
+        # dense gradient does not (predicted 4.1x on a ring) -- `auto` picks the owner-partitioned row exchange there (7.3-7.9x)
+        args.grad_exchange = "auto" if args.workload == "mindlarge" else "dense"
     B_PER_GPU, VOCAB = WORKLOADS[args.workload]["batch"], WORKLOADS[args.workload]["vocab"]
     M_ROWS = B_PER_GPU * (H + C) * L
 
@@ -422,6 +453,11 @@ def main():
         }
         if distributed:
             out["grad_exchange"] = trainer.exchange_info()
+        elif not args.no_extras:
+            try:
+                out["multi_gpu_prediction"] = predict_multi_gpu(median_ms)
+            except Exception as e:                         # an extra must never cost the headline line
+                out["multi_gpu_prediction"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and not args.no_extras:
             # the forward-only (evaluation-mode) rate of the same workload, outside the timed region
             mod.eval()

@@ -1032,6 +1032,26 @@ def test_mindlarge_shaped_rank_batch_train_step(engine):
     assert losses[-1] < l1
 
 
+def test_mindlarge_shaped_rank_batch_matches_oracle(engine):
+    """BASELINE configs[2] at its per-rank shape -- V = 150,000, 64 impressions per GPU, fixed MIND shape (50 clicks, 5
+    candidates, 30 tokens) -- AGAINST THE ORACLE, not only by properties (`configs_untested`): evaluation-mode
+    scores and loss within the 1e-3 contract (and the engine's own bar), on the exact shape a rank of the 8-GPU job sees."""
+    from newsreclib_amd.synthetic import make_batch
+    params = O.make_params(150_000, seed=21)
+    batch = make_batch(64, 150_000, "fixed", seed=9)
+    orc = O.NRMSOracle(params, num_heads=15, p_drop=0.2)
+    ref, _ = orc.loss_and_grads(batch, False)
+    mod = build_module(params, p_drop=0.2).eval()
+    dev_batch = batch_to(batch, DEV)
+    with torch.no_grad():
+        scores = mod.forward(dev_batch)
+        loss = mod.model_step(dev_batch)[0]
+    err_s, err_l = _maxerr(scores, ref["scores"]), abs(float(loss) - float(ref["loss"]))
+    print(f"configs[2] rank shape [{engine}]: scores max abs err {err_s:.3e}, loss err {err_l:.3e}")
+    assert tuple(scores.shape) == (64, 5)
+    assert err_s <= TOL and err_l <= TOL and err_s <= _eng_tol(engine, 5e-5, 5e-4)
+
+
 def test_plm_news_encoder_matches_reference_plm(tmp_path, engine):
     """BASELINE config 4 path on a tiny roberta-shaped body: product ``PLM`` (HF body on PyTorch-ROCm +
     ONE HIP call for dropout/MHA/dropout/additive attention) vs the reference's PLM module."""
