@@ -101,7 +101,8 @@ int nrl_get_gemm_engine(void);
  * to (the environment variables NRL_<NAME>=0/1 set the same defaults at load time).  Bit order of the mask:
  *   0 "news_fused"      gather + in-projection + token attention of the news encoder in one kernel (bf16x3 engine,
  *                       L <= 32, D = 20 * heads in [288, 316])
- *   1 "news_fused_bwd"  (default OFF) q|k|v recomputed inside the attention backward instead of saved
+ *   1 "news_fused_bwd"  RETIRED (ABI v14): reserved, always 0 -- nrl_set_option(.., 1) and an options word with the bit set are
+ *                       rejected.  (q|k|v recomputed inside the attention backward: measured slower, kernel in tools/experimental/)
  *   2 "news_attn_mfma"  token-attention backward of the fused news path on the matrix cores from head-major q|k|v slabs
  *   3 "news_planes"     x / dqkv of that path as pre-split bf16 fragment-block planes (DMA-only weight gradient)
  *   4 "news_od_planes"  o / dy of that path as planes too
@@ -122,8 +123,8 @@ int nrl_get_gemm_engine(void);
  *  15 "news_pad_share"  (ABI v13) evaluation forward of the fused news path (nothing saved, p_drop == 0): the run of padding tokens
  *                       from token 15 on is ONE row (identical embedding row, no dropout), so a news whose tokens 15 .. L - 1 are
  *                       all the padding id is computed on its first 16 token rows only; bit-identical to computing every row
- *  16 "news_tail_od"    (ABI v13, default OFF: measured slower) the out-projection's activation gradient of the fused news path
- *                       inside the fused tail backward (the dy planes are read back by the wave that wrote them; one launch fewer)
+ *  16 "news_tail_od"    RETIRED (ABI v14): reserved, always 0 (the out-projection's activation gradient inside the fused tail backward:
+ *                       measured slower, code in tools/experimental/)
  *  17 "user_proj"       (ABI v13) the NRMS user encoder's in-projection inside its across-users attention kernel (bf16x3 engine,
  *                       32 <= users <= 128 per call, D = 20 * heads in [288, 316]) instead of a separate GEMM launch
  * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
@@ -173,9 +174,8 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
 /* Backward of the above (autograd of text.py:222-236 incl. embedding_dense_backward with
  * padding_idx=0: rows of id 0 receive no gradient).  d_out (N, D).  Adds into `g` and into
  * d_emb_table (vocab, D).  `ws` must be the workspace the forward filled.
- * emb_table: the table the forward read (unchanged since).  On the fused path (bf16x3 engine, reference geometry)
- * the forward does NOT save q|k|v: the backward re-gathers the rows and recomputes them per head inside the
- * attention-backward kernel (nrl_news_fused.h); NULL is accepted only where that path is off.
+ * emb_table: the table the forward read (unchanged since); not read by any current path (the recomputing backward that
+ * re-gathered rows from it was retired in ABI v14) -- may be NULL.
  * sorted_positions: optional (may be NULL) output of nrl_sort_positions over the flat (N*L) id vector: N*L + 1 entries,
  * the positions by ascending id and then the number of id-0 positions.  When given, the table gradient is reduced in
  * id-sorted order (one atomic per (id, 64-row segment)) instead of one atomic per element -- frequent tokens otherwise

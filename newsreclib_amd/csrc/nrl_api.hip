@@ -32,11 +32,11 @@ static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_B
 std::atomic<uint32_t> g_opt_default{[] {
   uint32_t m = 0;
   for (int i = 0; i < O_COUNT; ++i) {
-    // (off: the measured losers -- news_tail_od, round 4: the fused tail backward grows 337 -> 488 us, the launch it replaces
-    //  took 135: step 2.92 vs 2.89 ms, two alternating pairs)
+    // (off: the measured losers; news_fused_bwd and news_tail_od are retired bits, see opt_retired)
     const bool dflt = i != O_NEWS_FUSED_BWD && i != O_USER_FORK && i != O_NEWS_FORK && i != O_NEWS_TAIL_OD;
     const char* e = getenv(kOptEnv[i]);
-    const bool v = e == nullptr ? dflt : (dflt ? e[0] != '0' : e[0] == '1');
+    bool v = e == nullptr ? dflt : (dflt ? e[0] != '0' : e[0] == '1');
+    if (opt_retired(i)) v = false;           // (bits kept for the mask's layout; their kernels left the library in ABI v14)
     m |= v ? (1u << i) : 0u;
   }
   return m;
@@ -143,6 +143,8 @@ int nrl_set_option(const char* name, int32_t value) {
   NRL_REQUIRE(name != nullptr, "set_option: null name");
   for (int i = 0; i < O_COUNT; ++i)
     if (!strcmp(name, kOptName[i])) {
+      NRL_REQUIRE(value == 0 || !opt_retired(i), "set_option: '%s' was retired in ABI v14 (its kernel lost its A/B and lives in "
+                  "tools/experimental/; the bit is reserved and must stay 0)", name);
       if (value != 0) g_opt_default.fetch_or(1u << i);
       else g_opt_default.fetch_and(~(1u << i));
       return NRL_OK;
@@ -195,7 +197,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     NewsFusedArgs a;
     a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
     a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.o = w.o;
-    const bool planes = !opt(O_NEWS_FUSED_BWD) && opt(O_NEWS_ATTN_MFMA) && opt(O_NEWS_PLANES);
+    const bool planes = opt(O_NEWS_ATTN_MFMA) && opt(O_NEWS_PLANES);
     BlockShape sf = s;
     sf.od_planes = planes && opt(O_NEWS_OD_PLANES);
     // (training only: in an evaluation forward the second copy of y costs more than the additive-attention GEMM saves)
@@ -209,7 +211,7 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
     }
     a.x_save = (save_for_backward && !planes) ? w.x : nullptr;
     a.x_planes = (save_for_backward && planes) ? reinterpret_cast<unsigned char*>(w.x) : nullptr;
-    a.qkv_save = (save_for_backward && !opt(O_NEWS_FUSED_BWD)) ? w.qkv : nullptr;   // else recomputed in the backward
+    a.qkv_save = save_for_backward ? w.qkv : nullptr;
     a.qkv_head_major = opt(O_NEWS_ATTN_MFMA) ? 1 : 0;
     a.lse = save_for_backward ? w.lse : nullptr;
     // evaluation (nothing saved, no dropout): the run of padding tokens from token 15 on is ONE row -- partition the news into
@@ -264,15 +266,14 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   NRL_TRY(carve_ws(ws, ws_bytes, s, true, &w));
   const Dropout d1 = make_dropout(p_drop, seed, stream0), d2 = make_dropout(p_drop, seed, stream0 + 1);
   BlockPlanes bp;
-  const bool fused = news_fused_on(s, seq_len) && opt(O_NEWS_FUSED_BWD);
-  const bool slabs = news_fused_on(s, seq_len) && !opt(O_NEWS_FUSED_BWD) && opt(O_NEWS_ATTN_MFMA);   // what the forward saved
+  const bool slabs = news_fused_on(s, seq_len) && opt(O_NEWS_ATTN_MFMA);   // what the forward saved
   const bool planes = slabs && opt(O_NEWS_PLANES);
   BlockShape sb_ = s;
   sb_.od_planes = planes && opt(O_NEWS_OD_PLANES);
   sb_.aa_planes = sb_.od_planes && opt(O_NEWS_AA_PLANES) && w.yp != nullptr && (s.D & 15) == 12 && s.Q <= 224;
   sb_.tail = news_tail_on(sb_, seq_len, w);
   sb_.tail_bwd = sb_.tail && sb_.aa_planes && news_tail_bwd_on(sb_, seq_len, w);
-  NRL_TRY(block_planes(p, s, w, false, &bp, st, (fused || slabs) ? s.heads : 0));  // filled by the forward
+  NRL_TRY(block_planes(p, s, w, false, &bp, st, slabs ? s.heads : 0));  // filled by the forward
   // news_fork: the back-half weight gradients leave phase 2 for a side stream of phase 1 (a phase-2 call of a two-phase
   // caller evaluates the same predicate and skips them)
   sb_.forked = news_fork_on(sb_);
@@ -283,7 +284,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       NRL_TRY(fork_set(&fs));
       side.s = fs->s[0]; side.fork = fs->fork; side.join = fs->join[0];
     }
-    NRL_TRY(block_bwd_phase1(p, g, sb_, w, bp, d2, d_out, st, fused || slabs, sb_.forked ? &side : nullptr));
+    NRL_TRY(block_bwd_phase1(p, g, sb_, w, bp, d2, d_out, st, slabs, sb_.forked ? &side : nullptr));
     if (slabs) {
       // token attention backward on the matrix cores from the head-major q|k|v slabs (nrl_news_fused.h)
       NewsAttnBwdArgs a;
@@ -291,16 +292,6 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       a.heads = s.heads; a.scale = s.geom.scale; a.hpw = 1; a.planes = planes ? 1 : 0;
       if (planes && opt(O_NEWS_QKV_PLANES)) NRL_TRY(launch_news_attn_bwd_p(a, st));   // operands split once, into LDS planes
       else NRL_TRY(launch_news_attn_bwd(a, st));
-    }
-    if (fused) {
-      // q|k|v recomputed per head + the attention backward on the matrix cores in one kernel (nrl_news_fused.h)
-      NewsFusedBwdArgs a;
-      NRL_REQUIRE(emb_table != nullptr && ((uintptr_t)emb_table & 15) == 0,
-                  "news_encoder_bwd: emb_table (16-byte aligned) is needed to recompute q|k|v");
-      a.table = emb_table; a.ids = ids; a.img = bp.rp.in_heads.img; a.n_news = n_news; a.L = seq_len; a.D = s.D;
-      a.heads = s.heads; a.dh = s.dh; a.scale = s.geom.scale; a.drop1 = d1; a.d_o = w.d_o; a.lse = w.lse;
-      a.dqkv = w.dqkv;
-      NRL_TRY(launch_news_fused_bwd(a, st));
     }
     // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
     const KCSlab dq_hp{w.dqkv, s.M};

@@ -106,8 +106,8 @@ static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 // one module get the same word, two modules in one process may differ); options == 0 means "the process defaults", which
 // start from the NRL_* environment and change through nrl_set_option.
 //   news_fused      NRL_NEWS_FUSED=0       gather + in-projection + token attention as separate kernels (nrl_news_fused.h)
-//   news_fused_bwd  NRL_NEWS_FUSED_BWD=1   q|k|v not saved, recomputed inside the matrix-core attention backward (slower:
-//                                          160 VGPRs of fragments held through it, 78 spills; profiles/r02_fused_bwd_ab.txt)
+//   news_fused_bwd  (RETIRED in ABI v14: the bit is reserved and always 0)  q|k|v recomputed inside the matrix-core attention
+//                                          backward: 1.69 ms against 0.82; the kernel lives in tools/experimental/nrl_news_fused_bwd.h
 //   news_attn_mfma  NRL_NEWS_ATTN_MFMA=0   q|k|v saved as packed rows, attn_bwd_small (fp32 VALU) instead of the slabs +
 //                                          news_attn_bwd_kernel
 //   news_planes     NRL_NEWS_PLANES=0      x / dqkv stay fp32 (no fragment-block planes, nrl_wgrad_planes.h)
@@ -136,15 +136,17 @@ static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 //                                          instead of ONE row for the run of padding tokens from token 15 on (no dropout:
 //                                          identical rows; news_classify_kernel + the SHARE shapes of news_fused_fwd_kernel /
 //                                          news_tail_fwd_kernel; bit-identical output)
-//   news_tail_od    NRL_NEWS_TAIL_OD=1     (default OFF) the out-projection's activation gradient d_o = dy W_o as phase D of the
-//                                          fused tail backward (nrl_news_tail.h) instead of its own row-panel launch --
-//                                          measured slower: 337 -> 488 us for the kernel against the 135 us launch it replaces
+//   news_tail_od    (RETIRED in ABI v14: the bit is reserved and always 0)  the out-projection's activation gradient as phase D of
+//                                          the fused tail backward: 337 -> 488 us for the kernel against the 135 us launch it replaced;
+//                                          tools/experimental/nrl_news_tail_phase_d.inc
 //   user_proj       NRL_USER_PROJ=0        the user encoder's in-projection as its own tiled GEMM launch (+ the weight split in
 //                                          front of it) instead of inside the across-users attention kernel (ua_fwd_proj_kernel)
 enum {
   O_NEWS_FUSED = 0, O_NEWS_FUSED_BWD, O_NEWS_ATTN_MFMA, O_NEWS_PLANES, O_NEWS_OD_PLANES, O_NEWS_AA_PLANES, O_WGRAD_2STEP,
   O_WGRAD_WS, O_ROWPANEL, O_X3_DMA, O_NEWS_TAIL, O_NEWS_TAIL_BWD, O_USER_FORK, O_NEWS_FORK, O_NEWS_QKV_PLANES, O_NEWS_PAD_SHARE, O_NEWS_TAIL_OD, O_USER_PROJ, O_COUNT
 };
+// bits whose kernels were moved out of the library (ABI v14; tools/experimental/): kept in the mask's layout, always 0
+static inline bool opt_retired(int bit) { return bit == O_NEWS_FUSED_BWD || bit == O_NEWS_TAIL_OD; }
 extern std::atomic<uint32_t> g_opt_default;  // (nrl_api.hip)
 extern thread_local int64_t t_opts;
 static inline bool opt(int bit) {
@@ -160,7 +162,8 @@ struct OptScope {
   ~OptScope() { t_opts = prev; }
 };
 static inline bool options_field_ok(int32_t v) {
-  return v == 0 || ((v & NRL_OPTIONS_EXPLICIT) && (v & ~(NRL_OPTIONS_EXPLICIT | ((1 << O_COUNT) - 1))) == 0);
+  return v == 0 || ((v & NRL_OPTIONS_EXPLICIT) && (v & ~(NRL_OPTIONS_EXPLICIT | ((1 << O_COUNT) - 1))) == 0 &&
+                    (v & ((1 << O_NEWS_FUSED_BWD) | (1 << O_NEWS_TAIL_OD))) == 0);
 }
 
 static int wgrad_splits(int64_t rows_out, int cols_out, int64_t K, int bm, int bn) {
@@ -648,9 +651,6 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
     b.y_planes = reinterpret_cast<const unsigned char*>(w.yp); b.w = w.w; b.d_out = d_out; b.img_a = bp.rp.tail_a.img;
     b.img_ad = bp.rp.tail_ad.img; b.q_a = P->att_query; b.n_news = s.pool_groups; b.L = s.pool_len; b.D = D; b.Q = Q;
     b.drop2 = drop2; b.dpre_planes = tpl; b.dy_planes = dyp; b.dq_a = G->att_query;
-    // d_o = dy W_o inside the same launch (phase D) when the dgrad image has the tail's geometry
-    const bool od_fused = opt(O_NEWS_TAIL_OD) && bp.rp.out_d.nblk == NT_FB && bp.rp.out_d.kblocks == NT_KB;
-    if (od_fused) { b.img_od = bp.rp.out_d.img; b.d_o = w.d_o; }
     NRL_TRY(news_tail_bwd(b, st));
     if (side != nullptr && side->s != nullptr && news_fork_on(s)) {
       NRL_HIP(hipEventRecord(side->fork, st));
@@ -659,7 +659,7 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
       NRL_HIP(hipEventRecord(side->join, side->s));      // the caller makes `st` wait for it at the end of phase 1
     }
     // d_o = dy W_o
-    if (!od_fused) NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
+    NRL_TRY(rp_dispatch(KCPlanesG{dyp, s.M, ncb}, bp.rp.out_d, EpiStore{w.d_o, D}, s.M, D, D, st));
     if (!attention_elsewhere) {
     if (block_attn_x3(s)) NRL_TRY(attn_bwd_x3(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));
     else NRL_TRY(attn_bwd(w.qkv, w.o, w.d_o, w.lse, w.dqkv, s.geom, st));

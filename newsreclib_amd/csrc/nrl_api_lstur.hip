@@ -612,18 +612,6 @@ int nrl_gru_bwd(const NrlGruParams* p, const NrlGruGrads* g, const float* hist, 
   const int64_t B = s.B, T = s.T;
   const SplitWeight si = planes_view(w.planes_ih, 3 * Hd, Din), sh = planes_view(w.planes_hh, 3 * Hd, Hd);
   NRL_HIP(hipMemcpyAsync(w.dh, d_out, (size_t)B * Hd * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (cur_engine() == ENGINE_BF16X3 && gru_step_bwd_fused_ok(Hd) && sh.lo_t == sh.hi_t + 32) {
-    // one launch per BPTT step (nrl_gru_fused.h): the product dgh_t W_hh with the whole reduction inside a workgroup, the gate
-    // backward of step t - 1 in its epilogue; only the last step's gate backward is its own launch
-    NRL_TRY(gru_gate_bwd(w.g + (T - 1) * B * 3 * Hd, w.ghn + (T - 1) * B * Hd, w.hs + (T - 1) * B * Hd, lengths, (int)(T - 1), B, Hd,
-                         w.dh, w.g + (T - 1) * B * 3 * Hd, w.dgh + (T - 1) * B * 3 * Hd, st));
-    for (int64_t t = T - 1; t >= 0; --t) {
-      const int64_t tp = t - 1;
-      NRL_TRY(gru_step_bwd_fused(w.dgh + t * B * 3 * Hd, sh.hi_t, sh.ld_t, w.dh, tp >= 0 ? w.g + tp * B * 3 * Hd : nullptr,
-                                 tp >= 0 ? w.ghn + tp * B * Hd : nullptr, tp >= 0 ? w.hs + tp * B * Hd : nullptr,
-                                 tp >= 0 ? w.dgh + tp * B * 3 * Hd : nullptr, lengths, (int)tp, B, Hd, st));
-    }
-  } else {
   for (int64_t t = T - 1; t >= 0; --t) {
     float* g_t = w.g + t * B * 3 * Hd;
     float* dgh_t = w.dgh + t * B * 3 * Hd;
@@ -631,7 +619,6 @@ int nrl_gru_bwd(const NrlGruParams* p, const NrlGruGrads* g, const float* hist, 
     // dh_{t-1} = z * dh_t + dgh_t W_hh (split-K partial sums added onto the direct term)
     NRL_TRY(gemm_step(dgh_t, 3 * Hd, RCPlain{p->weight_hh, Hd, Hd, 0}, sh.hi_t, sh.lo_t, sh.ld_t, w.dh, Hd, B, Hd, 3 * Hd,
                       st));
-  }
   }
   if (d_h0 != nullptr)
     NRL_HIP(hipMemcpyAsync(d_h0, w.dh, (size_t)B * Hd * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -560,25 +560,19 @@ static inline int launch_news_tail_fwd(const NewsTailArgs& a, hipStream_t st) {
 //                                                  order) * d_pre^T (B: the accumulators of phase A, split once), two halves
 // Outputs: d_pre and dy as (hi, lo) planes over the real rows (operands of the two weight gradients and of the
 // out-projection's activation gradient), dq_a through LDS + one atomic per query and workgroup.
-// OD (round 4): the out-projection's activation gradient in the same kernel,
-//   d_o = dy W_o                                  phase D: d_o^T (o features x tokens) = W_o^T (A: the row-panel dgrad image
-//                                                  `out_d`, natural k order, half a k-block per ring slot) * dy^T (B: the dy
-//                                                  planes this wave has just written, read back as fragments -- its own rows)
-// so the launch `rp_gemm<KCPlanesG, EpiStore>` (135 us at B = 128: 0.26 GB of dy planes read from HBM) disappears; d_o leaves as
-// the fp32 rows the token-attention backward reads.
-template <int WAVES, int ABL = 0, bool OD = false>
+// (Round 4's phase D -- the out-projection's activation gradient d_o = dy W_o in the same kernel -- grew it 337 -> 488 us to remove a
+//  135 us launch: tools/experimental/nrl_news_tail_phase_d.inc.)
+template <int WAVES, int ABL = 0>
 __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const NewsTailBwdArgs P) {
   using Cfg = NtCfg<WAVES>;
   constexpr int NT_SLOT = Cfg::BSLOT, NT_SLOTS = Cfg::SLOTS, LOOK = Cfg::LOOK, KPC = Cfg::KPC;
   constexpr int NPC = (NT_QS + KPC - 1) / KPC;         // phase-C chunks per half of the features
   constexpr int NT_NCHUNK_C = NT_KS + 2 * NPC;         // chunks of phases A and C
-  constexpr int NT_NCHUNK = NT_NCHUNK_C + (OD ? 2 * NT_KB : 0);   // + phase D: (k-block, half of the feature blocks)
-  static_assert(!OD || 2 * 10 * 1024 <= NT_SLOT, "phase-D chunk must fit a ring slot");
   constexpr int PPW = (2 * KPC * 10 + WAVES - 1) / WAVES > (2 * NT_QB + WAVES - 1) / WAVES ? (2 * KPC * 10 + WAVES - 1) / WAVES
                                                                                              : (2 * NT_QB + WAVES - 1) / WAVES;
   static_assert(2 * NT_QB * 1024 <= NT_SLOT && 2 * KPC * 10 * 1024 <= NT_SLOT, "chunk must fit a ring slot");
   constexpr int STREAM = (ABL & 64) ? 0 : 1;          // d_pre / dy planes: streaming stores (probe: ABL 64 = plain)
-  constexpr int STREAM_DY = OD ? 0 : STREAM;          // (phase D reads the dy planes back: keep them in the cache hierarchy)
+  constexpr int STREAM_DY = STREAM;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NT_SLOTS * NT_SLOT + 2048 + WAVES * NT_DROW * 4];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -629,17 +623,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const News
         piece = piece < pieces ? piece : pieces - 1;
         const int ks = piece / (2 * nfb), rem = piece - ks * 2 * nfb;      // rem = fb * 2 + plane
         glds16_saddr(src + ((size_t)((KPC * p + ks) * NT_FB + fb0) * 2 + rem) * 1024, lane_off, dst + (uint32_t)piece * 1024u);
-      }
-    } else if (OD && c < NT_NCHUNK) {
-      // phase D: k-block kb of the out-projection dgrad image, feature blocks of the half (10 or 9) x (hi, lo): one contiguous run
-      const int j = c - NT_NCHUNK_C, kb = j >> 1, half = j & 1;
-      const int fb0 = half ? 10 : 0, pieces = (half ? 9 : 10) * 2;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(P.img_od) + (size_t)(kb * NT_FB + fb0) * 2048;
-#pragma unroll
-      for (int q = 0; q < PPW; ++q) {
-        int piece = wave + q * WAVES;
-        piece = piece < pieces ? piece : pieces - 1;
-        glds16_saddr(src + piece * 1024, lane_off, dst + (uint32_t)piece * 1024u);
       }
     }
   };
@@ -917,104 +900,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) news_tail_bwd_kernel(const News
   phase_c(std::integral_constant<int, 0>{});
   phase_c(std::integral_constant<int, 1>{});
 
-  // =============================== phase D: d_o^T = W_o^T dy^T ============================================
-  if constexpr (OD) {
-    // B fragments: the 8 consecutive features 32 kb + 8g .. + 7 of this lane's token, from the dy planes written above (this
-    // wave's own rows; every chunk top's vmcnt(0) has long retired those stores) -- the loader of the forward's phase 1
-    const unsigned char* drow[2];
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
-      drow[tb] = P.dy_planes + ((mrow[tb] >> 4) * NT_FB + (g >> 1)) * 1024 + (mrow[tb] & 15) * 32 + (g & 1) * 16;
-    auto load_dy = [&](int kb, bf16x8 (&dh)[2], bf16x8 (&dl)[2]) {
-      const bool dead = kb == NT_KB - 1 && g >= 2;     // block column 19 does not exist
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const unsigned char* p = drow[tb] + (dead ? 0 : kb * 2048);
-        uint4 h = *reinterpret_cast<const uint4*>(p), l = *reinterpret_cast<const uint4*>(p + 512);
-        if (dead) { h = make_uint4(0u, 0u, 0u, 0u); l = h; }
-        dh[tb] = __builtin_bit_cast(bf16x8, h);
-        dl[tb] = __builtin_bit_cast(bf16x8, l);
-      }
-    };
-    f32x4 oacc[NT_FB][2];
-#pragma unroll
-    for (int fb = 0; fb < NT_FB; ++fb)
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) oacc[fb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // one half-chunk: feature blocks fb0 .. fb0 + nfb - 1 (pairs of blocks, fragments fetched one pair ahead)
-    auto pd_half = [&](auto half_c, int slot, const bf16x8 (&dh)[2], const bf16x8 (&dl)[2]) {
-      constexpr int half = decltype(half_c)::value;
-      constexpr int fb0 = half ? 10 : 0, nfb = half ? 9 : 10, npairs = (nfb + 1) / 2;
-      const unsigned char* base = smem + slot * NT_SLOT + lane * 16;
-      auto rd = [&](int p, bf16x8 (&wh)[2], bf16x8 (&wl)[2]) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int fb = 2 * p + jj < nfb ? 2 * p + jj : nfb - 1;
-          wh[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048);
-          wl[jj] = *reinterpret_cast<const bf16x8*>(base + fb * 2048 + 1024);
-        }
-      };
-      auto mm = [&](int p, const bf16x8 (&wh)[2], const bf16x8 (&wl)[2]) {
-#pragma unroll
-        for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
-            if (2 * p + jj < nfb)
-#pragma unroll
-              for (int tb = 0; tb < 2; ++tb)
-                oacc[fb0 + 2 * p + jj][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? wl[jj] : wh[jj], pass == 0 ? dl[tb] : dh[tb],
-                                                                                     oacc[fb0 + 2 * p + jj][tb], 0, 0, 0);
-      };
-      bf16x8 wh0[2], wl0[2], wh1[2], wl1[2];
-      rd(0, wh0, wl0);
-#pragma unroll
-      for (int p = 0; p < npairs; p += 2) {
-        if (p + 1 < npairs) rd(p + 1, wh1, wl1);
-        mm(p, wh0, wl0);
-        if (p + 1 < npairs) {
-          if (p + 2 < npairs) rd(p + 2, wh0, wl0);
-          mm(p + 1, wh1, wl1);
-        }
-      }
-    };
-    bf16x8 dha[2], dla[2], dhb[2], dlb[2];
-    auto kstep = [&](int kb, const bf16x8 (&ch)[2], const bf16x8 (&cl)[2], bf16x8 (&nh)[2], bf16x8 (&nl)[2]) {
-      const int c = NT_NCHUNK_C + 2 * kb;
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      issue_chunk(c + LOOK);
-      load_dy(kb + 1 < NT_KB ? kb + 1 : kb, nh, nl);
-      __builtin_amdgcn_sched_barrier(0);
-      pd_half(std::integral_constant<int, 0>{}, c % NT_SLOTS, ch, cl);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      issue_chunk(c + 1 + LOOK);
-      __builtin_amdgcn_sched_barrier(0);
-      pd_half(std::integral_constant<int, 1>{}, (c + 1) % NT_SLOTS, ch, cl);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // (phase C's last chunk top has waited vmcnt(0) after the first half's dy stores; the second half's stores are waited
-    //  for by the first kstep's vmcnt(0) -- but the FIRST fragment load must not overtake them: wait here)
-    wait_vmcnt<0>();
-    load_dy(0, dha, dla);
-    for (int kb = 0; kb < NT_KB; kb += 2) {
-      kstep(kb, dha, dla, dhb, dlb);
-      kstep(kb + 1, dhb, dlb, dha, dla);
-    }
-    // d_o rows: lane (l15, g) holds features 16 fb + 4g .. + 3 of token 16 tb + l15 -> one 16-byte store each
-#pragma unroll
-    for (int fb = 0; fb < NT_FB; ++fb) {
-      const int f0 = 16 * fb + 4 * g;
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        int64_t m = mrow[tb];
-        asm volatile("" : "+v"(m));
-        if (!(ABL & 2) && news_ok && tok_ok[tb] && f0 < D)
-          *reinterpret_cast<float4*>(P.d_o + m * D + f0) = make_float4(oacc[fb][tb][0], oacc[fb][tb][1], oacc[fb][tb][2], oacc[fb][tb][3]);
-      }
-    }
-  }
   // dq_a: the workgroup's sums -> one atomic per query
   __syncthreads();
   if (tid < Q) atomicAdd(P.dq_a + tid, dq_s[tid]);
@@ -1027,12 +912,7 @@ static inline int launch_news_tail_bwd(const NewsTailBwdArgs& a, hipStream_t st)
   NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
   NRL_REQUIRE(a.D == 300 && a.Q < 16 * NT_QB && a.Q % 4 == 0 && a.L >= 1 && a.L <= 32, "fused news tail backward: unsupported geometry");
   NRL_REQUIRE((((uintptr_t)a.d_out | (uintptr_t)a.q_a) & 15) == 0, "fused news tail backward: 16-byte alignment");
-  if (a.d_o != nullptr) {
-    NRL_REQUIRE(a.img_od != nullptr && ((uintptr_t)a.d_o & 15) == 0, "fused news tail backward: the out-projection dgrad needs its image and an aligned d_o");
-    hipLaunchKernelGGL((news_tail_bwd_kernel<WAVES, ABL, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((news_tail_bwd_kernel<WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
-  }
+  hipLaunchKernelGGL((news_tail_bwd_kernel<WAVES, ABL>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }

@@ -42,10 +42,6 @@ struct NewsTailBwdArgs {
   unsigned char* dpre_planes;     // out: (Q + 15) / 16 block columns per 16-row block
   unsigned char* dy_planes;       // out: 19 block columns
   float* dq_a;                    // (Q), accumulated
-  // optional (both or neither): the out-projection's activation gradient in the same launch -- d_o (n_news * L, D) fp32 rows =
-  // dy W_o, with `img_od` the row-panel dgrad image of W_o (19 column blocks x 10 k-blocks, natural k order, no bias)
-  const uint16_t* img_od = nullptr;
-  float* d_o = nullptr;
 };
 
 constexpr int NT_QS = 7;           // k-steps of phase C (pairs of query blocks)

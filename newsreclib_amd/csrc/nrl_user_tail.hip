@@ -246,7 +246,7 @@ int user_tail_fwd(const UserTailArgs& a, hipStream_t st) {
 // The same fusion for the backward of that back half (attention.py:34-40 and the out-projection, in reverse): per user
 //   c_l = d_out . y_l;  da_l = w_l (c_l - sum_l' w_l' c_l');  d_pre = da q_a (1 - t^2) (in place over t);  dq_a += sum_l da_l t_l
 //   dy = (d_pre W_a + w_l d_out) * dropout;  d_o = dy W_o
-// instead of pool_bwd_pre + two row-panel launches (14 + 18 + 17 us at B = 128).  MEASURED NULL, opt-in (user_tail_bwd_ok).  d_pre and dy go through LDS block planes
+// instead of pool_bwd_pre + two row-panel launches (14 + 18 + 17 us at B = 128); used for calls of <= 64 users (user_tail_bwd_ok).  d_pre and dy go through LDS block planes
 // exactly as o and y do in the forward; the weight images are the row-panel dgrad images (att_d: 7 k-blocks over the queries,
 // out_d: 10 over the features).
 constexpr int UT_KBQ = 7, UT_FBQ = 2 * UT_KBQ;
@@ -397,13 +397,15 @@ __global__ void __launch_bounds__(UT_WAVES * 64) ut_bwd_kernel(const UserTailBwd
 }
 
 bool user_tail_bwd_ok(int64_t groups, int H, int D, int Q, int nblk_ad, int nblk_od, int kb_ad, int kb_od) {
-  // OFF unless NRL_USER_TAIL_BWD=1: correct (the user-encoder, golden, quirk and full-size parity tests pass with it: 38 passed)
-  // but no faster than the three launches it replaces -- 2.92 / 2.94 vs 2.92 / 2.92 ms per step in two alternating pairs; its
-  // per-query column loop (d_pre, dq_a) and 138 KB of LDS (one workgroup per CU) take what the two saved launches gave.
-  static const bool on = [] {
+  // One launch instead of three pays where the launches are latency, not work: up to 64 users per call (round 5, same-box
+  // alternating pairs: configs[0], B = 32: 1.0701 / 1.0700 vs 1.0792 / 1.0768 ms per step; B = 128: 2.8324 / 2.8385 vs 2.8427 / 2.8302,
+  // nothing -- its per-query column loop and 138 KB of LDS, one workgroup per CU, take what the two saved launches give once
+  // there are more users than CUs to spare).  NRL_USER_TAIL_BWD=0 / 1 forces it off / on for every size (A/B, tests).
+  static const int mode = [] {
     const char* e = getenv("NRL_USER_TAIL_BWD");
-    return e != nullptr && e[0] == '1';
+    return e == nullptr ? -1 : (e[0] == '1' ? 1 : 0);
   }();
+  const bool on = mode < 0 ? groups <= 64 : mode == 1;
   return on && user_tail_ok(groups, H, D, Q, nblk_od, 16 * UT_NCB_T) && nblk_ad >= UT_NCB_Y && kb_ad == UT_KBQ && kb_od == UT_KB && Q <= 224;
 }
 
