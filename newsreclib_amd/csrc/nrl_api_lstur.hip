@@ -51,8 +51,18 @@ static bool cnn_conv_planes_ok(const CnnShape& s) {
   return on && s.W == 3 && s.L <= 63 && s.F <= 320 && s.N < (1LL << 31);
 }
 static int cnn_conv_kt(const CnnShape& s) { return s.L <= 31 ? 1 : 2; }   // k-tiles of 32 padded rows per news
-static int cnn_ncb_x(const CnnShape& s) { return (s.D + 16) / 16; }     // + the ones column
+static int cnn_ncb_x(const CnnShape& s) { return ((s.D + 16) / 16 + 1) & ~1; }   // + the ones column; EVEN: a tap of the tap-padded
+                                                                                 // reduction index is whole 32-wide k-blocks (KCWindowPlanes)
 static int cnn_ncb_dc(const CnnShape& s) { return (s.F + 15) / 16; }
+
+static bool cnn_rp_ok(const CnnShape& s);
+// x ONLY as planes (round 5): the lookup writes the planes the weight gradient reads, the convolution forward reads them through
+// KCWindowPlanes against a tap-padded weight image -- no fp32 x, no conversion launch.  Forward and backward evaluate the same
+// predicate (shape, engine, switches).  NRL_CONV_X_PLANES=0 keeps the fp32 rows + planes_from_rows (A/B).
+static bool cnn_x_planes_on(const CnnShape& s) {
+  static const bool on = [] { const char* e = getenv("NRL_CONV_X_PLANES"); return !(e != nullptr && e[0] == '0'); }();
+  return on && cnn_conv_planes_ok(s) && cnn_rp_ok(s) && cur_engine() == ENGINE_BF16X3;
+}
 
 // conv forward / dgrad and additive-attention forward / dgrad on the row-panel kernel (bf16x3, widths <= 320)
 struct CnnRp {
@@ -64,7 +74,7 @@ static bool cnn_rp_ok(const CnnShape& s) {
 }
 static size_t cnn_rp_elems(const CnnShape& s) {
   if (!cnn_rp_ok(s)) return 0;
-  return rp_image_elems(rp_nblk_for(s.F), rp_kblocks(s.W * s.D, false)) + rp_image_elems(rp_nblk_for(s.D), rp_kblocks(s.W * s.F, false)) +
+  return rp_image_elems(rp_nblk_for(s.F), rp_kblocks(s.W * 16 * cnn_ncb_x(s), false)) + rp_image_elems(rp_nblk_for(s.D), rp_kblocks(s.W * s.F, false)) +
          rp_image_elems(rp_nblk_for(s.Q), rp_kblocks(s.F, false)) + rp_image_elems(rp_nblk_for(s.F), rp_kblocks(s.Q, false));
 }
 // carve (and, in the forward, build in ONE launch) the four images
@@ -83,7 +93,15 @@ static int cnn_rp_images(const NrlCnnParams* p, const CnnShape& s, const CnnWs& 
     }
     q += rp_image_elems(nblk, im->kblocks);
   };
-  add(&r->conv_f, p->conv_weight, (int64_t)s.W * s.D, 1, s.F, s.W * s.D, false);   // c = window(x) Wc^T
+  if (cnn_x_planes_on(s)) {
+    // c = window(x planes) Wc^T over the tap-padded reduction index k' = tap * (16 ncb_x) + d
+    const int nblk = rp_nblk_for(s.F), dp = 16 * cnn_ncb_x(s);
+    r->conv_f.img = q; r->conv_f.nblk = nblk; r->conv_f.kblocks = rp_kblocks(s.W * dp, false);
+    if (fill) rp_jobs_add_kpad(&jobs, p->conv_weight, (int64_t)s.W * s.D, 1, s.F, s.W, s.D, dp, q, nblk);
+    q += rp_image_elems(nblk, r->conv_f.kblocks);
+  } else {
+    add(&r->conv_f, p->conv_weight, (int64_t)s.W * s.D, 1, s.F, s.W * s.D, false);   // c = window(x) Wc^T
+  }
   add(&r->conv_d, p->conv_weight, 0, 0, s.D, s.W * s.F, true);                     // dx = window'(dc) Wc (taps reversed)
   if (p->att_weight != nullptr) {
     add(&r->att_f, p->att_weight, s.F, 1, s.Q, s.F, false);                        // t = c W_a^T
@@ -199,12 +217,13 @@ static int gemm_wgrad_any(const float* dy, int I, const BOp& b, int J, float* dW
 
 // dWc[f, t*D + d] += sum_m dc[m, f] x[m + t - pad, d] ; db_c += colsum(dc)
 static int cnn_conv_wgrad(const CnnShape& s, const CnnWs& w, const float* dc, const float* x, int F, float* d_weight,
-                          float* d_bias, hipStream_t st) {
+                          float* d_bias, hipStream_t st, bool x_planes_ready = false) {
   const int KD = s.W * s.D;
   if (w.xpl != nullptr && cur_engine() == ENGINE_BF16X3) {
     const int ncb_x = cnn_ncb_x(s), ncb_dc = cnn_ncb_dc(s);
     const int kt = cnn_conv_kt(s);
-    NRL_TRY(launch_planes_from_rows(x, s.D, s.N, s.L, s.D, ncb_x, 2 * kt, true, w.xpl, st));
+    // (x planes: written by the forward's lookup when the convolution forward read them too; converted here otherwise)
+    if (!x_planes_ready) NRL_TRY(launch_planes_from_rows(x, s.D, s.N, s.L, s.D, ncb_x, 2 * kt, true, w.xpl, st));
     NRL_TRY(launch_planes_from_rows(dc, F, s.N, s.L, F, ncb_dc, 2 * kt, false, w.dpl, st));
     if (kt == 1)
       return launch_wgrad_planes_conv<5, 2, 1>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 32, F, s.D, d_weight, d_bias,
@@ -325,6 +344,14 @@ int nrl_cnn_encoder_fwd(const NrlCnnParams* p, const float* emb_table, int64_t v
     NRL_TRY(split_weight(p->conv_weight, s.F, KD, w.planes_conv, &sc, st));
     NRL_TRY(split_weight(p->att_weight, s.Q, s.F, w.planes_att, &sa, st));
   }
+  if (cnn_x_planes_on(s) && rp.on && w.xpl != nullptr) {
+    // x = dropout(emb[ids]) as planes only; c = dropout(relu(conv(x) + b)) straight from them
+    const int ncb_x = cnn_ncb_x(s), nrb = 2 * cnn_conv_kt(s);
+    NRL_REQUIRE(s.M * (int64_t)s.D < (1LL << 32), "dropout index space is 32-bit");
+    NRL_TRY(launch_embedding_rows_planes(emb_table, ids, s.N, s.L, s.D, ncb_x, nrb, drop1, w.xpl, st));
+    const KCWindowPlanes a{w.xpl, s.M, s.L, nrb, ncb_x, s.W, s.pad};
+    NRL_TRY(rp_dispatch(a, rp.conv_f, EpiLinear{w.c, s.F, p->conv_bias, 2, drop2, s.F}, s.M, s.F, s.W * 16 * ncb_x, st));
+  } else {
   // x = dropout(emb[ids])                                  (text.py:165-166)
   NRL_TRY(embedding_rows_fwd(emb_table, ids, s.M, s.D, drop1, 0, w.x, st));
   // c = dropout(relu(conv(x) + b))                         (text.py:169-171), K = W*D over overlapping rows
@@ -337,6 +364,7 @@ int nrl_cnn_encoder_fwd(const NrlCnnParams* p, const float* emb_table, int64_t v
     } else {
       NRL_TRY(launch_gemm<NRL_TILE>(a, KCPlain{p->conv_weight, KD, s.F}, epi, s.M, s.F, KD, 1, st));
     }
+  }
   }
   // t = tanh(c W_a^T + b_a); w = softmax(t . q_a); out = sum w c      (attention.py:34-40)
   NRL_TRY(gemm_fwd(KCPlain{w.c, s.F, s.M}, p->att_weight, sa, EpiLinear{w.t, s.Q, p->att_bias, 1, nodrop, s.Q}, s.M,
@@ -371,7 +399,7 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
                      rp.on ? &rp.att_d : nullptr));
   // dW_a += d_pre^T c ; db_a += colsum(d_pre)
   NRL_TRY(gemm_wgrad(w.t, s.Q, w.c, s.F, g->att_weight, g->att_bias, s.M, st));
-  NRL_TRY(cnn_conv_wgrad(s, w, w.dc, w.x, s.F, g->conv_weight, g->conv_bias, st));
+  NRL_TRY(cnn_conv_wgrad(s, w, w.dc, w.x, s.F, g->conv_weight, g->conv_bias, st, cnn_x_planes_on(s) && rp.on && w.xpl != nullptr));
   // dx[m, d] = dropout1 * sum_{t', f} dc[m + t' - pad', f] Wc[f, (W-1-t')*D + d]
   {
     const KCWindow a{w.dc, s.M, s.F, s.L, s.W, s.W - 1 - s.pad};

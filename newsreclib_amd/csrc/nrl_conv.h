@@ -48,6 +48,43 @@ struct KCWindow {
   }
 };
 
+// KCWindow over x stored ONLY as (hi, lo) bf16 fragment-block planes padded per news (round 5; the layout the convolution weight
+// gradient reads, nrl_wgrad_planes.h: block (news * nrb + row / 16, cb) at ((..) * ncb + cb) * 1024, hi plane then lo plane, row
+// r % 16 at 32 (r % 16), rows >= L zero).  The reduction index is tap-padded: k' = tap * (16 ncb) + d, so with an even ncb a tap
+// is ncb / 2 whole k-blocks and a lane's 8 consecutive k are 16 contiguous bytes of one plane row -- token row t + tap - pad of the
+// same news, or nothing (a tap that crosses the news boundary).  No fp32 copy of x exists on this path and no split is done here.
+struct KCWindowPlanes {
+  static constexpr int kLayout = SRC_KC;
+  static constexpr bool kPreSplit = true;
+  const unsigned char* p;
+  int64_t rows;            // real token rows n_news * L
+  int L, nrb, ncb, W, pad;
+  struct State {
+    const unsigned char* news;   // first block of the row's news
+    int t;                       // token position inside the news, or -(1 << 20): a row past the end
+  };
+  __device__ __forceinline__ State init(int64_t m) const {
+    const bool ok = m < rows;
+    const int64_t mm = ok ? m : 0;
+    const int64_t n = mm / L;
+    return State{p + n * nrb * (int64_t)ncb * 1024, ok ? (int)(mm - n * L) : -(1 << 20)};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int) const {
+    const int kb = k >> 5, per_tap = ncb >> 1;
+    const int tap = kb / per_tap;
+    const int d = (k & ~4) - tap * (ncb << 4);
+    int src = s.t + tap - pad;
+    src = (src >= 0 && src < L) ? src : 0;                 // (an invalid tap reads a valid address; `finish` zeroes it)
+    return *reinterpret_cast<const float4*>(s.news + ((src >> 4) * ncb + (d >> 4)) * 1024 + ((k & 4) ? 512 : 0) + (src & 15) * 32 +
+                                            ((d >> 3) & 1) * 16);
+  }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
+    const int tap = (k >> 5) / (ncb >> 1);
+    const int src = s.t + tap - pad;
+    if (k >= kend || src < 0 || src >= L) v = f4zero();
+  }
+};
+
 // KCWindow over the LIVE token rows only (see KCPlanesLive, nrl_gemm.h): the convolution's activation gradient dx feeds
 // nothing but the embedding-table scatter, which has no use for the rows of the padding id.  GEMM row r is the r-th live
 // token position (`list`, position order).

@@ -52,6 +52,10 @@ struct RpImageJob {
   // kappa != 0: inside every k-block of 32 the reduction index follows the accumulator-to-fragment permutation of the fused
   // news tail (nrl_news_tail.h): slot 8g + e holds logical k = 32 kb + (e < 4 ? 4g + e : 16 + 4g + e - 4)
   int kappa;
+  // kpad_dp > 0 (round 5): the reduction index is TAP-PADDED -- image k' = tap * kpad_dp + d is logical k = tap * kpad_d + d for
+  // d < kpad_d, a zero row for kpad_d <= d < kpad_dp.  The convolution forward over x as fragment-block planes (KCWindowPlanes,
+  // nrl_conv.h): a tap is a whole number of 32-wide k-blocks of the planes' padded feature width (320 at D = 300)
+  int kpad_d, kpad_dp;
 };
 constexpr int RP_MAX_JOBS = 12;
 struct RpImageJobs {
@@ -105,6 +109,11 @@ static __global__ void __launch_bounds__(256) rp_weight_image_kernel(const RpIma
       if (head < J.kperm_heads) k = head * 20 + d;
       else if (k != J.K || J.bias == nullptr) live = false;
     }
+    if (J.kpad_dp > 0) {
+      const int tap = k / J.kpad_dp, d = k - tap * J.kpad_dp;
+      live = live && d < J.kpad_d;
+      k = tap * J.kpad_d + d;
+    }
     if (J.kheads > 0) {
       const int head = k >> 6, c = k & 63;
       live = live && head < J.kheads && c < 3 * J.kdh;
@@ -143,7 +152,7 @@ static inline RpImageJob* rp_jobs_add(RpImageJobs* js, const float* src, int64_t
   RpImageJob& J = js->job[js->count];
   J.src = src; J.bias = bias; J.img = img; J.sn = sn; J.sk = sk; J.N = N; J.K = K; J.nblk = nblk;
   J.kblocks = rp_kblocks(K, bias != nullptr); J.heads = 0; J.dh = 0; J.conv_f = 0; J.conv_w = 0; J.kheads = 0; J.kdh = 0; J.kperm_heads = 0;
-  J.kappa = 0;
+  J.kappa = 0; J.kpad_d = 0; J.kpad_dp = 0;
   js->first_thread[js->count + 1] = js->first_thread[js->count] + (int64_t)J.kblocks * nblk * 64;
   js->count += 1;
   return &J;
@@ -155,6 +164,16 @@ static inline RpImageJob* rp_jobs_add_qkv_heads(RpImageJobs* js, const float* w_
   RpImageJob* J = rp_jobs_add(js, w_in, D, 1, heads * 64, D, b_in, img, heads * 4);
   J->heads = heads;
   J->dh = dh;
+  return J;
+}
+// image whose reduction index is tap-padded (see RpImageJob::kpad_dp): K' = taps * dp image rows, logical K = taps * d
+static inline RpImageJob* rp_jobs_add_kpad(RpImageJobs* js, const float* src, int64_t sn, int64_t sk, int N, int taps, int d,
+                                           int dp, uint16_t* img, int nblk) {
+  RpImageJob* J = rp_jobs_add(js, src, sn, sk, N, taps * d, nullptr, img, nblk);
+  J->kpad_d = d;
+  J->kpad_dp = dp;
+  J->kblocks = rp_kblocks(taps * dp, false);
+  js->first_thread[js->count] = js->first_thread[js->count - 1] + (int64_t)J->kblocks * nblk * 64;
   return J;
 }
 // image whose reduction index runs over head planes (the in-projection dgrad of the fused news path: dx = dqkv W_in

@@ -694,6 +694,69 @@ static __global__ void __launch_bounds__(256) planes_from_rows_kernel(const Plan
     *reinterpret_cast<uint4*>(dst + 512) = make_uint4(l[0], l[1], l[2], l[3]);
   }
 }
+// x = dropout(E[ids]) written ONLY as those planes (round 5): the embedding lookup of the CNN text encoders whose convolution
+// forward reads planes too (KCWindowPlanes, nrl_conv.h) -- no fp32 copy of x, no conversion launch in the backward.  Element (row m,
+// column d) gets the keep multiplier of flat index m * D + d (the lookup's stream), the ones column sits at column D of the real rows.
+struct EmbeddingPlanesArgs {
+  const float* table;
+  const int64_t* ids;
+  int64_t n_news;
+  int L, D, ncb, nrb;
+  Dropout drop;
+  unsigned char* dst;
+};
+static __global__ void __launch_bounds__(256) embedding_rows_planes_kernel(const EmbeddingPlanesArgs P) {
+  const int64_t news = blockIdx.x;
+  __shared__ int64_t s_id[64];
+  if (threadIdx.x < 64) s_id[threadIdx.x] = (int)threadIdx.x < P.L ? P.ids[news * P.L + threadIdx.x] : 0;
+  __syncthreads();
+  const int items = P.nrb * P.ncb * 32;                      // (row block, block column, row, half row of 8 features)
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int half = it & 1, r16 = (it >> 1) & 15, rest = it >> 5;
+    const int mbi = rest / P.ncb, cb = rest - mbi * P.ncb;
+    const int r = 16 * mbi + r16, col0 = 16 * cb + 8 * half;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (r < P.L) {
+      const float* row = P.table + s_id[r] * (int64_t)P.D + col0;
+      const uint32_t idx = (uint32_t)(news * P.L + r) * (uint32_t)P.D + (uint32_t)col0;
+      if (col0 < P.D) {
+        v0 = *reinterpret_cast<const float4*>(row);
+        if (P.drop.thresh != 0u) {
+          v0.x *= P.drop.mult(idx);     v0.y *= P.drop.mult(idx + 1);
+          v0.z *= P.drop.mult(idx + 2); v0.w *= P.drop.mult(idx + 3);
+        }
+      }
+      if (col0 + 4 < P.D) {
+        v1 = *reinterpret_cast<const float4*>(row + 4);
+        if (P.drop.thresh != 0u) {
+          v1.x *= P.drop.mult(idx + 4); v1.y *= P.drop.mult(idx + 5);
+          v1.z *= P.drop.mult(idx + 6); v1.w *= P.drop.mult(idx + 7);
+        }
+      }
+      if (col0 == P.D) v0.x = 1.0f;
+      if (col0 + 4 == P.D) v1.x = 1.0f;
+    }
+    uint32_t h[4], l[4];
+    split_pair(v0.x, v0.y, h[0], l[0]);
+    split_pair(v0.z, v0.w, h[1], l[1]);
+    split_pair(v1.x, v1.y, h[2], l[2]);
+    split_pair(v1.z, v1.w, h[3], l[3]);
+    unsigned char* dst = P.dst + ((P.nrb * news + mbi) * P.ncb + cb) * 1024 + r16 * 32 + half * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(dst + 512) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+}
+static inline int launch_embedding_rows_planes(const float* table, const int64_t* ids, int64_t n_news, int L, int D, int ncb, int nrb,
+                                               const Dropout& drop, void* dst, hipStream_t st) {
+  if (n_news <= 0) return NRL_OK;
+  NRL_REQUIRE(table && ids && dst && L > 0 && L <= 16 * nrb && L <= 64 && D % 4 == 0 && ncb * 16 >= D + 1 &&
+                  ((uintptr_t)table & 15) == 0 && n_news < (1LL << 31), "embedding_rows_planes: bad arguments");
+  const EmbeddingPlanesArgs P{table, ids, n_news, L, D, ncb, nrb, drop, (unsigned char*)dst};
+  hipLaunchKernelGGL(embedding_rows_planes_kernel, dim3((unsigned)n_news), dim3(256), 0, st, P);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
 static inline size_t planes_from_rows_bytes(int64_t n_news, int ncb, int nrb) { return (size_t)n_news * nrb * ncb * 1024; }
 static inline int launch_planes_from_rows(const float* src, int64_t ld, int64_t n_news, int L, int ncols, int ncb, int nrb, bool ones,
                                           void* dst, hipStream_t st) {

@@ -241,15 +241,29 @@ def test_conv_weight_gradient_from_planes_equals_the_fp32_fed_kernel(shape, tmp_
         pytest.skip("bf16x3 path")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for flag in ("0", "1"):
+    # "0": fp32 rows everywhere; "1x": x as fp32 rows, converted for the planes weight gradient (round 4); "1": x ONLY as planes,
+    # written by the lookup and read by the convolution forward through KCWindowPlanes too (round 5)
+    for flag, xp in (("0", "0"), ("1x", "0"), ("1", "1")):
         f = str(tmp_path / ("g%s.npz" % flag))
-        env = dict(os.environ, NRL_CONV_WGRAD_PLANES=flag)
+        env = dict(os.environ, NRL_CONV_WGRAD_PLANES=flag[0], NRL_CONV_X_PLANES=xp)
         subprocess.run([sys.executable, "-c", _CONV_WGRAD_SCRIPT, root, f] + [str(v) for v in shape], check=True, env=env,
                        timeout=600)
         res[flag] = np.load(f)
-    a, b = res["0"], res["1"]
+    a, b = res["0"], res["1x"]
     assert np.array_equal(a["out"], b["out"])
     assert np.array_equal(a["g0"], b["g0"])                                  # table gradient: sorted segments, fixed order
+    # the x-planes forward multiplies the same (hi, lo) operands in another k order (taps padded to whole k-blocks): equal to rounding
+    c = res["1"]
+    so = max(1.0, float(np.abs(a["out"]).max()))
+    assert float(np.abs(a["out"] - c["out"]).max()) <= 1e-5 * so
+    # (a ReLU whose pre-activation is within rounding of 0 may open in one k order and stay shut in the other: each such gate moves
+    #  one filter's weight gradient and three embedding rows by ~|dc| -- a handful of entries, bounded; everything else to rounding)
+    for k in ("g0", "g1", "g2", "g3", "g4", "g5"):
+        scale = max(1.0, float(np.abs(a[k]).max()))
+        d = np.abs(a[k] - c[k])
+        off = float((d > 2e-5 * scale).mean())
+        # (one flipped gate touches three rows of a 500-row table = 0.6 % of its entries)
+        assert off <= (2e-2 if k == "g0" else 2e-3) and float(d.max()) <= 0.05 * scale, (k, off, float(d.max()), scale)
     for k in ("g1", "g2"):                                                   # conv weight (F, 1, W, D), conv bias
         scale = max(1.0, float(np.abs(a[k]).max()))
         assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
