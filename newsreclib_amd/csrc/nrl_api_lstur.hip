@@ -53,7 +53,7 @@ static bool cnn_conv_planes_ok(const CnnShape& s) {
 static int cnn_conv_kt(const CnnShape& s) { return s.L <= 31 ? 1 : 2; }   // k-tiles of 32 padded rows per news
 static int cnn_ncb_x(const CnnShape& s) { return ((s.D + 16) / 16 + 1) & ~1; }   // + the ones column; EVEN: a tap of the tap-padded
                                                                                  // reduction index is whole 32-wide k-blocks (KCWindowPlanes)
-static int cnn_ncb_dc(const CnnShape& s) { return (s.F + 15) / 16; }
+static int cnn_ncb_dc(const CnnShape& s) { return ((s.F + 15) / 16 + 1) & ~1; }   // EVEN, as cnn_ncb_x
 
 static bool cnn_rp_ok(const CnnShape& s);
 // x ONLY as planes (round 5): the lookup writes the planes the weight gradient reads, the convolution forward reads them through
@@ -64,9 +64,19 @@ static bool cnn_x_planes_on(const CnnShape& s) {
   return on && cnn_conv_planes_ok(s) && cnn_rp_ok(s) && cur_engine() == ENGINE_BF16X3;
 }
 
+// ... and dc (the convolution output's gradient) ONLY as planes: written by the additive-attention dgrad's epilogue
+// (EpiPoolBwdNewsPlanes), read by the convolution's activation gradient over the live rows (KCWindowLivePlanes, tap-padded
+// transposed image `conv_dp`) and by the weight gradient.  The backward falls back to fp32 dc when it has no sorted positions.
+// NRL_CONV_DC_PLANES=0: fp32 dc + planes_from_rows (A/B).
+static bool cnn_dc_planes_on(const CnnShape& s) {
+  static const bool on = [] { const char* e = getenv("NRL_CONV_DC_PLANES"); return !(e != nullptr && e[0] == '0'); }();
+  static const bool live = [] { const char* e = getenv("NRL_LIVE_ROWS"); return !(e != nullptr && e[0] == '0'); }();
+  return on && live && cnn_x_planes_on(s);
+}
+
 // conv forward / dgrad and additive-attention forward / dgrad on the row-panel kernel (bf16x3, widths <= 320)
 struct CnnRp {
-  RpImage conv_f, conv_d, att_f, att_d;
+  RpImage conv_f, conv_d, att_f, att_d, conv_dp;
   bool on = false;
 };
 static bool cnn_rp_ok(const CnnShape& s) {
@@ -75,7 +85,8 @@ static bool cnn_rp_ok(const CnnShape& s) {
 static size_t cnn_rp_elems(const CnnShape& s) {
   if (!cnn_rp_ok(s)) return 0;
   return rp_image_elems(rp_nblk_for(s.F), rp_kblocks(s.W * 16 * cnn_ncb_x(s), false)) + rp_image_elems(rp_nblk_for(s.D), rp_kblocks(s.W * s.F, false)) +
-         rp_image_elems(rp_nblk_for(s.Q), rp_kblocks(s.F, false)) + rp_image_elems(rp_nblk_for(s.F), rp_kblocks(s.Q, false));
+         rp_image_elems(rp_nblk_for(s.Q), rp_kblocks(s.F, false)) + rp_image_elems(rp_nblk_for(s.F), rp_kblocks(s.Q, false)) +
+         rp_image_elems(rp_nblk_for(s.D), rp_kblocks(s.W * 16 * cnn_ncb_dc(s), false));
 }
 // carve (and, in the forward, build in ONE launch) the four images
 static int cnn_rp_images(const NrlCnnParams* p, const CnnShape& s, const CnnWs& w, bool fill, CnnRp* r, hipStream_t st) {
@@ -106,6 +117,16 @@ static int cnn_rp_images(const NrlCnnParams* p, const CnnShape& s, const CnnWs& 
   if (p->att_weight != nullptr) {
     add(&r->att_f, p->att_weight, s.F, 1, s.Q, s.F, false);                        // t = c W_a^T
     add(&r->att_d, p->att_weight, 1, s.F, s.F, s.Q, false);                        // dc = d_pre W_a
+  }
+  if (cnn_dc_planes_on(s)) {
+    // dx = window'(dc planes) Wc over k' = t' * (16 ncb_dc) + f (taps reversed, tap-padded)
+    const int nblk = rp_nblk_for(s.D), fp = 16 * cnn_ncb_dc(s);
+    r->conv_dp.img = q; r->conv_dp.nblk = nblk; r->conv_dp.kblocks = rp_kblocks(s.W * fp, false);
+    if (fill) {
+      RpImageJob* J = rp_jobs_add_kpad(&jobs, p->conv_weight, 0, 0, s.D, s.W, s.F, fp, q, nblk);
+      J->conv_f = s.F; J->conv_w = s.W;
+    }
+    q += rp_image_elems(nblk, r->conv_dp.kblocks);
   }
   if (fill) NRL_TRY(rp_jobs_launch(jobs, st));
   return NRL_OK;
@@ -217,14 +238,14 @@ static int gemm_wgrad_any(const float* dy, int I, const BOp& b, int J, float* dW
 
 // dWc[f, t*D + d] += sum_m dc[m, f] x[m + t - pad, d] ; db_c += colsum(dc)
 static int cnn_conv_wgrad(const CnnShape& s, const CnnWs& w, const float* dc, const float* x, int F, float* d_weight,
-                          float* d_bias, hipStream_t st, bool x_planes_ready = false) {
+                          float* d_bias, hipStream_t st, bool x_planes_ready = false, bool dc_planes_ready = false) {
   const int KD = s.W * s.D;
   if (w.xpl != nullptr && cur_engine() == ENGINE_BF16X3) {
     const int ncb_x = cnn_ncb_x(s), ncb_dc = cnn_ncb_dc(s);
     const int kt = cnn_conv_kt(s);
     // (x planes: written by the forward's lookup when the convolution forward read them too; converted here otherwise)
     if (!x_planes_ready) NRL_TRY(launch_planes_from_rows(x, s.D, s.N, s.L, s.D, ncb_x, 2 * kt, true, w.xpl, st));
-    NRL_TRY(launch_planes_from_rows(dc, F, s.N, s.L, F, ncb_dc, 2 * kt, false, w.dpl, st));
+    if (!dc_planes_ready) NRL_TRY(launch_planes_from_rows(dc, F, s.N, s.L, F, ncb_dc, 2 * kt, false, w.dpl, st));
     if (kt == 1)
       return launch_wgrad_planes_conv<5, 2, 1>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 32, F, s.D, d_weight, d_bias,
                                                cnn_conv_planes_splits(), st, w.wsc);
@@ -395,11 +416,19 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
   // additive attention backward: t -> d_pre in place, dq_a
   NRL_TRY(pool_bwd_pre(d_out, w.c, w.w, w.t, p->att_query, g->att_query, s.N, s.L, s.Q, s.F, st));
   // dc = (d_pre W_a + w * d_out) * dropout2 * [c > 0]       (pre-ReLU gradient)
+  const bool x_pl = cnn_x_planes_on(s) && rp.on && w.xpl != nullptr;
+  const bool dc_pl = x_pl && cnn_dc_planes_on(s) && sorted_positions != nullptr && w.dpl != nullptr;
+  if (dc_pl) {
+    const EpiPoolBwdNewsPlanes epi{EpiPoolBwd{nullptr, s.F, w.w, d_out, s.L, drop2, w.c}, w.dpl, cnn_ncb_dc(s), 2 * cnn_conv_kt(s), s.L, s.F};
+    NRL_TRY(launch_planes_zero_pad_rows(w.dpl, s.N, s.L, cnn_ncb_dc(s), 2 * cnn_conv_kt(s), st));
+    NRL_TRY(rp_dispatch(KCPlain{w.t, s.Q, s.M}, rp.att_d, epi, s.M, s.F, s.Q, st));
+  } else {
   NRL_TRY(gemm_dgrad(w.t, p->att_weight, sa, EpiPoolBwd{w.dc, s.F, w.w, d_out, s.L, drop2, w.c}, s.M, s.Q, s.F, st,
                      rp.on ? &rp.att_d : nullptr));
+  }
   // dW_a += d_pre^T c ; db_a += colsum(d_pre)
   NRL_TRY(gemm_wgrad(w.t, s.Q, w.c, s.F, g->att_weight, g->att_bias, s.M, st));
-  NRL_TRY(cnn_conv_wgrad(s, w, w.dc, w.x, s.F, g->conv_weight, g->conv_bias, st, cnn_x_planes_on(s) && rp.on && w.xpl != nullptr));
+  NRL_TRY(cnn_conv_wgrad(s, w, w.dc, w.x, s.F, g->conv_weight, g->conv_bias, st, x_pl, dc_pl));
   // dx[m, d] = dropout1 * sum_{t', f} dc[m + t' - pad', f] Wc[f, (W-1-t')*D + d]
   {
     const KCWindow a{w.dc, s.M, s.F, s.L, s.W, s.W - 1 - s.pad};
@@ -421,7 +450,14 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
       NRL_REQUIRE((size_t)s.M * s.Q >= live_compact_ints(s.M), "cnn_encoder_bwd: scratch for the live-row list");
       const int32_t *list = nullptr, *cidx = nullptr, *n_live = nullptr;
       NRL_TRY(live_compact(ids, s.M, reinterpret_cast<int32_t*>(w.t), &list, &cidx, &n_live, st));
+      if (dc_pl) {
+        const int ncb_dc = cnn_ncb_dc(s);
+        const KCWindowPlanes ap{w.dpl, s.M, s.L, 2 * cnn_conv_kt(s), ncb_dc, s.W, s.W - 1 - s.pad};
+        NRL_TRY(rp_dispatch(KCWindowLivePlanes{ap, list, n_live}, rp.conv_dp, EpiDxLive{w.dx, s.D, drop1, list}, s.M, s.D,
+                            s.W * 16 * ncb_dc, st));
+      } else {
       NRL_TRY(rp_dispatch(KCWindowLive{a, list, n_live}, *rpd, EpiDxLive{w.dx, s.D, drop1, list}, s.M, s.D, KF, st));
+      }
       NRL_TRY(embedding_grad_sorted(w.dx, ids, sorted_positions, s.M, s.D, d_emb_table, st, cidx));
     } else if (sorted_positions != nullptr) {
       NRL_TRY(gemm_any(a, b_rc, hi, lo, 2 * Kp, EpiLinear{w.dx, s.D, nullptr, 0, drop1, s.D}, s.M, s.D, KF, st, rpd));

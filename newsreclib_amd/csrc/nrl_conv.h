@@ -14,6 +14,7 @@
 // unconditional tile loads of the first / last rows stay inside the allocation.
 #pragma once
 #include "nrl_gemm.h"
+#include "nrl_gemm_bf16x3.h"
 
 namespace nrl {
 
@@ -82,6 +83,84 @@ struct KCWindowPlanes {
     const int tap = (k >> 5) / (ncb >> 1);
     const int src = s.t + tap - pad;
     if (k >= kend || src < 0 || src >= L) v = f4zero();
+  }
+};
+
+// KCWindowPlanes over the LIVE token rows only (the convolution's activation gradient from dc planes; see KCWindowLive below)
+struct KCWindowLivePlanes {
+  static constexpr int kLayout = SRC_KC;
+  static constexpr bool kPreSplit = true;
+  static constexpr bool kLiveRows = true;
+  KCWindowPlanes w;
+  const int32_t* list;
+  const int32_t* n_live;
+  using State = KCWindowPlanes::State;
+  __device__ __forceinline__ int64_t live_rows() const { return *n_live; }
+  __device__ __forceinline__ State init(int64_t r) const {
+    const bool ok = r < *n_live;
+    State s = w.init(list[ok ? r : 0]);
+    if (!ok) s.t = -(1 << 20);
+    return s;
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int K) const { return w.load(s, k, K); }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t m, int k, int kend, bool b) const { w.finish(v, s, m, k, kend, b); }
+};
+
+// EpiPoolBwd (the additive attention's activation gradient with the pooling term, dropout and the ReLU gate) writing dc ONLY as
+// (hi, lo) fragment-block planes padded per news -- block (news * nrb + t / 16, cb), the layout of KCWindowPlanes and of the
+// convolution weight gradient -- instead of fp32 rows + a conversion launch.  The planes' padding must be zero (taps rotate into
+// it): the piece that holds the last real column of a row also clears the block columns' tail; the pad ROWS of every news are
+// cleared by planes_zero_pad_rows_kernel (nrl_wgrad_planes.h) in front of the launch.
+struct EpiPoolBwdNewsPlanes {
+  EpiPoolBwd inner;          // `c` unused; ldc = n_cols = row length of d_out / relu_src
+  unsigned char* planes;
+  int ncb, nrb, L, n_cols;
+  struct Row {
+    EpiPoolBwd::Row in;
+    unsigned char* news;     // first block of the row's news
+    int t;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const {
+    const int64_t n = m / L;
+    return Row{inner.row(m), planes + n * nrb * (int64_t)ncb * 1024, (int)(m - n * L)};
+  }
+  __device__ __forceinline__ unsigned char* at(const Row& r, int t, int n) const {
+    return r.news + ((t >> 4) * ncb + (n >> 4)) * 1024 + (t & 15) * 32 + (n & 15) * 2;
+  }
+  __device__ __forceinline__ void put4(unsigned char* dst, uint32_t h0, uint32_t h1, uint32_t l0, uint32_t l1) const {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + 512) = make_uint2(l0, l1);
+  }
+  // the piece that holds the last real columns of a row clears the tail of the block columns (<= 32 columns: a fixed, predicated
+  // unroll -- a data-dependent loop here keeps hipcc from unrolling the output stage around it and sends the accumulators to scratch)
+  __device__ __forceinline__ void pad_cols(const Row& r) const {
+    const int c0 = (n_cols + 3) & ~3;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c0 + 4 * q;
+      if (c < 16 * ncb) put4(at(r, r.t, c), 0u, 0u, 0u, 0u);
+    }
+  }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    float x = v + r.in.wm * r.in.g[n];
+    if (inner.drop.thresh != 0u) x *= inner.drop.mult(r.in.idx0 + (uint32_t)n);
+    if (r.in.src != nullptr && !(r.in.src[n] > 0.0f)) x = 0.0f;
+    uint32_t h, l;
+    split_pair(x, 0.0f, h, l);
+    unsigned char* dst = at(r, r.t, n);
+    *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(h & 0xFFFFu);
+    *reinterpret_cast<uint16_t*>(dst + 512) = (uint16_t)(l & 0xFFFFu);
+    if (n == n_cols - 1) pad_cols(r);
+  }
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const { return inner.vec_ok() && (n_cols & 3) == 0; }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    v = inner.apply4(r.in, n, v);
+    uint32_t h0, l0, h1, l1;
+    split_pair(v.x, v.y, h0, l0);
+    split_pair(v.z, v.w, h1, l1);
+    put4(at(r, r.t, n), h0, h1, l0, l1);
+    if (n + 4 >= n_cols) pad_cols(r);
   }
 };
 

@@ -757,6 +757,25 @@ static inline int launch_embedding_rows_planes(const float* table, const int64_t
   return NRL_OK;
 }
 
+// zero the pad rows (L <= r < 16 nrb) of every news of such planes: for a producer that writes only real rows (EpiPoolBwdNewsPlanes)
+static __global__ void __launch_bounds__(256) planes_zero_pad_rows_kernel(unsigned char* dst, int L, int ncb, int nrb) {
+  const int64_t news = blockIdx.x;
+  const int pad = 16 * nrb - L, items = pad * ncb * 2 * 2;          // (pad row, block column, plane, 16-byte half)
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int half = it & 1, plane = (it >> 1) & 1, rest = it >> 2;
+    const int cb = rest % ncb, r = L + rest / ncb;
+    *reinterpret_cast<uint4*>(dst + ((nrb * news + (r >> 4)) * ncb + cb) * 1024 + plane * 512 + (r & 15) * 32 + half * 16) =
+        make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+static inline int launch_planes_zero_pad_rows(void* dst, int64_t n_news, int L, int ncb, int nrb, hipStream_t st) {
+  if (n_news <= 0 || L >= 16 * nrb) return NRL_OK;
+  NRL_REQUIRE(dst && L > 0 && n_news < (1LL << 31), "planes_zero_pad_rows: bad arguments");
+  hipLaunchKernelGGL(planes_zero_pad_rows_kernel, dim3((unsigned)n_news), dim3(256), 0, st, (unsigned char*)dst, L, ncb, nrb);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
 static inline size_t planes_from_rows_bytes(int64_t n_news, int ncb, int nrb) { return (size_t)n_news * nrb * ncb * 1024; }
 static inline int launch_planes_from_rows(const float* src, int64_t ld, int64_t n_news, int L, int ncols, int ncb, int nrb, bool ones,
                                           void* dst, hipStream_t st) {

@@ -262,8 +262,9 @@ def test_conv_weight_gradient_from_planes_equals_the_fp32_fed_kernel(shape, tmp_
         scale = max(1.0, float(np.abs(a[k]).max()))
         d = np.abs(a[k] - c[k])
         off = float((d > 2e-5 * scale).mean())
-        # (one flipped gate touches three rows of a 500-row table = 0.6 % of its entries)
-        assert off <= (2e-2 if k == "g0" else 2e-3) and float(d.max()) <= 0.05 * scale, (k, off, float(d.max()), scale)
+        # (one flipped gate touches three rows of a 500-row table = 0.6 % of its entries, one filter's 900 of the 270 k weight
+        #  gradients = 0.33 %, one of the 300 bias gradients)
+        assert off <= 2e-2 and float(d.max()) <= 0.05 * scale, (k, off, float(d.max()), scale)
     for k in ("g1", "g2"):                                                   # conv weight (F, 1, W, D), conv bias
         scale = max(1.0, float(np.abs(a[k]).max()))
         assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
