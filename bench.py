@@ -209,7 +209,8 @@ def extra_plm(device, batch_size=8, steps=3):
                       "registry), d=768, 16 heads, L=96, B=8 (BASELINE.json configs[3])",
             "body_linears_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_linears),
             "body_attention_on_this_library": bool(mod.news_encoder.text_encoders["title"].nrl_attention),
-            "body_output_blocks_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_output_blocks)}
+            "body_output_blocks_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_output_blocks),
+            "body_embedding_tables_on_this_library": int(getattr(mod.news_encoder.text_encoders["title"], "nrl_embeddings", 0))}
 
 
 def predict_multi_gpu(step_ms: float, world: int = 8):

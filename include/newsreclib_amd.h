@@ -494,6 +494,12 @@ int nrl_mha_bwd(const NrlMhaParams* p, const NrlMhaGrads* g, const float* x, int
 /* nn.Embedding lookup alone (bit-exact), text.py:224. */
 int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,
                          float* out, void* stream);
+/* ABI v14: embedding_dense_backward of ANY nn.Embedding (the word / position / token-type tables of the PLM body, text.py:89):
+ * d_table[ids[p]] += d_out[p] for the n_ids positions in the id-sorted order `sorted_positions` (nrl_sort_positions: n_ids + 1
+ * entries, the last one unused here), one atomic per (id, 64-position segment, element) instead of one per element; the row
+ * `padding_idx` (< 0: none) receives nothing (nn.Embedding(padding_idx=...)).  dim <= 1024. */
+int nrl_embedding_grad(const float* d_out, const int64_t* ids, const int64_t* sorted_positions, int64_t n_ids, int32_t dim,
+                       int64_t padding_idx, float* d_table, void* stream);
 /* C(M,N) = A(M,K) * W(N,K)^T + bias  (nn.Linear) through the selected GEMM engine -- the same code path
  * (tile choice, LDS-DMA staging) the encoders' forward projections take.  The bf16x3 engine needs
  * nrl_linear_workspace_bytes(n, k) of workspace for the split weight planes; ws == NULL forces the exact

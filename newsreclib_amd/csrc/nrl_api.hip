@@ -499,6 +499,12 @@ int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, 
   return embedding_gather(table, ids, n_ids, dim, out, (hipStream_t)stream);
 }
 
+int nrl_embedding_grad(const float* d_out, const int64_t* ids, const int64_t* sorted_positions, int64_t n_ids, int32_t dim,
+                       int64_t padding_idx, float* d_table, void* stream) {
+  NRL_REQUIRE(d_out && ids && sorted_positions && d_table && n_ids >= 0 && dim > 0, "embedding_grad: bad arguments");
+  return embedding_grad_any(d_out, ids, sorted_positions, n_ids, dim, padding_idx, d_table, (hipStream_t)stream);
+}
+
 size_t nrl_linear_workspace_bytes(int32_t n, int32_t k) {
   // bf16 planes of W and W^T (tiled kernels), or the panel images of the forward (n columns over k) / the activation
   // gradient (k columns over n), whichever is larger

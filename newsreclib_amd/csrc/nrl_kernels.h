@@ -84,6 +84,9 @@ int adam_rows_advance(float* p, float* g, float* m, float* v, int64_t rows, int 
 
 int embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int D, float* out,
                      hipStream_t stream);
+// ... for any nn.Embedding: dim <= 1024, the row `padding_idx` (< 0: none) skipped
+int embedding_grad_any(const float* dx, const int64_t* ids, const int64_t* order, int64_t n_rows, int D, int64_t padding_idx,
+                       float* d_table, hipStream_t stream);
 // d_table[ids[p]] += dx[p] for p in id-sorted order (`order` = argsort(ids)); id 0 skipped
 int embedding_grad_sorted(const float* dx, const int64_t* ids, const int64_t* order, int64_t n_rows, int D,
                           float* d_table, hipStream_t stream, const int32_t* cidx = nullptr);

@@ -1307,6 +1307,74 @@ int embedding_grad_sorted(const float* dx, const int64_t* ids, const int64_t* or
   return NRL_OK;
 }
 
+// The same reduction for ANY nn.Embedding (round 5: the word / position / token-type tables of a transformer body, text.py:89 --
+// ATen's embedding_dense_backward there is a merge sort + three segment kernels, 2.6 ms of a config-4 step): dim <= 1024 (four
+// accumulators per thread), `padding_idx` (< 0: none) names the one row that receives no gradient -- it may sit anywhere in the
+// order, so it is skipped per position instead of by the "zeros sort first" shortcut of the kernel above.
+__global__ void __launch_bounds__(256)
+    embedding_grad_any_kernel(const float* __restrict__ dx, const int64_t* __restrict__ ids, const int64_t* __restrict__ order,
+                              int64_t n_rows, int D, int64_t padding_idx, float* __restrict__ d_table) {
+  __shared__ int64_t s_pos[EMB_SEG_ROWS], s_id[EMB_SEG_ROWS];
+  const int64_t beg = (int64_t)blockIdx.x * EMB_SEG_ROWS;
+  const int64_t end = beg + EMB_SEG_ROWS < n_rows ? beg + EMB_SEG_ROWS : n_rows;
+  const int n = (int)(end - beg);
+  const int tid = threadIdx.x;
+  if (tid < EMB_SEG_ROWS) {
+    const int64_t pos = tid < n ? order[beg + tid] : 0;
+    s_pos[tid] = pos;
+    s_id[tid] = tid < n ? ids[pos] : -1;
+  }
+  __syncthreads();
+  bool dk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dk[q] = tid + 256 * q < D;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t cur = -1;
+  auto flush = [&]() {
+    if (cur >= 0 && cur != padding_idx) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (dk[q]) atomicAdd(d_table + cur * D + tid + 256 * q, acc[q]);
+    }
+  };
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    float r[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u < EMB_SEG_ROWS ? j0 + u : EMB_SEG_ROWS - 1;
+      const bool live = j0 + u < n && s_id[j] != padding_idx;
+      const float* row = dx + s_pos[j] * D;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[u][q] = (live && dk[q]) ? row[tid + 256 * q] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j0 + u < n) {
+        const int64_t id = s_id[j0 + u];
+        if (id != cur) {
+          flush();
+          cur = id;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += r[u][q];
+      }
+    }
+  }
+  flush();
+}
+
+int embedding_grad_any(const float* dx, const int64_t* ids, const int64_t* order, int64_t n_rows, int D, int64_t padding_idx,
+                       float* d_table, hipStream_t stream) {
+  if (n_rows == 0) return NRL_OK;
+  NRL_REQUIRE(D > 0 && D <= 1024, "embedding_grad: dim > 1024 unsupported");
+  hipLaunchKernelGGL(embedding_grad_any_kernel, dim3((unsigned)ceil_div(n_rows, EMB_SEG_ROWS)), dim3(256), 0, stream, dx, ids, order,
+                     n_rows, D, padding_idx, d_table);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
 // ---- compaction of the LIVE token positions (id != 0) in position order -------------------------------------------------
 // list[c] = c-th live position, cidx[p] = number of live positions before p, counts[nb] = their total.  The last dgrad of a
 // text encoder runs over list (rows of one news stay together: its fragment loads share the 16-row blocks of the planes);

@@ -216,6 +216,42 @@ class NrlLinear(nn.Module):
         return f"in_features={self.in_features}, out_features={self.out_features}, engine=newsreclib_amd"
 
 
+class NrlEmbedding(nn.Module):
+    """Drop-in for an ``nn.Embedding`` of the PLM body: the SAME ``weight`` Parameter (state-dict key, optimizer membership
+    unchanged), lookup and gradient on this library (``ops_blocks.EmbeddingFn``)."""
+
+    def __init__(self, emb: nn.Embedding) -> None:
+        super().__init__()
+        self.num_embeddings, self.embedding_dim, self.padding_idx = emb.num_embeddings, emb.embedding_dim, emb.padding_idx
+        self.weight = emb.weight
+
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        w = self.weight
+        if not ids.is_cuda or ids.dtype != torch.int64 or w.dtype != torch.float32:
+            # construction-time / CPU calls of HF.  Counted like NrlLinear's: a GPU step that lands here is not on this library
+            FALLBACK_CALLS["embedding_cuda" if ids.is_cuda else "embedding_host"] += 1
+            return nn.functional.embedding(ids, w, self.padding_idx)
+        return ops_blocks.EmbeddingFn.apply(ids.contiguous(), w, self.padding_idx, _grad_bufs((w,)))
+
+    def extra_repr(self) -> str:
+        return f"{self.num_embeddings}, {self.embedding_dim}, padding_idx={self.padding_idx}, engine=newsreclib_amd"
+
+
+def swap_embeddings(module: nn.Module) -> int:
+    """Replaces the plain ``nn.Embedding`` tables below ``module`` (dim % 4 == 0, dim <= 1024, <= 2^20 rows, no max_norm /
+    scale_grad_by_freq / sparse) by ``NrlEmbedding`` in place; returns how many."""
+    n = 0
+    for name, child in list(module.named_children()):
+        if type(child) is nn.Embedding and child.embedding_dim % 4 == 0 and child.embedding_dim <= 1024 \
+                and child.num_embeddings <= (1 << 20) and child.max_norm is None and not child.scale_grad_by_freq \
+                and not child.sparse:
+            setattr(module, name, NrlEmbedding(child))
+            n += 1
+        else:
+            n += swap_embeddings(child)
+    return n
+
+
 def swap_linears(module: nn.Module) -> int:
     """Replaces every eligible ``nn.Linear`` below ``module`` by ``NrlLinear`` in place; returns how many."""
     n = 0
@@ -267,7 +303,8 @@ def swap_output_blocks(module: nn.Module) -> int:
 
 NRL_ATTENTION = "nrl_x3"
 # calls of the PLM body that did NOT run on this library's kernels (framework fallbacks), by kind; `reset_fallback_calls()` zeroes
-FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0, "output_block_cuda": 0, "output_block_host": 0}
+FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0, "output_block_cuda": 0, "output_block_host": 0,
+                  "embedding_cuda": 0, "embedding_host": 0}
 
 
 def reset_fallback_calls() -> None:
@@ -363,6 +400,11 @@ class PLM(nn.Module):
         self.nrl_linears = 0
         if os.environ.get("NRL_PLM_LINEAR", "1") != "0" and hasattr(self.plm_model, "encoder"):
             self.nrl_linears = swap_linears(self.plm_model.encoder)
+        # ... the word / position / token-type tables (trainable: text.py:70-73 freezes `layer.k.` names only) with this library's
+        # sorted-segment embedding gradient instead of ATen's merge sort + segment kernels; NRL_PLM_EMBEDDING=0 keeps them (A/B)
+        self.nrl_embeddings = 0
+        if os.environ.get("NRL_PLM_EMBEDDING", "1") != "0" and hasattr(self.plm_model, "embeddings"):
+            self.nrl_embeddings = swap_embeddings(self.plm_model.embeddings)
         # ... the dropout + residual + LayerNorm that ends both halves of every layer as one launch each way
         # (nrl_dropout_add_layernorm_fwd / _bwd); NRL_PLM_GLUE=0 keeps the three framework kernels (A/B)
         self.nrl_output_blocks = 0

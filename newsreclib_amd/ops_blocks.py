@@ -158,6 +158,42 @@ class LinearFn(GradAwareFunction):
         return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None, None)
 
 
+class EmbeddingFn(GradAwareFunction):
+    """``nn.Embedding`` of a third-party stack (the PLM body's word / position / token-type tables): bit-exact gather forward,
+    and ``embedding_dense_backward`` as the library's counting sort + sorted-segment reduction (``nrl_sort_positions`` +
+    ``nrl_embedding_grad``) instead of ATen's merge sort + three segment kernels; ``padding_idx`` receives no gradient."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx, grad_bufs):
+        from . import ops
+        ids = _chk(ids, torch.int64, "ids")
+        weight = _chk(weight, torch.float32, "embedding weight")
+        out = ops.embedding_gather(weight, ids)
+        if saving(ctx):
+            ctx.save_for_backward(ids)
+            ctx.shape, ctx.padding_idx, ctx.grad_bufs = tuple(weight.shape), padding_idx, grad_bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from . import ops
+        lib = _lib.load()
+        (ids,) = ctx.saved_tensors
+        V, D = ctx.shape
+        d_out = _chk(d_out.reshape(-1, D), torch.float32, "d_out")
+        flat = ids.reshape(-1)
+        order = ops.sort_positions(flat, V)
+        gb = ctx.grad_bufs[0] if ctx.grad_bufs is not None else None
+        if gb is not None:
+            target, ret = gb, None
+        else:
+            target = ret = torch.zeros((V, D), dtype=torch.float32, device=d_out.device)
+        pad = -1 if ctx.padding_idx is None else int(ctx.padding_idx)
+        _lib.check(lib.nrl_embedding_grad(d_out.data_ptr(), flat.data_ptr(), order.data_ptr(), flat.numel(), D, pad,
+                                          target.data_ptr(), _stream()), "nrl_embedding_grad")
+        return None, ret, None, None
+
+
 class SdpaFn(GradAwareFunction):
     """``F.scaled_dot_product_attention`` of a transformer body on the bf16x3 matrix-core kernels (``nrl_sdpa_fwd`` / ``_bwd``):
     q, k, v (N, L, H, dh) -- the projections' outputs viewed per head, NOT transposed -- -> (N, L, H, dh).  ``keep`` (N, L) uint8

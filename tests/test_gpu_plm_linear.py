@@ -347,7 +347,7 @@ def test_plm_full_width_step_runs_on_this_library(tmp_path):
     assert np.isfinite(before) and after < before, (before, after, losses)
     ne.FALLBACK_CALLS.update(fb_train)
     fb = dict(ne.FALLBACK_CALLS)
-    assert fb["linear_cuda"] == 0 and fb["attention"] == 0 and fb["output_block_cuda"] == 0, fb
+    assert fb["linear_cuda"] == 0 and fb["attention"] == 0 and fb["output_block_cuda"] == 0 and fb["embedding_cuda"] == 0, fb
 
 
 @pytest.mark.gpu
@@ -402,3 +402,28 @@ def test_trainable_linear_keeps_its_images_within_an_optimizer_step_only():
     with torch.no_grad():
         lin.weight.mul_(0.5)                            # torch.optim-style in-place update: the version counter moves
     check(*run())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,D,pad,n", [(50265, 768, 1, 38400), (514, 768, 1, 4224), (1, 768, None, 3000), (97, 20, 0, 500), (300, 1024, None, 77)])
+def test_embedding_gradient_of_any_table_matches_torch(V, D, pad, n):
+    """``ops_blocks.EmbeddingFn`` / ``nrl_embedding_grad`` (ABI v14): lookup bit-exact, gradient == ``embedding_dense_backward`` of
+    torch (fp64 reference) for the PLM body's three tables' shapes -- heavy duplicates (position ids, the one-row token-type
+    table), a padding row in the middle of the id range, dims up to 1024."""
+    from newsreclib_amd import ops_blocks
+    torch.manual_seed(V + n)
+    w = torch.randn(V, D, device=DEV, requires_grad=True)
+    zipf = (1.0 / torch.arange(1, V + 1, dtype=torch.float64)) ** 1.1
+    ids = torch.multinomial(zipf, n, replacement=True).to(DEV).reshape(-1, 1 if n % 96 else 96)
+    if pad is not None and V > 1:
+        ids.view(-1)[::7] = pad
+    g = torch.randn(*ids.shape, D, device=DEV)
+    out = ops_blocks.EmbeddingFn.apply(ids, w, pad, None)
+    assert torch.equal(out, torch.nn.functional.embedding(ids, w.detach(), pad))
+    out.backward(g)
+    w64 = w.detach().double().requires_grad_(True)
+    torch.nn.functional.embedding(ids, w64, pad).backward(g.double())
+    scale = max(1.0, float(w64.grad.abs().max()))
+    assert float((w.grad.double() - w64.grad).abs().max()) <= 2e-5 * scale
+    if pad is not None:
+        assert float(w.grad[pad].abs().max()) == 0.0
