@@ -494,6 +494,17 @@ int nrl_mha_bwd(const NrlMhaParams* p, const NrlMhaGrads* g, const float* x, int
 /* nn.Embedding lookup alone (bit-exact), text.py:224. */
 int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, int32_t dim,
                          float* out, void* stream);
+/* ABI v14: nn.Linear fused with the exact GELU of a BERT-family feed-forward block (HF RobertaIntermediate / RobertaOutput inside
+ * self.plm_model(**text), text.py:89).  bf16x3 engine, wide side >= 256 (nrl_linear_gelu_supported(n_wide) != 0); workspace and
+ * image_ready as nrl_linear_fwd_img / _bwd_img (nrl_linear_workspace_bytes(n, k)).
+ *   nrl_linear_gelu_fwd_img    h (m, n) = a W^T + bias (the GELU's input, kept for the backward), g (m, n) = gelu(h) = h Phi(h)
+ *   nrl_linear_dgrad_gelu_img  for the projection that CONSUMED g -- c = g W^T (+ bias), W (n, k), g (m, k):
+ *                              d_pre (m, k) = (d_c W) * gelu'(pre), i.e. the gradient at the GELU's input straight from the epilogue */
+int nrl_linear_gelu_fwd_img(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k, float* h, float* g,
+                            void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
+int nrl_linear_dgrad_gelu_img(const float* w, const float* d_c, const float* pre, int64_t m, int32_t n, int32_t k, float* d_pre,
+                              void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
+int32_t nrl_linear_gelu_supported(int32_t n_wide);
 /* ABI v14: embedding_dense_backward of ANY nn.Embedding (the word / position / token-type tables of the PLM body, text.py:89):
  * d_table[ids[p]] += d_out[p] for the n_ids positions in the id-sorted order `sorted_positions` (nrl_sort_positions: n_ids + 1
  * entries, the last one unused here), one atomic per (id, 64-position segment, element) instead of one per element; the row

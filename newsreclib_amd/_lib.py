@@ -182,6 +182,11 @@ SIGNATURES = {
                                c_int32, c_float, c_double, c_uint64, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nrl_linear_fwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                      c_size_t, c_int32, c_void_p]),
+    "nrl_linear_gelu_fwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                          c_size_t, c_int32, c_void_p]),
+    "nrl_linear_dgrad_gelu_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
+                                            c_int32, c_void_p]),
+    "nrl_linear_gelu_supported": (c_int32, [c_int32]),
     "nrl_embedding_grad": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p]),
     "nrl_linear_bwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_int32, c_void_p]),

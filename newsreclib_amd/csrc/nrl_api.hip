@@ -499,6 +499,30 @@ int nrl_embedding_gather(const float* table, const int64_t* ids, int64_t n_ids, 
   return embedding_gather(table, ids, n_ids, dim, out, (hipStream_t)stream);
 }
 
+// nn.Linear + exact GELU (a BERT-family feed-forward block's first half, ABI v14): h = a W^T + bias (saved), g = gelu(h)
+int nrl_linear_gelu_fwd_img(const float* a, const float* w, const float* bias, int64_t m, int32_t n, int32_t k, float* h, float* g,
+                            void* ws, size_t ws_bytes, int32_t image_ready, void* stream) {
+  NRL_REQUIRE(a && w && bias && h && g && m >= 0 && n > 0 && k > 0 && k % 4 == 0 && n % 4 == 0, "linear_gelu_fwd: bad arguments");
+  NRL_REQUIRE((((uintptr_t)a | (uintptr_t)w | (uintptr_t)h | (uintptr_t)g | (uintptr_t)bias) & 15) == 0, "linear_gelu_fwd: 16-byte alignment");
+  NRL_REQUIRE(cur_engine() == ENGINE_BF16X3 && lin_panels_on(n), "linear_gelu_fwd: bf16x3 engine and n >= 256 (nrl_linear_gelu_supported)");
+  NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0 && ws_bytes >= nrl_linear_workspace_bytes(n, k), "linear_gelu_fwd: workspace");
+  if (m == 0) return NRL_OK;
+  return linear_panels(a, w, k, 1, n, k, EpiLinearGelu{h, g, n, bias}, m, (uint16_t*)ws, (hipStream_t)stream, image_ready == 0);
+}
+
+// activation gradient of a projection whose INPUT was g = gelu(pre): d_pre (m, k) = (d_c W) * gelu'(pre) in the epilogue
+int nrl_linear_dgrad_gelu_img(const float* w, const float* d_c, const float* pre, int64_t m, int32_t n, int32_t k, float* d_pre,
+                              void* ws, size_t ws_bytes, int32_t image_ready, void* stream) {
+  NRL_REQUIRE(w && d_c && pre && d_pre && m >= 0 && n > 0 && k > 0 && k % 4 == 0 && n % 4 == 0, "linear_dgrad_gelu: bad arguments");
+  NRL_REQUIRE((((uintptr_t)w | (uintptr_t)d_c | (uintptr_t)pre | (uintptr_t)d_pre) & 15) == 0, "linear_dgrad_gelu: 16-byte alignment");
+  NRL_REQUIRE(cur_engine() == ENGINE_BF16X3 && lin_panels_on(k), "linear_dgrad_gelu: bf16x3 engine and k >= 256 (nrl_linear_gelu_supported)");
+  NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0 && ws_bytes >= nrl_linear_workspace_bytes(n, k), "linear_dgrad_gelu: workspace");
+  if (m == 0) return NRL_OK;
+  return linear_panels(d_c, w, 1, k, k, n, EpiGeluBwd{d_pre, k, pre}, m, (uint16_t*)ws, (hipStream_t)stream, image_ready == 0);
+}
+
+int32_t nrl_linear_gelu_supported(int32_t n_wide) { return (cur_engine() == ENGINE_BF16X3 && lin_panels_on(n_wide)) ? 1 : 0; }
+
 int nrl_embedding_grad(const float* d_out, const int64_t* ids, const int64_t* sorted_positions, int64_t n_ids, int32_t dim,
                        int64_t padding_idx, float* d_table, void* stream) {
   NRL_REQUIRE(d_out && ids && sorted_positions && d_table && n_ids >= 0 && dim > 0, "embedding_grad: bad arguments");

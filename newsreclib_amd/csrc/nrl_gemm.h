@@ -395,6 +395,77 @@ struct EpiStore {
   __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const { store4(r.out + n, v, stream); }
 };
 
+// GELU (exact: x Phi(x), the `gelu` of a BERT-family feed-forward block, text.py:89 -> HF RobertaIntermediate) around nn.Linear,
+// round 5.  Forward epilogue: h = v + bias is stored for the backward AND g = gelu(h) for the next projection -- the framework's
+// separate GELU kernel re-read h (0.52 GB per layer at 42k x 3072).  Backward epilogue of the NEXT projection's activation gradient:
+// d_h = v * gelu'(h) with v = d_g the product, instead of writing d_g and a GeluBackward pass over it.
+// erf through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) on v_rcp_f32 / v_exp_f32: ~20 issue slots per
+// element against ~50 for libm's erff -- with erff in the epilogues the fusion was a wash (89 vs 88-89 ms per config-4 step: the
+// epilogues' VALU cost what the two framework kernels had taken).  e2 = exp(-z^2), z = x / sqrt(2), serves BOTH the erf and the
+// density term of the derivative (exp(-x^2 / 2) is the same number).
+__device__ __forceinline__ float gelu_cdf_e2(float x, float& e2) {
+  const float z = x * 0.70710678118654752440f;
+  e2 = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(z), 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erf_abs = 1.0f - p * t * e2;                    // erf(|z|)
+  return 0.5f * (1.0f + copysignf(erf_abs, z));
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float e2;
+  return x * gelu_cdf_e2(x, e2);
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  float e2;
+  const float cdf = gelu_cdf_e2(x, e2);
+  return fmaf(x * 0.39894228040143267794f, e2, cdf);
+}
+struct EpiLinearGelu {
+  float* h;            // pre-activation (M, N), saved
+  float* g;            // gelu(h) (M, N)
+  int64_t ldc;
+  const float* bias;
+  struct Row {
+    float *h, *g;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{h + m * ldc, g + m * ldc}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    v += bias[n];
+    r.h[n] = v;
+    r.g[n] = gelu_f(v);
+  }
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const {
+    return (ldc & 3) == 0 && (((uintptr_t)h | (uintptr_t)g | (uintptr_t)bias) & 15) == 0;
+  }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    store4(r.h + n, v, 0);
+    store4(r.g + n, make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w)), 0);
+  }
+};
+struct EpiGeluBwd {
+  float* c;            // d_h (M, N)
+  int64_t ldc;
+  const float* pre;    // h (M, N): the GELU's input
+  struct Row {
+    float* out;
+    const float* pre;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc, pre + m * ldc}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const { r.out[n] = v * gelu_grad_f(r.pre[n]); }
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const { return (ldc & 3) == 0 && (((uintptr_t)c | (uintptr_t)pre) & 15) == 0; }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    const float4 p = *reinterpret_cast<const float4*>(r.pre + n);
+    store4(r.out + n, make_float4(v.x * gelu_grad_f(p.x), v.y * gelu_grad_f(p.y), v.z * gelu_grad_f(p.z), v.w * gelu_grad_f(p.w)), 0);
+  }
+};
+
 // additive-attention backward, fused: dy = (v + w[m] * d_out[group(m)][n]) * dropout(m, n)
 // (v = d_pre * W_a is the tanh-branch gradient, w * d_out the weighted-sum branch,
 // attention.py:34-40; the multiplier undoes text.py:230).

@@ -268,7 +268,10 @@ def swap_linears(module: nn.Module) -> int:
 def _fused_output_forward(self, hidden_states: torch.Tensor, input_tensor: torch.Tensor) -> torch.Tensor:
     """``LayerNorm(dropout(dense(hidden_states)) + input_tensor)`` of a BERT-family output block with the three elementwise
     passes after the projection as ONE launch (``ops_blocks.DropoutAddLayerNormFn``)."""
-    h = self.dense(hidden_states)
+    return _output_glue(self, self.dense(hidden_states), input_tensor)
+
+
+def _output_glue(self, h: torch.Tensor, input_tensor: torch.Tensor) -> torch.Tensor:
     ln = self.LayerNorm
     if h.dtype != torch.float32 or not h.is_cuda or ln.weight is None or ln.bias is None or h.shape[-1] % 4 or h.shape[-1] > 2048 \
             or h.numel() >= (1 << 32):
@@ -278,6 +281,44 @@ def _fused_output_forward(self, hidden_states: torch.Tensor, input_tensor: torch
     params = (ln.weight, ln.bias)
     return ops_blocks.DropoutAddLayerNormFn.apply(h.contiguous(), input_tensor.contiguous(), ln.weight, ln.bias, float(ln.eps), p,
                                                   _draw_seed() if p > 0.0 else 0, _grad_bufs(params))
+
+
+def _fused_ffn_chunk(self, attention_output: torch.Tensor) -> torch.Tensor:
+    """``RobertaLayer.feed_forward_chunk``: intermediate.dense -> GELU -> output.dense as ONE autograd function with the GELU and its
+    derivative inside the GEMM epilogues (``ops_blocks.FfnFn``), then the fused dropout + residual + LayerNorm of the output block."""
+    d1, d2 = self.intermediate.dense, self.output.dense
+    x = attention_output
+    if x.dtype != torch.float32 or not x.is_cuda or not bool(_lib.load().nrl_linear_gelu_supported(d1.out_features)):
+        FALLBACK_CALLS["ffn_cuda" if x.is_cuda else "ffn_host"] += 1
+        return self.output(self.intermediate(x), x)
+    p = (d1.weight, d1.bias, d2.weight, d2.bias)
+
+    def images(lin):
+        trainable = lin.weight.requires_grad or lin.bias.requires_grad
+        if trainable and lin._images is not None:
+            lin._images.invalidate()
+        return lin._images if not trainable else (lin._step_images if ops_blocks.step_images_allowed() else None)
+
+    y = ops_blocks.FfnFn.apply(x.contiguous(), *p, _grad_bufs(p), images(d1), images(d2))
+    return _output_glue(self.output, y, x)
+
+
+def swap_ffn_blocks(module: nn.Module) -> int:
+    """Gives every layer below ``module`` whose feed-forward half is ``intermediate`` (NrlLinear + exact GELU) -> ``output`` (NrlLinear
+    + the fused glue) the one-function form above; returns how many.  Parameters and state-dict keys are untouched."""
+    import types
+    n = 0
+    for m in module.modules():
+        inter, out = getattr(m, "intermediate", None), getattr(m, "output", None)
+        if inter is None or out is None or not hasattr(m, "feed_forward_chunk"):
+            continue
+        act = getattr(inter, "intermediate_act_fn", None)
+        exact_gelu = act is nn.functional.gelu or type(act).__name__ == "GELUActivation" or isinstance(act, nn.GELU) and act.approximate == "none"
+        if isinstance(getattr(inter, "dense", None), NrlLinear) and isinstance(getattr(out, "dense", None), NrlLinear) and exact_gelu \
+                and isinstance(getattr(out, "LayerNorm", None), nn.LayerNorm) and isinstance(getattr(out, "dropout", None), nn.Dropout):
+            m.feed_forward_chunk = types.MethodType(_fused_ffn_chunk, m)
+            n += 1
+    return n
 
 
 def swap_output_blocks(module: nn.Module) -> int:
@@ -304,7 +345,7 @@ def swap_output_blocks(module: nn.Module) -> int:
 NRL_ATTENTION = "nrl_x3"
 # calls of the PLM body that did NOT run on this library's kernels (framework fallbacks), by kind; `reset_fallback_calls()` zeroes
 FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0, "output_block_cuda": 0, "output_block_host": 0,
-                  "embedding_cuda": 0, "embedding_host": 0}
+                  "embedding_cuda": 0, "embedding_host": 0, "ffn_cuda": 0, "ffn_host": 0}
 
 
 def reset_fallback_calls() -> None:
@@ -410,6 +451,11 @@ class PLM(nn.Module):
         self.nrl_output_blocks = 0
         if os.environ.get("NRL_PLM_GLUE", "1") != "0" and hasattr(self.plm_model, "encoder"):
             self.nrl_output_blocks = swap_output_blocks(self.plm_model.encoder)
+        # ... the feed-forward half of every layer as one autograd function with the GELU (and its derivative) inside the GEMM
+        # epilogues; NRL_PLM_FFN=0 keeps the two projections + the framework's GELU kernels (A/B)
+        self.nrl_ffn_blocks = 0
+        if os.environ.get("NRL_PLM_FFN", "1") != "0" and self.nrl_linears and self.nrl_output_blocks and hasattr(self.plm_model, "encoder"):
+            self.nrl_ffn_blocks = swap_ffn_blocks(self.plm_model.encoder)
         # ... and its self-attention on this library's bf16x3 kernels (nrl_sdpa_fwd / _bwd: heads of 64 over <= 128 tokens; other
         # shapes fall through to the framework's SDPA inside the interface); NRL_PLM_ATTENTION=0 keeps the HF path (A/B)
         self.nrl_attention = False

@@ -158,6 +158,99 @@ class LinearFn(GradAwareFunction):
         return (d_a.view(ctx.in_shape) if need_a else None, rets[0], rets[1], None, None)
 
 
+def _image_ws(images, which, w, lib, device):
+    """-> (workspace, ready flag, key to commit) of a projection's matrix-core images (FrozenImages or per call)."""
+    ws, ready, key = images.buffer(which, w, lib, device) if images is not None else (None, 0, None)
+    if ws is None:
+        N, K = w.shape
+        ws = torch.empty(max(lib.nrl_linear_workspace_bytes(N, K), 256), dtype=torch.uint8, device=device)
+    return ws, ready, key
+
+
+class FfnFn(GradAwareFunction):
+    """The feed-forward half of a BERT-family layer up to its second projection (HF ``RobertaIntermediate`` + the ``dense`` of
+    ``RobertaOutput``, inside ``self.plm_model(**text)``, reference text.py:89): y = gelu(x W1^T + b1) W2^T + b2 with the exact GELU
+    in the first GEMM's epilogue (``nrl_linear_gelu_fwd_img``: h saved, g handed on) and its derivative in the epilogue of the second
+    projection's activation gradient (``nrl_linear_dgrad_gelu_img``: d_h straight from d_y W2) -- the framework's two elementwise
+    passes over the (rows, 3072) activation, 5.4 ms of a config-4 step, are gone.  A frozen layer keeps neither x nor g."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, grad_bufs, images1, images2):
+        lib = _lib.load()
+        x = _chk(x, torch.float32, "input")
+        w1, b1, w2, b2 = (_chk(t, torch.float32, "ffn parameter") for t in (w1, b1, w2, b2))
+        N1, K1 = w1.shape
+        N2, K2 = w2.shape
+        if x.shape[-1] != K1 or K2 != N1 or b1.shape != (N1,) or b2.shape != (N2,):
+            raise ValueError("newsreclib_amd: inconsistent feed-forward shapes")
+        x2 = x.reshape(-1, K1)
+        M = x2.shape[0]
+        dev = x.device
+        h = torch.empty((M, N1), dtype=torch.float32, device=dev)
+        g = torch.empty((M, N1), dtype=torch.float32, device=dev)
+        ws, ready, key = _image_ws(images1, "fwd", w1, lib, dev)
+        _lib.check(lib.nrl_linear_gelu_fwd_img(x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), M, N1, K1, h.data_ptr(), g.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), ready, _stream()), "nrl_linear_gelu_fwd")
+        if key is not None:
+            images1.commit("fwd", key)
+        y = torch.empty((M, N2), dtype=torch.float32, device=dev)
+        ws, ready, key = _image_ws(images2, "fwd", w2, lib, dev)
+        _lib.check(lib.nrl_linear_fwd_img(g.data_ptr(), w2.data_ptr(), b2.data_ptr(), M, N2, K2, y.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), ready, _stream()), "nrl_linear_fwd")
+        if key is not None:
+            images2.commit("fwd", key)
+        if saving(ctx):
+            need_w1 = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            need_w2 = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+            ctx.save_for_backward(x2 if need_w1 else None, h, g if need_w2 else None, w1, b1, w2, b2)
+            ctx.grad_bufs, ctx.engine, ctx.in_shape = grad_bufs, _lib.engine_code(), tuple(x.shape)
+            ctx.images = (images1, images2)
+        return y.view(*x.shape[:-1], N2)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        _lib.require_engine(ctx.engine, "feed-forward block")
+        x2, h, g, w1, b1, w2, b2 = ctx.saved_tensors
+        N1, K1 = w1.shape
+        N2, K2 = w2.shape
+        d_y = _chk(d_y.reshape(-1, N2), torch.float32, "d_out")
+        M = d_y.shape[0]
+        dev = d_y.device
+        need_x = ctx.needs_input_grad[0]
+        need_w1, need_w2 = x2 is not None, g is not None
+        images1, images2 = ctx.images
+        rets = [None] * 4
+        gb = ctx.grad_bufs
+        if need_w2:
+            bufs, r = _grad_targets([w2, b2], gb[2:4] if gb is not None else None)
+            rets[2:4] = r
+            ws = torch.empty(256, dtype=torch.uint8, device=dev)          # (weight gradient only: no image)
+            _lib.check(lib.nrl_linear_bwd_img(g.data_ptr(), w2.data_ptr(), d_y.data_ptr(), M, N2, K2, None, bufs[0].data_ptr(),
+                                              bufs[1].data_ptr(), ws.data_ptr(), ws.numel(), 0, _stream()), "nrl_linear_bwd")
+        d_x = None
+        if need_x or need_w1:
+            d_h = torch.empty((M, N1), dtype=torch.float32, device=dev)
+            ws, ready, key = _image_ws(images2, "bwd", w2, lib, dev)
+            _lib.check(lib.nrl_linear_dgrad_gelu_img(w2.data_ptr(), d_y.data_ptr(), h.data_ptr(), M, N2, K2, d_h.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), ready, _stream()), "nrl_linear_dgrad_gelu")
+            if key is not None:
+                images2.commit("bwd", key)
+            dw = db = None
+            if need_w1:
+                bufs, r = _grad_targets([w1, b1], gb[0:2] if gb is not None else None)
+                rets[0:2] = r
+                dw, db = bufs[0].data_ptr(), bufs[1].data_ptr()
+            d_x = torch.empty((M, K1), dtype=torch.float32, device=dev) if need_x else None
+            ws, ready, key = _image_ws(images1, "bwd", w1, lib, dev)
+            _lib.check(lib.nrl_linear_bwd_img(x2.data_ptr() if need_w1 else None, w1.data_ptr(), d_h.data_ptr(), M, N1, K1,
+                                              d_x.data_ptr() if need_x else None, dw, db, ws.data_ptr(), ws.numel(), ready,
+                                              _stream()), "nrl_linear_bwd")
+            if key is not None:
+                images1.commit("bwd", key)
+        return (d_x.view(ctx.in_shape) if need_x else None, rets[0], rets[1], rets[2], rets[3], None, None, None)
+
+
 class EmbeddingFn(GradAwareFunction):
     """``nn.Embedding`` of a third-party stack (the PLM body's word / position / token-type tables): bit-exact gather forward,
     and ``embedding_dense_backward`` as the library's counting sort + sorted-segment reduction (``nrl_sort_positions`` +

@@ -427,3 +427,40 @@ def test_embedding_gradient_of_any_table_matches_torch(V, D, pad, n):
     assert float((w.grad.double() - w64.grad).abs().max()) <= 2e-5 * scale
     if pad is not None:
         assert float(w.grad[pad].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,D,F", [(1000, 768, 3072), (77, 256, 512), (4100, 320, 1024)])
+@pytest.mark.parametrize("frozen", [False, True])
+def test_feed_forward_block_with_gelu_in_the_epilogues_matches_torch(M, D, F, frozen):
+    """``ops_blocks.FfnFn`` (ABI v14: ``nrl_linear_gelu_fwd_img`` / ``nrl_linear_dgrad_gelu_img``): y = gelu(x W1^T + b1) W2^T + b2 with
+    the exact GELU and its derivative inside the GEMM epilogues, against fp64 torch: output, input gradient and -- trainable
+    block -- all four parameter gradients; a frozen block (layers 0-7 of the PLM body) still passes the gradient to its input."""
+    from newsreclib_amd import _lib, ops_blocks
+    _lib.set_gemm_engine("bf16x3")
+    torch.manual_seed(M + F)
+    l1, l2 = torch.nn.Linear(D, F).to(DEV), torch.nn.Linear(F, D).to(DEV)
+    if frozen:
+        for p in list(l1.parameters()) + list(l2.parameters()):
+            p.requires_grad_(False)
+    x = torch.randn(M, D, device=DEV, requires_grad=True)
+    gy = torch.randn(M, D, device=DEV)
+    y = ops_blocks.FfnFn.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, None, None, None)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    d1, d2 = torch.nn.Linear(D, F).double().to(DEV), torch.nn.Linear(F, D).double().to(DEV)
+    d1.load_state_dict({k: v.double() for k, v in l1.state_dict().items()})
+    d2.load_state_dict({k: v.double() for k, v in l2.state_dict().items()})
+    ref = d2(torch.nn.functional.gelu(d1(xd)))
+    ref.backward(gy.double())
+
+    def close(a, b, tol=1e-4):
+        assert float((a.double() - b).abs().max()) <= tol * max(1e-6, float(b.abs().max()))
+
+    close(y, ref.detach())
+    close(x.grad, xd.grad)
+    if not frozen:
+        close(l1.weight.grad, d1.weight.grad); close(l1.bias.grad, d1.bias.grad)
+        close(l2.weight.grad, d2.weight.grad); close(l2.bias.grad, d2.bias.grad)
+    else:
+        assert l1.weight.grad is None and l2.weight.grad is None
