@@ -480,9 +480,22 @@ static int gemm_wgrad(const float* dy, int I, const float* x, int J, float* dW, 
       return (int)(sp > max_s ? max_s : (sp < 1 ? 1 : sp));
     };
     if (I > 512 && opt(O_WGRAD_WS)) {
-      static const int ws_splits = [] { const char* e = getenv("NRL_WGRAD_WS_SPLITS"); return e ? atoi(e) : 32; }();
-      return launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, M >= (int64_t)ws_splits * 512 ? ws_splits : splits(256), st,
-                                                  scratch, scratch_floats);
+      // k-splits of the wave-specialised kernel: a multiple of 8 (split -> XCD mapping), chosen by a two-term cost in k-tile units,
+      // rounds of 256 workgroups x (k-tiles per split + the epilogue's atomics, ~12 k-tiles' worth: profiles/r05_wgrad_ws_probe.txt --
+      // 768 x 768 over 38400 rows: 16 splits 0.172 ms, 32 splits 0.195 ms; 3072 x 768: 8 splits 0.675, 32 splits 0.732).
+      // NRL_WGRAD_WS_SPLITS forces a count (A/B runs).
+      static const int forced = [] { const char* e = getenv("NRL_WGRAD_WS_SPLITS"); return e ? atoi(e) : 0; }();
+      int ws_splits = forced;
+      if (ws_splits <= 0) {
+        const int64_t tiles = ceil_div(I, 256) * ceil_div(J + 1, 160), ktiles = ceil_div(M, 32);
+        int64_t best = -1;
+        for (int sp = 8; sp <= 64; sp += 8) {
+          if (sp > 8 && ktiles / sp < 8) break;         // (at least 8 k-tiles per split)
+          const int64_t cost = ceil_div(tiles * sp, 256) * (ceil_div(ktiles, sp) + 12);
+          if (best < 0 || cost < best) best = cost, ws_splits = sp;
+        }
+      }
+      return launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, ws_splits, st, scratch, scratch_floats);
     }
     if (I > 512) return launch_gemm_bf16x3<X3_TILE_BIG>(a, b, epi, I, J + 1, M, splits(256), st);
     // small outputs: LDS-DMA staged, transposition at the fragment read (0.35 -> 0.30 ms at 300 x 300;

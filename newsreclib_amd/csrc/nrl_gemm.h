@@ -275,6 +275,12 @@ struct RCPlain {
     if (r < rows) return p + k * ld + r;
     return (ones && r == rows) ? nrl_dma_ones16 : nrl_dma_zero16;
   }
+  // the same matrix as "column pointer + k * stride" (nrl_gemm_ws.h's loaders: the row clamp, the 64-bit multiply and the edge
+  // selects once per task instead of once per 16 bytes): (k, r .. r + 3) at col(r) + k * kstride() while live(r), else (fill(r), 0, 0, 0)
+  __device__ __forceinline__ const float* col(int64_t r, int64_t) const { return p + (r < rows ? r : rows - 4); }
+  __device__ __forceinline__ int64_t kstride(int64_t) const { return ld; }
+  __device__ __forceinline__ bool live(int64_t r) const { return r < rows; }
+  __device__ __forceinline__ float fill(int64_t r) const { return (ones && r == rows) ? 1.f : 0.f; }
 };
 
 // the same head-plane matrix read k-major (weight gradient: k = activation row, r = logical column head * 64 + c)
@@ -290,6 +296,13 @@ struct RCSlab {
   __device__ __forceinline__ void finish(float4& v, int64_t k, int64_t r, int64_t kend) const {
     if (k >= kend || r >= rows) v = f4zero();
   }
+  __device__ __forceinline__ const float* col(int64_t r, int64_t K) const {
+    const int64_t rc = r < rows ? r : rows - 4;
+    return p + (rc >> 6) * K * 64 + (rc & 63);
+  }
+  __device__ __forceinline__ int64_t kstride(int64_t) const { return 64; }
+  __device__ __forceinline__ bool live(int64_t r) const { return r < rows; }
+  __device__ __forceinline__ float fill(int64_t) const { return 0.f; }
 };
 
 // ---------------------------------------------------------------------------------------------
