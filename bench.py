@@ -210,7 +210,9 @@ def extra_plm(device, batch_size=8, steps=3):
             "body_linears_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_linears),
             "body_attention_on_this_library": bool(mod.news_encoder.text_encoders["title"].nrl_attention),
             "body_output_blocks_on_this_library": int(mod.news_encoder.text_encoders["title"].nrl_output_blocks),
-            "body_embedding_tables_on_this_library": int(getattr(mod.news_encoder.text_encoders["title"], "nrl_embeddings", 0))}
+            "body_embedding_tables_on_this_library": int(getattr(mod.news_encoder.text_encoders["title"], "nrl_embeddings", 0)),
+            "body_ffn_blocks_as_one_function": int(getattr(mod.news_encoder.text_encoders["title"], "nrl_ffn_blocks", 0)),
+            "body_attention_blocks_as_one_function": int(getattr(mod.news_encoder.text_encoders["title"], "nrl_attention_blocks", 0))}
 
 
 def predict_multi_gpu(step_ms: float, world: int = 8):

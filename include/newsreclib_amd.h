@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 14
+#define NRL_ABI_VERSION 15
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -505,6 +505,24 @@ int nrl_linear_gelu_fwd_img(const float* a, const float* w, const float* bias, i
 int nrl_linear_dgrad_gelu_img(const float* w, const float* d_c, const float* pre, int64_t m, int32_t n, int32_t k, float* d_pre,
                               void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
 int32_t nrl_linear_gelu_supported(int32_t n_wide);
+/* ABI v15: the query / key / value projections of a transformer layer (HF RobertaSelfAttention.query / .key / .value inside
+ * self.plm_model(**text), text.py:89) -- three nn.Linear (n, k) of ONE input -- as one GEMM each way, and activation gradients that
+ * land on a residual stream with the other branch's gradient added in the epilogue.  bf16x3 engine; n and k multiples of 256 with
+ * at most 12 column panels (nrl_linear3_supported(n, k) != 0); workspace nrl_linear3_workspace_bytes(n, k), image_ready as in
+ * nrl_linear_fwd_img (one image of the three weights per direction).
+ *   nrl_linear3_fwd_img       c (3, m, n): c[q] = a (m, k) W_q^T + b_q
+ *   nrl_linear3_dgrad_img     d_a (m, k) = add + sum_q d_c[q] W_q, d_c (3, m, n) stacked like c; add (m, k) or NULL
+ *   nrl_linear_dgrad_add_img  d_a (m, k) = add + d_c (m, n) W (n, k) (k >= 256; workspace nrl_linear_workspace_bytes(n, k))
+ * The weight gradients stay three nrl_linear_bwd_img calls (d_a == NULL). */
+int32_t nrl_linear3_supported(int32_t n, int32_t k);
+size_t nrl_linear3_workspace_bytes(int32_t n, int32_t k);
+int nrl_linear3_fwd_img(const float* a, const float* w0, const float* w1, const float* w2, const float* b0, const float* b1,
+                        const float* b2, int64_t m, int32_t n, int32_t k, float* c, void* ws, size_t ws_bytes, int32_t image_ready,
+                        void* stream);
+int nrl_linear3_dgrad_img(const float* d_c, const float* w0, const float* w1, const float* w2, int64_t m, int32_t n, int32_t k,
+                          const float* add, float* d_a, void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
+int nrl_linear_dgrad_add_img(const float* d_c, const float* w, int64_t m, int32_t n, int32_t k, const float* add, float* d_a,
+                             void* ws, size_t ws_bytes, int32_t image_ready, void* stream);
 /* ABI v14: embedding_dense_backward of ANY nn.Embedding (the word / position / token-type tables of the PLM body, text.py:89):
  * d_table[ids[p]] += d_out[p] for the n_ids positions in the id-sorted order `sorted_positions` (nrl_sort_positions: n_ids + 1
  * entries, the last one unused here), one atomic per (id, 64-position segment, element) instead of one per element; the row

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -187,6 +187,14 @@ SIGNATURES = {
     "nrl_linear_dgrad_gelu_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
                                             c_int32, c_void_p]),
     "nrl_linear_gelu_supported": (c_int32, [c_int32]),
+    "nrl_linear3_supported": (c_int32, [c_int32, c_int32]),
+    "nrl_linear3_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "nrl_linear3_fwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                      c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "nrl_linear3_dgrad_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                        c_void_p, c_size_t, c_int32, c_void_p]),
+    "nrl_linear_dgrad_add_img": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_int32, c_void_p]),
     "nrl_embedding_grad": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p]),
     "nrl_linear_bwd_img": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_int32, c_void_p]),

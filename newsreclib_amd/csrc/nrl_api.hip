@@ -521,6 +521,86 @@ int nrl_linear_dgrad_gelu_img(const float* w, const float* d_c, const float* pre
   return linear_panels(d_c, w, 1, k, k, n, EpiGeluBwd{d_pre, k, pre}, m, (uint16_t*)ws, (hipStream_t)stream, image_ready == 0);
 }
 
+// ---- three projections of one input (query / key / value of a transformer layer) as one GEMM each way, ABI v15 -----------
+// forward image: 3 n output columns over k, panel p of weight p / (n / 256); backward image: k output columns over the 3 n
+// concatenated reduction rows, part q of panel p at k-block q * (n / 32)
+static inline bool lin3_ok(int n, int k) {
+  return cur_engine() == ENGINE_BF16X3 && opt(O_ROWPANEL) && n % (16 * LIN_PANEL_BLOCKS) == 0 && k % (16 * LIN_PANEL_BLOCKS) == 0 &&
+         3 * lin_panels(n) <= RP_MAX_JOBS && 3 * lin_panels(k) <= RP_MAX_JOBS;
+}
+int32_t nrl_linear3_supported(int32_t n, int32_t k) { return (n > 0 && k > 0 && lin3_ok(n, k)) ? 1 : 0; }
+size_t nrl_linear3_workspace_bytes(int32_t n, int32_t k) {
+  size_t e = lin_image_elems(3 * n, k);
+  if (lin_image_elems(k, 3 * n) > e) e = lin_image_elems(k, 3 * n);
+  return align_up(e * sizeof(uint16_t), 256);
+}
+
+int nrl_linear3_fwd_img(const float* a, const float* w0, const float* w1, const float* w2, const float* b0, const float* b1,
+                        const float* b2, int64_t m, int32_t n, int32_t k, float* c, void* ws, size_t ws_bytes, int32_t image_ready,
+                        void* stream) {
+  NRL_REQUIRE(a && w0 && w1 && w2 && b0 && b1 && b2 && c && m >= 0 && n > 0 && k > 0, "linear3_fwd: bad arguments");
+  NRL_REQUIRE(lin3_ok(n, k), "linear3_fwd: bf16x3 engine, n and k multiples of 256, at most 12 panels (nrl_linear3_supported)");
+  NRL_REQUIRE((((uintptr_t)a | (uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)c) & 15) == 0,
+              "linear3_fwd: 16-byte alignment");
+  NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0 && ws_bytes >= nrl_linear3_workspace_bytes(n, k), "linear3_fwd: workspace");
+  if (m == 0) return NRL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int pp = lin_panels(n), P = 3 * pp, kb = rp_kblocks(k, false), pw = 16 * LIN_PANEL_BLOCKS;
+  const size_t pe = rp_image_elems(LIN_PANEL_BLOCKS, kb);
+  uint16_t* img = (uint16_t*)ws;
+  if (image_ready == 0) {
+    const float* w[3] = {w0, w1, w2};
+    RpImageJobs jobs;
+    rp_jobs_init(&jobs);
+    for (int p = 0; p < P; ++p)      // element (column j, reduction i) = W_q[j][i]
+      rp_jobs_add(&jobs, w[p / pp] + (int64_t)(p % pp) * pw * k, k, 1, pw, k, nullptr, img + (size_t)p * pe, LIN_PANEL_BLOCKS);
+    NRL_TRY(rp_jobs_launch(jobs, st));
+  }
+  RpImage im;
+  im.img = img; im.nblk = LIN_PANEL_BLOCKS; im.kblocks = kb;
+  return launch_rp_gemm<LIN_PANEL_BLOCKS, 4, 0, 2>(KCPlain{a, k, m}, im, EpiLinearParts{c, m * (int64_t)n, n, b0, b1, b2}, m, 3 * n, k, st, P);
+}
+
+// d_a (m, k) = add + sum_q d_c[q] (m, n) W_q (n, k);  d_c: the three gradients stacked (3, m, n);  add (m, k) or NULL
+int nrl_linear3_dgrad_img(const float* d_c, const float* w0, const float* w1, const float* w2, int64_t m, int32_t n, int32_t k,
+                          const float* add, float* d_a, void* ws, size_t ws_bytes, int32_t image_ready, void* stream) {
+  NRL_REQUIRE(d_c && w0 && w1 && w2 && d_a && m >= 0 && n > 0 && k > 0, "linear3_dgrad: bad arguments");
+  NRL_REQUIRE(lin3_ok(n, k), "linear3_dgrad: bf16x3 engine, n and k multiples of 256, at most 12 panels (nrl_linear3_supported)");
+  NRL_REQUIRE((((uintptr_t)d_c | (uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)add | (uintptr_t)d_a) & 15) == 0,
+              "linear3_dgrad: 16-byte alignment");
+  NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0 && ws_bytes >= nrl_linear3_workspace_bytes(n, k), "linear3_dgrad: workspace");
+  if (m == 0) return NRL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = lin_panels(k), kbp = n / 32, kb = 3 * kbp, pw = 16 * LIN_PANEL_BLOCKS;
+  const size_t pe = rp_image_elems(LIN_PANEL_BLOCKS, kb), part = rp_image_elems(LIN_PANEL_BLOCKS, kbp);
+  uint16_t* img = (uint16_t*)ws;
+  if (image_ready == 0) {
+    const float* w[3] = {w0, w1, w2};
+    RpImageJobs jobs;
+    rp_jobs_init(&jobs);
+    for (int p = 0; p < P; ++p)      // element (column j, reduction i of part q) = W_q[i][j]
+      for (int q = 0; q < 3; ++q)
+        rp_jobs_add(&jobs, w[q] + (int64_t)p * pw, 1, k, pw, n, nullptr, img + (size_t)p * pe + (size_t)q * part, LIN_PANEL_BLOCKS);
+    NRL_TRY(rp_jobs_launch(jobs, st));
+  }
+  RpImage im;
+  im.img = img; im.nblk = LIN_PANEL_BLOCKS; im.kblocks = kb;
+  const KCParts A{d_c, n, m, n, m * (int64_t)n};
+  if (add != nullptr) return launch_rp_gemm<LIN_PANEL_BLOCKS, 4, 0, 2>(A, im, EpiAddStore{d_a, k, add}, m, k, 3 * n, st, P);
+  return launch_rp_gemm<LIN_PANEL_BLOCKS, 4, 0, 2>(A, im, EpiStore{d_a, k}, m, k, 3 * n, st, P);
+}
+
+// d_a (m, k) = add (m, k) + d_c (m, n) W (n, k): nrl_linear_bwd_img's activation gradient landing on a residual stream
+int nrl_linear_dgrad_add_img(const float* d_c, const float* w, int64_t m, int32_t n, int32_t k, const float* add, float* d_a,
+                             void* ws, size_t ws_bytes, int32_t image_ready, void* stream) {
+  NRL_REQUIRE(d_c && w && add && d_a && m >= 0 && n > 0 && k > 0 && k % 4 == 0 && n % 4 == 0, "linear_dgrad_add: bad arguments");
+  NRL_REQUIRE((((uintptr_t)d_c | (uintptr_t)w | (uintptr_t)add | (uintptr_t)d_a) & 15) == 0, "linear_dgrad_add: 16-byte alignment");
+  NRL_REQUIRE(cur_engine() == ENGINE_BF16X3 && lin_panels_on(k), "linear_dgrad_add: bf16x3 engine and k >= 256 (nrl_linear_gelu_supported)");
+  NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0 && ws_bytes >= nrl_linear_workspace_bytes(n, k), "linear_dgrad_add: workspace");
+  if (m == 0) return NRL_OK;
+  return linear_panels(d_c, w, 1, k, k, n, EpiAddStore{d_a, k, add}, m, (uint16_t*)ws, (hipStream_t)stream, image_ready == 0);
+}
+
 int32_t nrl_linear_gelu_supported(int32_t n_wide) { return (cur_engine() == ENGINE_BF16X3 && lin_panels_on(n_wide)) ? 1 : 0; }
 
 int nrl_embedding_grad(const float* d_out, const int64_t* ids, const int64_t* sorted_positions, int64_t n_ids, int32_t dim,

@@ -84,6 +84,35 @@ struct KCPlain {
   }
 };
 
+// three (rows x kp) row-major matrices side by side along k: element (row r, k) of [P0 | P1 | P2] lives at
+// p[(k / kp) * part_stride + r * ld + k % kp] -- the activation gradient of three projections of ONE input (the query / key /
+// value projections of a transformer layer) is a single GEMM over the concatenated reduction, round 5.  kp % 32 == 0: the lanes
+// of one k-block share their part.
+struct KCParts {
+  static constexpr int kLayout = SRC_KC;
+  const float* p;
+  int64_t ld;
+  int64_t rows;
+  int kp;
+  int64_t part_stride;
+  struct State {
+    const float* ptr;
+    bool ok;
+  };
+  __device__ __forceinline__ State init(int64_t r) const {
+    const bool ok = r < rows;
+    return State{p + (ok ? r : 0) * ld, ok};
+  }
+  __device__ __forceinline__ float4 load(const State& s, int k, int K) const {
+    const int kc = k < K ? k : K - 4;
+    const int64_t hop = part_stride - kp;
+    return *reinterpret_cast<const float4*>(s.ptr + kc + (kc >= kp ? hop : 0) + (kc >= 2 * kp ? hop : 0));
+  }
+  __device__ __forceinline__ void finish(float4& v, const State& s, int64_t, int k, int kend, bool) const {
+    if (!s.ok || k >= kend) v = f4zero();
+  }
+};
+
 // "head-plane" activation of the fused news path (nrl_news_fused.h): logical element (row m, k' = head * 64 + c) of
 // a (rows x heads * 64) matrix lives at p[(head * rows + m) * 64 + c] -- one (rows x 64) row-major plane per head,
 // so the L rows x 64 floats of a (news, head) pair are ONE contiguous slab for the attention kernels that produce it
@@ -476,6 +505,55 @@ struct EpiGeluBwd {
   __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
     const float4 p = *reinterpret_cast<const float4*>(r.pre + n);
     store4(r.out + n, make_float4(v.x * gelu_grad_f(p.x), v.y * gelu_grad_f(p.y), v.z * gelu_grad_f(p.z), v.w * gelu_grad_f(p.w)), 0);
+  }
+};
+
+// three projections of one input in ONE GEMM (round 5): column n of [C0 | C1 | C2], part q = n / np, goes to row m of the
+// (M, np) matrix at c + q * part_stride with that part's bias -- the attention kernels read q, k, v as three plain matrices
+struct EpiLinearParts {
+  float* c;
+  int64_t part_stride;
+  int np;
+  const float* b0;
+  const float* b1;
+  const float* b2;
+  struct Row {
+    float* out;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * np}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const {
+    const int q = (n >= np ? 1 : 0) + (n >= 2 * np ? 1 : 0), nn = n - q * np;
+    const float* b = q == 0 ? b0 : (q == 1 ? b1 : b2);
+    r.out[q * part_stride + nn] = v + b[nn];
+  }
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const {
+    return (np & 3) == 0 && (part_stride & 3) == 0 && (((uintptr_t)c | (uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0;
+  }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    const int q = (n >= np ? 1 : 0) + (n >= 2 * np ? 1 : 0), nn = n - q * np;
+    const float* b = q == 0 ? b0 : (q == 1 ? b1 : b2);
+    const float4 bv = *reinterpret_cast<const float4*>(b + nn);
+    store4(r.out + q * part_stride + nn, make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w), 0);
+  }
+};
+// c = v + add: an activation gradient that lands on a tensor with a second consumer (the residual stream of a transformer layer)
+// takes the other branch's gradient in the epilogue instead of leaving the sum to a framework kernel
+struct EpiAddStore {
+  float* c;
+  int64_t ldc;
+  const float* add;    // (M, N), same leading dimension
+  struct Row {
+    float* out;
+    const float* add;
+  };
+  __device__ __forceinline__ Row row(int64_t m) const { return Row{c + m * ldc, add + m * ldc}; }
+  __device__ __forceinline__ void operator()(const Row& r, int64_t, int n, float v) const { r.out[n] = v + r.add[n]; }
+  static constexpr bool kVec4 = true;
+  __device__ __forceinline__ bool vec_ok() const { return (ldc & 3) == 0 && (((uintptr_t)c | (uintptr_t)add) & 15) == 0; }
+  __device__ __forceinline__ void vec4(const Row& r, int64_t, int n, float4 v) const {
+    const float4 a = *reinterpret_cast<const float4*>(r.add + n);
+    store4(r.out + n, make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w), 0);
   }
 };
 

@@ -299,8 +299,20 @@ def _fused_ffn_chunk(self, attention_output: torch.Tensor) -> torch.Tensor:
             lin._images.invalidate()
         return lin._images if not trainable else (lin._step_images if ops_blocks.step_images_allowed() else None)
 
+    out, ln = self.output, self.output.LayerNorm
+    if _FFN_GLUE and ln.weight is not None and ln.bias is not None and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and x.numel() < (1 << 32) \
+            and d2.out_features == d1.in_features:
+        # ... and the layer's closing dropout + residual + LayerNorm inside the same function (the first projection's activation
+        # gradient takes the residual branch's gradient in its epilogue)
+        pd = float(out.dropout.p) if out.training else 0.0
+        pp = p + (ln.weight, ln.bias)
+        return ops_blocks.FfnBlockFn.apply(x.contiguous(), *pp, float(ln.eps), pd, _draw_seed() if pd > 0.0 else 0, _grad_bufs(pp),
+                                           images(d1), images(d2))
     y = ops_blocks.FfnFn.apply(x.contiguous(), *p, _grad_bufs(p), images(d1), images(d2))
     return _output_glue(self.output, y, x)
+
+
+_FFN_GLUE = os.environ.get("NRL_PLM_FFN_GLUE", "1") != "0"      # (A/B: the closing glue inside the feed-forward function)
 
 
 def swap_ffn_blocks(module: nn.Module) -> int:
@@ -345,12 +357,37 @@ def swap_output_blocks(module: nn.Module) -> int:
 NRL_ATTENTION = "nrl_x3"
 # calls of the PLM body that did NOT run on this library's kernels (framework fallbacks), by kind; `reset_fallback_calls()` zeroes
 FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0, "output_block_cuda": 0, "output_block_host": 0,
-                  "embedding_cuda": 0, "embedding_host": 0, "ffn_cuda": 0, "ffn_host": 0}
+                  "embedding_cuda": 0, "embedding_host": 0, "ffn_cuda": 0, "ffn_host": 0, "attention_block_cuda": 0,
+                  "attention_block_host": 0}
 
 
 def reset_fallback_calls() -> None:
     for k in FALLBACK_CALLS:
         FALLBACK_CALLS[k] = 0
+
+
+def _key_padding_keep(module, attention_mask, N: int, L: int):
+    """-> (ok, keep): the (N, L) uint8 key-padding mask (1 = attend; None: no mask) behind HF's 4-D mask of a bidirectional encoder,
+    or ok == False for a mask that is not one.  HF materialises the encoder's mask as (N, 1, L, L); whether its query rows are all the
+    same row is a property of the MODEL (encoder vs decoder), so it is verified on the first call of each module (one device
+    comparison + sync) and remembered on the module."""
+    if attention_mask is None:
+        return True, None
+    m = attention_mask
+    if not (m.dim() == 4 and m.shape[0] == N and m.shape[1] == 1 and m.shape[3] == L and m.shape[2] in (1, L)):
+        return False, None
+    if m.shape[2] == L:
+        invariant = getattr(module, "_nrl_mask_query_invariant", None)
+        if invariant is None:
+            invariant = bool(torch.equal(m, m[:, :, :1, :].expand_as(m)))
+            try:
+                module._nrl_mask_query_invariant = invariant
+            except Exception:
+                pass
+        if not invariant:
+            return False, None
+    row = m[:, 0, 0, :]
+    return True, (row if row.dtype == torch.bool else (row == 0)).to(torch.uint8)
 
 
 def _nrl_body_attention(module, query, key, value, attention_mask, dropout: float = 0.0, scaling=None, **kwargs):
@@ -362,29 +399,12 @@ def _nrl_body_attention(module, query, key, value, attention_mask, dropout: floa
     N, H, L, dh = query.shape
     ok = (query.is_cuda and query.dtype == torch.float32 and key.shape == query.shape and value.shape == query.shape
           and _lib.engine_code() == 2 and ops_blocks.sdpa_supported(N, L, H, dh))     # (2 = the bf16x3 engine)
-    # a causal / query-dependent mask is NOT a key-padding mask.  HF materialises the bidirectional encoder's mask as (N, 1, L, L);
-    # whether its query rows are all the same row is a property of the MODEL (encoder vs decoder), so it is verified on the
-    # first call of each attention module (one device comparison + sync) and remembered on the module
+    # a causal / query-dependent mask is NOT a key-padding mask
     if kwargs.get("is_causal") or getattr(module, "is_causal", False):
         ok = False
     keep = None
-    if ok and attention_mask is not None:
-        m = attention_mask
-        if m.dim() == 4 and m.shape[0] == N and m.shape[1] == 1 and m.shape[3] == L and m.shape[2] in (1, L):
-            if m.shape[2] == L:
-                invariant = getattr(module, "_nrl_mask_query_invariant", None)
-                if invariant is None:
-                    invariant = bool(torch.equal(m, m[:, :, :1, :].expand_as(m)))
-                    try:
-                        module._nrl_mask_query_invariant = invariant
-                    except Exception:
-                        pass
-                ok = invariant
-            if ok:
-                row = m[:, 0, 0, :]
-                keep = (row if row.dtype == torch.bool else (row == 0)).to(torch.uint8)
-        else:
-            ok = False
+    if ok:
+        ok, keep = _key_padding_keep(module, attention_mask, N, L)
     if ok and float(dropout) > 0.0 and N * H >= (1 << 18):     # (the kernels' 32-bit dropout counter: nrl_sdpa_x3.hip)
         ok = False
     if not ok:
@@ -395,6 +415,79 @@ def _nrl_body_attention(module, query, key, value, attention_mask, dropout: floa
     out = ops_blocks.SdpaFn.apply(query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2), keep, scale, p,
                                   _draw_seed() if p > 0.0 else 0)
     return out, None
+
+
+def _fused_attention_forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                             past_key_values=None, **kwargs):
+    """``RobertaAttention.forward`` (self-attention + ``RobertaSelfOutput``) as ONE autograd function, ``ops_blocks.AttnBlockFn``: the
+    query / key / value projections as one GEMM each way, the residual branch's gradient added in the activation-gradient epilogue.
+    Anything the function does not cover (cross attention, caches, attention weights asked for, causal or query-dependent masks,
+    shapes off the kernels) runs the module's own forward -- which still uses this library's per-op replacements."""
+    sa, so = self.self, self.output
+    x = hidden_states
+    ok = (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and encoder_hidden_states is None
+          and past_key_values is None and not getattr(self, "is_cross_attention", False) and not kwargs.get("output_attentions")
+          and not getattr(sa, "is_causal", False) and not kwargs.get("is_causal")
+          and getattr(sa.config, "_attn_implementation", None) == NRL_ATTENTION and _lib.engine_code() == 2)
+    keep = None
+    if ok:
+        N, L, K = x.shape
+        H, dh = sa.num_attention_heads, sa.attention_head_size
+        ln = so.LayerNorm
+        ok = (ops_blocks.sdpa_supported(N, L, H, dh) and bool(_lib.load().nrl_linear3_supported(H * dh, K))
+              and so.dense.in_features == H * dh and so.dense.out_features == K
+              and ln.weight is not None and ln.bias is not None and K % 4 == 0 and K <= 2048 and x.numel() < (1 << 32))
+        p_attn = float(sa.dropout.p) if sa.training else 0.0
+        if ok and p_attn > 0.0 and N * H >= (1 << 18):
+            ok = False
+        if ok:
+            ok, keep = _key_padding_keep(sa, attention_mask, N, L)
+    if not ok:
+        FALLBACK_CALLS["attention_block_cuda" if (torch.is_tensor(x) and x.is_cuda) else "attention_block_host"] += 1
+        return self._nrl_module_forward(hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask, past_key_values,
+                                        **kwargs)
+    lins = (sa.query, sa.key, sa.value)
+    trainable = any(l.weight.requires_grad or l.bias.requires_grad for l in lins)
+    if trainable:
+        self._nrl_qkv_images.invalidate()
+    img_qkv = self._nrl_qkv_images if not trainable else (self._nrl_qkv_step_images if ops_blocks.step_images_allowed() else None)
+    od = so.dense
+    o_train = od.weight.requires_grad or od.bias.requires_grad
+    if o_train and od._images is not None:
+        od._images.invalidate()
+    img_o = od._images if not o_train else (od._step_images if ops_blocks.step_images_allowed() else None)
+    p_hid = float(so.dropout.p) if so.training else 0.0
+    params = (sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias, od.weight, od.bias,
+              ln.weight, ln.bias)
+    y = ops_blocks.AttnBlockFn.apply(x.contiguous(), keep, *params, H, float(sa.scaling), p_attn, _draw_seed() if p_attn > 0.0 else 0,
+                                     float(ln.eps), p_hid, _draw_seed() if p_hid > 0.0 else 0, _grad_bufs(params), img_qkv, img_o)
+    return y, None
+
+
+def swap_attention_blocks(module: nn.Module) -> int:
+    """Gives every ``RobertaAttention``-shaped module below ``module`` (``self`` with NrlLinear query / key / value, ``output`` with an
+    NrlLinear ``dense`` + dropout + LayerNorm) the one-function forward above; returns how many.  Parameters and state-dict keys are
+    untouched; the module's own forward stays reachable for everything the function does not cover."""
+    import types
+    n = 0
+    for m in module.modules():
+        sa, so = getattr(m, "self", None), getattr(m, "output", None)
+        if sa is None or so is None or not all(isinstance(getattr(sa, k, None), NrlLinear) for k in ("query", "key", "value")):
+            continue
+        if not (isinstance(getattr(so, "dense", None), NrlLinear) and isinstance(getattr(so, "LayerNorm", None), nn.LayerNorm)
+                and isinstance(getattr(so, "dropout", None), nn.Dropout) and isinstance(getattr(sa, "dropout", None), nn.Dropout)
+                and hasattr(sa, "num_attention_heads") and hasattr(sa, "attention_head_size") and hasattr(sa, "scaling")
+                and hasattr(sa, "config") and so.dense._images is not None):
+            continue
+        if sa.query.in_features != sa.key.in_features or sa.query.in_features != sa.value.in_features \
+                or not (sa.query.out_features == sa.key.out_features == sa.value.out_features):
+            continue
+        m._nrl_module_forward = m.forward
+        m._nrl_qkv_images = ops_blocks.FrozenImages()
+        m._nrl_qkv_step_images = ops_blocks.FrozenImages(allow_trainable=True)
+        m.forward = types.MethodType(_fused_attention_forward, m)
+        n += 1
+    return n
 
 
 def register_body_attention() -> bool:
@@ -465,6 +558,12 @@ class PLM(nn.Module):
                 self.nrl_attention = True
             except Exception:      # (a transformers version that validates the name against a closed list)
                 self.nrl_attention = False
+        # ... and the attention half of every layer as one autograd function (one q | k | v GEMM each way, the residual gradient in the
+        # activation-gradient epilogue); NRL_PLM_ATTN_BLOCK=0 keeps the per-op modules (A/B)
+        self.nrl_attention_blocks = 0
+        if os.environ.get("NRL_PLM_ATTN_BLOCK", "1") != "0" and self.nrl_attention and self.nrl_linears and self.nrl_output_blocks \
+                and os.environ.get("NRL_PLM_IMAGE_CACHE", "1") != "0" and hasattr(self.plm_model, "encoder"):
+            self.nrl_attention_blocks = swap_attention_blocks(self.plm_model.encoder)
         for name, param in self.plm_model.base_model.named_parameters():   # text.py:69-73
             for layer in (frozen_layers or []):
                 if "layer." + str(layer) + "." in name:

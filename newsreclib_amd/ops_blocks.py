@@ -380,6 +380,253 @@ class DropoutAddLayerNormFn(GradAwareFunction):
         return (d_x if d_x is not None else d_res, d_res, rets[0], rets[1], None, None, None, None)
 
 
+def _glue_fwd(lib, h, residual, gamma, beta, eps, p_drop, seed, save):
+    """LayerNorm(dropout(h) + residual) on (rows, dim) -> (y, z, stats); z, stats None unless ``save``."""
+    rows, dim = h.shape
+    y = torch.empty_like(h)
+    z = torch.empty_like(h) if save else None
+    stats = torch.empty((2, rows), dtype=torch.float32, device=h.device) if save else None
+    _lib.check(lib.nrl_dropout_add_layernorm_fwd(
+        h.data_ptr(), residual.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, dim, float(eps), float(p_drop), int(seed), 0,
+        z.data_ptr() if save else None, stats[0].data_ptr() if save else None, stats[1].data_ptr() if save else None,
+        y.data_ptr(), _stream()), "nrl_dropout_add_layernorm_fwd")
+    return y, z, stats
+
+
+def _glue_bwd(lib, d_y, z, stats, gamma, p_drop, seed, dg, db):
+    """-> (gradient of the dropout's input, gradient of the residual); the same tensor when there is no dropout."""
+    rows, dim = z.shape
+    d_res = torch.empty_like(z)
+    d_h = torch.empty_like(z) if p_drop > 0.0 else None
+    _lib.check(lib.nrl_dropout_add_layernorm_bwd(
+        d_y.data_ptr(), z.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), rows, dim, p_drop, seed, 0,
+        d_h.data_ptr() if d_h is not None else None, d_res.data_ptr(), dg, db, _stream()), "nrl_dropout_add_layernorm_bwd")
+    return (d_h if d_h is not None else d_res), d_res
+
+
+def _wgrad_only(lib, a2, w, d_c, M, dw, db, dev):
+    """d_w += d_c^T a, d_bias += colsum(d_c) of one nn.Linear (no activation gradient, no image)."""
+    N, K = w.shape
+    ws = torch.empty(256, dtype=torch.uint8, device=dev)
+    _lib.check(lib.nrl_linear_bwd_img(a2.data_ptr(), w.data_ptr(), d_c.data_ptr(), M, N, K, None, dw.data_ptr(), db.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), 0, _stream()), "nrl_linear_bwd")
+
+
+class AttnBlockFn(GradAwareFunction):
+    """The attention half of a BERT-family layer as ONE autograd function (HF ``RobertaAttention`` = ``RobertaSelfAttention`` +
+    ``RobertaSelfOutput`` inside ``self.plm_model(**text)``, reference text.py:89):
+    y = LayerNorm(dropout(sdpa(x Wq^T + bq, x Wk^T + bk, x Wv^T + bv) Wo^T + bo) + x).
+    Round 5: the three projections are one GEMM (``nrl_linear3_fwd_img``: x streamed once, 9 column panels in one launch), their
+    activation gradient is one GEMM over the concatenated reduction (``nrl_linear3_dgrad_img``) whose epilogue adds the residual
+    branch's gradient -- the framework's two gradient adds per layer for q / k / v and the one for the residual stream are gone."""
+
+    @staticmethod
+    def forward(ctx, x, keep, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, heads, scale, p_attn, seed_attn, eps, p_hid, seed_hid,
+                grad_bufs, images_qkv, images_o):
+        lib = _lib.load()
+        x = _chk(x, torch.float32, "input")
+        params = [_chk(t, torch.float32, "attention-block parameter") for t in (wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta)]
+        wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta = params
+        if x.dim() != 3:
+            raise ValueError("newsreclib_amd: attention block expects (batch, seq, dim)")
+        Nb, L, K = x.shape
+        n = wq.shape[0]
+        if wq.shape != (n, K) or wk.shape != (n, K) or wv.shape != (n, K) or wo.shape != (K, n) or n % heads or \
+                any(b.shape != (n,) for b in (bq, bk, bv)) or bo.shape != (K,) or gamma.shape != (K,) or beta.shape != (K,):
+            raise ValueError("newsreclib_amd: inconsistent attention-block shapes")
+        dh = n // heads
+        if keep is not None:
+            keep = _chk(keep, torch.uint8, "key mask")
+            if tuple(keep.shape) != (Nb, L):
+                raise ValueError("newsreclib_amd: attention-block key mask must be (batch, seq)")
+        dev = x.device
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        save = saving(ctx)
+        # q | k | v stacked: (3, M, n)
+        qkv = torch.empty((3, M, n), dtype=torch.float32, device=dev)
+        nbytes = lib.nrl_linear3_workspace_bytes(n, K)
+        ws, ready, key = images_qkv.buffer_multi("fwd", (wq, wk, wv), nbytes, dev) if images_qkv is not None else (None, 0, None)
+        if ws is None:
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        _lib.check(lib.nrl_linear3_fwd_img(x2.data_ptr(), wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), bq.data_ptr(), bk.data_ptr(),
+                                           bv.data_ptr(), M, n, K, qkv.data_ptr(), ws.data_ptr(), ws.numel(), ready, _stream()),
+                   "nrl_linear3_fwd")
+        if key is not None:
+            images_qkv.commit("fwd", key)
+        o = torch.empty((M, n), dtype=torch.float32, device=dev)
+        lse = torch.empty((Nb * heads, L), dtype=torch.float32, device=dev) if save else None
+        _lib.check(lib.nrl_sdpa_fwd(qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), keep.data_ptr() if keep is not None else None,
+                                    Nb, L, heads, dh, float(scale), float(p_attn), int(seed_attn), 0, o.data_ptr(),
+                                    lse.data_ptr() if save else None, _stream()), "nrl_sdpa_fwd")
+        h = torch.empty((M, K), dtype=torch.float32, device=dev)
+        ws, ready, key = _image_ws(images_o, "fwd", wo, lib, dev)
+        _lib.check(lib.nrl_linear_fwd_img(o.data_ptr(), wo.data_ptr(), bo.data_ptr(), M, K, n, h.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          ready, _stream()), "nrl_linear_fwd")
+        if key is not None:
+            images_o.commit("fwd", key)
+        y, z, stats = _glue_fwd(lib, h, x2, gamma, beta, eps, p_hid, seed_hid, save)
+        if save:
+            nig = ctx.needs_input_grad
+            need_wqkv = any(nig[2:8])
+            ctx.save_for_backward(x2 if need_wqkv else None, qkv, o, lse, z, stats, keep, *params)
+            ctx.cfg = (heads, float(scale), float(p_attn), int(seed_attn), float(p_hid), int(seed_hid), (Nb, L, K))
+            ctx.grad_bufs, ctx.engine, ctx.images = grad_bufs, _lib.engine_code(), (images_qkv, images_o)
+        return y.view(Nb, L, K)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        _lib.require_engine(ctx.engine, "attention block")
+        x2, qkv, o, lse, z, stats, keep, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta = ctx.saved_tensors
+        heads, scale, p_attn, seed_attn, p_hid, seed_hid, (Nb, L, K) = ctx.cfg
+        images_qkv, images_o = ctx.images
+        n = wq.shape[0]
+        dh = n // heads
+        M = Nb * L
+        dev = d_y.device
+        d_y = _chk(d_y.reshape(M, K), torch.float32, "d_out")
+        nig = ctx.needs_input_grad
+        gb = ctx.grad_bufs
+        rets = [None] * 10
+
+        def targets(i0, ps):
+            bufs, r = _grad_targets(ps, gb[i0:i0 + len(ps)] if gb is not None else None)
+            rets[i0:i0 + len(ps)] = r
+            return bufs
+
+        dg = dbt = None
+        if nig[10] or nig[11]:
+            bufs = targets(8, [gamma, beta])
+            dg, dbt = bufs[0].data_ptr(), bufs[1].data_ptr()
+        d_h, d_res = _glue_bwd(lib, d_y, z, stats, gamma, p_hid, seed_hid, dg, dbt)
+        # out-projection: weight gradient + d_o
+        dw = db = None
+        need_wo = nig[8] or nig[9]
+        if need_wo:
+            bufs = targets(6, [wo, bo])
+            dw, db = bufs[0].data_ptr(), bufs[1].data_ptr()
+        d_o = torch.empty((M, n), dtype=torch.float32, device=dev)
+        ws, ready, key = _image_ws(images_o, "bwd", wo, lib, dev)
+        _lib.check(lib.nrl_linear_bwd_img(o.data_ptr() if need_wo else None, wo.data_ptr(), d_h.data_ptr(), M, K, n, d_o.data_ptr(), dw, db,
+                                          ws.data_ptr(), ws.numel(), ready, _stream()), "nrl_linear_bwd")
+        if key is not None:
+            images_o.commit("bwd", key)
+        dqkv = torch.empty((3, M, n), dtype=torch.float32, device=dev)
+        _lib.check(lib.nrl_sdpa_bwd(qkv[0].data_ptr(), qkv[1].data_ptr(), qkv[2].data_ptr(), keep.data_ptr() if keep is not None else None,
+                                    o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), Nb, L, heads, dh, scale, p_attn, seed_attn, 0,
+                                    dqkv[0].data_ptr(), dqkv[1].data_ptr(), dqkv[2].data_ptr(), _stream()), "nrl_sdpa_bwd")
+        for q, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+            if nig[2 + 2 * q] or nig[3 + 2 * q]:
+                bufs = targets(2 * q, [w, b])
+                _wgrad_only(lib, x2, w, dqkv[q], M, bufs[0], bufs[1], dev)
+        d_x = None
+        if nig[0]:
+            d_x = torch.empty((M, K), dtype=torch.float32, device=dev)
+            nbytes = lib.nrl_linear3_workspace_bytes(n, K)
+            ws, ready, key = images_qkv.buffer_multi("bwd", (wq, wk, wv), nbytes, dev) if images_qkv is not None else (None, 0, None)
+            if ws is None:
+                ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+            _lib.check(lib.nrl_linear3_dgrad_img(dqkv.data_ptr(), wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), M, n, K, d_res.data_ptr(),
+                                                 d_x.data_ptr(), ws.data_ptr(), ws.numel(), ready, _stream()), "nrl_linear3_dgrad")
+            if key is not None:
+                images_qkv.commit("bwd", key)
+            d_x = d_x.view(Nb, L, K)
+        return (d_x, None, *rets, *([None] * 10))
+
+
+class FfnBlockFn(GradAwareFunction):
+    """``FfnFn`` + the dropout / residual / LayerNorm that ends the layer (HF ``RobertaOutput``) as one function:
+    LayerNorm(dropout(gelu(x W1^T + b1) W2^T + b2) + x).  The first projection's activation gradient takes the residual branch's
+    gradient in its epilogue (``nrl_linear_dgrad_add_img``) instead of leaving the sum to a framework add."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p_hid, seed_hid, grad_bufs, images1, images2):
+        lib = _lib.load()
+        x = _chk(x, torch.float32, "input")
+        w1, b1, w2, b2, gamma, beta = (_chk(t, torch.float32, "ffn parameter") for t in (w1, b1, w2, b2, gamma, beta))
+        N1, K1 = w1.shape
+        N2, K2 = w2.shape
+        if x.shape[-1] != K1 or K2 != N1 or N2 != K1 or b1.shape != (N1,) or b2.shape != (N2,) or gamma.shape != (N2,) or beta.shape != (N2,):
+            raise ValueError("newsreclib_amd: inconsistent feed-forward block shapes")
+        x2 = x.reshape(-1, K1)
+        M = x2.shape[0]
+        dev = x.device
+        save = saving(ctx)
+        hh = torch.empty((M, N1), dtype=torch.float32, device=dev)
+        g = torch.empty((M, N1), dtype=torch.float32, device=dev)
+        ws, ready, key = _image_ws(images1, "fwd", w1, lib, dev)
+        _lib.check(lib.nrl_linear_gelu_fwd_img(x2.data_ptr(), w1.data_ptr(), b1.data_ptr(), M, N1, K1, hh.data_ptr(), g.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), ready, _stream()), "nrl_linear_gelu_fwd")
+        if key is not None:
+            images1.commit("fwd", key)
+        t = torch.empty((M, N2), dtype=torch.float32, device=dev)
+        ws, ready, key = _image_ws(images2, "fwd", w2, lib, dev)
+        _lib.check(lib.nrl_linear_fwd_img(g.data_ptr(), w2.data_ptr(), b2.data_ptr(), M, N2, K2, t.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), ready, _stream()), "nrl_linear_fwd")
+        if key is not None:
+            images2.commit("fwd", key)
+        y, z, stats = _glue_fwd(lib, t, x2, gamma, beta, eps, p_hid, seed_hid, save)
+        if save:
+            nig = ctx.needs_input_grad
+            need_w1, need_w2 = nig[1] or nig[2], nig[3] or nig[4]
+            ctx.save_for_backward(x2 if need_w1 else None, hh, g if need_w2 else None, z, stats, w1, b1, w2, b2, gamma, beta)
+            ctx.cfg = (float(p_hid), int(seed_hid), tuple(x.shape))
+            ctx.grad_bufs, ctx.engine, ctx.images = grad_bufs, _lib.engine_code(), (images1, images2)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        _lib.require_engine(ctx.engine, "feed-forward block")
+        x2, hh, g, z, stats, w1, b1, w2, b2, gamma, beta = ctx.saved_tensors
+        p_hid, seed_hid, in_shape = ctx.cfg
+        images1, images2 = ctx.images
+        N1, K1 = w1.shape
+        N2, K2 = w2.shape
+        M = z.shape[0]
+        dev = d_y.device
+        d_y = _chk(d_y.reshape(M, N2), torch.float32, "d_out")
+        nig = ctx.needs_input_grad
+        gb = ctx.grad_bufs
+        rets = [None] * 6
+
+        def targets(i0, ps):
+            bufs, r = _grad_targets(ps, gb[i0:i0 + len(ps)] if gb is not None else None)
+            rets[i0:i0 + len(ps)] = r
+            return bufs
+
+        dg = dbt = None
+        if nig[5] or nig[6]:
+            bufs = targets(4, [gamma, beta])
+            dg, dbt = bufs[0].data_ptr(), bufs[1].data_ptr()
+        d_t, d_res = _glue_bwd(lib, d_y, z, stats, gamma, p_hid, seed_hid, dg, dbt)
+        if g is not None:
+            bufs = targets(2, [w2, b2])
+            _wgrad_only(lib, g, w2, d_t, M, bufs[0], bufs[1], dev)
+        d_x = None
+        if not nig[0] and x2 is None:
+            return (None, *rets, None, None, None, None, None, None)
+        d_h = torch.empty((M, N1), dtype=torch.float32, device=dev)
+        ws, ready, key = _image_ws(images2, "bwd", w2, lib, dev)
+        _lib.check(lib.nrl_linear_dgrad_gelu_img(w2.data_ptr(), d_t.data_ptr(), hh.data_ptr(), M, N2, K2, d_h.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), ready, _stream()), "nrl_linear_dgrad_gelu")
+        if key is not None:
+            images2.commit("bwd", key)
+        if x2 is not None:
+            bufs = targets(0, [w1, b1])
+            _wgrad_only(lib, x2, w1, d_h, M, bufs[0], bufs[1], dev)
+        if nig[0]:
+            d_x = torch.empty((M, K1), dtype=torch.float32, device=dev)
+            ws, ready, key = _image_ws(images1, "bwd", w1, lib, dev)
+            _lib.check(lib.nrl_linear_dgrad_add_img(d_h.data_ptr(), w1.data_ptr(), M, N1, K1, d_res.data_ptr(), d_x.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), ready, _stream()), "nrl_linear_dgrad_add")
+            if key is not None:
+                images1.commit("bwd", key)
+            d_x = d_x.view(in_shape)
+        return (d_x, *rets, None, None, None, None, None, None)
+
+
 def sdpa_supported(n_batch: int, seq_len: int, heads: int, head_dim: int) -> bool:
     return bool(_lib.load().nrl_sdpa_supported(int(n_batch), int(seq_len), int(heads), int(head_dim)))
 
@@ -454,6 +701,24 @@ class FrozenImages:
         ready = 1 if self._key.get(which) == key else 0
         if not ready:
             self._key[which] = None          # a failed build must not leave the previous key standing over a half-written image
+        return buf, ready, key
+
+    def buffer_multi(self, which: str, weights, nbytes: int, device):
+        """``buffer`` for ONE image built from several weights (the fused query / key / value projections): any trainable one makes
+        the image a trainable weight's."""
+        trainable = any(w.requires_grad for w in weights)
+        if trainable and not self._allow_trainable:
+            self.invalidate()
+            return None, 0, None
+        key = (tuple((w.data_ptr(), w._version, tuple(w.shape), bool(w.requires_grad)) for w in weights), _lib.engine_code(),
+               _lib.options_word(), str(device), _IMAGE_GENERATION[0], _STEP_GENERATION[0] if self._allow_trainable else 0)
+        buf = self._buf.get(which)
+        if buf is None or buf.device != device or buf.numel() < nbytes:
+            buf = self._buf[which] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._key[which] = None
+        ready = 1 if self._key.get(which) == key else 0
+        if not ready:
+            self._key[which] = None
         return buf, ready, key
 
     def commit(self, which: str, key) -> None:

@@ -322,6 +322,7 @@ def test_plm_full_width_step_runs_on_this_library(tmp_path):
         recs_fpath=None, optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None).to(DEV)
     te = mod.news_encoder.text_encoders["title"]
     assert te.nrl_linears == 72 and te.nrl_attention and te.nrl_output_blocks == 24
+    assert te.nrl_ffn_blocks == 12 and te.nrl_attention_blocks == 12 and te.nrl_embeddings >= 2
     trainer = NRMSTrainer(mod, lr=1e-4)
     b = make_batch(8, vocab=50000, mode="fixed", seed=1, L=96, device=DEV)
     for part in ("x_hist", "x_cand"):
@@ -348,6 +349,7 @@ def test_plm_full_width_step_runs_on_this_library(tmp_path):
     ne.FALLBACK_CALLS.update(fb_train)
     fb = dict(ne.FALLBACK_CALLS)
     assert fb["linear_cuda"] == 0 and fb["attention"] == 0 and fb["output_block_cuda"] == 0 and fb["embedding_cuda"] == 0, fb
+    assert fb["ffn_cuda"] == 0 and fb["attention_block_cuda"] == 0, fb
 
 
 @pytest.mark.gpu
@@ -464,3 +466,106 @@ def test_feed_forward_block_with_gelu_in_the_epilogues_matches_torch(M, D, F, fr
         close(l2.weight.grad, d2.weight.grad); close(l2.bias.grad, d2.bias.grad)
     else:
         assert l1.weight.grad is None and l2.weight.grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,D,F", [(1000, 768, 3072), (77, 256, 512)])
+@pytest.mark.parametrize("frozen", [False, True])
+def test_feed_forward_block_with_its_closing_layer_norm_matches_torch(M, D, F, frozen):
+    """``ops_blocks.FfnBlockFn`` (ABI v15: ``nrl_linear_dgrad_add_img``): LayerNorm(gelu(x W1^T + b1) W2^T + b2 + x) -- the residual
+    branch's gradient is added in the epilogue of the first projection's activation gradient -- against fp64 torch (no dropout)."""
+    from newsreclib_amd import _lib, ops_blocks
+    _lib.set_gemm_engine("bf16x3")
+    torch.manual_seed(M + F + 1)
+    l1, l2, ln = torch.nn.Linear(D, F).to(DEV), torch.nn.Linear(F, D).to(DEV), torch.nn.LayerNorm(D).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.3, 0.3)
+    mods = (l1, l2, ln)
+    if frozen:
+        for m in mods:
+            for p in m.parameters():
+                p.requires_grad_(False)
+    x = torch.randn(M, D, device=DEV, requires_grad=True)
+    gy = torch.randn(M, D, device=DEV)
+    y = ops_blocks.FfnBlockFn.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, ln.weight, ln.bias, float(ln.eps), 0.0, 0, None, None, None)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    d1, d2, dn = torch.nn.Linear(D, F).double().to(DEV), torch.nn.Linear(F, D).double().to(DEV), torch.nn.LayerNorm(D).double().to(DEV)
+    for d, l in zip((d1, d2, dn), mods):
+        d.load_state_dict({k: v.double() for k, v in l.state_dict().items()})
+    ref = dn(d2(torch.nn.functional.gelu(d1(xd))) + xd)
+    ref.backward(gy.double())
+
+    def close(a, b, tol=1e-4):
+        assert float((a.double() - b).abs().max()) <= tol * max(1e-6, float(b.abs().max()))
+
+    close(y, ref.detach())
+    close(x.grad, xd.grad)
+    if not frozen:
+        for l, d in zip(mods, (d1, d2, dn)):
+            close(l.weight.grad, d.weight.grad); close(l.bias.grad, d.bias.grad)
+    else:
+        assert l1.weight.grad is None and ln.weight.grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,L,masked", [(12, 96, True), (5, 40, False)])
+@pytest.mark.parametrize("frozen", [False, True])
+def test_attention_block_as_one_function_matches_torch(N, L, masked, frozen):
+    """``ops_blocks.AttnBlockFn`` (ABI v15: ``nrl_linear3_fwd_img`` / ``nrl_linear3_dgrad_img``): LayerNorm(sdpa(x Wq^T + bq, x Wk^T + bk,
+    x Wv^T + bv) Wo^T + bo + x) with ONE GEMM for the three projections each way and the residual gradient in the activation-gradient
+    epilogue -- output, input gradient and all ten parameter gradients against fp64 torch (no dropout, key-padding mask)."""
+    from newsreclib_amd import _lib, ops_blocks
+    _lib.set_gemm_engine("bf16x3")
+    D, H = 768, 12
+    torch.manual_seed(N * L)
+    lq, lk, lv, lo = (torch.nn.Linear(D, D).to(DEV) for _ in range(4))
+    ln = torch.nn.LayerNorm(D).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.3, 0.3)
+    mods = (lq, lk, lv, lo, ln)
+    if frozen:
+        for m in mods:
+            for p in m.parameters():
+                p.requires_grad_(False)
+    keep = None
+    if masked:
+        lens = torch.randint(L // 3, L + 1, (N,), device=DEV)
+        keep = (torch.arange(L, device=DEV)[None, :] < lens[:, None]).to(torch.uint8)
+    x = torch.randn(N, L, D, device=DEV, requires_grad=True)
+    gy = torch.randn(N, L, D, device=DEV)
+    params = (lq.weight, lq.bias, lk.weight, lk.bias, lv.weight, lv.bias, lo.weight, lo.bias, ln.weight, ln.bias)
+    imgs = ops_blocks.FrozenImages() if frozen else None
+    for _ in range(2 if frozen else 1):          # (second pass of a frozen block: the kept images)
+        x.grad = None
+        y = ops_blocks.AttnBlockFn.apply(x, keep, *params, H, (D // H) ** -0.5, 0.0, 0, float(ln.eps), 0.0, 0, None, imgs, None)
+        y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    dq, dk, dv, do = (torch.nn.Linear(D, D).double().to(DEV) for _ in range(4))
+    dn = torch.nn.LayerNorm(D).double().to(DEV)
+    dmods = (dq, dk, dv, do, dn)
+    for d, l in zip(dmods, mods):
+        d.load_state_dict({k: v.double() for k, v in l.state_dict().items()})
+
+    def heads(t):
+        return t.view(N, L, H, D // H).transpose(1, 2)
+
+    am = None if keep is None else keep.bool()[:, None, None, :]
+    att = torch.nn.functional.scaled_dot_product_attention(heads(dq(xd)), heads(dk(xd)), heads(dv(xd)), attn_mask=am)
+    ref = dn(do(att.transpose(1, 2).reshape(N, L, D)) + xd)
+    ref.backward(gy.double())
+
+    def close(a, b, tol=2e-4):
+        assert float((a.double() - b).abs().max()) <= tol * max(1e-6, float(b.abs().max()))
+
+    close(y, ref.detach())
+    close(x.grad, xd.grad)
+    if not frozen:
+        for l, d in zip(mods, dmods):
+            close(l.weight.grad, d.weight.grad)
+            if l is lk:     # softmax is shift-invariant: the key bias has NO gradient (fp64: 1e-15) -- rounding noise against the others' scale
+                assert float(l.bias.grad.abs().max()) <= 2e-4 * float(dq.bias.grad.abs().max())
+            else:
+                close(l.bias.grad, d.bias.grad)
+    else:
+        assert lq.weight.grad is None and lo.weight.grad is None
