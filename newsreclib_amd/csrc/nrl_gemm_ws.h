@@ -37,7 +37,7 @@ __device__ __forceinline__ int ws_lds_off(int row, int chunk) {
   return pr * 64 + ((chunk ^ ((4 - ((pr >> 2) & 3) + (pr >> 4)) & 3)) * 16);
 }
 
-// ABL (probe builds only, tools/wgrad_ws_probe.hip): 1 = no epilogue, 2 = loaders store unsplit bits, 4 = no MFMAs, 8 = no global loads, 16 = one LDS buffer re-read by the MFMA waves, 32 = MFMA waves read their fragments once
+// ABL (probe builds only, tools/wgrad_ws_probe.hip): 1 = no epilogue, 2 = loaders store unsplit bits, 4 = no MFMAs, 8 = no global loads, 16 = one LDS buffer re-read by the MFMA waves, 32 = MFMA waves read their fragments once, 64 = no barriers, 128 = loaders re-read k-tile 0
 template <int NL, int WM, int WN, int TM, int TN, class AOp, class BOp, class Epi, bool FULLK, int ABL = 0>
 __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
     gemm_bf16x3_ws_kernel(const AOp A, const BOp B, const Epi epi, const int64_t M, const int N, const int64_t K,
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
               else S.r[q][e] = *reinterpret_cast<const float4*>(t_next[q] + e * t_stride[q]);
             }
           }
-          t_next[q] += BK * t_stride[q];
+          if constexpr (!(ABL & 128)) t_next[q] += BK * t_stride[q];      // (128: every k-tile re-reads the first one -- cache hits)
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -211,6 +211,12 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
       store_tiles((tt + 3) & 1, kk(tt + 3), S0);
       ws_barrier<ABL>();
     }
+    // (Tried on top, both slower, tools/wgrad_ws_probe.hip history / profiles/r05_ab.txt: the refill's loads issued in pairs BETWEEN the
+    //  four row splits -- hipcc's vmcnt bookkeeping across the loop's back edge then waits for all but the newest loads, 3.7 us per
+    //  k-tile against 2.0 -- and odd loader waves splitting first, fetching after -- the two orders meet at the back edge and the
+    //  register sets get copied, 7 us.  An L2 prefetch by the MFMA waves, one LDS-DMA dword per 128-byte line 2..12 k-tiles ahead,
+    //  changed nothing: with the loaders re-reading ONE k-tile out of cache their time only falls from 1.9 to 1.27 us per k-tile --
+    //  it is the issue of 56 KiB-instructions through the CU's one address unit plus the split, not the memory latency.)
     auto tail = [&](int t2, Stage& cur_next, Stage& refill) {
       if (t2 >= ntiles) return;
       if (t2 + 3 < ntiles) load_tiles(kk(t2 + 3), refill);

@@ -95,7 +95,7 @@ int main() {
       printf("I=%4d J=%4d %-44s %.3f ms (%.0f TF-bf16/s)\n", I, J, name, t, gf / t);
       fflush(stdout);
     };
-    for (int sp : {4, 8, 16, 17, 32})  {
+    for (int sp : {8, 16, 24, 32})  {
       char nm[64];
       snprintf(nm, sizeof nm, "product, atomics, splits=%d", sp);
       run(nm, [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, sp, st); });
@@ -124,6 +124,8 @@ int main() {
       fflush(stdout);
     };
     run("product", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, 1, st); });
+    run("no MFMAs, loaders re-read k-tile 0 (133)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 133>(a, b, epi, I, J + 1, M, 1, st); });
+    run("product but loaders re-read k-tile 0 (129)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 129>(a, b, epi, I, J + 1, M, 1, st); });
     run("no global loads (9)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 9>(a, b, epi, I, J + 1, M, 1, st); });
     run("no loads, no split (11)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 11>(a, b, epi, I, J + 1, M, 1, st); });
     run("no loads, no split, no LDS reads in the loop (43)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 43>(a, b, epi, I, J + 1, M, 1, st); });
