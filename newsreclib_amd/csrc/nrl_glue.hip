@@ -98,12 +98,19 @@ __global__ void __launch_bounds__(256) glue_ln_fwd_kernel(const GlueArgs A) {
   }
 }
 
-// RPW rows per wave, one after the other: the column sums of the two parameter gradients stay in registers across them, go
-// through LDS once per workgroup and leave as one atomic per column and workgroup.
-template <int NV, bool PARAMS>
-__global__ void __launch_bounds__(256) glue_ln_bwd_kernel(const GlueArgs A, const int rpw) {
-  __shared__ float s_red[PARAMS ? 2 * 3 * NV * 256 : 1];
+// RPW rows per wave, one after the other: the column sums of the two parameter gradients stay in registers across them, meet
+// in LDS once per workgroup (LDS float atomics into ONE 2 x dim image) and leave as one global atomic per column and workgroup.
+// WAVES = 16 with parameter gradients: the global atomics serialise per address at ~100 ns, so a launch costs (workgroups x 0.1 us)
+// whatever else it does -- 960 four-wave workgroups at 38400 x 768: 146 us against 60 without parameter gradients, 513 us at 3840
+// workgroups (round 5, tools/glue_bwd_time.py); sixteen waves per workgroup keep the same waves in flight behind 240 atomics per address.
+template <int NV, bool PARAMS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) glue_ln_bwd_kernel(const GlueArgs A, const int rpw) {
+  __shared__ float s_red[PARAMS ? 2 * NV * 256 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if constexpr (PARAMS) {
+    for (int i = threadIdx.x; i < 2 * NV * 256; i += WAVES * 64) s_red[i] = 0.f;
+    __syncthreads();
+  }
   const int dim = A.dim;
   const float inv = 1.0f / (float)dim;
   float4 gsum[NV], bsum[NV], gv[NV];
@@ -113,13 +120,36 @@ __global__ void __launch_bounds__(256) glue_ln_bwd_kernel(const GlueArgs A, cons
     gsum[i] = bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     gv[i] = c < dim ? *reinterpret_cast<const float4*>(A.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+  const int64_t row0 = ((int64_t)blockIdx.x * WAVES + wave) * rpw;
+  // the next row's d_y / z are in flight while this row is reduced and written (a wave walks its rows one after the other:
+  // without the prefetch every row paid a full memory latency -- 146 us against 42 for the one-row-per-wave form at 38400 x 768)
+  float4 ndy[NV], nz[NV];
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](int64_t row) {
+    const bool on = row < A.rows;
+    const int64_t r = on ? row : A.rows - 1;
+    const float* dyr = A.x + r * dim;
+    const float* zr = A.res + r * dim;
+    nmean = A.mean[r]; nrstd = A.rstd[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      ndy[i] = nz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < dim) {
+        ndy[i] = *reinterpret_cast<const float4*>(dyr + c);
+        nz[i] = *reinterpret_cast<const float4*>(zr + c);
+      }
+    }
+  };
+  if (row0 < A.rows) fetch(row0);
   for (int q = 0; q < rpw; ++q) {
     const int64_t row = row0 + q;
     if (row >= A.rows) break;
-    const float* dyr = A.x + row * dim;
-    const float* zr = A.res + row * dim;
-    const float mean = A.mean[row], rstd = A.rstd[row];
+    float4 cdy[NV], cz[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { cdy[i] = ndy[i]; cz[i] = nz[i]; }
+    const float mean = nmean, rstd = nrstd;
+    if (q + 1 < rpw) fetch(row + 1);
     float4 g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -127,7 +157,7 @@ __global__ void __launch_bounds__(256) glue_ln_bwd_kernel(const GlueArgs A, cons
       const int c = 4 * (lane + 64 * i);
       g[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < dim) {
-        const float4 dy = *reinterpret_cast<const float4*>(dyr + c), zv = *reinterpret_cast<const float4*>(zr + c);
+        const float4 dy = cdy[i], zv = cz[i];
         xh[i] = make_float4((zv.x - mean) * rstd, (zv.y - mean) * rstd, (zv.z - mean) * rstd, (zv.w - mean) * rstd);
         g[i] = make_float4(dy.x * gv[i].x, dy.y * gv[i].y, dy.z * gv[i].z, dy.w * gv[i].w);
         s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -163,33 +193,19 @@ __global__ void __launch_bounds__(256) glue_ln_bwd_kernel(const GlueArgs A, cons
     }
   }
   if constexpr (PARAMS) {
-    // waves 1..3 park their sums, wave 0 adds them in wave order and issues the atomics
-    if (wave > 0) {
-      float* mine = s_red + (size_t)(wave - 1) * 2 * NV * 256;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        *reinterpret_cast<float4*>(mine + (i * 64 + lane) * 4) = gsum[i];
-        *reinterpret_cast<float4*>(mine + NV * 256 + (i * 64 + lane) * 4) = bsum[i];
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < dim) {
+        atomicAdd(s_red + c, gsum[i].x); atomicAdd(s_red + c + 1, gsum[i].y); atomicAdd(s_red + c + 2, gsum[i].z); atomicAdd(s_red + c + 3, gsum[i].w);
+        float* sb = s_red + NV * 256 + c;
+        atomicAdd(sb, bsum[i].x); atomicAdd(sb + 1, bsum[i].y); atomicAdd(sb + 2, bsum[i].z); atomicAdd(sb + 3, bsum[i].w);
       }
     }
     __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int c = 4 * (lane + 64 * i);
-        if (c < dim) {
-          float4 gs = gsum[i], bs = bsum[i];
-#pragma unroll
-          for (int w = 0; w < 3; ++w) {
-            const float4 a = *reinterpret_cast<const float4*>(s_red + (size_t)w * 2 * NV * 256 + (i * 64 + lane) * 4);
-            const float4 b = *reinterpret_cast<const float4*>(s_red + (size_t)w * 2 * NV * 256 + NV * 256 + (i * 64 + lane) * 4);
-            gs.x += a.x; gs.y += a.y; gs.z += a.z; gs.w += a.w;
-            bs.x += b.x; bs.y += b.y; bs.z += b.z; bs.w += b.w;
-          }
-          atomicAdd(A.dgamma + c, gs.x); atomicAdd(A.dgamma + c + 1, gs.y); atomicAdd(A.dgamma + c + 2, gs.z); atomicAdd(A.dgamma + c + 3, gs.w);
-          atomicAdd(A.dbeta + c, bs.x); atomicAdd(A.dbeta + c + 1, bs.y); atomicAdd(A.dbeta + c + 2, bs.z); atomicAdd(A.dbeta + c + 3, bs.w);
-        }
-      }
+    for (int c = threadIdx.x; c < dim; c += WAVES * 64) {
+      atomicAdd(A.dgamma + c, s_red[c]);
+      atomicAdd(A.dbeta + c, s_red[NV * 256 + c]);
     }
   }
 }
@@ -208,15 +224,19 @@ static int glue_fwd_nv(const GlueArgs& a, hipStream_t st) {
 }
 template <int NV>
 static int glue_bwd_nv(const GlueArgs& a, hipStream_t st) {
-  // rows per wave: enough workgroups to fill the chip (>= 4 per CU), few enough that the parameter-gradient atomics stay cheap
-  int rpw = 1;
-  if (a.dgamma != nullptr) {
-    rpw = (int)((a.rows + 4095) / 4096);
-    rpw = rpw < 1 ? 1 : (rpw > 64 ? 64 : rpw);
+  if (a.dgamma == nullptr) {
+    const int64_t blocks = (a.rows + 3) / 4;
+    hipLaunchKernelGGL((glue_ln_bwd_kernel<NV, false, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, 1);
+    NRL_LAUNCH_CHECK();
+    return NRL_OK;
   }
-  const int64_t blocks = (a.rows + 4 * rpw - 1) / (4 * rpw);
-  if (a.dgamma != nullptr) hipLaunchKernelGGL((glue_ln_bwd_kernel<NV, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, rpw);
-  else hipLaunchKernelGGL((glue_ln_bwd_kernel<NV, false>), dim3((unsigned)blocks), dim3(256), 0, st, a, rpw);
+  // with parameter gradients: ~256 workgroups (one global atomic per column and workgroup), WAVES x rpw rows each
+  constexpr int WAVES = NV <= 3 ? 16 : (NV == 4 ? 8 : 4);       // (registers: 16 waves of a CU share 512 per lane and SIMD)
+  static const int forced = [] { const char* e = getenv("NRL_GLUE_RPW"); return e ? atoi(e) : 0; }();      // (A/B runs)
+  int rpw = forced > 0 ? forced : (int)((a.rows + 256 * WAVES - 1) / (256 * WAVES));
+  rpw = rpw < 1 ? 1 : (rpw > 256 ? 256 : rpw);
+  const int64_t blocks = (a.rows + WAVES * rpw - 1) / (WAVES * rpw);
+  hipLaunchKernelGGL((glue_ln_bwd_kernel<NV, true, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a, rpw);
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
