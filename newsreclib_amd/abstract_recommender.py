@@ -74,6 +74,8 @@ class AbstractRecommender(LightningModuleBase):
         candidates in ONE call (identical vectors, half the launches); the PLM encoder's seq-first attention
         couples the news of a call (text.py:92-96), so there the reference's two calls are kept."""
         if self.hparams.use_plm:
+            # (the transformer BODY is per news: one pass over both calls' texts, news_encoder.PLM.share_body; the tails stay two)
+            self.news_encoder.share_plm_bodies(batch["x_hist"], batch["x_cand"])
             return (self.news_encoder(batch["x_hist"], seed=seed),
                     self.news_encoder(batch["x_cand"], seed=seed, stream_base=4))
         n_hist = batch["batch_hist"].shape[0]

@@ -574,9 +574,49 @@ class PLM(nn.Module):
         self.dropout = nn.Dropout(p=dropout_probability)
         self.num_heads = num_heads
 
+    def share_body(self, texts) -> bool:
+        """Runs the transformer body ONCE over the news of several upcoming ``forward`` calls (round 5).  The reference calls this
+        encoder twice per step (history, candidates: nrms_module.py:232,236) and the two calls must stay two for everything AFTER the
+        body -- its seq-first attention runs across the news of a call (text.py:92-96) -- but the body itself treats every news on its
+        own (self-attention within a news, key-padding mask per news), so its hidden states over [history; candidates] are row for row
+        those of the two calls.  The small call is the inefficient one (3,840 token rows at B = 8: its GEMMs run at a third to two
+        thirds of the large call's rate and it doubles the launches and the trainable layers' image builds).  Only for texts with the
+        same keys, sequence length and device (a shorter call padded to the longer one would change the tail, which attends over
+        token positions without a mask); ``forward`` picks its rows up by the identity of ``input_ids``.  NRL_PLM_SHARE_BODY=0: off."""
+        self._shared = []
+        if len(texts) < 2 or os.environ.get("NRL_PLM_SHARE_BODY", "1") == "0":
+            return False
+        groups = {}
+        for t in texts:
+            if not (isinstance(t, dict) and torch.is_tensor(t.get("input_ids")) and t["input_ids"].dim() == 2
+                    and all(torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == t["input_ids"].shape[0] for v in t.values())):
+                continue
+            sig = tuple(sorted((k, tuple(v.shape[1:]), str(v.dtype), str(v.device)) for k, v in t.items()))
+            groups.setdefault(sig, []).append(t)
+        shared = False
+        for group in groups.values():        # (e.g. title texts of both calls in one pass, abstract texts in another)
+            if len(group) < 2:
+                continue
+            merged = {k: torch.cat([t[k] for t in group], dim=0) for k in group[0]}
+            hidden = self.plm_model(**merged)[0]
+            # (split, not slices: its backward is ONE concatenation of the calls' gradients)
+            for t, h in zip(group, torch.split(hidden, [int(t["input_ids"].shape[0]) for t in group], dim=0)):
+                self._shared.append((t["input_ids"], h))
+            shared = True
+        return shared
+
     def forward(self, text: Dict[str, torch.Tensor], seed: Optional[int] = None, order=None,
                 stream0: int = 0) -> torch.Tensor:
-        hidden = self.plm_model(**text)[0]                      # (N, L, D)
+        hidden = None
+        shared = getattr(self, "_shared", None)
+        if shared:
+            for i, (ids, h) in enumerate(shared):
+                if ids is text.get("input_ids"):
+                    hidden = h.contiguous()
+                    del shared[i]
+                    break
+        if hidden is None:
+            hidden = self.plm_model(**text)[0]                      # (N, L, D)
         p = float(self.dropout.p) if self.training else 0.0
         if p > 0.0 and seed is None:
             seed = _draw_seed()
@@ -639,6 +679,20 @@ class NewsEncoder(nn.Module):
                 assert isinstance(input_dim, int) and input_dim > 0
                 assert isinstance(query_dim, int) and query_dim > 0
                 self.combine_layer = AdditiveAttention(input_dim=input_dim, query_dim=query_dim)
+
+    def share_plm_bodies(self, *news_dicts) -> int:
+        """Before several ``forward`` calls of one step (history news, candidate news): every PLM text encoder runs its transformer
+        body once over the texts of all of them (``PLM.share_body``).  Returns how many encoders did."""
+        if not self.encode_text:
+            return 0
+        groups = {}
+        for name, enc in self.text_encoders.items():
+            if isinstance(enc, PLM):
+                texts = groups.setdefault(id(enc), (enc, []))[1]
+                for nd in news_dicts:
+                    if name in nd:
+                        texts.append(nd[name])
+        return sum(1 for enc, texts in groups.values() if enc.share_body(texts))
 
     def set_text_order(self, order) -> None:
         """Re-register the text encoders in the given attribute order (state_dict keys are unchanged)."""

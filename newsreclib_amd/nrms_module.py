@@ -178,6 +178,8 @@ class NRMSModule(AbstractRecommender):
         if self.hparams.use_plm:
             # the PLM encoder's seq-first attention runs ACROSS THE NEWS OF ONE CALL (text.py:92-96), so the two
             # calls of the reference (:232,236) are NOT interchangeable with one call over [history; candidates]
+            # (the transformer BODY treats every news on its own: it runs once over both calls' news, news_encoder.PLM.share_body)
+            self.news_encoder.share_plm_bodies(batch["x_hist"], batch["x_cand"])
             hist_vec = self.news_encoder(batch["x_hist"])
             cand_vec = self.news_encoder(batch["x_cand"])
             return self.score_news_vectors(hist_vec, cand_vec, batch)

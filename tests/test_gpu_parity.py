@@ -1446,3 +1446,61 @@ def test_trainer_deferred_user_weight_gradients_match_the_in_line_backward(B, mo
         assert scale > 0 and _maxerr(a, b) <= 2e-5 * scale, (_maxerr(a, b), scale)
     # parameters after three Adam steps: a noise-level gradient may flip the sign of a +-lr step, nothing more
     assert _maxerr(finals["0"], finals["1"]) <= 2.1e-4 * 3
+
+
+@pytest.mark.gpu
+def test_plm_body_shared_by_the_two_encoder_calls_changes_nothing(tmp_path, monkeypatch):
+    """``PLM.share_body`` (round 5): the transformer body runs ONCE over [history; candidates] and the two calls of the reference
+    (nrms_module.py:232,236) keep their own tails -- loss and every gradient equal the two-body-call form (dropout off), and the
+    sharing really happened (one body call instead of two)."""
+    from functools import partial
+
+    from newsreclib_amd import _lib
+    from newsreclib_amd.nrms_module import NRMSModule
+    from tests.helpers import PLM_HEADS, PLM_Q, make_tiny_roberta
+    _lib.set_gemm_engine("bf16x3")
+    path = make_tiny_roberta(str(tmp_path))
+    torch.manual_seed(11)
+    mod = NRMSModule(
+        dataset_attributes=["title", "abstract"], attributes2encode=["title"],
+        outputs={"train": ["preds", "targets", "cand_news_size"], "val": [], "test": []},
+        dual_loss_training=False, dual_loss_coef=None, loss="cross_entropy_loss", late_fusion=False,
+        temperature=None, use_plm=True, pretrained_embeddings_path=None, plm_model=path, frozen_layers=[0],
+        embed_dim=96, num_heads=PLM_HEADS, query_dim=PLM_Q, dropout_probability=0.2, top_k_list=[5, 10],
+        num_categ_classes=18, num_sent_classes=3, save_recs=False, recs_fpath=None,
+        optimizer=partial(torch.optim.Adam, lr=1e-4), scheduler=None).to(DEV).eval()
+    rng = np.random.default_rng(5)
+    hist_sizes, cand_sizes, L = [4, 2, 5], [5, 5, 5], 12
+
+    def toks(n):
+        ids = rng.integers(3, 200, (n, L))
+        lens = rng.integers(3, L + 1, n)
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+        return {"input_ids": torch.from_numpy(np.where(m == 1, ids, 1)), "attention_mask": torch.from_numpy(m)}
+
+    batch = batch_to({"x_hist": {"title": toks(sum(hist_sizes))}, "x_cand": {"title": toks(sum(cand_sizes))},
+                      "batch_hist": torch.repeat_interleave(torch.arange(3), torch.tensor(hist_sizes)),
+                      "batch_cand": torch.repeat_interleave(torch.arange(3), torch.tensor(cand_sizes)),
+                      "labels": torch.tensor([1., 0, 0, 0, 0] * 3), "user_ids": torch.arange(3) + 1,
+                      "user_idx": torch.arange(3)}, DEV)
+    te = mod.news_encoder.text_encoders["title"]
+    calls = []
+    hook = te.plm_model.register_forward_hook(lambda m, a, k, o: calls.append(1), with_kwargs=True)
+
+    def run(share):
+        monkeypatch.setenv("NRL_PLM_SHARE_BODY", "1" if share else "0")
+        mod.zero_grad(set_to_none=True)
+        calls.clear()
+        loss = mod.model_step(batch)[0]
+        loss.backward()
+        return float(loss), len(calls), {n: p.grad.detach().clone() for n, p in mod.named_parameters() if p.grad is not None}
+
+    l2, c2, g2 = run(False)
+    l1, c1, g1 = run(True)
+    hook.remove()
+    assert (c2, c1) == (2, 1)
+    assert abs(l1 - l2) <= 1e-6 * max(1.0, abs(l2))
+    assert g1.keys() == g2.keys() and len(g1) > 10
+    for n in g1:
+        scale = max(1e-6, float(g2[n].abs().max()))
+        assert float((g1[n] - g2[n]).abs().max()) <= 2e-5 * scale + 1e-9, n
