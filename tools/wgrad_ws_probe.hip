@@ -111,6 +111,16 @@ int main() {
     run("(11) + MFMA waves read nothing in the loop (43)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 43>(a, b, epi, I, J + 1, M, 32, st); });
     run("no epilogue, MFMA waves read nothing (33)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 33>(a, b, epi, I, J + 1, M, 32, st); });
   }
+  // a k extent that is not whole k-tiles (13200 rows = 440 news x 30 tokens) against the whole-tile form one tile shorter
+  for (auto IJ : {std::pair<int, int>{768, 768}, {3072, 768}}) {
+    const int I = IJ.first, J = IJ.second;
+    const RCPlain a{dy, I, I, 0}, b{x, J, J, 1};
+    const EpiAtomicWB epi{dw, J, db, J};
+    for (int64_t Mk : {(int64_t)13184, (int64_t)13200}) {
+      const float t = time_ms([&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, Mk, 8, st); }, st);
+      printf("I=%4d J=%4d K=%lld rows (K %% 32 = %d), 8 splits: %.3f ms\n", I, J, (long long)Mk, (int)(Mk % 32), t);
+    }
+  }
   // per-k-tile pace of ONE workgroup per CU over 1200 k-tiles (splits = 1): 1, 16 and 256 workgroups
   for (auto IJ : {std::pair<int, int>{256, 159}, {4096, 159}, {4096, 2559}}) {
     const int I = IJ.first, J = IJ.second;
