@@ -21,6 +21,20 @@
 
 namespace nrl {
 
+// split_pair for operands that are NOT neighbours in registers (round 5).  The loaders' pairs are (k, k + 1) of one row -- the same
+// component of two different loaded float4s.  `split_pair` builds a two-float vector for the conversion and lets hipcc pick
+// v_pk_add_f32 for the subtraction: both want ALIGNED REGISTER PAIRS, so every pair cost moves (180 v_mov per three k-tiles, placed
+// right behind the loads).  The four instructions below take any registers: same values bit for bit (v_cvt_pk_bf16_f32 rounds to
+// nearest even, the difference is exact), 768 x 768 x 38400 0.174 -> 0.152 ms, 3072 x 768 0.70 -> 0.56 ms (0.96 PF/s).
+__device__ __forceinline__ void ws_split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  float la, lb;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(la) : "v"(a), "v"(ha));
+  asm("v_sub_f32 %0, %1, %2" : "=v"(lb) : "v"(b), "v"(hb));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(la), "v"(lb));
+}
+
 template <int ABL>
 __device__ __forceinline__ void ws_barrier() {
   if constexpr (!(ABL & 64)) __builtin_amdgcn_s_barrier();      // (64: probe builds without any barrier)
@@ -166,7 +180,8 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
 #pragma unroll
               for (int p = 0; p < 4; ++p) {
                 if constexpr (ABL & 2) { h[p] = __float_as_uint(v[2 * p]); l[p] = __float_as_uint(v[2 * p + 1]); }
-                else split_pair(v[2 * p], v[2 * p + 1], h[p], l[p]);
+                else if constexpr (ABL & 512) split_pair(v[2 * p], v[2 * p + 1], h[p], l[p]);       // (the r01..r05 form, for the probe)
+                else ws_split_pair(v[2 * p], v[2 * p + 1], h[p], l[p]);
               }
               const int off = ws_lds_off(row, ko);
               *reinterpret_cast<uint4*>(hi_plane + off) = make_uint4(h[0], h[1], h[2], h[3]);
@@ -193,6 +208,47 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
     // The steady-state loop is three UNCONDITIONAL steps (every tile it touches exists), the last <= 5 steps are straight-line
     // code behind it: the three sets keep fixed roles, so none of them becomes a loop-carried array the compiler copies
     // (the r01..r04 form guarded every step inside the loop: 32 v_mov_b64 per iteration and spills once the loads got cheaper).
+    // steady state of whole-tile extents: the refill's eight loads per task go out in PAIRS between the four row splits of the tile
+    // being staged.  As one block they queue on the CU's one address unit (56 KiB-instructions x >= 16 clocks per k-tile, all four
+    // loader waves in the same phase right behind the barrier) while the vector ALUs idle, and then the ALUs split while the
+    // address unit idles.  (This form only pays once the split no longer builds register pairs, `ws_split_pair`: with them hipcc put
+    // the pair moves right behind the loads and drained vmcnt(0) every k-tile -- 3.7 us per k-tile against 2.0.  Round-robin medians,
+    // profiles/r05_wgrad_ws_probe.txt: 768 x 768 x 38400  0.163 (pairs) -> 0.148 (ws_split_pair) -> 0.143 ms (this form);
+    // 3072 x 768  0.643 -> 0.545 -> 0.522 ms = 1.04 PF/s.  ABL & 256: the two-block form, for the probe.)
+    auto fused_step = [&](Stage& SL, int buf, Stage& SS) {
+      unsigned char* base = smem + buf * BUF;
+#pragma unroll
+      for (int q = 0; q < NT_L; ++q) {
+        if (!t_any[q]) continue;
+        const int wt = wave + q * NL;
+        const int lrow = (t_isb[q] ? wt - WT_A : wt) * 64 + 4 * rq;
+        unsigned char* hi_plane = base + (t_isb[q] ? 2 * PLANE_A : 0);
+        unsigned char* lo_plane = hi_plane + (t_isb[q] ? PLANE_B : PLANE_A);
+        {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 2 * j; e < 2 * j + 2; ++e) SL.r[q][e] = *reinterpret_cast<const float4*>(t_next[q] + e * t_stride[q]);
+            const int row = lrow + j;
+            const int off = ws_lds_off(row, ko);
+            const float v[8] = {(&SS.r[q][0].x)[j], (&SS.r[q][1].x)[j], (&SS.r[q][2].x)[j], (&SS.r[q][3].x)[j],
+                                (&SS.r[q][4].x)[j], (&SS.r[q][5].x)[j], (&SS.r[q][6].x)[j], (&SS.r[q][7].x)[j]};
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ws_split_pair(v[2 * p], v[2 * p + 1], h[p], l[p]);
+            if (!t_live[q]) {
+#pragma unroll
+              for (int p = 0; p < 4; ++p) { h[p] = (j == 0 && t_fill[q] != 0.f) ? 0x3f803f80u : 0u; l[p] = 0u; }
+            }
+            if (t_on[q]) {
+              *reinterpret_cast<uint4*>(hi_plane + off) = make_uint4(h[0], h[1], h[2], h[3]);
+              *reinterpret_cast<uint4*>(lo_plane + off) = make_uint4(l[0], l[1], l[2], l[3]);
+            }
+          }
+        }
+        t_next[q] += BK * t_stride[q];
+      }
+    };
     Stage S0, S1, S2;
     load_tiles(kk(0), S0);
     if (ntiles > 1) load_tiles(kk(1), S1);
@@ -200,6 +256,16 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
     store_tiles(0, kk(0), S0);
     ws_barrier<ABL>();                       // barrier 0: tile 0 visible
     int tt = 0;
+    if constexpr (FULLK && !(ABL & 256)) {
+      for (; tt + 5 < ntiles; tt += 3) {
+        fused_step(S0, (tt + 1) & 1, S1);
+        ws_barrier<ABL>();
+        fused_step(S1, (tt + 2) & 1, S2);
+        ws_barrier<ABL>();
+        fused_step(S2, (tt + 3) & 1, S0);
+        ws_barrier<ABL>();
+      }
+    }
     for (; tt + 5 < ntiles; tt += 3) {
       load_tiles(kk(tt + 3), S0);
       store_tiles((tt + 1) & 1, kk(tt + 1), S1);
@@ -211,12 +277,10 @@ __global__ void __launch_bounds__((NL + WM * WN) * 64, 2)
       store_tiles((tt + 3) & 1, kk(tt + 3), S0);
       ws_barrier<ABL>();
     }
-    // (Tried on top, both slower, tools/wgrad_ws_probe.hip history / profiles/r05_ab.txt: the refill's loads issued in pairs BETWEEN the
-    //  four row splits -- hipcc's vmcnt bookkeeping across the loop's back edge then waits for all but the newest loads, 3.7 us per
-    //  k-tile against 2.0 -- and odd loader waves splitting first, fetching after -- the two orders meet at the back edge and the
-    //  register sets get copied, 7 us.  An L2 prefetch by the MFMA waves, one LDS-DMA dword per 128-byte line 2..12 k-tiles ahead,
-    //  changed nothing: with the loaders re-reading ONE k-tile out of cache their time only falls from 1.9 to 1.27 us per k-tile --
-    //  it is the issue of 56 KiB-instructions through the CU's one address unit plus the split, not the memory latency.)
+    // (Also tried, profiles/r05_ab.txt: odd loader waves splitting first and fetching after -- the two orders meet at the back edge and
+    //  the register sets get copied, 7 us per k-tile; an L2 prefetch by the MFMA waves, one LDS-DMA dword per 128-byte line 2..12
+    //  k-tiles ahead -- no change: with the loaders re-reading ONE k-tile out of cache their time only fell from 1.9 to 1.27 us per
+    //  k-tile, it was the issue of 56 KiB-instructions through the address unit plus the split, not the memory latency.)
     auto tail = [&](int t2, Stage& cur_next, Stage& refill) {
       if (t2 >= ntiles) return;
       if (t2 + 3 < ntiles) load_tiles(kk(t2 + 3), refill);

@@ -19,6 +19,9 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace nrl
 using namespace nrl;
+#ifndef WS_CHECK_ABL
+#define WS_CHECK_ABL 0
+#endif
 
 #define CK(x)                                                \
   do {                                                       \
@@ -76,7 +79,7 @@ int main() {
       CK(hipMemsetAsync(dw, 0, (size_t)I * J * 4, st));
       CK(hipMemsetAsync(db, 0, 65536, st));
       CK(hipMemsetAsync(dw2, 0, (size_t)I * J * 4 + 65536, st));
-      launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, 16, st);
+      launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, WS_CHECK_ABL>(a, b, epi, I, J + 1, M, 16, st);
       launch_gemm_bf16x3<4, 2, 4, 5, 0>(a, b, EpiAtomicWB{dw2, J, db2, J}, I, J + 1, M, 24, st);
       CK(hipStreamSynchronize(st));
       std::vector<float> h1((size_t)I * J), h2((size_t)I * J), b1(I), b2(I);
@@ -100,6 +103,8 @@ int main() {
       snprintf(nm, sizeof nm, "product, atomics, splits=%d", sp);
       run(nm, [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, sp, st); });
     }
+    run("split through register pairs as before (512), cost-rule splits", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 512>(a, b, epi, I, J + 1, M, I > 768 ? 8 : 16, st); });
+    run("loads and splits as two blocks (256), cost-rule splits", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 256>(a, b, epi, I, J + 1, M, I > 768 ? 8 : 16, st); });
     run("two-step reduction, splits=32", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5>(a, b, epi, I, J + 1, M, 32, st, scratch, scratch_floats); });
     run("no epilogue (1)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 1>(a, b, epi, I, J + 1, M, 32, st); });
     run("no epilogue, no split (3)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 3>(a, b, epi, I, J + 1, M, 32, st); });
@@ -110,6 +115,23 @@ int main() {
     run("(11) + MFMA waves read one buffer (27)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 27>(a, b, epi, I, J + 1, M, 32, st); });
     run("(11) + MFMA waves read nothing in the loop (43)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 43>(a, b, epi, I, J + 1, M, 32, st); });
     run("no epilogue, MFMA waves read nothing (33)", [&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 33>(a, b, epi, I, J + 1, M, 32, st); });
+  }
+  // the three loader forms, round-robin (clocks and boxes move single measurements by +-10 %): median of 7 passes of 10 launches
+  for (auto IJ : {std::pair<int, int>{768, 768}, {3072, 768}}) {
+    const int I = IJ.first, J = IJ.second;
+    const RCPlain a{dy, I, I, 0}, b{x, J, J, 1};
+    const EpiAtomicWB epi{dw, J, db, J};
+    const int sp = I > 768 ? 8 : 16;
+    std::vector<float> t0, t1, t2;
+    for (int pass = 0; pass < 7; ++pass) {
+      t0.push_back(time_ms([&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 0>(a, b, epi, I, J + 1, M, sp, st); }, st));
+      t1.push_back(time_ms([&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 512>(a, b, epi, I, J + 1, M, sp, st); }, st));
+      t2.push_back(time_ms([&] { launch_gemm_bf16x3_ws<4, 2, 2, 8, 5, 256>(a, b, epi, I, J + 1, M, sp, st); }, st));
+    }
+    auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    auto mn = [](std::vector<float> v) { return *std::min_element(v.begin(), v.end()); };
+    printf("I=%4d J=%4d round-robin x7, %d splits: product %.3f (min %.3f) | split through register pairs (512) %.3f (min %.3f) | loads and splits as two blocks (256) %.3f (min %.3f) ms\n",
+           I, J, sp, med(t0), mn(t0), med(t1), mn(t1), med(t2), mn(t2));
   }
   // a k extent that is not whole k-tiles (13200 rows = 440 news x 30 tokens) against the whole-tile form one tile shorter
   for (auto IJ : {std::pair<int, int>{768, 768}, {3072, 768}}) {
