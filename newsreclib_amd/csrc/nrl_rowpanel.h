@@ -323,12 +323,33 @@ struct RpPreSplit<T, std::enable_if_t<T::kPreSplit>> : std::true_type {};
 template <int NBLK, int WAVES, class AOp, class Epi, int DEEP = 0, int RB = 2>
 __global__ void __launch_bounds__(WAVES * 64, 2)
     rp_gemm_kernel(const AOp A, const uint16_t* __restrict__ img_base, const Epi epi, const int64_t M, const int N,
-                   const int K, const int kblocks, const int64_t panel_elems) {
+                   const int K, const int kblocks, const int64_t panel_elems, const int panels, const int panel_group,
+                   const int64_t row_blocks) {
   // blockIdx.y = column panel of a WIDE output (N > 16 NBLK: nn.Linear layers of a transformer body, nrl_linear_fwd): panel p
   // owns columns [p * 16 NBLK, ...) and its own fragment-ordered image, `panel_elems` uint16 further on.  Row blocks are the
   // fast grid axis, so the workgroups in flight share one panel image (L2-resident) and stream the activation rows.
-  const uint16_t* __restrict__ img = img_base + (int64_t)blockIdx.y * panel_elems;
-  const int n_panel0 = (int)blockIdx.y * (NBLK * 16);
+  //
+  // Round 5, wide outputs: with the row blocks as the fast axis every panel re-streams the WHOLE activation (12 times at N = 3072:
+  // 1.6 of the 2.8 GB a feed-forward GEMM of config 4 moved were those re-reads, profiles/r05_plm_lstur_pmc.txt, and its matrix pipe sat
+  // at 0.40 against 0.52 for the 768-wide layers).  panel_group > 0: a 1-D grid, workgroup id -> (XCD = id % 8, place on that XCD);
+  // an XCD owns the row blocks rb % 8 == xcd and walks them panel GROUP by panel group, the panel_group panels of one row block on
+  // consecutive places -- they run on the same XCD at the same time, so the row block crosses HBM -> L2 once per group while the
+  // group's images (panel_group x 0.79 MB at K = 768) stay L2-resident.
+  int64_t rb_idx = blockIdx.x;
+  int panel = (int)blockIdx.y;
+  if (panel_group > 0) {
+    const int64_t id = blockIdx.x;
+    const int xcd = (int)(id % 8);
+    const int64_t local = id / 8;
+    const int64_t rx = (row_blocks + 7) / 8;                  // row blocks per XCD (the last ones of some XCDs do not exist)
+    const int64_t per_group = rx * panel_group;
+    const int64_t grp = local / per_group, rem = local % per_group;
+    rb_idx = (rem / panel_group) * 8 + xcd;
+    panel = (int)(grp * panel_group + rem % panel_group);
+    if (rb_idx >= row_blocks || panel >= panels) return;      // (before any barrier: the whole workgroup leaves)
+  }
+  const uint16_t* __restrict__ img = img_base + (int64_t)panel * panel_elems;
+  const int n_panel0 = panel * (NBLK * 16);
   constexpr int CHUNK = NBLK * 2048;          // bytes of one k-block of the image
   constexpr int PIECES = 2 * NBLK;            // 1-KiB pieces per chunk
   constexpr int G = (PIECES + WAVES - 1) / WAVES;
@@ -339,7 +360,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.x * (WAVES * 16 * RB);
+  const int64_t m0 = rb_idx * (WAVES * 16 * RB);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
   // this wave's share of a chunk: pieces wave, wave + WAVES, ... (clamped: a duplicate rewrites the same bytes)
@@ -513,8 +534,26 @@ int launch_rp_gemm(const AOp& A, const RpImage& B, const Epi& epi, int64_t M, in
               "row-panel GEMM: image / shape mismatch");
   const int64_t blocks = ceil_div(M, WAVES * 16 * RB);
   NRL_REQUIRE(blocks < (1LL << 31), "gemm grid too large");
-  hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP, RB>), dim3((unsigned)blocks, (unsigned)panels), dim3(WAVES * 64), 0,
-                     stream, A, B.img, epi, M, N, K, B.kblocks, (int64_t)rp_image_elems(NBLK, B.kblocks));
+  // panel grouping of wide outputs (see the kernel): NRL_RP_PANEL_GROUP = 0 restores the row-blocks-fast 2-D grid (A/B runs)
+  // (the group size must DIVIDE the panel count: a padded last group leaves holes in every XCD's walk -- 3 panels in groups of 2:
+  //  0.214 ms against 0.165 at 38400 x 768 x 768)
+  static const int group_env = [] { const char* e = getenv("NRL_RP_PANEL_GROUP"); return e ? atoi(e) : -1; }();
+  int group = 0;
+  if (panels > 1) {
+    if (group_env >= 0) group = group_env;
+    else group = panels % 3 == 0 ? 3 : (panels % 4 == 0 ? 4 : (panels % 2 == 0 ? 2 : 0));
+    if (group > panels || (group > 0 && panels % group != 0)) group = 0;
+  }
+  if (group > 0) {
+    const int64_t rx = ceil_div(blocks, 8), groups = ceil_div(panels, group);
+    const int64_t grid = 8 * rx * group * groups;
+    NRL_REQUIRE(grid < (1LL << 31), "gemm grid too large");
+    hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP, RB>), dim3((unsigned)grid), dim3(WAVES * 64), 0, stream, A, B.img,
+                       epi, M, N, K, B.kblocks, (int64_t)rp_image_elems(NBLK, B.kblocks), panels, group, blocks);
+  } else {
+    hipLaunchKernelGGL((rp_gemm_kernel<NBLK, WAVES, AOp, Epi, DEEP, RB>), dim3((unsigned)blocks, (unsigned)panels), dim3(WAVES * 64), 0,
+                       stream, A, B.img, epi, M, N, K, B.kblocks, (int64_t)rp_image_elems(NBLK, B.kblocks), panels, 0, blocks);
+  }
   NRL_LAUNCH_CHECK();
   return NRL_OK;
 }
