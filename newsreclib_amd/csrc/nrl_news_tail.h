@@ -111,7 +111,7 @@ __device__ __forceinline__ float nt_tanh(float x) {
 }
 
 // ABL (tools/nt_probe.hip only; product code uses 0): 1 = no dropout hash, 2 = no training stores, 4 = no weight DMA,
-// 8 = no phase-1 MFMAs, 16 = no phase-2 MFMAs, 32 = no pooling reduction
+// 8 = no phase-1 MFMAs, 16 = no phase-2 MFMAs, 32 = no pooling reduction, 64 = plain y stores, 128 = `o` from cache-resident planes
 // SAVE: 0 = evaluation (nothing but `out`), 1 = training (y planes + w; the fused backward recomputes tanh), 2 = training with
 // the tanh output t as well (backward through pool_bwd_pre)
 // The kernel's work for one wave's news in two compile-time shapes: NTB = 2 token blocks, and (SH: pad-row sharing, a short
@@ -180,7 +180,10 @@ __device__ __forceinline__ void news_tail_fwd_body(const NewsTailArgs& P, unsign
     const int t = tb * 16 + l15;
     tok_ok[tb] = t < L;
     mrow[tb] = row0 + (tok_ok[tb] ? t : L - 1);
-    orow[tb] = P.o_planes + ((mrow[tb] >> 4) * NT_FB + (g >> 1)) * 1024 + (mrow[tb] & 15) * 32 + (g & 1) * 16;
+    // (probe, ABL 128: every news reads the `o` planes of one of the first 64 news -- 2.3 MB, cache-resident: the loads are issued,
+    //  nothing comes from HBM.  The upper bound of what handing `o` over on chip could save this kernel, tools/nt_probe.hip)
+    const int64_t mo = (ABL & 128) ? (news & 63) * L + (tok_ok[tb] ? t : L - 1) : mrow[tb];
+    orow[tb] = P.o_planes + ((mo >> 4) * NT_FB + (g >> 1)) * 1024 + (mo & 15) * 32 + (g & 1) * 16;
   }
   auto load_o = [&](int kb, bf16x8 (&oh)[2], bf16x8 (&ol)[2]) {
     // block column 19 (k-block 9, g >= 2) does not exist: read a valid address, zero the fragment

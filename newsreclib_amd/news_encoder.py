@@ -361,9 +361,16 @@ FALLBACK_CALLS = {"linear_cuda": 0, "linear_host": 0, "attention": 0, "output_bl
                   "attention_block_host": 0}
 
 
+# `PLM.share_body`: how often ONE body pass served the encoder calls of a step -- with the calls already at one sequence length,
+# after padding the shorter calls to the longest -- and how often it was refused (each call then pays its own body pass)
+SHARE_BODY_CALLS = {"hit_same_length": 0, "hit_padded": 0, "miss": 0}
+
+
 def reset_fallback_calls() -> None:
     for k in FALLBACK_CALLS:
         FALLBACK_CALLS[k] = 0
+    for k in SHARE_BODY_CALLS:
+        SHARE_BODY_CALLS[k] = 0
 
 
 def _key_padding_keep(module, attention_mask, N: int, L: int):
@@ -580,28 +587,65 @@ class PLM(nn.Module):
         body -- its seq-first attention runs across the news of a call (text.py:92-96) -- but the body itself treats every news on its
         own (self-attention within a news, key-padding mask per news), so its hidden states over [history; candidates] are row for row
         those of the two calls.  The small call is the inefficient one (3,840 token rows at B = 8: its GEMMs run at a third to two
-        thirds of the large call's rate and it doubles the launches and the trainable layers' image builds).  Only for texts with the
-        same keys, sequence length and device (a shorter call padded to the longer one would change the tail, which attends over
-        token positions without a mask); ``forward`` picks its rows up by the identity of ``input_ids``.  NRL_PLM_SHARE_BODY=0: off."""
+        thirds of the large call's rate and it doubles the launches and the trainable layers' image builds).
+
+        Real batches pad each call to ITS OWN longest text (rec_dataset.py:181), so the calls' sequence lengths normally differ
+        (round 6): the shorter calls are then right-padded to the longest with the body's padding id under attention mask 0 --
+        masked keys get weight exactly 0 and the position ids of a roberta-type body come from the ids (padding -> padding_idx), so
+        the real columns are unchanged -- and every call gets back ITS OWN columns ``[:, :L_call]`` (the tail attends over token
+        positions without a mask: it must not see the extra ones).  Refused (``SHARE_BODY_CALLS["miss"]``; each call then runs its own
+        body pass) when the padding would add more than a quarter to the token rows, when the body has no padding id, or when a text
+        carries a per-token tensor this function does not know how to pad.  ``forward`` picks its rows up by the identity of
+        ``input_ids``.  NRL_PLM_SHARE_BODY=0: off."""
         self._shared = []
         if len(texts) < 2 or os.environ.get("NRL_PLM_SHARE_BODY", "1") == "0":
             return False
+        pad_values = {"attention_mask": 0, "token_type_ids": 0}
+        pad_id = getattr(getattr(self.plm_model, "config", None), "pad_token_id", None)
         groups = {}
         for t in texts:
             if not (isinstance(t, dict) and torch.is_tensor(t.get("input_ids")) and t["input_ids"].dim() == 2
                     and all(torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == t["input_ids"].shape[0] for v in t.values())):
                 continue
-            sig = tuple(sorted((k, tuple(v.shape[1:]), str(v.dtype), str(v.device)) for k, v in t.items()))
+            # same keys, dtypes, device and trailing shape PAST the token axis; the token axis itself may differ
+            sig = tuple(sorted((k, tuple(v.shape[2:]), str(v.dtype), str(v.device), v.dim()) for k, v in t.items()))
             groups.setdefault(sig, []).append(t)
         shared = False
         for group in groups.values():        # (e.g. title texts of both calls in one pass, abstract texts in another)
             if len(group) < 2:
                 continue
-            merged = {k: torch.cat([t[k] for t in group], dim=0) for k in group[0]}
+            lens = [int(t["input_ids"].shape[1]) for t in group]
+            L_max = max(lens)
+            padded = any(l != L_max for l in lens)
+            if padded:
+                rows = sum(int(t["input_ids"].shape[0]) * l for t, l in zip(group, lens))
+                extra = sum(int(t["input_ids"].shape[0]) * (L_max - l) for t, l in zip(group, lens))
+                per_token = all(v.dim() == 1 or int(v.shape[1]) == l for t, l in zip(group, lens) for v in t.values())
+                known = all(k == "input_ids" or k in pad_values or v.dim() == 1 for t in group for k, v in t.items())
+                if pad_id is None or not per_token or not known or 4 * extra > rows:
+                    SHARE_BODY_CALLS["miss"] += 1
+                    continue
+
+                def widen(t, l):
+                    if l == L_max:
+                        out = dict(t)
+                    else:
+                        out = {k: (v if v.dim() == 1 else torch.nn.functional.pad(
+                            v, (0, L_max - l), value=(pad_id if k == "input_ids" else pad_values[k]))) for k, v in t.items()}
+                    if "attention_mask" not in out:           # (a call without a mask attends to every one of ITS columns)
+                        m = torch.zeros(out["input_ids"].shape, dtype=torch.int64, device=out["input_ids"].device)
+                        m[:, :l] = 1
+                        out["attention_mask"] = m
+                    return out
+                wide = [widen(t, l) for t, l in zip(group, lens)]
+                merged = {k: torch.cat([w[k] for w in wide], dim=0) for k in wide[0]}
+            else:
+                merged = {k: torch.cat([t[k] for t in group], dim=0) for k in group[0]}
             hidden = self.plm_model(**merged)[0]
             # (split, not slices: its backward is ONE concatenation of the calls' gradients)
-            for t, h in zip(group, torch.split(hidden, [int(t["input_ids"].shape[0]) for t in group], dim=0)):
-                self._shared.append((t["input_ids"], h))
+            for t, l, h in zip(group, lens, torch.split(hidden, [int(t["input_ids"].shape[0]) for t in group], dim=0)):
+                self._shared.append((t["input_ids"], h if l == L_max else h[:, :l]))
+            SHARE_BODY_CALLS["hit_padded" if padded else "hit_same_length"] += 1
             shared = True
         return shared
 

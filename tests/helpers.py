@@ -101,11 +101,11 @@ PLM_CFG = dict(vocab_size=200, hidden_size=96, num_hidden_layers=2, num_attentio
 PLM_HEADS, PLM_Q = 6, 32
 
 
-def make_tiny_roberta(save_dir, seed=17):
+def make_roberta(save_dir, cfg, seed, w_std):
     """Random-init roberta-shaped body with portable (numpy default_rng) weights, saved where
     ``AutoModel.from_pretrained`` can load it -- there is no network / HF cache for roberta-base."""
     from transformers import RobertaConfig, RobertaModel
-    model = RobertaModel(RobertaConfig(**PLM_CFG), add_pooling_layer=False)
+    model = RobertaModel(RobertaConfig(**cfg), add_pooling_layer=False)
     rng = np.random.default_rng(seed)
     sd = model.state_dict()
     new = {}
@@ -116,14 +116,59 @@ def make_tiny_roberta(save_dir, seed=17):
         elif k.endswith("LayerNorm.weight"):
             new[k] = torch.from_numpy((1.0 + 0.05 * rng.standard_normal(tuple(v.shape))).astype(np.float32))
         else:
-            new[k] = torch.from_numpy((0.08 * rng.standard_normal(tuple(v.shape))).astype(np.float32))
+            new[k] = torch.from_numpy((w_std * rng.standard_normal(tuple(v.shape))).astype(np.float32))
     model.load_state_dict(new)
     model.save_pretrained(save_dir)
     return save_dir
 
 
-def make_plm_tail_params(dim=96, query_dim=PLM_Q, seed=23):
-    """MHA + additive-attention parameters of the PLM encoder tail (reference state_dict key names)."""
+def make_tiny_roberta(save_dir, seed=17):
+    return make_roberta(save_dir, PLM_CFG, seed, 0.08)
+
+
+# roberta-base SHAPE (BASELINE configs[3]: d = 768, 12 layers, 12 body heads, 3072 feed-forward); the body's own dropouts are 0
+# so that a train-mode step is a function of the tail's injected masks only (tests/golden/make_golden_plm_full.py)
+PLM_FULL_CFG = dict(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                    max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2,
+                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+PLM_FULL_HEADS, PLM_FULL_Q, PLM_FULL_FROZEN, PLM_FULL_OUT_SCALE = 16, 200, list(range(8)), 0.5
+
+
+def make_full_roberta(save_dir, seed=41):
+    # std 0.02 = roberta-base's own initializer_range.  (Larger random weights COLLAPSE the body: at 0.04 the hidden states of a
+    # news' 96 positions have cosine similarity 0.99997, every attention-type gradient -- q / k projections, the additive
+    # attention -- falls to ~1e-7 of the others and the reference's own fp32 run reproduces its fp64 run only to 3 % there.)
+    return make_roberta(save_dir, PLM_FULL_CFG, seed, 0.02)
+
+
+def plm_full_inputs(seed=7, L_hist=96, L_cand=64, hist_sizes=(7, 5, 6), cand_sizes=(3, 4, 3)):
+    """Two ragged PLM calls (history / candidates) of tokenizer-shaped dicts with a padded tail per news (pad id 1, mask 0); each
+    side is padded to ITS OWN longest text, as the reference's collate does (rec_dataset.py:181: ``padding=True`` per call)."""
+    rng = np.random.default_rng(seed)
+
+    def toks(n, L):
+        ids = rng.integers(3, PLM_FULL_CFG["vocab_size"], (n, L))
+        lens = rng.integers(20, L + 1, n)
+        lens[0] = L                                   # one news fills the window
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+        return {"input_ids": torch.from_numpy(np.where(m == 1, ids, 1)), "attention_mask": torch.from_numpy(m)}
+
+    B = len(hist_sizes)
+    labels = []
+    for c in cand_sizes:
+        y = np.zeros(c, np.float32)
+        y[rng.integers(0, c)] = 1.0
+        labels.append(y)
+    return {"x_hist": {"title": toks(sum(hist_sizes), L_hist)}, "x_cand": {"title": toks(sum(cand_sizes), L_cand)},
+            "batch_hist": torch.repeat_interleave(torch.arange(B), torch.tensor(hist_sizes)),
+            "batch_cand": torch.repeat_interleave(torch.arange(B), torch.tensor(cand_sizes)),
+            "labels": torch.from_numpy(np.concatenate(labels)), "user_ids": torch.arange(B) + 1, "user_idx": torch.arange(B),
+            "batch_size": B}
+
+
+def make_plm_tail_params(dim=96, query_dim=PLM_Q, seed=23, out_scale=1.0):
+    """MHA + additive-attention parameters of the PLM encoder tail (reference state_dict key names); ``out_scale`` shrinks the
+    out-projection (the full-width fixture keeps |scores| ~ 1 with it, where the 1e-3 contract is meant)."""
     rng = np.random.default_rng(seed)
     shapes = {"multihead_attention.in_proj_weight": (3 * dim, dim), "multihead_attention.in_proj_bias": (3 * dim,),
               "multihead_attention.out_proj.weight": (dim, dim), "multihead_attention.out_proj.bias": (dim,),
@@ -132,6 +177,8 @@ def make_plm_tail_params(dim=96, query_dim=PLM_Q, seed=23):
     out = {}
     for k in sorted(shapes):
         scale = 0.1 if k.endswith("query") else (0.05 if k.endswith("bias") else 1.0 / np.sqrt(dim))
+        if k.endswith("out_proj.weight"):
+            scale *= out_scale
         out[k] = torch.from_numpy((scale * rng.standard_normal(shapes[k])).astype(np.float32))
     return out
 

@@ -1043,6 +1043,45 @@ def test_mindlarge_shaped_rank_batch_matches_oracle(engine):
     assert err_s <= TOL and err_l <= TOL and err_s <= _eng_tol(engine, 5e-5, 5e-4)
 
 
+def test_mindlarge_shaped_rank_batch_train_step_matches_oracle(engine):
+    """The TRAIN-mode half of the test above: BASELINE configs[2] at its per-rank shape -- V = 150,000,
+    64 impressions, 3,520 news of 30 tokens -- under the oracle's own dropout draw (same counter-based masks): scores, loss and
+    EVERY parameter gradient (the 150,000 x 300 table gradient included) against ``NRMSOracle.loss_and_grads``."""
+    from newsreclib_amd.synthetic import make_batch
+    if "mindlarge_train" not in _FULL_ORACLE:              # (one oracle step on the host cores, shared by both engines)
+        params = O.make_params(150_000, seed=21)
+        batch = make_batch(64, 150_000, "fixed", seed=9)
+        orc = O.NRMSOracle(params, num_heads=15, p_drop=0.2)
+        out, grads = orc.loss_and_grads(batch, True, seed=777)
+        _FULL_ORACLE["mindlarge_train"] = (params, batch, {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}, grads)
+    params, batch, ref, ref_grads = _FULL_ORACLE["mindlarge_train"]
+    mod = build_module(params, p_drop=0.2).train()
+    te = mod.news_encoder.text_encoders["title"]
+    orig = te.forward
+    te.forward = lambda text, seed=None, **kw: orig(text, seed=777, **kw)
+    dev_batch = batch_to(batch, DEV)
+    loss, preds, *_ = mod.model_step(dev_batch)
+    scores = mod.forward(dev_batch)
+    err_s, err_l = _maxerr(scores, ref["scores"]), abs(float(loss) - float(ref["loss"]))
+    assert err_s <= TOL and err_l <= TOL and err_s <= _eng_tol(engine, 5e-5, 5e-4)
+    loss.backward()
+    worst = 0.0
+    for k, got in module_grads(mod).items():
+        want = ref_grads[k]
+        scale = max(1e-3, float(want.abs().max()))
+        d = (got.detach().cpu() - want).abs()
+        if k.endswith("in_proj_bias"):                 # zero-true-gradient key bias: rounding noise on both sides
+            d[300:600] = 0
+        rel = float(d.max()) / scale
+        worst = max(worst, rel)
+        nrm = abs(float(got.norm()) - float(want.norm())) / max(1e-6, float(want.norm()))
+        assert rel <= _eng_tol(engine, 2e-4, 1e-3) and nrm <= 1e-3, (k, rel, nrm)
+    emb = module_grads(mod)[O.EMB_KEY]
+    assert float(emb[0].abs().max()) == 0.0             # padding_idx = 0 (text.py:215-217)
+    print(f"configs[2] rank shape, train [{engine}]: scores max abs err {err_s:.3e}, loss err {err_l:.3e}, worst gradient error "
+          f"relative to the parameter's largest gradient {worst:.3e}")
+
+
 def test_plm_news_encoder_matches_reference_plm(tmp_path, engine):
     """BASELINE config 4 path on a tiny roberta-shaped body: product ``PLM`` (HF body on PyTorch-ROCm +
     ONE HIP call for dropout/MHA/dropout/additive attention) vs the reference's PLM module."""

@@ -833,3 +833,51 @@ def test_frozen_image_cache_keys_and_invalidation():
     assert im.buffer("fwd", w, FakeLib, dev) == (None, 0, None)
     w.requires_grad_(False)                       # ... and frozen again: the old image must not be trusted
     assert im.buffer("fwd", w, FakeLib, dev)[1] == 0
+
+
+def test_plm_body_shared_across_calls_of_different_lengths(tmp_path):
+    """the reference pads each encoder call to its own longest text (rec_dataset.py:181), so history and
+    candidate calls normally differ in sequence length.  ``PLM.share_body`` pads the shorter call (padding id, mask 0), runs ONE
+    body pass and hands each call its own columns back: on the host body the hidden states are EXACTLY those of separate calls;
+    hits and refusals are counted (a padding overhead above a quarter of the token rows is refused)."""
+    from newsreclib_amd import news_encoder as ne
+    from tests.helpers import PLM_HEADS, PLM_Q, make_tiny_roberta
+    enc = ne.PLM(plm_model=make_tiny_roberta(str(tmp_path)), frozen_layers=[0], embed_dim=96, use_mhsa=True, apply_reduce_dim=False,
+                 reduced_embed_dim=None, num_heads=PLM_HEADS, query_dim=PLM_Q, dropout_probability=0.2).eval()
+    rng = np.random.default_rng(0)
+
+    def toks(n, L, mask=True):
+        ids = rng.integers(3, 200, (n, L))
+        lens = rng.integers(3, L + 1, n)
+        lens[0] = L
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+        out = {"input_ids": torch.from_numpy(np.where(m == 1, ids, 1))}
+        if mask:
+            out["attention_mask"] = torch.from_numpy(m)
+        return out
+
+    ne.reset_fallback_calls()
+    with torch.no_grad():
+        a, b, c = toks(9, 20), toks(4, 17), toks(3, 20)
+        ref = [enc.plm_model(**t)[0] for t in (a, b, c)]
+        assert enc.share_body([a, b, c])
+        assert ne.SHARE_BODY_CALLS == {"hit_same_length": 0, "hit_padded": 1, "miss": 0}
+        for (ids, h), t, r in zip(enc._shared, (a, b, c), ref):
+            assert ids is t["input_ids"] and h.shape == r.shape and torch.equal(h, r)
+        # (forward() picks the rows up by the identity of input_ids -- on the GPU: tests/test_gpu_plm_full.py; the tail has no host path)
+        # equal lengths: plain concatenation
+        assert enc.share_body([a, c]) and ne.SHARE_BODY_CALLS["hit_same_length"] == 1
+        # too much padding (4 x 5 x 15 extra rows > 180 + 25 real ones): refused, counted, nothing shared
+        d = toks(5, 5)
+        assert not enc.share_body([a, d]) and ne.SHARE_BODY_CALLS["miss"] == 1 and not enc._shared
+        # texts without a mask attend to all of THEIR columns: the padded call must not attend to the extra ones
+        e, f = toks(5, 12, mask=False), toks(2, 9, mask=False)
+        ref = [enc.plm_model(**t)[0] for t in (e, f)]
+        assert enc.share_body([e, f])
+        for (ids, h), r in zip(enc._shared, ref):
+            assert float((h - r).abs().max()) <= 1e-5
+    os.environ["NRL_PLM_SHARE_BODY"] = "0"
+    try:
+        assert not enc.share_body([a, b])
+    finally:
+        del os.environ["NRL_PLM_SHARE_BODY"]

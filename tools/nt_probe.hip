@@ -214,6 +214,10 @@ static int run(int64_t N, int L) {
   report("eval  no MFMAs at all", time_ms([&] { launch_news_tail_fwd<WV, 24>(ae, st); }, st));
   report("eval  no MFMAs, no DMA", time_ms([&] { launch_news_tail_fwd<WV, 28>(ae, st); }, st));
   report("eval  no pooling reduction", time_ms([&] { launch_news_tail_fwd<WV, 32>(ae, st); }, st));
+  // round 6: the upper bound of a front + tail fusion for THIS kernel -- `o` never read from HBM
+  report("eval  o planes cache-resident", time_ms([&] { launch_news_tail_fwd<WV, 128>(ae, st); }, st));
+  report("train o planes cache-resident", time_ms([&] { launch_news_tail_fwd<WV, 128>(a, st); }, st));
+  report("train o resident, no stores", time_ms([&] { launch_news_tail_fwd<WV, 130>(a, st); }, st));
   report("eval, again", time_ms([&] { launch_news_tail_fwd<WV, 0>(ae, st); }, st));
   report("train, again", time_ms([&] { launch_news_tail_fwd<WV, 0>(a, st); }, st));
   {
