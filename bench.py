@@ -107,17 +107,22 @@ def cpu_baseline(time_budget_s=20.0):
 
 
 def _timed_steps(trainer, batch, steps, warmup):
+    """-> (median, min, max) seconds per step over `steps` steps after `warmup` untimed ones; every step between its own pair of
+    events on the launch stream (one ~1 us host call each), one synchronize at the end."""
     for _ in range(warmup):
         trainer.step(batch)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         trainer.step(batch)
+        marks[i + 1].record()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    return statistics.median(ms) * 1e-3, ms[0] * 1e-3, ms[-1] * 1e-3
 
 
-def extra_lstur(device, batch_size=128, steps=15):
+def extra_lstur(device, batch_size=128, steps=15):   # (median of 15 timed steps after 3 untimed)
     """BASELINE.json configs[4]: LSTUR (CNN news encoder, title 30 + abstract 50 tokens, 300 filters, window 3, category
     embedding 100, GRU 700 user encoder, 45,215 users) train step under the same click_predictor API, B = 128."""
     from functools import partial
@@ -139,11 +144,12 @@ def extra_lstur(device, batch_size=128, steps=15):
         pretrained_embeddings=torch.randn(VOCAB, 300) * 0.3).to(device)
     trainer = NRMSTrainer(mod, lr=LR)
     batch = attach_layout(add_lstur_fields(make_batch(batch_size, VOCAB, "fixed", seed=1234, device=device), VOCAB))
-    dt = _timed_steps(trainer, batch, steps, 3)
+    dt, dt_min, dt_max = _timed_steps(trainer, batch, steps, 3)
     # algorithmic FLOPs (SURVEY.md Appendix A, config-5 extras): 52.8 MFLOP per news forward (title 16.2 + 3.6, abstract 27 + 6),
     # 55 news + <= 294 MFLOP of GRU per impression, train step = 3 x forward
     flops = 3.0 * (55 * 52.8e6 + 294e6) * batch_size
     return {"value": round(batch_size / dt, 1), "unit": "impressions/s", "ms_per_step": round(dt * 1e3, 3),
+            "basis": "median of %d steps" % steps, "min_max_ms": [round(dt_min * 1e3, 3), round(dt_max * 1e3, 3)],
             "config": "LSTUR MINDsmall-shaped train step, B=128, title 30 + abstract 50 tokens, GRU 700 (BASELINE.json configs[4])",
             "roofline": {"bound": "mfma", "scope": "whole step (not one kernel)", "algorithmic_flops_per_step": flops,
                          "achieved": round(3 * flops / dt / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -152,7 +158,7 @@ def extra_lstur(device, batch_size=128, steps=15):
                                  "MFMA peak; timed steps: %d" % steps}}
 
 
-def extra_plm(device, batch_size=8, steps=3):
+def extra_plm(device, batch_size=8, steps=7):
     """BASELINE.json configs[3]: NRMS with the PLM news encoder (roberta-base SHAPE, random init -- no network for the
     checkpoint; d = 768, 16 heads, L = 96, layers 0-7 frozen), B = 8 as in the reference's experiment file.  The
     transformer body is HF's module graph on PyTorch-ROCm (attention, layer norms, GELU: third-party) with its nn.Linear
@@ -188,7 +194,31 @@ def extra_plm(device, batch_size=8, steps=3):
     pb = prepare_batch(b)
     _timed_steps(trainer, pb, 1, 1)            # warm-up (first-call mask check of the body attention, image builds)
     _ne.reset_fallback_calls()
-    dt = _timed_steps(trainer, pb, steps, 0)
+    dt, dt_min, dt_max = _timed_steps(trainer, pb, steps, 0)
+    share_calls = dict(_ne.SHARE_BODY_CALLS)
+    fallbacks = dict(_ne.FALLBACK_CALLS)
+    # the same step with each encoder call running its own body pass (NRL_PLM_SHARE_BODY=0), and on a batch whose two calls
+    # differ in sequence length, as a collate that pads each call to its own longest text produces them (rec_dataset.py:181;
+    # ADVICE round 5): history 96 tokens, candidates 80 -- one body pass over the padded union vs two passes
+    variants = {}
+    b2 = make_batch(batch_size, vocab=50000, mode="fixed", seed=1, L=96, device=device)
+    for part, Lp_ in (("x_hist", 96), ("x_cand", 80)):
+        ids = b2[part]["title"].clamp_min(3)[:, :Lp_].contiguous()
+        b2[part]["title"] = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    pb2 = prepare_batch(b2)
+    prev = os.environ.get("NRL_PLM_SHARE_BODY")
+    try:
+        for name, batch_v, share in (("two_body_passes", pb, "0"), ("cand_80_tokens_one_padded_pass", pb2, "1"),
+                                     ("cand_80_tokens_two_passes", pb2, "0")):
+            os.environ["NRL_PLM_SHARE_BODY"] = share
+            _ne.reset_fallback_calls()
+            v, _, _ = _timed_steps(trainer, batch_v, 3, 1)
+            variants[name] = {"ms_per_step": round(v * 1e3, 1), "share_body_calls": dict(_ne.SHARE_BODY_CALLS)}
+    finally:
+        if prev is None:
+            os.environ.pop("NRL_PLM_SHARE_BODY", None)
+        else:
+            os.environ["NRL_PLM_SHARE_BODY"] = prev
     # algorithmic FLOPs: body forward 2 x (4 d^2 + 2 d f) per token and layer + 4 L d per token and layer of attention;
     # dgrad through all 12 layers (the embeddings train, text.py:70-73), weight gradients for the 4 unfrozen layers;
     # tail (seq-first MHA across the news of a call + additive attention, d = 768) forward x 3
@@ -198,12 +228,14 @@ def extra_plm(device, batch_size=8, steps=3):
     tail_fwd = tokens * 2 * d * (3 * d + d + 200) + 4 * 48 * 16 * Lp * (n_hist ** 2 + n_cand ** 2)
     flops = body_fwd * (2.0 + 4.0 / 12.0) + 3.0 * tail_fwd
     return {"value": round(batch_size / dt, 2), "unit": "impressions/s", "ms_per_step": round(dt * 1e3, 1),
+            "basis": "median of %d steps; one body pass over both encoder calls (equal sequence lengths)" % steps,
+            "min_max_ms": [round(dt_min * 1e3, 1), round(dt_max * 1e3, 1)], "share_body_calls": share_calls, "variants": variants,
             "roofline": {"bound": "mfma", "scope": "whole step (not one kernel)", "algorithmic_flops_per_step": flops,
                          "achieved": round(3 * flops / dt / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(3 * flops / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                          "note": "issued bf16 FLOPs (3 per fp32 product) against the dense bf16 MFMA peak, i.e. fp32-equivalent "
                                  "FLOPs against 833 TF; timed steps: %d" % steps},
-            "framework_fallback_calls": dict(_ne.FALLBACK_CALLS),
+            "framework_fallback_calls": fallbacks,
             "config": "NRMS-PLM train step, roberta-base-shaped random body (HF module graph; its 72 projections on this library's "
                       "GEMM engine via news_encoder.NrlLinear, its self-attention on nrl_sdpa_fwd / _bwd via the HF attention "
                       "registry), d=768, 16 heads, L=96, B=8 (BASELINE.json configs[3])",
@@ -451,37 +483,59 @@ def main():
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "gemm_engine": args.engine,
                        "optimizer": ("lazy-dense table Adam (bit-identical to dense Adam after flush), rolling flush period 64; "
                                      "dense Adam kernel for the non-table parameters") if trainer.lazy_tables else "dense Adam"},
-            "build_id": build_id, "git_head": git_head(),
+            "build_id": build_id, "git_head": git_head() or "none on this box (no .git in the snapshot): build_id is the content hash of the kernel sources",
             "roofline": roof,
         }
         if distributed:
             out["grad_exchange"] = trainer.exchange_info()
-        elif not args.no_extras:
-            try:
-                out["multi_gpu_prediction"] = predict_multi_gpu(median_ms)
-            except Exception as e:                         # an extra must never cost the headline line
-                out["multi_gpu_prediction"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and not args.no_extras:
             # the forward-only (evaluation-mode) rate of the same workload, outside the timed region
             mod.eval()
             with torch.no_grad():
-                for i in range(3):
+                # 20 untimed forwards: after a host-only pause the clocks take ~20 forwards to settle (0.61 -> 0.52 ms per forward
+                # behind a 1.5 s pause, tools/eval_idle_probe.py); then four groups of ten, every group reported IN ORDER
+                for i in range(20):
                     mod.forward(batches[i % N_BATCHES])
                 torch.cuda.synchronize()
-                # four groups of five forwards, the median group: one allocator stall (a first-time pool growth: 80 ms seen once
-                # in round 5) must not become "the evaluation rate"
                 groups = []
-                for _ in range(4):
+                for gi in range(4):
                     t1 = time.perf_counter()
-                    for i in range(5):
+                    for i in range(10):
                         mod.forward(batches[i % N_BATCHES])
                     torch.cuda.synchronize()
-                    groups.append((time.perf_counter() - t1) / 5)
+                    groups.append((time.perf_counter() - t1) / 10)
+            groups_in_order = list(groups)
             groups.sort()
             fdt = 0.5 * (groups[1] + groups[2])
+            # the same forward with the per-token q|k|v table switched off (every position projected again: rounds 1-5's path)
+            from newsreclib_amd.news_encoder import MHSAAddAtt
+            uses = dict(MHSAAddAtt.TOKEN_TABLE_USES)
+            prev_tt = os.environ.get("NRL_TOKEN_TABLE")
+            os.environ["NRL_TOKEN_TABLE"] = "0"
+            try:
+                with torch.no_grad():
+                    for i in range(10):
+                        mod.forward(batches[i % N_BATCHES])
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(20):
+                        mod.forward(batches[i % N_BATCHES])
+                    torch.cuda.synchronize()
+                    plain_ms = (time.perf_counter() - t1) / 20 * 1e3
+            finally:
+                if prev_tt is None:
+                    del os.environ["NRL_TOKEN_TABLE"]
+                else:
+                    os.environ["NRL_TOKEN_TABLE"] = prev_tt
             mod.train()
             out["forward_only"] = {"value": round(B_PER_GPU / fdt, 1), "unit": "impressions/s", "ms": round(fdt * 1e3, 4),
-                                   "group_ms": [round(g * 1e3, 4) for g in groups]}
+                                   "group_ms": [round(g * 1e3, 4) for g in groups],
+                                   "group_ms_in_order": [round(g * 1e3, 4) for g in groups_in_order],
+                                   "token_table": {"tables_built": uses["built"], "forwards_from_it": uses["forwards"],
+                                                   "note": "q|k|v of the 70,000 vocabulary ids projected once per weight version "
+                                                           "(outside the timed groups: the first untimed forward builds it), "
+                                                           "gathered per position; news vectors torch.equal to the table-less forward"},
+                                   "without_token_table_ms": round(plain_ms, 4)}
         if world == 1 and args.engine != "f32" and not args.no_extras:
             # the exact-fp32 projection engine on the same workload (extra key, outside the timed region), with its own
             # roofline: the in-projection GEMM with the fused gather, against the fp32 MFMA peak
@@ -524,6 +578,15 @@ def main():
                 except Exception as e:                     # an extra must never cost the headline line
                     out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
+        if not distributed and not args.no_extras:
+            # host-only model of the 8-GPU step.  LAST of the device-side extras on purpose (round 6): its host work (sort-based
+            # torch.unique over 1.7 M ids on the framework's thread pool, nine times) was what set off the ~85 ms stall that
+            # rounds 4-5 saw once inside the evaluation loop that used to follow it -- tools/eval_idle_probe.py:
+            # 9 stalls in 33 processes with this host work in front of the loop, 0 in 21 (+ 24 rounds inside one) without it; DESIGN section 5
+            try:
+                out["multi_gpu_prediction"] = predict_multi_gpu(median_ms)
+            except Exception as e:                         # an extra must never cost the headline line
+                out["multi_gpu_prediction"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NRL_ABI_VERSION 15
+#define NRL_ABI_VERSION 16
 
 #define NRL_OK 0
 #define NRL_E_INVALID (-1)   /* bad argument (shape / alignment / null) */
@@ -171,6 +171,25 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
                          const int64_t* ids, int64_t n_news, int32_t seq_len, double p_drop,
                          uint64_t seed, uint32_t stream0, int32_t save_for_backward, float* out,
                          void* ws, size_t ws_bytes, void* stream);
+/* ---- evaluation forwards from a per-token q|k|v table (ABI v16) --------------------------------------------------
+ * Validation / test re-encode every news of every impression under FROZEN weights (rec_dataset.py:98-121,
+ * nrms_module.py:398-535), and without dropout the q|k|v rows of a token position depend on its token id alone
+ * (text.py:224,229).  nrl_token_table_build runs the in-projection ONCE per vocabulary id -- plus the weight images the
+ * back half needs -- into a caller-owned buffer; nrl_news_encoder_fwd_table is MHSAAddAtt.forward (text.py:222-236,
+ * evaluation mode) from it: ids (N, L) -> out (N, D), the per-head 32 x 64 q|k|v image gathered by token id instead of
+ * computed.  A table row holds the bits the projection of nrl_news_encoder_fwd produces for that id, so `out` is EQUAL
+ * (torch.equal) to that call's with p_drop = 0, save_for_backward = 0.  The buffer is valid for exactly the parameter values
+ * (embedding table, in/out projection, additive-attention linear) it was built from: the CALLER rebuilds it after any
+ * update; `att_query` is read from `p` at every call.  bf16x3 engine, fused-news-encoder geometry only
+ * (nrl_token_table_supported; D = 300, 15 heads, L <= 32, Q <= 208); nrl_token_table_bytes returns 0 outside it. */
+int32_t nrl_token_table_supported(int32_t seq_len, int32_t embed_dim, int32_t num_heads, int32_t query_dim);
+size_t nrl_token_table_bytes(int64_t vocab, int32_t embed_dim, int32_t num_heads, int32_t query_dim);
+int nrl_token_table_build(const NrlBlockParams* p, const float* emb_table, int64_t vocab, void* table, size_t table_bytes,
+                          void* stream);
+size_t nrl_news_encoder_fwd_table_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t num_heads);
+int nrl_news_encoder_fwd_table(const NrlBlockParams* p, const void* table, size_t table_bytes, int64_t vocab,
+                               const int64_t* ids, int64_t n_news, int32_t seq_len, float* out, void* ws, size_t ws_bytes,
+                               void* stream);
 /* Backward of the above (autograd of text.py:222-236 incl. embedding_dense_backward with
  * padding_idx=0: rows of id 0 receive no gradient).  d_out (N, D).  Adds into `g` and into
  * d_emb_table (vocab, D).  `ws` must be the workspace the forward filled.

@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_siz
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnewsreclib_amd.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class NrlBlockParams(ctypes.Structure):
@@ -96,6 +96,12 @@ SIGNATURES = {
     "nrl_news_encoder_fwd": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                        c_double, c_uint64, c_uint32, c_int32, c_void_p, c_void_p, c_size_t,
                                        c_void_p]),
+    "nrl_token_table_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+    "nrl_token_table_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
+    "nrl_token_table_build": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "nrl_news_encoder_fwd_table_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "nrl_news_encoder_fwd_table": (c_int32, [POINTER(NrlBlockParams), c_void_p, c_size_t, c_int64, c_void_p, c_int64, c_int32,
+                                             c_void_p, c_void_p, c_size_t, c_void_p]),
     "nrl_news_encoder_bwd": (c_int32, [POINTER(NrlBlockParams), POINTER(NrlBlockGrads), c_void_p, c_void_p, c_int64,
                                        c_void_p, c_void_p, c_int64, c_int32, c_double, c_uint64, c_uint32,
                                        c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),

@@ -225,16 +225,43 @@ class AbstractRecommender(LightningModuleBase):
         with open(fpath, "w") as f:
             json.dump(recommendations, f)
 
+    # -- evaluation epochs (nrms_module.py:398-535) run under frozen weights: every ``MHSAAddAtt`` text encoder serves its forwards
+    #    from ONE per-token q|k|v table for the length of the epoch (news_encoder.MHSAAddAtt.token_table; results torch.equal) ----
+    def _token_tables(self, enter: bool) -> None:
+        import contextlib
+        stack = getattr(self, "_tt_stack", None)
+        if stack is not None:
+            stack.close()
+            self._tt_stack = None
+        if not enter:
+            return
+        stack = contextlib.ExitStack()
+        seen = set()
+        enc = getattr(self, "news_encoder", None)
+        for te in (getattr(enc, "text_encoders", {}) or {}).values():
+            if hasattr(te, "token_table") and id(te) not in seen:
+                seen.add(id(te))
+                stack.enter_context(te.token_table())
+        self._tt_stack = stack
+
+    def on_validation_epoch_start(self) -> None:
+        self._token_tables(True)
+
+    def on_test_epoch_start(self) -> None:
+        self._token_tables(True)
+
     def on_train_epoch_end(self) -> None:
         self._epoch_end("train", self.training_step_outputs)
 
     def on_validation_epoch_end(self) -> None:
+        self._token_tables(False)
         logs = self._epoch_end("val", self.val_step_outputs)
         if "val/loss" in logs:
             self.val_loss_best = min(self.val_loss_best, logs["val/loss"])
             self.log("val/loss_best", self.val_loss_best, prog_bar=True, logger=True, sync_dist=True)
 
     def on_test_epoch_end(self) -> None:
+        self._token_tables(False)
         self._epoch_end("test", self.test_step_outputs)
 
     # -- reference: abstract_recommender.py:89-108 ---------------------------------------------------

@@ -249,6 +249,121 @@ int nrl_news_encoder_fwd(const NrlBlockParams* p, const float* emb_table, int64_
   return block_fwd(p, a_in, s, w, d2, save_for_backward != 0, true, out, (hipStream_t)stream);
 }
 
+// ---- evaluation forwards from a per-token q|k|v table (ABI v16; kernels: nrl_news_fused.h) -------------------------------
+// table buffer = [fragment-ordered weight images: per-head q|k|v (the build's), W_o over the plane slots, W_a in kappa order
+// (the fused tail's)] [q|k|v of every vocabulary id, head-major]; every offset is a function of (vocab, D, heads, Q) only
+struct TokenTable {
+  size_t img_heads, img_o, img_a, qkv, bytes;     // byte offsets
+};
+static TokenTable token_table_layout(int64_t vocab, int D, int heads) {
+  TokenTable t;
+  auto al = [](size_t n) { return align_up(n, 256); };
+  size_t off = 0;
+  t.img_heads = off; off += al(rp_image_elems(heads * 4, NF_KB) * 2);
+  t.img_o = off; off += al(rp_image_elems(NT_FB, NT_KB) * 2);
+  t.img_a = off; off += al(rp_image_elems(NT_QB, NT_KS) * 2);
+  t.qkv = off; off += al(news_qkv_table_floats(vocab, heads) * sizeof(float));
+  t.bytes = off;
+  return t;
+}
+static bool token_table_geometry_ok(int L, int D, int heads, int Q) {
+  return news_fused_ok(L, D, heads) && news_tail_geometry_ok(L, D, Q, heads);
+}
+
+int32_t nrl_token_table_supported(int32_t seq_len, int32_t embed_dim, int32_t num_heads, int32_t query_dim) {
+  return (num_heads > 0 && token_table_geometry_ok(seq_len, embed_dim, num_heads, query_dim)) ? 1 : 0;
+}
+
+size_t nrl_token_table_bytes(int64_t vocab, int32_t embed_dim, int32_t num_heads, int32_t query_dim) {
+  if (vocab <= 0 || num_heads <= 0 || !token_table_geometry_ok(32, embed_dim, num_heads, query_dim)) return 0;
+  if (news_qkv_table_floats(vocab, num_heads) >= (1ull << 32)) return 0;
+  return token_table_layout(vocab, embed_dim, num_heads).bytes;
+}
+
+int nrl_token_table_build(const NrlBlockParams* p, const float* emb_table, int64_t vocab, void* table, size_t table_bytes,
+                          void* stream) {
+  NRL_TRY(check_params(p));
+  const EngineScope engine_scope(p->gemm_engine);
+  const OptScope opt_scope(p->options);
+  NRL_REQUIRE(emb_table && table && vocab > 0, "token_table_build: bad arguments");
+  NRL_REQUIRE(((uintptr_t)emb_table & 15) == 0 && ((uintptr_t)table & 255) == 0, "token_table_build: the embedding table must be 16-byte, the token table 256-byte aligned");
+  const int D = p->embed_dim, heads = p->num_heads, Q = p->query_dim;
+  NRL_REQUIRE(token_table_geometry_ok(32, D, heads, Q), "token_table_build: geometry outside the fused news encoder (D = 300, 15 heads, Q <= 208)");
+  NRL_REQUIRE(cur_engine() == ENGINE_BF16X3, "token_table_build: the bf16x3 engine only (the exact-fp32 engine has no fused news encoder)");
+  const size_t need = nrl_token_table_bytes(vocab, D, heads, Q);
+  NRL_REQUIRE(need > 0, "token_table_build: vocabulary too large for one table (2^32 floats)");
+  if (table_bytes < need) {
+    set_error("token table too small: %zu < %zu bytes", table_bytes, need);
+    return NRL_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const TokenTable t = token_table_layout(vocab, D, heads);
+  unsigned char* base = static_cast<unsigned char*>(table);
+  uint16_t* img_heads = reinterpret_cast<uint16_t*>(base + t.img_heads);
+  RpImageJobs jobs;
+  rp_jobs_init(&jobs);
+  rp_jobs_add_qkv_heads(&jobs, p->in_proj_weight, D, p->in_proj_bias, img_heads, heads, D / heads);
+  rp_jobs_add_kperm(&jobs, p->out_proj_weight, D, 1, D, heads, reinterpret_cast<uint16_t*>(base + t.img_o), NT_FB, p->out_proj_bias);
+  rp_jobs_add_kappa(&jobs, p->att_weight, D, 1, Q, D, p->att_bias, reinterpret_cast<uint16_t*>(base + t.img_a), NT_QB, NT_KS);
+  NRL_TRY(rp_jobs_launch(jobs, st));
+  return launch_news_qkv_table(emb_table, vocab, D, heads, img_heads, reinterpret_cast<float*>(base + t.qkv), st);
+}
+
+// workspace of the table forward: the `o` planes + the short-first news list of the pad-row sharing
+static size_t table_fwd_planes_bytes(int64_t n_news, int L, int heads) {
+  const int64_t M = n_news * L;
+  return align_up((size_t)((M + 31) / 32 * 32) * (size_t)(heads + (heads + 3) / 4) * 16 * sizeof(float), 256);
+}
+size_t nrl_news_encoder_fwd_table_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t num_heads) {
+  if (n_news <= 0 || seq_len <= 0 || num_heads <= 0) return 0;
+  return table_fwd_planes_bytes(n_news, seq_len, num_heads) + align_up((size_t)(n_news + 2) * sizeof(int32_t), 256);
+}
+
+int nrl_news_encoder_fwd_table(const NrlBlockParams* p, const void* table, size_t table_bytes, int64_t vocab,
+                               const int64_t* ids, int64_t n_news, int32_t seq_len, float* out, void* ws, size_t ws_bytes,
+                               void* stream) {
+  NRL_TRY(check_params(p));
+  const EngineScope engine_scope(p->gemm_engine);
+  const OptScope opt_scope(p->options);
+  NRL_REQUIRE(table && ids && out && vocab > 0 && n_news >= 0 && seq_len > 0, "news_encoder_fwd_table: bad arguments");
+  NRL_REQUIRE(cur_engine() == ENGINE_BF16X3, "news_encoder_fwd_table: the bf16x3 engine only");
+  if (n_news == 0) return NRL_OK;
+  const int D = p->embed_dim, heads = p->num_heads, Q = p->query_dim;
+  NRL_REQUIRE(token_table_geometry_ok(seq_len, D, heads, Q), "news_encoder_fwd_table: geometry outside the fused news encoder");
+  const size_t need_t = nrl_token_table_bytes(vocab, D, heads, Q);
+  NRL_REQUIRE(need_t > 0 && table_bytes >= need_t, "news_encoder_fwd_table: not a table of this vocabulary / geometry");
+  NRL_REQUIRE(n_news * (int64_t)seq_len < (1LL << 31), "news_encoder_fwd_table: too many token rows for one call");
+  NRL_REQUIRE(ws != nullptr && ((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+  const size_t need_w = nrl_news_encoder_fwd_table_workspace_bytes(n_news, seq_len, heads);
+  if (ws_bytes < need_w) {
+    set_error("workspace too small: %zu < %zu bytes", ws_bytes, need_w);
+    return NRL_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const TokenTable t = token_table_layout(vocab, D, heads);
+  const unsigned char* base = static_cast<const unsigned char*>(table);
+  unsigned char* o_planes = static_cast<unsigned char*>(ws);
+  int32_t* hdr = reinterpret_cast<int32_t*>(o_planes + table_fwd_planes_bytes(n_news, seq_len, heads));
+  NewsTabArgs a;
+  a.tab = reinterpret_cast<const float*>(base + t.qkv); a.ids = ids; a.n_news = n_news; a.vocab = vocab; a.L = seq_len;
+  a.heads = heads; a.scale = 1.0f / sqrtf((float)(D / heads)); a.o_planes = o_planes;
+  if (opt(O_NEWS_PAD_SHARE) && seq_len >= 17) {
+    NRL_TRY(launch_news_classify(ids, n_news, seq_len, hdr, hdr + 2, st));
+    a.n_short = hdr; a.perm = hdr + 2;
+  }
+  {
+    ProfScope prof(st, 4.0 * (double)n_news * seq_len * seq_len * D);
+    NRL_TRY(launch_news_tab_attn_fwd(a, st));
+  }
+  NewsTailArgs tl;
+  tl.o_planes = o_planes; tl.img_o = reinterpret_cast<const uint16_t*>(base + t.img_o);
+  tl.img_a = reinterpret_cast<const uint16_t*>(base + t.img_a); tl.q_a = p->att_query;
+  tl.n_news = n_news; tl.L = seq_len; tl.D = D; tl.Q = Q; tl.drop2 = make_dropout(0.0, 0, 0); tl.out = out;
+  tl.y_planes = nullptr; tl.t = nullptr; tl.w = nullptr;
+  tl.perm = a.perm; tl.n_short = a.n_short;
+  return news_tail_fwd(tl, st);
+}
+
 int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const float* emb_table,
                          float* d_emb_table, int64_t vocab, const int64_t* ids, const int64_t* sorted_positions,
                          int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed, uint32_t stream0,

@@ -66,6 +66,9 @@ struct NewsFusedArgs {
   // row 15; `o` is written for rows 0 .. 15 only (the tail kernel, given the same lists, never reads the rest).  Both null: off.
   const int32_t* perm = nullptr;
   const int32_t* n_short = nullptr;
+  // TBL (token q|k|v table, evaluation: nrl_token_table_build): `ids` is unused -- "news" n is the run of 32 vocabulary ids
+  // 32 n .. 32 n + 31 (ids >= vocab: zero rows) and only the head-major q|k|v slabs are written (qkv_save = the table)
+  int64_t vocab = 0;
 };
 
 // One launch that partitions the news of an evaluation call into short (token 15 and everything after it is the padding id;
@@ -178,8 +181,13 @@ typedef uint4 __attribute__((may_alias)) nap_u4a;
 // ahead.  4: TWO workgroups per CU (2 x 16 KB ring + 4 images = 66 KB each), chunks one ahead -- the two waves of a SIMD then
 // belong to different workgroups and share no barrier, so one's softmax / store phase runs under the other's MFMAs (what took the
 // tail kernels from 0.25 to 0.20 ms, nrl_news_tail.h); every weight byte is streamed L2 -> LDS once per 4 news instead of once per 8.
-template <int DH, bool SAVE, int ABL = 0, bool SHARE = false, int WV = NF_WAVES>
+// TBL (round 6): the in-projection of the VOCABULARY instead of a batch -- no dropout, no attention, nothing written but the q|k|v
+// slabs.  The accumulators of a token row are produced by the same MFMAs in the same order as in every other shape of this
+// kernel (an MFMA's output row depends on its own A row only), so a table row is bit for bit what an evaluation forward computes
+// for every position that holds this id; news_tab_attn_fwd_kernel below gathers them.
+template <int DH, bool SAVE, int ABL = 0, bool SHARE = false, int WV = NF_WAVES, bool TBL = false>
 __global__ void __launch_bounds__(WV * 64, 2) news_fused_fwd_kernel(const NewsFusedArgs P) {
+  static_assert(!TBL || (SAVE && !SHARE && ABL == 0), "table build: the slab-saving shape, no sharing, no probe switches");
   static_assert(DH == 20, "image packing below assumes 3 * dh <= 64 with dh = 20");
   static_assert(WV == 8 || WV == 4, "8 waves (whole-head ring) or 4 waves (two-slot ring)");
   constexpr int RING = WV == 8 ? NF_RING : 2 * 16384;
@@ -265,9 +273,10 @@ __global__ void __launch_bounds__(WV * 64, 2) news_fused_fwd_kernel(const NewsFu
     for (int rb = 0; rb < 2; ++rb) {
       const int t = rb * 16 + l15;
       okr[rb] = news_ok && t < L;
+      if constexpr (TBL) okr[rb] = okr[rb] && row0 + t < P.vocab;   // (L == 32: row0 + t is the vocabulary id itself)
       growr[rb] = row0 + (okr[rb] ? t : 0);
       if (SHARE && rb == 1 && short_w) continue;          // (row block 1 of a short news is never computed)
-      const float* rowp = P.table + P.ids[growr[rb]] * (int64_t)D;
+      const float* rowp = P.table + (TBL ? (okr[rb] ? growr[rb] : 0) : P.ids[growr[rb]]) * (int64_t)D;
 #pragma unroll
       for (int kb = 0; kb < NF_KB; ++kb) {
         const int k = kb * 32 + 8 * g;
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(WV * 64, 2) news_fused_fwd_kernel(const NewsFu
         v0.z *= m0 * P.drop1.mult(idx + 2); v0.w *= m0 * P.drop1.mult(idx + 3);
         v1.x *= m1 * P.drop1.mult(idx + 4); v1.y *= m1 * P.drop1.mult(idx + 5);
         v1.z *= m1 * P.drop1.mult(idx + 6); v1.w *= m1 * P.drop1.mult(idx + 7);
-        if constexpr (SAVE) {
+        if constexpr (SAVE && !TBL) {
           if (P.x_planes == nullptr && okr[rb]) {
             if (in0) store4(P.x_save + growr[rb] * D + k, v0, NT);
             if (in1) store4(P.x_save + growr[rb] * D + k + 4, v1, NT);
@@ -311,7 +320,7 @@ __global__ void __launch_bounds__(WV * 64, 2) news_fused_fwd_kernel(const NewsFu
           if (k + 4 == D) v1.x = 1.0f;
         }
         rp_split8(v0, v1, ah[rb][kb], al[rb][kb]);
-        if constexpr (SAVE) {
+        if constexpr (SAVE && !TBL) {
           if (P.x_planes != nullptr && news_ok) {
             // block (mb = 2 news + rb, cb = 2 kb + (g >> 1)): row l15, columns 8 (g & 1) .. + 7 (pad rows: zeros + the ones column)
             unsigned char* dst = P.x_planes + (((news * 2 + rb) * 20 + 2 * kb + (g >> 1)) * 2) * 512 + l15 * 32 + (g & 1) * 16;
@@ -325,7 +334,7 @@ __global__ void __launch_bounds__(WV * 64, 2) news_fused_fwd_kernel(const NewsFu
 
   // image (q columns = O, column 60 = log-sum-exp of the query) of head `hp` -> global, 16-byte row stores
   auto flush_o = [&](int hp) {
-    if (!news_ok || (ABL & 8)) return;
+    if (TBL || !news_ok || (ABL & 8)) return;
     // (the lane id is made opaque here: hipcc otherwise hoists every pass's address arithmetic out of the head
     //  loop and spills it -- the MFMA phase has no registers to spare)
     int ln = lane;
@@ -535,6 +544,10 @@ __global__ void __launch_bounds__(WV * 64, 2) news_fused_fwd_kernel(const NewsFu
         }
       };
       if constexpr (ABL & 256) save_qkv(0, 8);                 // (probe: the stores in front of the attention phase)
+      if constexpr (TBL) {                                     // table build: the slab is the result
+        save_qkv(0, 8);
+        continue;
+      }
 
       if constexpr (ABL & 1) continue;
       // ---- S^T = K Q^T on the matrix cores ---------------------------------------------------------------
@@ -696,6 +709,247 @@ static inline int launch_news_fused_fwd(const NewsFusedArgs& a_in, hipStream_t s
       }
       hipLaunchKernelGGL((news_fused_fwd_kernel<20, false, ABL>), grid, blk, 0, st, a);
     }
+  }
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+
+// =====================================================================================================
+// Evaluation forwards from a per-token q|k|v table (round 6; SURVEY.md section 8(f) row 3, reference rec_dataset.py:98-121 /
+// nrms_module.py:398-535: validation and test re-encode every news of every impression with FROZEN weights).
+//
+// Without dropout the q|k|v rows of a token position are a function of its token id alone (text.py:224,229: x = E[id], then
+// x W_in^T + b_in), and a MIND-shaped batch holds 211,200 positions over <= 14 k distinct ids (62 % of them the padding id).
+// `launch_news_qkv_table` runs the in-projection ONCE per vocabulary id (news_fused_fwd_kernel<.., TBL>: 70 k rows instead of
+// 211 k per forward, once per weight version) into
+//     table[(id >> 5)][head][id & 31][64 floats = q 20 | k 20 | v 20 | 0 4]        (256 contiguous bytes per (id, head))
+// and `news_tab_attn_fwd_kernel` below is the fused forward without its projection phase: one wavefront = one news, per head
+// the 32 x 64 image is GATHERED from the table (eight 16-byte loads per lane, the next head's in flight under this head's
+// arithmetic), then the same matrix-core attention, the same `o` planes.  No weight ring, no barrier, 35 KB of LDS per 4-wave
+// workgroup.  The attention code below is a copy of the phase in news_fused_fwd_kernel on purpose (that kernel's register
+// allocation is tuned and stays untouched); `test_token_table_forward_is_bit_identical` keeps the two from drifting apart:
+// a table row carries the bits the projection phase would produce, so `o` -- and every news vector -- must be EQUAL.
+struct NewsTabArgs {
+  const float* tab;         // token q|k|v table
+  const int64_t* ids;       // (n_news, L)
+  int64_t n_news, vocab;
+  int L, heads;
+  float scale;              // 1 / sqrt(dh)
+  unsigned char* o_planes;  // as NewsFusedArgs::o_planes
+  const int32_t* perm = nullptr;      // pad-row sharing lists (news_classify_kernel), or both null
+  const int32_t* n_short = nullptr;
+};
+
+constexpr int NTA_WAVES = 4;
+
+// O of head `hp` (image columns 0 .. 19) -> the head-permuted (hi, lo) planes (the flush of news_fused_fwd_kernel)
+__device__ __forceinline__ void nta_flush_o(const float* image, unsigned char* o_planes, int64_t row0, int hp, int heads, int Lw,
+                                            int lane) {
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  {
+    const int row = ln >> 1, half = ln & 1;
+    const int64_t m = row0 + row;
+    bf16x8 hi, lo;
+    rp_split8(*reinterpret_cast<const float4*>(image + row * NF_IMG_LD + half * 8),
+              *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + half * 8 + 4), hi, lo);
+    unsigned char* dst = o_planes + (((m >> 4) * 19 + hp) * 2) * 512 + (m & 15) * 32 + half * 16;
+    if (row < Lw) {
+      *reinterpret_cast<bf16x8*>(dst) = hi;
+      *reinterpret_cast<bf16x8*>(dst + 512) = lo;
+    }
+  }
+  {
+    const int row = ln & 31;
+    const int64_t m = row0 + row;
+    const float4 v = *reinterpret_cast<const float4*>(image + row * NF_IMG_LD + 16);
+    uint32_t h0, l0, h1, l1;
+    split_pair(v.x, v.y, h0, l0);
+    split_pair(v.z, v.w, h1, l1);
+    unsigned char* blk = o_planes + (((m >> 4) * 19 + heads + (hp >> 2)) * 2) * 512 + (m & 15) * 32;
+    if (row < Lw) {
+      if (ln < 32) {
+        *reinterpret_cast<uint2*>(blk + (hp & 3) * 8) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(blk + 512 + (hp & 3) * 8) = make_uint2(l0, l1);
+      } else if (hp == heads - 1 && (heads & 3) != 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int slot = (heads & 3) + q;
+          if (slot < 4) {
+            *reinterpret_cast<uint2*>(blk + slot * 8) = make_uint2(q == 0 ? 0x3F80u : 0u, 0u);
+            *reinterpret_cast<uint2*>(blk + 512 + slot * 8) = make_uint2(0u, 0u);
+          }
+        }
+      }
+    }
+  }
+}
+
+// the head loop of one news in two compile-time shapes: NI = 2 query blocks, and (a short news under pad-row sharing) NI = 1
+template <int DH, int NI>
+__device__ __forceinline__ void nta_heads(const NewsTabArgs& P, float* image, int64_t row0, int Lw, int lane) {
+  const int l15 = lane & 15, g = lane >> 4;
+  const int L = P.L, heads = P.heads;
+  // slot = pass * 64 + lane of the 32 x 16 float4 image: row = pass * 4 + g, 16-byte column l15.  Rows past the news (L < 32)
+  // read the last token's row: their keys are masked, their values meet P = 0, their query rows are never stored.
+  // (eight NAMED registers sets, not an array: a float4 array carried around the head loop stays in scratch memory -- hipcc
+  //  stores every load to the stack at the loop's end, behind a vmcnt(0), and reloads it at the top: no prefetch at all)
+  const float *s0, *s1, *s2, *s3, *s4, *s5, *s6, *s7;
+  float4 n0, n1, n2, n3, n4, n5, n6, n7;
+#define NTA_SRC(i)                                                                                        \
+  {                                                                                                       \
+    const int row = (i) * 4 + g;                                                                          \
+    const int64_t id = P.ids[row0 + (row < L ? row : L - 1)];                                             \
+    s##i = P.tab + ((size_t)((id >> 5) * heads) * 2048u + (size_t)(id & 31) * 64u + (size_t)l15 * 4u);    \
+  }
+  NTA_SRC(0) NTA_SRC(1) NTA_SRC(2) NTA_SRC(3) NTA_SRC(4) NTA_SRC(5) NTA_SRC(6) NTA_SRC(7)
+#undef NTA_SRC
+#define NTA_LOAD(i) n##i = *reinterpret_cast<const float4*>(s##i);
+  NTA_LOAD(0) NTA_LOAD(1) NTA_LOAD(2) NTA_LOAD(3) NTA_LOAD(4) NTA_LOAD(5) NTA_LOAD(6) NTA_LOAD(7)
+  for (int h = 0; h < heads; ++h) {
+    // this head's rows -> the private image; the next head's leave for the registers they came from
+#define NTA_PUT(i) *reinterpret_cast<float4*>(image + ((i) * 4 + g) * NF_IMG_LD + 4 * l15) = n##i;
+    NTA_PUT(0) NTA_PUT(1) NTA_PUT(2) NTA_PUT(3) NTA_PUT(4) NTA_PUT(5) NTA_PUT(6) NTA_PUT(7)
+#undef NTA_PUT
+    {
+      const int step = h + 1 < heads ? 2048 : 0;          // (last head: its own rows again, uniform control flow)
+      s0 += step; s1 += step; s2 += step; s3 += step; s4 += step; s5 += step; s6 += step; s7 += step;
+      NTA_LOAD(0) NTA_LOAD(1) NTA_LOAD(2) NTA_LOAD(3) NTA_LOAD(4) NTA_LOAD(5) NTA_LOAD(6) NTA_LOAD(7)
+      // (left alone, the scheduler sinks these loads below the attention phase -- to the end of the head, a few dozen
+      //  instructions in front of the wait for them)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- S^T = K Q^T on the matrix cores (as news_fused_fwd_kernel) --------------------------------------
+    bf16x8 kh[2], kl[2], qh[2], ql[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      nf_frag8(image + (b * 16 + l15) * NF_IMG_LD + DH, g, 1.0f, kh[b], kl[b]);
+      if (b < NI) nf_frag8(image + (b * 16 + l15) * NF_IMG_LD, g, P.scale, qh[b], ql[b]);
+    }
+    f32x4 s[2][2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) s[jb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < NI; ++ib)
+          s[jb][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? kl[jb] : kh[jb], pass == 0 ? ql[ib] : qh[ib],
+                                                              s[jb][ib], 0, 0, 0);
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) {
+      float e[8];
+      float m = -INFINITY;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = jb * 16 + 4 * g + r;
+          e[jb * 4 + r] = key < L ? s[jb][ib][r] : -INFINITY;
+          m = fmaxf(m, e[jb * 4 + r]);
+        }
+      m = fmaxf(m, nf_xor16(m, lane));
+      m = fmaxf(m, nf_xor32(m, lane));
+      constexpr float LOG2E = 1.4426950408889634f;
+      const float m2 = m * LOG2E;
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        e[q] = __builtin_amdgcn_exp2f(fmaf(e[q], LOG2E, -m2));
+        sum += e[q];
+      }
+      sum += nf_xor16(sum, lane);
+      sum += nf_xor32(sum, lane);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      rp_split8(make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv),
+                make_float4(e[4] * inv, e[5] * inv, e[6] * inv, e[7] * inv), ph[ib], pl[ib]);
+    }
+    bf16x8 vh[2], vl[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int d = db * 16 + l15;
+      nf_kfrag(image + 2 * DH + d, NF_IMG_LD, g, d < DH ? 1.0f : 0.f, vh[db], vl[db]);
+    }
+    f32x4 oacc[2][2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[ib][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+      for (int ib = 0; ib < NI; ++ib)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          oacc[ib][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? pl[ib] : ph[ib], pass == 0 ? vl[db] : vh[db],
+                                                                 oacc[ib][db], 0, 0, 0);
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (db * 16 + l15 < DH) image[(ib * 16 + 4 * g + r) * NF_IMG_LD + db * 16 + l15] = oacc[ib][db][r];
+    nta_flush_o(image, P.o_planes, row0, h, heads, Lw, lane);
+  }
+#undef NTA_LOAD
+}
+
+template <int DH, bool SHARE>
+__global__ void __launch_bounds__(NTA_WAVES * 64, 3) news_tab_attn_fwd_kernel(const NewsTabArgs P) {
+  static_assert(DH == 20, "image packing assumes 3 * dh <= 64 with dh = 20");
+  __shared__ __attribute__((aligned(16))) float smem[NTA_WAVES * NF_IMG_FLOATS + 4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const image = smem + wave * NF_IMG_FLOATS;
+  const int64_t news_v = (int64_t)blockIdx.x * NTA_WAVES + wave;
+  if (news_v >= P.n_news) return;                          // (no workgroup-level synchronisation anywhere below)
+  int64_t news = news_v;
+  bool short_w = false;
+  if constexpr (SHARE) {
+    news = __builtin_amdgcn_readfirstlane(P.perm[news_v]);
+    short_w = news_v < (int64_t)__builtin_amdgcn_readfirstlane(*P.n_short);
+  }
+  const int64_t row0 = news * P.L;
+  if (SHARE && short_w) nta_heads<DH, 1>(P, image, row0, 16, lane);
+  else nta_heads<DH, 2>(P, image, row0, P.L, lane);
+}
+
+static inline size_t news_qkv_table_floats(int64_t vocab, int heads) { return (size_t)((vocab + 31) / 32) * heads * 32 * 64; }
+
+// the table: the in-projection of every vocabulary id (news_fused_fwd_kernel in its TBL shape)
+static inline int launch_news_qkv_table(const float* emb_table, int64_t vocab, int D, int heads, const uint16_t* img_heads,
+                                        float* table, hipStream_t st) {
+  NRL_REQUIRE(news_fused_ok(32, D, heads) && vocab > 0, "token table: unsupported geometry");
+  NRL_REQUIRE(news_qkv_table_floats(vocab, heads) < (1ull << 32), "token table: more than 2^32 floats");
+  NewsFusedArgs a;
+  a.table = emb_table; a.ids = nullptr; a.img = img_heads; a.n_news = (vocab + 31) / 32; a.L = 32; a.D = D; a.heads = heads;
+  a.dh = 20; a.scale = 0.f; a.drop1 = make_dropout(0.0, 0, 0); a.o = nullptr; a.o_planes = nullptr; a.x_save = nullptr;
+  a.x_planes = nullptr; a.qkv_save = table; a.qkv_head_major = 1; a.lse = nullptr; a.vocab = vocab;
+  const int64_t blocks = ceil_div(a.n_news, NF_WAVES);
+  a.full_wgs = (int)blocks;
+  hipLaunchKernelGGL((news_fused_fwd_kernel<20, true, 0, false, NF_WAVES, true>), dim3((unsigned)blocks), dim3(NF_WAVES * 64), 0, st, a);
+  NRL_LAUNCH_CHECK();
+  return NRL_OK;
+}
+
+static inline int launch_news_tab_attn_fwd(const NewsTabArgs& a, hipStream_t st) {
+  if (a.n_news <= 0) return NRL_OK;
+  NRL_REQUIRE(a.L >= 1 && a.L <= 32 && a.heads > 0 && a.tab != nullptr && a.o_planes != nullptr, "token-table forward: bad arguments");
+  NRL_REQUIRE(news_qkv_table_floats(a.vocab, a.heads) < (1ull << 32), "token table: more than 2^32 floats");
+  const int64_t blocks = ceil_div(a.n_news, NTA_WAVES);
+  NRL_REQUIRE(blocks < (1LL << 31), "news grid too large");
+  if (a.perm != nullptr) {
+    NRL_REQUIRE(a.n_short != nullptr, "token-table forward: pad-row sharing needs both lists");
+    hipLaunchKernelGGL((news_tab_attn_fwd_kernel<20, true>), dim3((unsigned)blocks), dim3(NTA_WAVES * 64), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((news_tab_attn_fwd_kernel<20, false>), dim3((unsigned)blocks), dim3(NTA_WAVES * 64), 0, st, a);
   }
   NRL_LAUNCH_CHECK();
   return NRL_OK;

@@ -93,9 +93,16 @@ class NewsVectorCache:
         enc = self.module.news_encoder
         names = [k for k in self.table.attrs if k in TEXT_ATTRS or k in ("category", "subcategory")]
         out = []
-        for lo in range(0, self.table.num_news, self.chunk):
-            hi = min(lo + self.chunk, self.table.num_news)
-            out.append(enc({k: self.table.attrs[k][lo:hi] for k in names}))
+        import contextlib
+        with contextlib.ExitStack() as stack:
+            # one pass over the whole corpus under frozen weights: MHSAAddAtt text encoders run their in-projection once per
+            # VOCABULARY id instead of once per token position (news_encoder.MHSAAddAtt.token_table; same bits)
+            for te in {id(t): t for t in (getattr(enc, "text_encoders", {}) or {}).values()}.values():
+                if hasattr(te, "token_table"):
+                    stack.enter_context(te.token_table())
+            for lo in range(0, self.table.num_news, self.chunk):
+                hi = min(lo + self.chunk, self.table.num_news)
+                out.append(enc({k: self.table.attrs[k][lo:hi] for k in names}))
         self.vectors = torch.cat(out, dim=0)
         self.module.train(was_training)
         return self.vectors

@@ -51,11 +51,79 @@ class MHSAAddAtt(nn.Module):
         self.num_heads = num_heads
         self.table_grad_hook = None   # optional callable(table_grad, ids) (or callable(table_grad)): called from the backward once the
         # table gradient is complete, before the weight-gradient GEMMs (trainer.NRMSTrainer starts its all-reduce there)
+        self._tt_buf = self._tt_key = self._tt_seen_key = None       # token q|k|v table of evaluation forwards (below)
+        self._tt_seen, self._tt_pinned = 0, False
 
     def _params(self):
         mha, att = self.multihead_attention, self.additive_attention
         return (self.embedding_layer.weight, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                 mha.out_proj.bias, att.linear.weight, att.linear.bias, att.query)
+
+    # ---- evaluation forwards from a per-token q|k|v table (round 6; ops.token_table_build) ------------------------------
+    # Without dropout the q|k|v rows of a token position depend on its token id alone, and validation / test encode every news
+    # of every impression under frozen weights (rec_dataset.py:98-121, nrms_module.py:398-535): the in-projection runs once per
+    # VOCABULARY id and per weight version instead of once per position and forward.  The result is torch.equal to the table-less
+    # forward.  Two ways in:
+    #   * ``with encoder.token_table():`` -- the caller vouches that the weights do not change inside (an evaluation epoch:
+    #     ``AbstractRecommender.on_validation_epoch_start`` / ``_end``, ``evaluation.NewsVectorCache.build``);
+    #   * automatically, for forwards with the module in eval mode under ``torch.no_grad()``, keyed on every parameter's storage
+    #     and version counter and on this library's optimizer-step generation -- for TRAINABLE weights only while this
+    #     library's optimizer is the writer (``ops_blocks.step_images_allowed``: a foreign ``p.data`` writer moves no counter),
+    #     and only once the positions seen under the current weights reach the vocabulary size (a table build costs one
+    #     in-projection over V rows).  ``NRL_TOKEN_TABLE=0`` turns the automatic route off.
+    TOKEN_TABLE_USES = {"built": 0, "forwards": 0}
+
+    def _token_table_key(self, params):
+        return (tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in params[:-1]), _lib.engine_code(), _lib.options_word(),
+                ops_blocks._IMAGE_GENERATION[0], ops_blocks._STEP_GENERATION[0], int(self.num_heads))
+
+    def token_table(self):
+        """Context manager: forwards inside (eval mode, no grad) run from ONE table built at the first of them."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev = self._tt_pinned
+            self._tt_pinned = True
+            try:
+                yield self
+            finally:
+                self._tt_pinned = prev
+        return scope()
+
+    def drop_token_table(self) -> None:
+        self._tt_buf = self._tt_key = None
+
+    def _forward_from_token_table(self, text: torch.Tensor, params) -> Optional[torch.Tensor]:
+        if not (torch.is_tensor(text) and text.is_cuda and text.dim() == 2 and text.dtype == torch.int64):
+            return None
+        emb = params[0]
+        V, D = emb.shape
+        N, L = text.shape
+        if not ops.token_table_supported(L, D, self.num_heads, params[5].shape[0]):
+            return None
+        pinned = self._tt_pinned
+        if not pinned:
+            if os.environ.get("NRL_TOKEN_TABLE", "1") == "0":
+                return None
+            if any(t.requires_grad for t in params[:-1]) and not ops_blocks.step_images_allowed():
+                return None
+        key = self._token_table_key(params)
+        if self._tt_buf is None or self._tt_key != key:
+            if not pinned:
+                if self._tt_seen_key != key:
+                    self._tt_seen_key, self._tt_seen = key, 0
+                self._tt_seen += N * L
+                if self._tt_seen < V:
+                    return None
+            self._tt_key = None                 # (a failed build must not leave the old key over a half-written table)
+            self._tt_buf = ops.token_table_build(params, self.num_heads, self._tt_buf)
+            if self._tt_buf is None:
+                return None
+            self._tt_key = key
+            MHSAAddAtt.TOKEN_TABLE_USES["built"] += 1
+        MHSAAddAtt.TOKEN_TABLE_USES["forwards"] += 1
+        return ops.news_encoder_fwd_table(text, self._tt_buf, V, params[1:], self.num_heads)
 
     def forward(self, text: torch.Tensor, seed: Optional[int] = None,
                 order: Optional[torch.Tensor] = None, stream0: int = 0) -> torch.Tensor:
@@ -63,6 +131,10 @@ class MHSAAddAtt(nn.Module):
         if p > 0.0 and seed is None:
             seed = _draw_seed()
         params = self._params()
+        if not self.training and not torch.is_grad_enabled():
+            out = self._forward_from_token_table(text, params)
+            if out is not None:
+                return out
         return ops.NewsEncoderFn.apply(text, *params, self.num_heads, p, seed or 0, stream0, _grad_bufs(params),
                                        order, self.table_grad_hook)
 

@@ -451,6 +451,50 @@ def split_rows(x: torch.Tensor, n: int):
     return SplitRowsFn.apply(x, n) if x.requires_grad else (x[:n], x[n:])
 
 
+# ---- evaluation forwards of the news encoder from a per-token q|k|v table (include/newsreclib_amd.h, ABI v16) ------------
+def token_table_supported(seq_len: int, embed_dim: int, heads: int, query_dim: int) -> bool:
+    return _lib.engine_code() == 2 and bool(_lib.load().nrl_token_table_supported(int(seq_len), int(embed_dim), int(heads),
+                                                                                 int(query_dim)))
+
+
+def token_table_build(params: Sequence[torch.Tensor], heads: int, buf: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """``params`` = (embedding table, in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear.weight, linear.bias,
+    query) of an ``MHSAAddAtt``: runs the in-projection once per vocabulary id and builds the back half's weight images into
+    ``buf`` (reused when large enough).  None when the geometry has no table (``nrl_token_table_bytes`` == 0)."""
+    lib = _lib.load()
+    params = [_chk(t.detach(), torch.float32, "parameter") for t in params]
+    emb = params[0]
+    V, D = emb.shape
+    bp = _block_params(params[1:], heads, _lib.engine_code(), _lib.options_word())
+    nbytes = int(lib.nrl_token_table_bytes(V, D, int(heads), bp.query_dim))
+    if nbytes == 0:
+        return None
+    if buf is None or buf.numel() < nbytes or buf.device != emb.device:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)
+    _lib.check(lib.nrl_token_table_build(ctypes.byref(bp), emb.data_ptr(), V, buf.data_ptr(), buf.numel(), _stream()),
+               "nrl_token_table_build")
+    return buf
+
+
+def news_encoder_fwd_table(ids: torch.Tensor, table: torch.Tensor, vocab: int, params: Sequence[torch.Tensor],
+                           heads: int) -> torch.Tensor:
+    """``MHSAAddAtt.forward`` in evaluation mode from a table of ``token_table_build`` (``params`` without the embedding table:
+    the seven block parameters): ids (N, L) -> (N, D), EQUAL to the table-less evaluation forward."""
+    lib = _lib.load()
+    ids = _chk(ids, torch.int64, "ids")
+    if ids.dim() != 2:
+        raise ValueError("newsreclib_amd: token ids must be (num_news, num_tokens)")
+    N, L = ids.shape
+    params = [_chk(t.detach(), torch.float32, "parameter") for t in params]
+    bp = _block_params(params, heads, _lib.engine_code(), _lib.options_word())
+    out = torch.empty((N, bp.embed_dim), dtype=torch.float32, device=ids.device)
+    ws = torch.empty(max(int(lib.nrl_news_encoder_fwd_table_workspace_bytes(N, L, int(heads))), 256), dtype=torch.uint8,
+                     device=ids.device)
+    _lib.check(lib.nrl_news_encoder_fwd_table(ctypes.byref(bp), table.data_ptr(), table.numel(), int(vocab), ids.data_ptr(), N, L,
+                                              out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "nrl_news_encoder_fwd_table")
+    return out
+
+
 # ---- plain (non-autograd) entry points ----------------------------------------------------------
 def embedding_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()

@@ -20,6 +20,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--forwards", type=int, default=30)
     ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--prof", action="store_true", help="bench.py's instrumented pass (nrl_prof_enable) before the forwards")
+    ap.add_argument("--prepare", action="store_true", help="bench.py's 20 prepare_batch calls before the forwards")
+    ap.add_argument("--predict", action="store_true", help="bench.py's predict_multi_gpu (host-side torch.unique) before the forwards")
     a = ap.parse_args()
     from newsreclib_amd import _lib
     from newsreclib_amd.nrms_module import attach_layout
@@ -35,6 +38,24 @@ def main():
     for i in range(a.steps):
         trainer.step(batches[i % nb], batches[(i + 1) % nb])
     torch.cuda.synchronize()
+    if a.prof:
+        import ctypes
+        lib = _lib.load()
+        lib.nrl_prof_enable(1)
+        for i in range(a.steps):
+            trainer.step(batches[i % nb], batches[(i + 1) % nb])
+        torch.cuda.synchronize()
+        tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        lib.nrl_prof_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(flops))
+        lib.nrl_prof_enable(0)
+    if a.prepare:
+        from newsreclib_amd.nrms_module import prepare_batch
+        for i in range(20):
+            prepare_batch(batches[i % nb], bench.VOCAB)
+        torch.cuda.synchronize()
+    if a.predict:
+        bench.predict_multi_gpu(2.8)
+    print(f"flags: prof={a.prof} prepare={a.prepare} predict={a.predict}")
 
     def stats():
         s = torch.cuda.memory_stats()
