@@ -329,10 +329,11 @@ def main():
                          "one exchange whose RCCL calls have run on hardware, at world size 1)")
     args = ap.parse_args()
     if args.grad_exchange is None:
-        # configs[1] (B = 128 per GPU): the dense all-reduce hides under the weight gradients even on a ring (predicted 7.0x at 8
-        # GPUs) and is the one exchange whose RCCL calls have run on hardware; configs[2] (B = 64 per GPU, V = 150k): its 183 MB
-        # dense gradient does not (predicted 4.1x on a ring) -- `auto` picks the owner-partitioned row exchange there (7.3-7.9x)
-        args.grad_exchange = "auto" if args.workload == "mindlarge" else "dense"
+        # dense all-reduce for every workload: it is the one exchange whose RCCL calls have run on hardware (at world size 1; no
+        # multi-GPU node was available to any round).  `--grad-exchange auto` prices the three exchanges per step
+        # (trainer.predicted_wire_ms) and would pick the owner-partitioned row exchange for configs[2] (183 MB of dense gradient at
+        # B = 64 per GPU) -- whose all-to-all on a private stream has never run at world > 1 (round-5 advisor): opt-in until it has
+        args.grad_exchange = "dense"
     B_PER_GPU, VOCAB = WORKLOADS[args.workload]["batch"], WORKLOADS[args.workload]["vocab"]
     M_ROWS = B_PER_GPU * (H + C) * L
 
@@ -394,9 +395,16 @@ def main():
     # ---- second, instrumented pass (NOT the headline, feeds `roofline` only): HIP events around the dominant kernel
     # (nrl_prof, recorded on the launch stream) ----
     lib.nrl_prof_enable(1)
+    if hasattr(trainer.reduce, "measure"):
+        # (N > 1: event pairs around every wait for a collective -- how much of the exchange the backward did not hide; zeros at
+        #  world 1.  In this pass only: the timed region above carries no such instrumentation)
+        trainer.reduce.reset_exposed_wait()
+        trainer.reduce.measure = True
     for i in range(args.steps):
         trainer.step(batches[i % N_BATCHES], batches[(i + 1) % N_BATCHES])
     barrier()
+    if hasattr(trainer.reduce, "measure"):
+        trainer.reduce.measure = False
     tot_ms, launches, flops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     lib.nrl_prof_read(ctypes.byref(tot_ms), ctypes.byref(launches), ctypes.byref(flops))
     lib.nrl_prof_enable(0)
@@ -487,7 +495,23 @@ def main():
             "roofline": roof,
         }
         if distributed:
-            out["grad_exchange"] = trainer.exchange_info()
+            # self-diagnosing multi-GPU line: the exchange that ran, its bytes on the wire per rank, the
+            # wire time the xGMI model predicts for it and the MEASURED time the launch stream spent blocked on it, next to the
+            # overlap window it had; what the one-GPU step of this same build takes is `multi_gpu_prediction.compute_ms` of a
+            # `--gpus 1` run.  scaling_check: the 8-GPU speed-up the model predicts for this exchange, and the step time above which
+            # that prediction is falsified
+            gx = trainer.exchange_info()
+            pw = gx.get("predicted_wire_ms", {})
+            choice = gx.get("last_step_choice", gx.get("mode"))
+            key = "dense" if str(choice).startswith("dense") else ("owners" if "owner" in str(choice) else ("rows" if "row" in str(choice) else str(choice)))
+            pred = pw.get(key, {}) if isinstance(pw.get(key, {}), dict) else {}
+            overlap = 0.22 * median_ms
+            gx["per_step"] = {"exchange_chosen": choice, "bytes_on_the_wire_per_rank": gx.get("payload_bytes_per_rank"),
+                              "predicted_wire_ms": pred, "overlap_window_ms": round(overlap, 4),
+                              "predicted_exposed_ms": {m: round(max(0.0, v - overlap), 4) for m, v in pred.items()},
+                              "measured_exposed_wait_ms": gx["measured"]["exposed_wait_ms_per_step"],
+                              "steps_measured": gx["measured"]["steps_measured"]}
+            out["grad_exchange"] = gx
         if world == 1 and not args.no_extras:
             # the forward-only (evaluation-mode) rate of the same workload, outside the timed region
             mod.eval()

@@ -106,7 +106,7 @@ class MHSAAddAtt(nn.Module):
         if not pinned:
             if os.environ.get("NRL_TOKEN_TABLE", "1") == "0":
                 return None
-            if any(t.requires_grad for t in params[:-1]) and not ops_blocks.step_images_allowed():
+            if any(t.requires_grad for t in params[:-1]) and not ops_blocks.step_images_allowed(*params[:-1]):
                 return None
         key = self._token_table_key(params)
         if self._tt_buf is None or self._tt_key != key:
@@ -281,7 +281,7 @@ class NrlLinear(nn.Module):
         if trainable and self._images is not None:
             self._images.invalidate()        # trained now, maybe frozen again later: never meet an image of the old values
         # (a trainable weight's images survive a call only when this library's optimizer drives the step: ops_blocks.step_images_allowed)
-        images = self._images if not trainable else (self._step_images if ops_blocks.step_images_allowed() else None)
+        images = self._images if not trainable else (self._step_images if ops_blocks.step_images_allowed(self.weight, self.bias) else None)
         return ops_blocks.LinearFn.apply(x.contiguous(), self.weight, self.bias, _grad_bufs(params), images)
 
     def extra_repr(self) -> str:
@@ -369,7 +369,7 @@ def _fused_ffn_chunk(self, attention_output: torch.Tensor) -> torch.Tensor:
         trainable = lin.weight.requires_grad or lin.bias.requires_grad
         if trainable and lin._images is not None:
             lin._images.invalidate()
-        return lin._images if not trainable else (lin._step_images if ops_blocks.step_images_allowed() else None)
+        return lin._images if not trainable else (lin._step_images if ops_blocks.step_images_allowed(lin.weight, lin.bias) else None)
 
     out, ln = self.output, self.output.LayerNorm
     if _FFN_GLUE and ln.weight is not None and ln.bias is not None and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and x.numel() < (1 << 32) \
@@ -529,12 +529,13 @@ def _fused_attention_forward(self, hidden_states, attention_mask=None, encoder_h
     trainable = any(l.weight.requires_grad or l.bias.requires_grad for l in lins)
     if trainable:
         self._nrl_qkv_images.invalidate()
-    img_qkv = self._nrl_qkv_images if not trainable else (self._nrl_qkv_step_images if ops_blocks.step_images_allowed() else None)
+    img_qkv = self._nrl_qkv_images if not trainable else (
+        self._nrl_qkv_step_images if ops_blocks.step_images_allowed(*[t for l in lins for t in (l.weight, l.bias)]) else None)
     od = so.dense
     o_train = od.weight.requires_grad or od.bias.requires_grad
     if o_train and od._images is not None:
         od._images.invalidate()
-    img_o = od._images if not o_train else (od._step_images if ops_blocks.step_images_allowed() else None)
+    img_o = od._images if not o_train else (od._step_images if ops_blocks.step_images_allowed(od.weight, od.bias) else None)
     p_hid = float(so.dropout.p) if so.training else 0.0
     params = (sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias, od.weight, od.bias,
               ln.weight, ln.bias)

@@ -2,7 +2,9 @@
 nn.Linear + activation).  Same conventions as ``ops.py``."""
 from __future__ import annotations
 
+import contextlib
 import ctypes
+import weakref
 
 import torch
 
@@ -635,7 +637,16 @@ _IMAGE_GENERATION = [0]
 _STEP_GENERATION = [0]      # bumped by an optimizer that writes parameters through raw pointers (trainer.FusedAdam.begin_step)
 
 
-_STEP_DRIVERS = [0]         # optimizers of THIS library alive in the process (trainer.FusedAdam registers itself)
+# Optimizers of THIS library that are alive (held weakly: the permission below ends with the optimizer -- round-5 advisor: a
+# process-wide counter that only ever grew kept trainable-weight images for every module of the process once ANY trainer had
+# existed, including modules a foreign optimizer drives through ``p.data``).  Every parameter such an optimizer owns carries a weak
+# reference to it (``_nrl_step_driver``).
+_STEP_DRIVERS = weakref.WeakSet()
+_ANON_DRIVERS = []          # drivers registered without an object (a process-wide promise; tests)
+
+
+class _AnonDriver:
+    pass
 
 
 def next_optimizer_step() -> None:
@@ -643,18 +654,51 @@ def next_optimizer_step() -> None:
     _STEP_GENERATION[0] += 1
 
 
-def register_step_driver() -> None:
-    """Called by an optimizer that promises ``next_optimizer_step()`` before every parameter write (trainer.FusedAdam)."""
-    _STEP_DRIVERS[0] += 1
+def register_step_driver(driver=None, params=()) -> None:
+    """Called by an optimizer that promises ``next_optimizer_step()`` before every parameter write (trainer.FusedAdam): `driver` is
+    the optimizer (kept weakly), `params` the parameters it writes.  Without arguments: a process-wide promise for every weight."""
+    if driver is None:
+        driver = _AnonDriver()
+        _ANON_DRIVERS.append(driver)
+    _STEP_DRIVERS.add(driver)
+    ref = weakref.ref(driver)
+    for p in params:
+        p._nrl_step_driver = ref
 
 
-def step_images_allowed() -> bool:
-    """Whether images of TRAINABLE weights may be kept within an optimizer step.  Only under this library's own optimizer:
-    a foreign writer that updates through ``p.data`` (apex, legacy AdamW forks, EMA weight swaps, manual ``.data.copy_``)
-    moves neither the parameter's version counter nor the step generation, and the kernels would keep multiplying by the
-    old weights (round-4 advisor finding).  Outside ``trainer.NRMSTrainer`` -- the Lightning / Hydra drop-in path, whose
-    optimizer comes from the config -- a trainable weight's images are rebuilt on every call."""
-    return _STEP_DRIVERS[0] > 0
+def _owned_by_live_driver(w) -> bool:
+    ref = getattr(w, "_nrl_step_driver", None)
+    return ref is not None and ref() is not None
+
+
+@contextlib.contextmanager
+def no_step_drivers():
+    """The process as if no optimizer of this library existed (tests)."""
+    global _STEP_DRIVERS
+    saved, anon = _STEP_DRIVERS, list(_ANON_DRIVERS)
+    _STEP_DRIVERS = weakref.WeakSet()
+    del _ANON_DRIVERS[:]
+    try:
+        yield
+    finally:
+        _STEP_DRIVERS = saved
+        _ANON_DRIVERS[:] = anon
+
+
+def step_images_allowed(*weights) -> bool:
+    """Whether images (or tables) built from TRAINABLE weights may be kept within an optimizer step.  Only under this library's own
+    optimizer: a foreign writer that updates through ``p.data`` (apex, legacy AdamW forks, EMA weight swaps, manual
+    ``.data.copy_``) moves neither the parameter's version counter nor the step generation, and the kernels would keep multiplying
+    by the old weights (round-4 advisor finding).  With `weights` given, every trainable one of them must be OWNED by a live
+    optimizer of this library (or a process-wide promise must stand); without, any live driver answers for the process.  Outside
+    ``trainer.NRMSTrainer`` -- the Lightning / Hydra drop-in path, whose optimizer comes from the config -- a trainable weight's
+    images are rebuilt on every call."""
+    if len(_STEP_DRIVERS) == 0:
+        return False
+    if _ANON_DRIVERS:
+        return True
+    trainable = [w for w in weights if w is not None and getattr(w, "requires_grad", False)]
+    return all(_owned_by_live_driver(w) for w in trainable)
 
 
 def invalidate_frozen_images() -> None:

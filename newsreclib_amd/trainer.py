@@ -61,7 +61,8 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = 0
         from . import ops_blocks
-        ops_blocks.register_step_driver()      # this optimizer announces every parameter write (begin_step): per-step weight images are safe
+        # this optimizer announces every parameter write (begin_step): images of the weights it OWNS may live for a step
+        ops_blocks.register_step_driver(self, flat.params)
 
     def step(self, grad_scale: float = 1.0, zero_grad: bool = True) -> None:
         self.begin_step()
@@ -95,7 +96,41 @@ def allreduce_gradients(grad: torch.Tensor, group=None) -> float:
     return 1.0 / world
 
 
-class OverlappedGradReduce:
+class _ExposedWait:
+    """Measures what the launch stream spends BLOCKED on the gradient exchange (the part of the wire time the backward did not
+    hide): an event pair on the launch stream around every wait for a collective.  Off by default (``measure = False``: nothing is
+    recorded); bench.py switches it on for its instrumented pass.  ``exposed_wait_ms()`` -> mean per step, steps measured."""
+    measure = False
+
+    def _timed(self, fn):
+        if not self.measure or not torch.cuda.is_available():
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.__dict__.setdefault("_wait_events", []).append((a, b))
+        return out
+
+    def _step_measured(self) -> None:
+        if self.measure:
+            ev = self.__dict__.setdefault("_wait_events", [])
+            self.__dict__.setdefault("_wait_steps", []).append(ev[:])
+            del ev[:]
+
+    def exposed_wait_ms(self):
+        steps = self.__dict__.get("_wait_steps", [])
+        if not steps:
+            return 0.0, 0
+        torch.cuda.synchronize()
+        per_step = [sum(a.elapsed_time(b) for a, b in ev) for ev in steps]
+        return float(sum(per_step) / len(per_step)), len(per_step)
+
+    def reset_exposed_wait(self) -> None:
+        self.__dict__["_wait_steps"], self.__dict__["_wait_events"] = [], []
+
+
+class OverlappedGradReduce(_ExposedWait):
     """Two-piece gradient all-reduce over the flat buffer.
 
     The first parameter of the module (the (V, D) embedding table, >96 % of the gradient bytes) is
@@ -127,13 +162,14 @@ class OverlappedGradReduce:
         if not self._active():
             return 1.0
         if self._work is None:                      # the hook did not fire: reduce everything now
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._timed(lambda: dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group))
         else:
             if self.head < self.flat.numel:
-                dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
+                self._timed(lambda: dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group))
             for w in self._work:
-                w.wait()
+                self._timed(w.wait)
             self._work = None
+        self._step_measured()
         return 1.0 / dist.get_world_size(self.group)
 
     def finish_pipelined(self):
@@ -144,17 +180,19 @@ class OverlappedGradReduce:
             return
         scale = 1.0 / dist.get_world_size(self.group)
         if self._work is None:
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._timed(lambda: dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group))
+            self._step_measured()
             yield 0, self.flat.numel, scale
             return
         if self.head < self.flat.numel:
-            dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group)
+            self._timed(lambda: dist.all_reduce(self.flat.grad[self.head:], op=dist.ReduceOp.SUM, group=self.group))
             yield self.head, self.flat.numel, scale
         live = [(lo, hi) for lo, hi in zip(self.bounds[:-1], self.bounds[1:]) if hi > lo]
         for (lo, hi), w in zip(live, self._work):
-            w.wait()
+            self._timed(w.wait)
             yield lo, hi, scale
         self._work = None
+        self._step_measured()
 
     def info(self) -> Dict:
         world = dist.get_world_size(self.group) if self._active() else 1
@@ -171,8 +209,11 @@ XGMI_LINK_GBPS = 153.0      # MI355X: 7 point-to-point xGMI links per GPU, ~153 
 def predicted_wire_ms(mode: str, payload_bytes: float, world: int, gather_bytes: float = 0.0) -> Dict[str, float]:
     """Back-of-envelope wire time of one gradient exchange over xGMI (no RCCL protocol overhead):
     dense = sum all-reduce of `payload_bytes`; rows = all-gather where every rank contributes `payload_bytes`; owners =
-    all-to-all in which every rank sends `payload_bytes` in total (point-to-point pieces of 1/world each, so both models price
-    it the same) followed by an all-gather where every rank contributes `gather_bytes`.
+    all-to-all in which every rank sends `payload_bytes` in total, followed by an all-gather where every rank contributes
+    `gather_bytes`.  The all-to-all's pieces (payload / world to each peer) leave over all links at once under `direct`
+    (payload / world / bw); on a ring every piece crosses every hop towards its peer, i.e. the link next to a rank carries
+    ~ (world - 1) / 2 pieces of each of its ~ 2 neighbour directions: priced at (world - 1) / world * payload / bw (round-5 advisor:
+    payload / world under BOTH models biased `auto` towards this exchange).
     `ring`: every byte crosses one link per hop; `direct`: reduce-scatter + all-gather (or the all-gather) spread over all
     world - 1 links of the fully connected node."""
     if world <= 1:
@@ -182,9 +223,8 @@ def predicted_wire_ms(mode: str, payload_bytes: float, world: int, gather_bytes:
         ring = 2.0 * (world - 1) / world * payload_bytes / bw
         direct = 2.0 * (payload_bytes / world) / bw
     elif mode == "owners":
-        a2a = payload_bytes / world / bw
-        ring = a2a + (world - 1) * gather_bytes / bw
-        direct = a2a + gather_bytes / bw
+        ring = (world - 1) / world * payload_bytes / bw + (world - 1) * gather_bytes / bw
+        direct = payload_bytes / world / bw + gather_bytes / bw
     else:
         ring = (world - 1) * payload_bytes / bw
         direct = payload_bytes / bw
@@ -197,7 +237,7 @@ def wire_model() -> str:
     return "direct" if os.environ.get("NRL_WIRE_MODEL", "ring") == "direct" else "ring"
 
 
-class TouchedRowsExchange:
+class TouchedRowsExchange(_ExposedWait):
     """Gradient exchange that ships only the embedding-table rows a rank TOUCHED this step (SURVEY.md section 8e,
     "optional later"): the (V, D) table gradient is > 96 % of the flat gradient and a rank's batch touches at most
     B * (H + C) * L of its V rows.
@@ -382,7 +422,7 @@ def _sorted_unique_ids(ids: torch.Tensor, order: Optional[torch.Tensor] = None):
     return uniq, count
 
 
-class OwnerRowsExchange:
+class OwnerRowsExchange(_ExposedWait):
     """Owner-partitioned exchange of the touched embedding-table rows (``--grad-exchange owners`` / ``auto``; DESIGN section 6;
     reference leg: ``configs/trainer/ddp.yaml:4``, whose DDP all-reduces the dense (V, D) gradient).
 
@@ -729,7 +769,9 @@ class LazyTableAdam:
         t = self.opt.step_count + 1
         self._join_side()                # the previous step's flush slice (side stream) before anything here moves a row
         h = getattr(self, "_hint_ids", None)
-        hinted = self._hinted == t and h is not None and h.data_ptr() == ids.data_ptr() and h.numel() == ids.numel()
+        # (a hint is recognised by the identity of its id tensor -- the trainer keeps it on the prepared batch -- or, for callers
+        #  that pass views of one buffer, by address and length)
+        hinted = self._hinted == t and h is not None and (h is ids or (h.data_ptr() == ids.data_ptr() and h.numel() == ids.numel()))
         self._hinted, self._hint_ids = 0, None
         if not hinted:
             # (a hint for other ids than the ones that came: its rows were advanced to t - 1 and carry this step's tag -- their
@@ -1003,8 +1045,17 @@ class NRMSTrainer:
                 tab.check()        # (one scalar read-back, outside the step: a row that ever lagged past the window raises here)
 
     def exchange_info(self) -> Dict:
-        """What the data-parallel gradient exchange ships per rank and step (bench.py prints it for N > 1)."""
-        return self.reduce.info()
+        """What the data-parallel gradient exchange ships per rank and step (bench.py prints it for N > 1), with -- when
+        ``reduce.measure`` was on -- the MEASURED time the launch stream spent blocked on it next to the predicted wire time."""
+        info = self.reduce.info()
+        ms, n = self.reduce.exposed_wait_ms() if hasattr(self.reduce, "exposed_wait_ms") else (0.0, 0)
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        info["measured"] = {
+            "world": world, "exposed_wait_ms_per_step": round(ms, 4), "steps_measured": n,
+            "what": "event pairs on the launch stream around every wait for a collective of the step (dense: the tail all-reduce + "
+                    "the waits for the head slices; rows / owners: the whole finish, i.e. waits + the kernels adding the gathered "
+                    "rows): the part of the exchange the backward did NOT hide.  0 at world 1 (nothing is exchanged)."}
+        return info
 
     def _prefetch(self, next_batch: Dict) -> None:
         """The id work of the NEXT step, issued on the side stream while this one runs: concatenating its history / candidate
@@ -1016,15 +1067,23 @@ class NRMSTrainer:
             return
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)           # (this step's begin(): marks written, rows caught up; last step's update)
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
         with torch.cuda.stream(self._side):
             nb = self.module._prepare(next_batch)
             for t in (nb.get("x_all") or {}).values():
                 if torch.is_tensor(t):
                     t.record_stream(main)      # allocated under the side stream, read on the launch stream next step
-        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
-        if world == 1:
-            for tab, ids_of in self.lazy_tables:
-                tab.hint(ids_of(nb), self._side)
+            if world == 1:
+                # the ids of every lazy table are built HERE, on the stream that just produced x_all (an encoder registered under
+                # several attributes concatenates them: on the launch stream that read raced the side stream's writes, and the
+                # fresh tensor never matched the hint -- round-5 advisor), and kept on the prepared batch: the next ``step``
+                # hands ``begin`` the SAME tensor, which is how a hint is recognised
+                cache = nb.setdefault("_lazy_ids", {})
+                for i, (tab, ids_of) in enumerate(self.lazy_tables):
+                    ids = ids_of(nb)
+                    ids.record_stream(main)
+                    cache[i] = ids
+                    tab.hint(ids, self._side)
         self._next = (next_batch, nb)
 
     def _prefetch_pending(self) -> None:
@@ -1061,8 +1120,10 @@ class NRMSTrainer:
                 xa = batch.get("x_all", {})
                 if torch.is_tensor(xa.get("title")):
                     self.reduce.prepare(xa["title"], xa.get("title_order"))
-            for tab, ids_of in self.lazy_tables:
-                tab.begin(ids_of(batch), self._side)
+            cached = batch.get("_lazy_ids") or {}
+            for i, (tab, ids_of) in enumerate(self.lazy_tables):
+                ids = cached.get(i)
+                tab.begin(ids if ids is not None else ids_of(batch), self._side)
         # the next step's id work goes out from a forward hook of the news encoder: right AFTER the chip-filling kernels of the news
         # forward, so that it runs beside the user encoder's few-row launches (issued at the top of the step it ran beside the
         # fused forward and cost it what it saved: 0.545 -> 0.606 ms per launch, profiles/r05_ab.txt)
@@ -1107,7 +1168,7 @@ class NRMSTrainer:
                 p.main_grad.add_(p.grad)
                 p.grad = None
         if self.lazy_tables:
-            scale = self.reduce.finish()
+            scale = self._finish_exchange()
             world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
             scan = world > 1                               # other ranks' rows carry gradients too
             if rows_mode:
@@ -1131,6 +1192,16 @@ class NRMSTrainer:
             for lo, hi, scale in self.reduce.finish_pipelined():
                 self.opt.step_range(lo, hi, grad_scale=scale, zero_grad=True)
         else:
-            scale = self.reduce.finish()
+            scale = self._finish_exchange()
             self.opt.step(grad_scale=scale, zero_grad=True)
         return loss.detach()
+
+    def _finish_exchange(self) -> float:
+        """``reduce.finish()``; a row exchange's finish -- its waits AND the kernels that add the gathered rows -- is timed as one
+        piece when measuring is on (the dense exchange times its waits itself)."""
+        r = self.reduce
+        if isinstance(r, OverlappedGradReduce) or not getattr(r, "measure", False) or not r._active():
+            return r.finish()
+        scale = r._timed(r.finish)
+        r._step_measured()
+        return scale

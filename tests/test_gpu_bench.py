@@ -25,3 +25,10 @@ def test_bench_runs_under_torch_distributed_run_on_rccl(exchange):
     assert j["rccl_ranks"] == 1 and j["n_gpus"] == 1 and j["steps"] == 3 and j["value"] > 0
     assert j["unit"] == "impressions/s" and j["scaling"] == "weak" and "roofline" in j
     assert j["grad_exchange"]["mode"] == exchange and "predicted_wire_ms" in j["grad_exchange"]
+    # the self-diagnosing fields of a multi-GPU run exist and are zero at world 1 (nothing is exchanged)
+    ps, meas = j["grad_exchange"]["per_step"], j["grad_exchange"]["measured"]
+    for k in ("exchange_chosen", "bytes_on_the_wire_per_rank", "predicted_wire_ms", "overlap_window_ms", "predicted_exposed_ms",
+              "measured_exposed_wait_ms", "steps_measured"):
+        assert k in ps, k
+    assert meas["world"] == 1 and meas["exposed_wait_ms_per_step"] == 0.0 and ps["measured_exposed_wait_ms"] == 0.0
+    assert all(v == 0.0 for v in ps["predicted_wire_ms"].values())

@@ -381,16 +381,31 @@ def test_trainable_linear_keeps_its_images_within_an_optimizer_step_only():
 
     # without this library's optimizer in the process nothing of a trainable weight is kept: a writer through `p.data` (apex, EMA
     # swaps) moves neither the version counter nor the generation, and must still meet its own values (advisor, round 4)
-    drivers = ops_blocks._STEP_DRIVERS[0]
-    ops_blocks._STEP_DRIVERS[0] = 0
-    try:
+    with ops_blocks.no_step_drivers():
         check(*run())
         assert not nl._step_images._key
         lin.weight.data.mul_(0.75)                      # unannounced raw write
         check(*run())
-    finally:
-        ops_blocks._STEP_DRIVERS[0] = drivers
-    ops_blocks.register_step_driver()                   # (what trainer.FusedAdam.__init__ does)
+
+    # an optimizer of this library that owns OTHER parameters gives this layer nothing (round-5 advisor: the permission used to
+    # be a process-wide counter), and the permission ends with the optimizer that granted it
+    class _Driver:
+        pass
+    with ops_blocks.no_step_drivers():
+        other = torch.nn.Parameter(torch.zeros(4, device=DEV))
+        drv = _Driver()
+        ops_blocks.register_step_driver(drv, [other])
+        assert ops_blocks.step_images_allowed(other) and not ops_blocks.step_images_allowed(lin.weight, lin.bias)
+        check(*run())
+        assert not nl._step_images._key
+        mine = _Driver()
+        ops_blocks.register_step_driver(mine, [lin.weight, lin.bias])
+        assert ops_blocks.step_images_allowed(lin.weight, lin.bias)
+        del mine
+        import gc
+        gc.collect()
+        assert not ops_blocks.step_images_allowed(lin.weight, lin.bias)
+    ops_blocks.register_step_driver()                   # (a process-wide promise: what the tests below run under)
     y0, dx0, dw0 = run()
     check(y0, dx0, dw0)
     k0 = dict(nl._step_images._key)
