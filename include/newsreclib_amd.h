@@ -92,6 +92,10 @@ const char* nrl_last_error(void);
  *       (hi*hi + hi*lo + lo*hi) with fp32 accumulation; ~2^-16 relative per product, scores within
  *       1e-4 of the fp32 path (contract 1e-3), ~1.3-2x faster GEMMs.  Attention, softmax, pooling,
  *       loss and Adam are fp32 in both engines. */
+/* DEPRECATED as an interface (ABI v16): process-global mutable state, which SURVEY section 8(b) asks the boundary not to have.
+ * Hosts set NrlBlockParams.gemm_engine per call (newsreclib_amd/ops.py captures it at every forward and hands it to the
+ * backward); the setter stays for A/B scripts, the test fixture that runs the suite under both engines, and the entry points
+ * whose params struct has no engine field. */
 int nrl_set_gemm_engine(int32_t engine);
 int nrl_get_gemm_engine(void);
 
@@ -129,6 +133,8 @@ int nrl_get_gemm_engine(void);
  *                       32 <= users <= 128 per call, D = 20 * heads in [288, 316]) instead of a separate GEMM launch
  * Entry points whose params struct has no `options` field run under the process defaults: their forward and backward
  * must see the same defaults (newsreclib_amd/ops*.py compare nrl_get_options() at both). */
+/* DEPRECATED as an interface (ABI v16), for the same reason as nrl_set_gemm_engine: per-call NrlBlockParams.options is the
+ * path; the setter stays for A/B measurement scripts and equivalence tests. */
 int nrl_set_option(const char* name, int32_t value);
 /* Bit mask of the process-default switch values (bit order above). */
 int32_t nrl_get_options(void);
