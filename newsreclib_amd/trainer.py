@@ -738,6 +738,7 @@ class LazyTableAdam:
         # marks are still in use
         self.marks = [torch.zeros(self.rows, dtype=torch.int32, device=dev) for _ in range(2)]
         self._hinted = 0               # the step whose marks + catch-up were issued early (0: none)
+        self.hint_hits = self.hint_misses = 0   # hints the next ``begin`` recognised / did not (other ids came)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.period = int(period)
         assert 1 <= self.period < 127
@@ -772,6 +773,9 @@ class LazyTableAdam:
         # (a hint is recognised by the identity of its id tensor -- the trainer keeps it on the prepared batch -- or, for callers
         #  that pass views of one buffer, by address and length)
         hinted = self._hinted == t and h is not None and (h is ids or (h.data_ptr() == ids.data_ptr() and h.numel() == ids.numel()))
+        if self._hinted == t:                  # (counted: a hint that never matches is wasted side-stream work -- round-5 advisor)
+            self.hint_hits += int(hinted)
+            self.hint_misses += int(not hinted)
         self._hinted, self._hint_ids = 0, None
         if not hinted:
             # (a hint for other ids than the ones that came: its rows were advanced to t - 1 and carry this step's tag -- their
@@ -1093,7 +1097,9 @@ class NRMSTrainer:
 
     def step(self, batch: Dict, next_batch: Optional[Dict] = None) -> torch.Tensor:
         """One train step.  ``next_batch`` (optional): the batch the NEXT call will be given -- a loader that prefetches has it --
-        lets the trainer run that step's id bookkeeping beside this step (``_prefetch``); the result is bit-identical."""
+        lets the trainer run that step's id bookkeeping beside this step (``_prefetch``): same kernels on the same operands, and
+        the optimizer arithmetic is bit-identical to the in-line form (``test_lazy_table_adam_early_catch_up_is_bit_identical_to_
+        dense_adam``); two RUNS of a step still differ at the 1e-7 level, as any two runs do (the backward's atomics)."""
         nxt = getattr(self, "_next", None)
         if nxt is not None:
             if not getattr(self, "_side_joined", False) and self._side is not None:

@@ -173,6 +173,41 @@ def test_lstur_config5_shapes_train_step():
         assert torch.isfinite(gr).all() and float(gr.abs().max()) > 0.0, k
 
 
+def test_lstur_trainer_prefetch_hints_match_for_a_multi_attribute_encoder(engine):
+    """Round-5 advisor: an encoder registered under several attributes (LSTUR: title + abstract through ONE text encoder)
+    concatenates their ids for the lazy table optimizer; the prefetch built that concatenation on the launch stream -- racing the
+    side stream that had just produced x_all -- and the fresh tensor never matched the hint, so the early catch-up was silently
+    wasted.  The ids are now built on the side stream, kept on the prepared batch and recognised by identity: every announced
+    batch that came is a hit, for the word table AND the long-term user table, and the losses follow the plain loop."""
+    from newsreclib_amd.nrms_module import attach_layout
+    from newsreclib_amd.synthetic import add_lstur_fields, make_batch
+    from newsreclib_amd.trainer import NRMSTrainer
+    from oracle.lstur_oracle import make_lstur_params
+    cfg = dict(vocab=3000, n_categ=19, n_users=300, D=300, F=300, W=3, Q=200, categ_dim=100,
+               text_attrs=("title", "abstract"), text_order=("title", "abstract"), method="ini", p_drop=0.0, p_mask=0.0)
+    params = make_lstur_params(cfg["vocab"], cfg["n_categ"], cfg["n_users"], seed=4)
+    batches = [attach_layout(batch_to(add_lstur_fields(make_batch(12, vocab=cfg["vocab"], mode="ragged", seed=40 + i), cfg["vocab"],
+                                                       cfg["n_categ"], cfg["n_users"], 50, seed=60 + i), "cuda")) for i in range(3)]
+    losses = {}
+    for mode in ("plain", "prefetch"):
+        mod = build_lstur_module(cfg, params)
+        tr = NRMSTrainer(mod, lr=1e-4)
+        assert len(tr.lazy_tables) == 2                       # the word table and the long-term user table
+        ls = []
+        for i in range(5):
+            b, nb = batches[i % 3], batches[(i + 1) % 3]
+            ls.append(float(tr.step(b, nb) if mode == "prefetch" else tr.step(b)))
+        tr.flush()
+        torch.cuda.synchronize()
+        losses[mode] = ls
+        if mode == "prefetch":
+            for tab, _ in tr.lazy_tables:
+                assert (tab.hint_hits, tab.hint_misses) == (4, 0), (tab.hint_hits, tab.hint_misses)
+                tab.check()
+    for a, b in zip(losses["plain"], losses["prefetch"]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (a, b)
+
+
 _PERSISTENT_GRU_SCRIPT = r"""
 import numpy as np, torch
 from newsreclib_amd import _lib
