@@ -613,6 +613,20 @@ struct SideFork {
   hipEvent_t fork = nullptr, join = nullptr;
 };
 
+// The generic planes weight gradient as 8-wave workgroups (round 6: two waves per SIMD over the same tile and LDS stages; at B = 128
+// 0.173 -> 0.133 ms for the out-projection shape, 0.190 -> 0.167 for the additive-attention one, tools/wp_probe.hip).
+// NRL_WGRAD_PLANES_WAVES=4 restores the one-wave-per-SIMD shape of rounds 2-5 for all three planes weight gradients (A/B runs).
+static inline int wgrad_planes_waves() {
+  static const int v = [] { const char* e = getenv("NRL_WGRAD_PLANES_WAVES"); return e ? atoi(e) : 8; }();
+  return v;
+}
+template <int TM, int TN, class Epi>
+static int wgrad_planes_g_dispatch(const void* a, int ncb_a, const void* b, int ncb_b, int64_t rows, int64_t m_valid, int n_valid,
+                                   const Epi& epi, int nsplit, hipStream_t st, float* scratch) {
+  if (wgrad_planes_waves() == 4) return launch_wgrad_planes_g<TM, TN, 4>(a, ncb_a, b, ncb_b, rows, m_valid, n_valid, epi, nsplit, st, scratch);
+  return launch_wgrad_planes_g<TM, TN, 8>(a, ncb_a, b, ncb_b, rows, m_valid, n_valid, epi, nsplit, st, scratch);
+}
+
 // The weight gradients of the back half from planes: dW_a += d_pre^T y, dW_o += dy^T o (+ biases).  Partial tiles of the
 // two-step split-K go to `scratch` (scratch_floats of it), or straight to atomics when it is too small.
 static int block_wgrads_back_half(const NrlBlockGrads* G, const BlockShape& s, const BlockWs& w, hipStream_t st,
@@ -622,7 +636,7 @@ static int block_wgrads_back_half(const NrlBlockGrads* G, const BlockShape& s, c
   {
     // d_pre (pool_bwd_pre) and y (out-projection epilogue, with its ones column) as planes over the same rows
     static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
-    NRL_TRY((launch_wgrad_planes_g<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
+    NRL_TRY((wgrad_planes_g_dispatch<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
                                          EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st,
                                          scratch_for(wgrad_planes_g_scratch_floats(7, 5, (Q + 15) / 16, (D + 16) / 16, sp)))));
   }
@@ -630,7 +644,7 @@ static int block_wgrads_back_half(const NrlBlockGrads* G, const BlockShape& s, c
     // both operands are planes over the same (real) rows: DMA + transpose-read + MFMA only (wgrad_planes_g_kernel)
     static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_G_SPLITS"); return e ? atoi(e) : 64; }();
     const int ncb_o = s.heads + (s.heads + 3) / 4, ncb_dy = (D + 15) / 16;
-    NRL_TRY((launch_wgrad_planes_g<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
+    NRL_TRY((wgrad_planes_g_dispatch<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
                                          EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st,
                                          scratch_for(wgrad_planes_g_scratch_floats(5, 5, ncb_dy, ncb_o, sp)))));
   }
@@ -739,7 +753,7 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
     // dW_a += d_pre^T y ; db_a += colsum(d_pre)     (y is the post-dropout activation)
     if (s.aa_planes) {
       static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
-      NRL_TRY((launch_wgrad_planes_g<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
+      NRL_TRY((wgrad_planes_g_dispatch<7, 5>(w.tp, (Q + 15) / 16, w.yp, (D + 16) / 16, (s.M + 31) / 32 * 32, Q, D + 1,
                                            EpiAtomicWB{G->att_weight, D, G->att_bias, D}, sp, st,
                                            scratch_for(wgrad_planes_g_scratch_floats(7, 5, (Q + 15) / 16, (D + 16) / 16, sp)))));
     } else {
@@ -749,7 +763,7 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
     if (s.od_planes) {
       static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_G_SPLITS"); return e ? atoi(e) : 64; }();
       const int ncb_o = s.heads + (s.heads + 3) / 4, ncb_dy = (D + 15) / 16;
-      NRL_TRY((launch_wgrad_planes_g<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
+      NRL_TRY((wgrad_planes_g_dispatch<5, 5>(w.dy, ncb_dy, w.o, ncb_o, (s.M + 31) / 32 * 32, D, 16 * ncb_o,
                                            EpiAtomicWBPerm{G->out_proj_weight, D, G->out_proj_bias, s.heads}, sp, st,
                                            scratch_for(wgrad_planes_g_scratch_floats(5, 5, ncb_dy, ncb_o, sp)))));
     } else {
@@ -760,9 +774,13 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
   if (bf16_planes) {
     // both operands pre-split by their producers: pure DMA + transpose-read + MFMA kernel (nrl_wgrad_planes.h)
     static const int wp_splits = [] { const char* e = getenv("NRL_WGRAD_PLANES_SPLITS"); return e ? atoi(e) : 32; }();
-    return launch_wgrad_planes(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1,
-                               EpiAtomicWBHeads{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh}, wp_splits, st,
-                               scratch_for(wgrad_planes_scratch_floats(s.heads, 20, wp_splits)));
+    // round 6: two waves per SIMD over the same tile (8-wave workgroups): 0.37 -> 0.33-0.34 ms at B = 128 (tools/wp_probe.hip,
+    // profiles/r06_wgrad_planes_probe.txt); NRL_WGRAD_PLANES_WAVES=4 restores the one-wave-per-SIMD shape (A/B runs)
+    const int wp_waves = wgrad_planes_waves();
+    const EpiAtomicWBHeads epi_w{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh};
+    float* const sc_w = scratch_for(wgrad_planes_scratch_floats(s.heads, 20, wp_splits));
+    if (wp_waves == 4) return launch_wgrad_planes<0, 4>(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1, epi_w, wp_splits, st, sc_w);
+    return launch_wgrad_planes<0, 8>(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1, epi_w, wp_splits, st, sc_w);
   }
   if (dqkv_head_planes) {
     // dqkv in head planes (news_attn_bwd_kernel): 64 output rows per head, remapped to [Wq; Wk; Wv] rows on the way out

@@ -246,11 +246,14 @@ static int cnn_conv_wgrad(const CnnShape& s, const CnnWs& w, const float* dc, co
     // (x planes: written by the forward's lookup when the convolution forward read them too; converted here otherwise)
     if (!x_planes_ready) NRL_TRY(launch_planes_from_rows(x, s.D, s.N, s.L, s.D, ncb_x, 2 * kt, true, w.xpl, st));
     if (!dc_planes_ready) NRL_TRY(launch_planes_from_rows(dc, F, s.N, s.L, F, ncb_dc, 2 * kt, false, w.dpl, st));
-    if (kt == 1)
-      return launch_wgrad_planes_conv<5, 2, 1>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 32, F, s.D, d_weight, d_bias,
-                                               cnn_conv_planes_splits(), st, w.wsc);
-    return launch_wgrad_planes_conv<5, 2, 2>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 64, F, s.D, d_weight, d_bias,
-                                             cnn_conv_planes_splits(), st, w.wsc);
+    // (round 6: 8-wave workgroups, two waves per SIMD over the same tile -- wgrad_planes_waves(), nrl_api_internal.h)
+    const int sp = cnn_conv_planes_splits();
+    if (wgrad_planes_waves() == 4) {
+      if (kt == 1) return launch_wgrad_planes_conv<5, 2, 1, 4>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 32, F, s.D, d_weight, d_bias, sp, st, w.wsc);
+      return launch_wgrad_planes_conv<5, 2, 2, 4>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 64, F, s.D, d_weight, d_bias, sp, st, w.wsc);
+    }
+    if (kt == 1) return launch_wgrad_planes_conv<5, 2, 1, 8>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 32, F, s.D, d_weight, d_bias, sp, st, w.wsc);
+    return launch_wgrad_planes_conv<5, 2, 2, 8>(w.dpl, ncb_dc, w.xpl, ncb_x, s.N * 64, F, s.D, d_weight, d_bias, sp, st, w.wsc);
   }
   return gemm_wgrad_any(dc, F, rc_window(x, s.D, s.L, s.pad, 1, (int64_t)KD), KD, d_weight, d_bias, s.M, st);
 }

@@ -53,8 +53,17 @@ struct WgradPlanesArgs {
 
 // (split-K reduction in two steps: wgrad_reduce_kernel, nrl_gemm.h)
 // ABL (tools/wp_probe.hip only): 1 = no DMA inside the loop, 2 = no MFMAs
-template <class Epi, int ABL = 0>
-__global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesArgs P, const Epi epi) {
+// NW (round 6): wavefronts per workgroup over the SAME 256 x 160 tile and the same three LDS stages.  4 = (2 x 2), one wave per
+// SIMD, 8 x 5 accumulator blocks each (rounds 2-5).  8 = (4 x 2), TWO waves per SIMD, 4 x 5 blocks each: a k-tile's fixed costs
+// -- the counted wait, the barrier, the first fragment reads behind it, the scalar address arithmetic of the DMA issues -- are
+// paid by one wave while its SIMD neighbour runs MFMAs (HISTORY.md section 8.0b priced them at 0.28 us per k-tile with one wave
+// per SIMD); every wave issues 7 one-KiB pieces per k-tile (4 of A, 3 of B: the 20 B pieces over 8 waves leave four
+// duplicates, which rewrite the same bytes).
+template <class Epi, int ABL = 0, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 1) wgrad_planes_kernel(const WgradPlanesArgs P, const Epi epi) {
+  static_assert(NW == 4 || NW == 8, "4 waves (2 x 2) or 8 waves (4 x 2)");
+  constexpr int RBW = 32 / NW;                             // row blocks per wave: 8 or 4
+  constexpr int NA = 32 / NW, NB = (20 + NW - 1) / NW;     // DMA pieces per wave and k-tile: 8 + 5 or 4 + 3
   extern __shared__ __attribute__((aligned(1024))) unsigned char wp_smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -77,39 +86,44 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesA
   if (kt0 >= kt1) return;
   const int nkt = (int)(kt1 - kt0);
 
-  // ---- DMA: one-KiB pieces (a 16 x 16 block, both planes): 8 A + 5 B pieces per wave and k-tile ------------------
-  //   A piece (q, wave) = (hh = q >> 1, mbi = q & 1, cb = wave): LDS [hh][mbi][cb][p][512]
-  //   B piece pb = 4 q + wave = (mbi = pb / 10, cb = pb % 10):    LDS [mbi][cb][p][512]
+  // ---- DMA: one-KiB pieces (a 16 x 16 block, both planes).  LDS stage = A [hh 0..3][mbi 0..1][cb 0..3] | B [mbi 0..1][cb 0..9].
+  //   A piece pa = q * NW + wave (q < NA): (hh * 2 + mbi) = pa >> 2, cb = pa & 3 -- LDS byte pa * 1024
+  //   B piece pb = q * NW + wave (q < NB), clamped to 19: mbi = pb / 10, cb = pb % 10 -- LDS byte A_STAGE + pb * 1024
   // Wave-uniform base pointers of the split's first k-tile live in SGPRs; a k-tile advances them by a constant.
   static_assert(WP_TN == 5, "piece dealing below assumes 32 A + 20 B pieces");
-  const unsigned char* base_a[8];
-  const unsigned char* base_b[5];
+  const unsigned char* base_a[NA];
+  const unsigned char* base_b[NB];
+  uint32_t lds_b[NB];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    int head = 4 * tm + (q >> 1);
+  for (int q = 0; q < NA; ++q) {
+    const int pa = q * NW + wave;
+    int head = 4 * tm + (pa >> 3);
     head = head < P.heads ? head : P.heads - 1;           // empty head slots of the last tile: rows dropped by the epilogue
-    base_a[q] = P.a + (((int64_t)head * P.n_mb + 2 * kt0 + (q & 1)) * 4 + wave) * 1024;
+    base_a[q] = P.a + (((int64_t)head * P.n_mb + 2 * kt0 + ((pa >> 2) & 1)) * 4 + (pa & 3)) * 1024;
   }
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const int pb = 4 * q + wave, mbi = pb / 10, cb = pb - mbi * 10;
+  for (int q = 0; q < NB; ++q) {
+    int pb = q * NW + wave;
+    pb = pb < 20 ? pb : 19;
+    const int mbi = pb / 10, cb = pb - mbi * 10;
     base_b[q] = P.b + ((2 * kt0 + mbi) * P.ncb_b + 10 * tn + cb) * 1024;
+    lds_b[q] = (uint32_t)WP_A_STAGE + (uint32_t)pb * 1024u;
   }
   const int64_t step_a = 2 * 4 * 1024, step_b = 2 * (int64_t)P.ncb_b * 1024;
   const uint32_t lane16 = (uint32_t)lane * 16u;
-  // pieces [c0, c1) of this wave's 13 (0..7: A, 8..12: B) of k-tile `rel` (relative to kt0) into `stage`
+  // pieces [c0, c1) of this wave's NA + NB (0 .. NA - 1: A, then B) of k-tile `rel` (relative to kt0) into `stage`
   auto issue = [&](int rel, int stage, int c0, int c1) {
-    const uint32_t sbase = smem_base + (uint32_t)stage * WP_STAGE + (uint32_t)wave * 1024u;
+    const uint32_t sbase = smem_base + (uint32_t)stage * WP_STAGE;
 #pragma unroll
     for (int c = c0; c < c1; ++c) {
-      if (c < 8) glds16_saddr(base_a[c] + rel * step_a, lane16, sbase + (uint32_t)c * 4096u);
-      else glds16_saddr(base_b[c - 8] + rel * step_b, lane16, sbase + (uint32_t)WP_A_STAGE + (uint32_t)(c - 8) * 4096u);
+      if (c < NA) glds16_saddr(base_a[c] + rel * step_a, lane16, sbase + (uint32_t)(c * NW + wave) * 1024u);
+      else glds16_saddr(base_b[c - NA] + rel * step_b, lane16, sbase + lds_b[c - NA]);
     }
   };
 
-  f32x4 acc[8][WP_TN];
+  f32x4 acc[RBW][WP_TN];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < RBW; ++i)
 #pragma unroll
     for (int j = 0; j < WP_TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -124,21 +138,22 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesA
     return __builtin_bit_cast(bf16x8, v);
   };
 
-  issue(0, 0, 0, 13);
-  issue(nkt > 1 ? 1 : 0, 1, 0, 13);
+  issue(0, 0, 0, NA + NB);
+  issue(nkt > 1 ? 1 : 0, 1, 0, NA + NB);
   int stage = 0;
   for (int it = 0; it < nkt; ++it) {
     // tile `it` (issued two iterations ago) has landed for this wave: at most the pieces of tile it + 1 are in flight
-    if constexpr (ABL & 1) wait_vmcnt<0>(); else wait_vmcnt<WP_PIECES / 4>();
+    if constexpr (ABL & 1) wait_vmcnt<0>(); else wait_vmcnt<NA + NB>();
     __builtin_amdgcn_s_barrier();                          // ... and for every wave; stage (it + 2) % 3 is free
     const int nx = it + 2 < nkt ? it + 2 : nkt - 1;        // uniform control flow: the tail re-fetches the last tile
     const int st2 = stage == 0 ? 2 : stage - 1;            // (it + 2) % 3
-    // (the 13 DMA issues of tile it + 2 are spread over the eight row steps below: as one block in front of the
-    //  MFMAs their scalar address arithmetic was ~1000 cycles per k-tile that nothing overlapped)
+    // (the DMA issues of tile it + 2 are spread over the row steps below: as one block in front of the MFMAs their scalar
+    //  address arithmetic was ~1000 cycles per k-tile that nothing overlapped)
     auto issue_part = [&](int step) {
       if constexpr (!(ABL & 1)) {
         __builtin_amdgcn_sched_barrier(0);
-        issue(nx, st2, step < 5 ? 2 * step : 5 + step, step < 5 ? 2 * step + 2 : 6 + step);   // 2 2 2 2 2 1 1 1
+        if constexpr (NW == 4) issue(nx, st2, step < 5 ? 2 * step : 5 + step, step < 5 ? 2 * step + 2 : 6 + step);   // 2 2 2 2 2 1 1 1
+        else issue(nx, st2, step < 3 ? 2 * step : 6, step < 3 ? 2 * step + 2 : 7);                                   // 2 2 2 1
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -155,7 +170,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesA
     // A fragments of row block i + 1 are fetched while the MFMAs of row block i run (two named sets; on its own hipcc
     // reads each fragment right before its first MFMA and waits for the LDS there)
     auto read_a = [&](int i, bf16x8& ah, bf16x8& al) {
-      const int hh = 2 * wm + (i >> 2), cb = i & 3;
+      const int hh = NW == 4 ? 2 * wm + (i >> 2) : wm, cb = i & 3;
       const uint32_t a0 = sa + (uint32_t)((hh * 2 + 0) * 4 + cb) * 1024u, a1 = sa + (uint32_t)((hh * 2 + 1) * 4 + cb) * 1024u;
       ah = frag(a0, a1);
       al = frag(a0 + 512u, a1 + 512u);
@@ -172,15 +187,15 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesA
     bf16x8 ah0, al0, ah1, al1;
     read_a(0, ah0, al0);
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) {
+    for (int i = 0; i < RBW; i += 2) {
       read_a(i + 1, ah1, al1);
       mfma_row(i, ah0, al0);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 3 * WP_TN, 0);
       issue_part(i);
-      if (i + 2 < 8) read_a(i + 2, ah0, al0);
+      if (i + 2 < RBW) read_a(i + 2, ah0, al0);
       mfma_row(i + 1, ah1, al1);
-      if (i + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      if (i + 2 < RBW) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 3 * WP_TN, 0);
       issue_part(i + 1);
     }
@@ -190,16 +205,16 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_kernel(const WgradPlanesA
 
   if (P.scratch != nullptr) {
     const EpiStore part{P.scratch + ((int64_t)split * tiles_total + t) * (256 * 32 * WP_TN), 32 * WP_TN};
-    store_accumulators<8, WP_TN>(part, acc, 0, 0, wm, wn, l15, g, 256, 32 * WP_TN);
+    store_accumulators<RBW, WP_TN>(part, acc, 0, 0, wm, wn, l15, g, 256, 32 * WP_TN);
   } else {
-    store_accumulators<8, WP_TN>(epi, acc, (int64_t)tm * 256, tn * 32 * WP_TN, wm, wn, l15, g, P.M, P.N);
+    store_accumulators<RBW, WP_TN>(epi, acc, (int64_t)tm * 256, tn * 32 * WP_TN, wm, wn, l15, g, P.M, P.N);
   }
 }
 
 static inline size_t wgrad_planes_scratch_floats(int heads, int ncb_b, int nsplit) {
   return (size_t)nsplit * ((heads + 3) / 4) * (ncb_b / (2 * WP_TN)) * 256 * 32 * WP_TN;
 }
-template <int ABL = 0, class Epi>
+template <int ABL = 0, int NW = 4, class Epi>
 static inline int launch_wgrad_planes(const void* a_planes, const void* b_planes, int64_t n_news, int heads, int ncb_b,
                                       int n_valid, const Epi& epi, int nsplit, hipStream_t st, float* scratch = nullptr) {
   if (n_news <= 0) return NRL_OK;
@@ -219,12 +234,12 @@ static inline int launch_wgrad_planes(const void* a_planes, const void* b_planes
   int dev = 0;
   NRL_HIP(hipGetDevice(&dev));
   if (!((attr_done.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
-    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<Epi, ABL>),
+    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<Epi, ABL, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, WP_STAGES * WP_STAGE));
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
   }
   P.scratch = P.nsplit > 1 ? scratch : nullptr;
-  hipLaunchKernelGGL((wgrad_planes_kernel<Epi, ABL>), dim3((unsigned)blocks), dim3(256), WP_STAGES * WP_STAGE, st, P, epi);
+  hipLaunchKernelGGL((wgrad_planes_kernel<Epi, ABL, NW>), dim3((unsigned)blocks), dim3(NW * 64), WP_STAGES * WP_STAGE, st, P, epi);
   NRL_LAUNCH_CHECK();
   if (P.scratch != nullptr) {
     const int tiles = P.tiles_m * P.tiles_n;
@@ -255,17 +270,28 @@ struct WgradPlanesGArgs {
   float* scratch;           // (nsplit, tiles, BM x BN) partial tiles, or null
 };
 
-template <int TM, int TN, class Epi>
-__global__ void __launch_bounds__(256, 1) wgrad_planes_g_kernel(const WgradPlanesGArgs P, const Epi epi) {
+// NW (round 6): 4 = (2 x 2) waves, TM x TN accumulator blocks each, one wave per SIMD (rounds 2-5).  8 = (4 x 2) waves over the SAME
+// tile and LDS stages, two waves per SIMD: the 2 TM row blocks are dealt to the four wave rows as evenly as they go (TM = 5:
+// 3, 3, 2, 2; TM = 7: 4, 4, 3, 3) -- waves w and w + 4 share a SIMD, so every SIMD carries TM row blocks either way.
+template <int TM, int TN, class Epi, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 1) wgrad_planes_g_kernel(const WgradPlanesGArgs P, const Epi epi) {
+  static_assert(NW == 4 || NW == 8, "4 waves (2 x 2) or 8 waves (4 x 2)");
   constexpr int A_ST = 4 * TM * 1024, B_ST = 4 * TN * 1024, STAGE = A_ST + B_ST;
-  constexpr int NP = TM + TN;                              // pieces per wave and k-tile
-  constexpr int PER_STEP = (NP + TM - 1) / TM;
+  constexpr int NPA_ALL = 4 * TM, NP_ALL = 4 * (TM + TN);  // one-KiB pieces of a k-tile (A first)
+  static_assert(NP_ALL % NW == 0, "pieces are dealt evenly to the waves");
+  constexpr int NP = NP_ALL / NW;                          // pieces per wave and k-tile
+  constexpr int RQ = (2 * TM) / (NW / 2), RR = (2 * TM) % (NW / 2);
+  constexpr int RB = NW == 4 ? TM : RQ + (RR > 0 ? 1 : 0);  // accumulator row blocks per wave (the most any wave row has)
+  constexpr int PER_STEP = (NP + RB - 1) / RB;
   extern __shared__ __attribute__((aligned(1024))) unsigned char wp_smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
+  // this wave's row blocks of the tile: [r0, r0 + nrows)
+  const int r0 = NW == 4 ? wm * TM : (wm < RR ? wm * (RQ + 1) : RR * (RQ + 1) + (wm - RR) * RQ);
+  const int nrows = NW == 4 ? TM : RQ + (wm < RR ? 1 : 0);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wp_smem;
 
   const int tiles_total = P.tiles_m * P.tiles_n;
@@ -281,37 +307,41 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_g_kernel(const WgradPlane
   if (kt0 >= kt1) return;
   const int nkt = (int)(kt1 - kt0);
 
-  // piece (q, wave) of an operand = (block column cbi = (4 q + wave) >> 1, row block mbi = (4 q + wave) & 1): LDS [cbi][mbi][p][512]
-  const unsigned char* base_a[TM];
-  const unsigned char* base_b[TN];
-#pragma unroll
-  for (int q = 0; q < TM; ++q) {
-    const int pa = 4 * q + wave;
-    int cb = 2 * TM * tm + (pa >> 1);
-    cb = cb < P.ncb_a ? cb : P.ncb_a - 1;                  // block columns past the matrix: rows dropped by the epilogue
-    base_a[q] = P.a + ((2 * kt0 + (pa & 1)) * P.ncb_a + cb) * 1024;
-  }
-#pragma unroll
-  for (int q = 0; q < TN; ++q) {
-    const int pb = 4 * q + wave;
-    int cb = 2 * TN * tn + (pb >> 1);
-    cb = cb < P.ncb_b ? cb : P.ncb_b - 1;
-    base_b[q] = P.b + ((2 * kt0 + (pb & 1)) * P.ncb_b + cb) * 1024;
-  }
+  // piece p = NW q + wave of the k-tile: p < 4 TM: operand A, else operand B (p - 4 TM); inside an operand piece pp = (block column
+  // cbi = pp >> 1, row block mbi = pp & 1): LDS [cbi][mbi][p][512] = byte pp * 1024 of the operand's part of the stage
+  const unsigned char* base[NP];
+  int64_t step[NP];
+  uint32_t lds_off[NP];
   const int64_t step_a = 2 * (int64_t)P.ncb_a * 1024, step_b = 2 * (int64_t)P.ncb_b * 1024;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int pc = NW * q + wave;
+    if (pc < NPA_ALL) {
+      int cb = 2 * TM * tm + (pc >> 1);
+      cb = cb < P.ncb_a ? cb : P.ncb_a - 1;                // block columns past the matrix: rows dropped by the epilogue
+      base[q] = P.a + ((2 * kt0 + (pc & 1)) * P.ncb_a + cb) * 1024;
+      step[q] = step_a;
+      lds_off[q] = (uint32_t)pc * 1024u;
+    } else {
+      const int pb = pc - NPA_ALL;
+      int cb = 2 * TN * tn + (pb >> 1);
+      cb = cb < P.ncb_b ? cb : P.ncb_b - 1;
+      base[q] = P.b + ((2 * kt0 + (pb & 1)) * P.ncb_b + cb) * 1024;
+      step[q] = step_b;
+      lds_off[q] = (uint32_t)A_ST + (uint32_t)pb * 1024u;
+    }
+  }
   const uint32_t lane16 = (uint32_t)lane * 16u;
   auto issue = [&](int rel, int stage, int c0, int c1) {
-    const uint32_t sbase = smem_base + (uint32_t)stage * STAGE + (uint32_t)wave * 1024u;
+    const uint32_t sbase = smem_base + (uint32_t)stage * STAGE;
 #pragma unroll
-    for (int c = c0; c < c1; ++c) {
-      if (c < TM) glds16_saddr(base_a[c] + rel * step_a, lane16, sbase + (uint32_t)c * 4096u);
-      else if (c < NP) glds16_saddr(base_b[c - TM] + rel * step_b, lane16, sbase + (uint32_t)A_ST + (uint32_t)(c - TM) * 4096u);
-    }
+    for (int c = c0; c < c1; ++c)
+      if (c < NP) glds16_saddr(base[c] + rel * step[c], lane16, sbase + lds_off[c]);
   };
 
-  f32x4 acc[TM][TN];
+  f32x4 acc[RB][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -343,25 +373,31 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_g_kernel(const WgradPlane
     }
     bf16x8 ah[2], al[2];
     {
-      const uint32_t a0 = sa + (uint32_t)(wm * TM) * 2048u;
+      const uint32_t a0 = sa + (uint32_t)r0 * 2048u;
       ah[0] = frag(a0);
       al[0] = frag(a0 + 512u);
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if (i + 1 < TM) {
-        const uint32_t a0 = sa + (uint32_t)(wm * TM + i + 1) * 2048u;
+    for (int i = 0; i < RB; ++i) {
+      // (a wave row with one row block fewer runs its last step without MFMAs -- wave-uniform -- but still issues its share of
+      //  the DMA; the fragment it reads ahead then belongs to the next wave row: a valid address, never used)
+      if (i + 1 < RB) {
+        const uint32_t a0 = sa + (uint32_t)(r0 + i + 1 < 2 * TM ? r0 + i + 1 : 2 * TM - 1) * 2048u;
         ah[(i + 1) & 1] = frag(a0);
         al[(i + 1) & 1] = frag(a0 + 512u);
       }
+      if (NW == 4 || i < nrows) {
 #pragma unroll
-      for (int pass = 0; pass < 3; ++pass)
+        for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i & 1] : ah[i & 1], pass == 0 ? bl[j] : bh[j],
-                                                             acc[i][j], 0, 0, 0);
-      if (i + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 3 * TN, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i & 1] : ah[i & 1], pass == 0 ? bl[j] : bh[j],
+                                                               acc[i][j], 0, 0, 0);
+      }
+      if constexpr (NW == 4) {
+        if (i + 1 < RB) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TN, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       issue(nx, st2, i * PER_STEP, (i + 1) * PER_STEP);    // this k-tile's DMA issues spread over the row steps
       __builtin_amdgcn_sched_barrier(0);
@@ -370,18 +406,21 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_g_kernel(const WgradPlane
   }
   wait_vmcnt<0>();
 
+  // (a wave stores its own row blocks only: the row bound clips the accumulator rows past them)
   if (P.scratch != nullptr) {
     const EpiStore part{P.scratch + ((int64_t)split * tiles_total + t) * (32 * TM * 32 * TN), 32 * TN};
-    store_accumulators<TM, TN>(part, acc, 0, 0, wm, wn, l15, g, 32 * TM, 32 * TN);
+    store_accumulators<RB, TN>(part, acc, (int64_t)r0 * 16, 0, 0, wn, l15, g, (int64_t)(r0 + nrows) * 16, 32 * TN);
   } else {
-    store_accumulators<TM, TN>(epi, acc, (int64_t)tm * (32 * TM), tn * (32 * TN), wm, wn, l15, g, P.M, P.N);
+    const int64_t m_tile = (int64_t)tm * (32 * TM);
+    const int64_t m_end = m_tile + (int64_t)(r0 + nrows) * 16;
+    store_accumulators<RB, TN>(epi, acc, m_tile + (int64_t)r0 * 16, tn * (32 * TN), 0, wn, l15, g, m_end < P.M ? m_end : P.M, P.N);
   }
 }
 
 static inline size_t wgrad_planes_g_scratch_floats(int TM, int TN, int ncb_a, int ncb_b, int nsplit) {
   return (size_t)nsplit * ((ncb_a + 2 * TM - 1) / (2 * TM)) * ((ncb_b + 2 * TN - 1) / (2 * TN)) * (32 * TM) * (32 * TN);
 }
-template <int TM, int TN, class Epi>
+template <int TM, int TN, int NW = 4, class Epi>
 static inline int launch_wgrad_planes_g(const void* a_planes, int ncb_a, const void* b_planes, int ncb_b, int64_t rows,
                                         int64_t m_valid, int n_valid, const Epi& epi, int nsplit, hipStream_t st,
                                         float* scratch = nullptr) {
@@ -405,12 +444,12 @@ static inline int launch_wgrad_planes_g(const void* a_planes, int ncb_a, const v
   int dev = 0;
   NRL_HIP(hipGetDevice(&dev));
   if (!((attr_done.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
-    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_g_kernel<TM, TN, Epi>),
+    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_g_kernel<TM, TN, Epi, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
   }
   P.scratch = P.nsplit > 1 ? scratch : nullptr;
-  hipLaunchKernelGGL((wgrad_planes_g_kernel<TM, TN, Epi>), dim3((unsigned)blocks), dim3(256), LDS, st, P, epi);
+  hipLaunchKernelGGL((wgrad_planes_g_kernel<TM, TN, Epi, NW>), dim3((unsigned)blocks), dim3(NW * 64), LDS, st, P, epi);
   NRL_LAUNCH_CHECK();
   if (P.scratch != nullptr) {
     const int tiles = P.tiles_m * P.tiles_n;
@@ -464,13 +503,20 @@ struct EpiConvWB {
 
 // KT = k-tiles of 32 rows per news (1: L <= 31, three LDS stages of one news each; 2: L <= 63, two stages -- the same bytes
 // in flight); the rotation is modulo 32 KT.
-template <int TM, int TN, int KT, class Epi>
-__global__ void __launch_bounds__(256, 1) wgrad_planes_conv_kernel(const WgradPlanesGArgs P, const Epi epi) {
+// NW (round 6): 4 = (2 x 2) waves, one per SIMD; 8 = (4 x 2) waves over the same tile and LDS stages, two per SIMD, the 2 TM row
+// blocks dealt 3, 3, 2, 2 to the wave rows (waves w and w + 4 share a SIMD: TM row blocks per SIMD either way) -- as
+// wgrad_planes_g_kernel above.
+template <int TM, int TN, int KT, class Epi, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 1) wgrad_planes_conv_kernel(const WgradPlanesGArgs P, const Epi epi) {
+  static_assert(NW == 4 || NW == 8, "4 waves (2 x 2) or 8 waves (4 x 2)");
   constexpr int NS = 3, TNS = NS * TN;
   constexpr int A_ST = 4 * TM * KT * 1024, B_ST = 4 * TN * KT * 1024, STAGE = A_ST + B_ST;
   constexpr int STAGES = KT == 1 ? 3 : 2, PD = STAGES - 1;     // news in flight ahead of the one being multiplied
-  constexpr int NPA = TM * KT, NPB = TN * KT, NP = NPA + NPB;  // one-KiB pieces per wave and news
-  constexpr int PER_STEP = (NP + TM * KT - 1) / (TM * KT);
+  constexpr int NPA_ALL = 4 * TM * KT, NP_ALL = 4 * (TM + TN) * KT;   // one-KiB pieces of a news (A first)
+  constexpr int NP = (NP_ALL + NW - 1) / NW;                   // pieces per wave and news (a remainder is dealt as duplicates)
+  constexpr int RQ = (2 * TM) / (NW / 2), RR = (2 * TM) % (NW / 2);
+  constexpr int RB = NW == 4 ? TM : RQ + (RR > 0 ? 1 : 0);     // accumulator row blocks per wave
+  constexpr int PER_STEP = (NP + RB * KT - 1) / (RB * KT);
   constexpr int ROWS = 32 * KT;
   extern __shared__ __attribute__((aligned(1024))) unsigned char wp_smem[];
   const int tid = threadIdx.x;
@@ -478,6 +524,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_conv_kernel(const WgradPl
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
+  const int rb0 = NW == 4 ? wm * TM : (wm < RR ? wm * (RQ + 1) : RR * (RQ + 1) + (wm - RR) * RQ);
+  const int nrows = NW == 4 ? TM : RQ + (wm < RR ? 1 : 0);
   const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wp_smem;
 
   const int tiles_total = P.tiles_m * P.tiles_n;
@@ -493,37 +541,42 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_conv_kernel(const WgradPl
   if (kt0 >= kt1) return;
   const int nkt = (int)(kt1 - kt0);
 
-  // piece pa = 4 q + wave of an operand = (block column cbi = pa / (2 KT), row block mbi = pa % (2 KT)): LDS [cbi][mbi][p][512]
-  const unsigned char* base_a[NPA];
-  const unsigned char* base_b[NPB];
-#pragma unroll
-  for (int q = 0; q < NPA; ++q) {
-    const int pa = 4 * q + wave;
-    int cb = 2 * TM * tm + pa / (2 * KT);
-    cb = cb < P.ncb_a ? cb : P.ncb_a - 1;
-    base_a[q] = P.a + ((2 * KT * kt0 + pa % (2 * KT)) * P.ncb_a + cb) * 1024;
-  }
-#pragma unroll
-  for (int q = 0; q < NPB; ++q) {
-    const int pb = 4 * q + wave;
-    int cb = 2 * TN * tn + pb / (2 * KT);
-    cb = cb < P.ncb_b ? cb : P.ncb_b - 1;                  // block columns past the matrix: dropped by the epilogue (col > D)
-    base_b[q] = P.b + ((2 * KT * kt0 + pb % (2 * KT)) * P.ncb_b + cb) * 1024;
-  }
+  // piece pc = NW q + wave of the news (clamped: a duplicate rewrites the same bytes): pc < 4 TM KT: operand A, else operand B
+  // (pc - 4 TM KT); inside an operand piece pp = (block column cbi = pp / (2 KT), row block mbi = pp % (2 KT)): LDS [cbi][mbi][p][512]
+  const unsigned char* base[NP];
+  int64_t step[NP];
+  uint32_t lds_off[NP];
   const int64_t step_a = 2 * KT * (int64_t)P.ncb_a * 1024, step_b = 2 * KT * (int64_t)P.ncb_b * 1024;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    int pc = NW * q + wave;
+    pc = pc < NP_ALL ? pc : NP_ALL - 1;
+    if (pc < NPA_ALL) {
+      int cb = 2 * TM * tm + pc / (2 * KT);
+      cb = cb < P.ncb_a ? cb : P.ncb_a - 1;
+      base[q] = P.a + ((2 * KT * kt0 + pc % (2 * KT)) * P.ncb_a + cb) * 1024;
+      step[q] = step_a;
+      lds_off[q] = (uint32_t)pc * 1024u;
+    } else {
+      const int pb = pc - NPA_ALL;
+      int cb = 2 * TN * tn + pb / (2 * KT);
+      cb = cb < P.ncb_b ? cb : P.ncb_b - 1;                  // block columns past the matrix: dropped by the epilogue (col > D)
+      base[q] = P.b + ((2 * KT * kt0 + pb % (2 * KT)) * P.ncb_b + cb) * 1024;
+      step[q] = step_b;
+      lds_off[q] = (uint32_t)A_ST + (uint32_t)pb * 1024u;
+    }
+  }
   const uint32_t lane16 = (uint32_t)lane * 16u;
   auto issue = [&](int rel, int stage, int c0, int c1) {
-    const uint32_t sbase = smem_base + (uint32_t)stage * STAGE + (uint32_t)wave * 1024u;
+    const uint32_t sbase = smem_base + (uint32_t)stage * STAGE;
 #pragma unroll
-    for (int c = c0; c < c1; ++c) {
-      if (c < NPA) glds16_saddr(base_a[c] + rel * step_a, lane16, sbase + (uint32_t)c * 4096u);
-      else if (c < NP) glds16_saddr(base_b[c - NPA] + rel * step_b, lane16, sbase + (uint32_t)A_ST + (uint32_t)(c - NPA) * 4096u);
-    }
+    for (int c = c0; c < c1; ++c)
+      if (c < NP) glds16_saddr(base[c] + rel * step[c], lane16, sbase + lds_off[c]);
   };
 
-  f32x4 acc[TM][TNS];
+  f32x4 acc[RB][TNS];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < TNS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -572,27 +625,32 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_conv_kernel(const WgradPl
         }
       bf16x8 ah[2], al[2];
       {
-        const uint32_t a0 = sa + (uint32_t)(wm * TM) * CBS;
+        const uint32_t a0 = sa + (uint32_t)rb0 * CBS;
         ah[0] = frag2(a0 + off[u][1][0], a0 + off[u][1][1]);
         al[0] = frag2(a0 + 512u + off[u][1][0], a0 + 512u + off[u][1][1]);
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (i + 1 < TM) {
-          const uint32_t a0 = sa + (uint32_t)(wm * TM + i + 1) * CBS;
+      for (int i = 0; i < RB; ++i) {
+        if (i + 1 < RB) {
+          // (a wave row with one row block fewer reads ahead into the next wave row's block: a valid address, never multiplied)
+          const uint32_t a0 = sa + (uint32_t)(rb0 + i + 1 < 2 * TM ? rb0 + i + 1 : 2 * TM - 1) * CBS;
           ah[(i + 1) & 1] = frag2(a0 + off[u][1][0], a0 + off[u][1][1]);
           al[(i + 1) & 1] = frag2(a0 + 512u + off[u][1][0], a0 + 512u + off[u][1][1]);
         }
+        if (NW == 4 || i < nrows) {
 #pragma unroll
-        for (int pass = 0; pass < 3; ++pass)
+          for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
-          for (int j = 0; j < TNS; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i & 1] : ah[i & 1], pass == 0 ? bl[j] : bh[j],
-                                                               acc[i][j], 0, 0, 0);
-        if (i + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TNS, 0);
+            for (int j = 0; j < TNS; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 1 ? al[i & 1] : ah[i & 1], pass == 0 ? bl[j] : bh[j],
+                                                                 acc[i][j], 0, 0, 0);
+        }
+        if constexpr (NW == 4) {
+          if (i + 1 < RB) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * TNS, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        issue(nx, st2, (u * TM + i) * PER_STEP, (u * TM + i + 1) * PER_STEP);
+        issue(nx, st2, (u * RB + i) * PER_STEP, (u * RB + i + 1) * PER_STEP);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -600,11 +658,14 @@ __global__ void __launch_bounds__(256, 1) wgrad_planes_conv_kernel(const WgradPl
   }
   wait_vmcnt<0>();
 
+  // (a wave stores its own row blocks only: the row bound clips the accumulator rows past them)
   if (P.scratch != nullptr) {
     const EpiStore part{P.scratch + ((int64_t)split * tiles_total + t) * (32 * TM * 32 * TNS), 32 * TNS};
-    store_accumulators<TM, TNS>(part, acc, 0, 0, wm, wn, l15, g, 32 * TM, 32 * TNS);
+    store_accumulators<RB, TNS>(part, acc, (int64_t)rb0 * 16, 0, 0, wn, l15, g, (int64_t)(rb0 + nrows) * 16, 32 * TNS);
   } else {
-    store_accumulators<TM, TNS>(epi, acc, (int64_t)tm * (32 * TM), tn * (32 * TNS), wm, wn, l15, g, P.M, P.N);
+    const int64_t m_tile = (int64_t)tm * (32 * TM);
+    const int64_t m_end = m_tile + (int64_t)(rb0 + nrows) * 16;
+    store_accumulators<RB, TNS>(epi, acc, m_tile + (int64_t)rb0 * 16, tn * (32 * TNS), 0, wn, l15, g, m_end < P.M ? m_end : P.M, P.N);
   }
 }
 
@@ -613,7 +674,7 @@ static inline size_t wgrad_planes_conv_scratch_floats(int TM, int TN, int ncb_a,
 }
 // a: dc planes (ncb_a block columns, F = m_valid filters), b: x planes (ncb_b block columns holding D features + the ones
 // column); rows = padded rows (32 per news).  dw (F, 3 D), db (F).
-template <int TM, int TN, int KT>
+template <int TM, int TN, int KT, int NW = 4>
 static inline int launch_wgrad_planes_conv(const void* a_planes, int ncb_a, const void* b_planes, int ncb_b, int64_t rows,
                                            int64_t m_valid, int D, float* dw, float* db, int nsplit, hipStream_t st,
                                            float* scratch = nullptr) {
@@ -640,12 +701,12 @@ static inline int launch_wgrad_planes_conv(const void* a_planes, int ncb_a, cons
   int dev = 0;
   NRL_HIP(hipGetDevice(&dev));
   if (!((attr_done.load(std::memory_order_relaxed) >> (dev & 63)) & 1u)) {
-    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_conv_kernel<TM, TN, KT, Epi>),
+    NRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_conv_kernel<TM, TN, KT, Epi, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
   }
   P.scratch = P.nsplit > 1 ? scratch : nullptr;
-  hipLaunchKernelGGL((wgrad_planes_conv_kernel<TM, TN, KT, Epi>), dim3((unsigned)blocks), dim3(256), LDS, st, P, epi);
+  hipLaunchKernelGGL((wgrad_planes_conv_kernel<TM, TN, KT, Epi, NW>), dim3((unsigned)blocks), dim3(NW * 64), LDS, st, P, epi);
   NRL_LAUNCH_CHECK();
   if (P.scratch != nullptr) {
     const int tiles = P.tiles_m * P.tiles_n;

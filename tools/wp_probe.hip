@@ -114,6 +114,18 @@ int main() {
           }
         }
     printf("correctness (37 news, 5 splits): worst |err| / sum|a b| = %.3e, outside 3e-5: %zu\n", worst, bad);
+    // round 6: the 8-wave workgroup (two waves per SIMD over the same tile) must produce the same sums
+    CK(hipMemset(dw, 0, (size_t)900 * 300 * 4));
+    CK(hipMemset(dbias, 0, 900 * 4));
+    if (launch_wgrad_planes<0, 8>(da, db_, n_news, heads, ncb_b, D + 1, epi, 5, st) != NRL_OK) return 1;
+    CK(hipStreamSynchronize(st));
+    std::vector<float> hw8((size_t)900 * 300), hb8(900);
+    CK(hipMemcpy(hw8.data(), dw, hw8.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hb8.data(), dbias, hb8.size() * 4, hipMemcpyDeviceToHost));
+    double d8 = 0, mx = 0;
+    for (size_t i = 0; i < hw.size(); ++i) { d8 = std::max(d8, (double)fabs(hw[i] - hw8[i])); mx = std::max(mx, (double)fabs(hw[i])); }
+    for (size_t i = 0; i < hb.size(); ++i) d8 = std::max(d8, (double)fabs(hb[i] - hb8[i]));
+    printf("8-wave workgroup vs 4-wave: max |difference| %.3e (|dW| max %.3e; split-K atomics reorder the sums)\n", d8, mx);
   }
   {
     // ---- speed at B = 128 -----------------------------------------------------------------------------
@@ -141,6 +153,12 @@ int main() {
       printf("%-40s %.3f ms\n", name, ms / 20);
     };
     timeit("32 splits", [&] { launch_wgrad_planes<0>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
+    timeit("32 splits, 8 waves (2 per SIMD)", [&] { launch_wgrad_planes<0, 8>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
+    timeit("32 splits, 8 waves, no DMA in the loop", [&] { launch_wgrad_planes<1, 8>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
+    timeit("32 splits, 8 waves, no MFMAs", [&] { launch_wgrad_planes<2, 8>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
+    timeit("32 splits, again", [&] { launch_wgrad_planes<0>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
+    timeit("32 splits, 8 waves, again", [&] { launch_wgrad_planes<0, 8>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
+    timeit("64 splits, 8 waves", [&] { launch_wgrad_planes<0, 8>(da, db_, n_news, heads, ncb_b, D + 1, epi, 64, st); });
     timeit("32 splits, no DMA in the loop", [&] { launch_wgrad_planes<1>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
     timeit("32 splits, no MFMAs", [&] { launch_wgrad_planes<2>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
     timeit("32 splits, no DMA, no MFMAs", [&] { launch_wgrad_planes<3>(da, db_, n_news, heads, ncb_b, D + 1, epi, 32, st); });
@@ -209,6 +227,26 @@ int main() {
           worst = std::max(worst, err); bad += err > 3e-5;
         }
       printf("generic 300 x 301 (1312 rows, 7 splits): worst |err| / sum|a b| = %.3e, outside 3e-5: %zu\n", worst, bad);
+      // round 6: the 8-wave workgroups (row blocks 3, 3, 2, 2 / 4, 4, 3, 3 over the four wave rows), with and without the scratch path
+      for (int variant = 0; variant < 3; ++variant) {
+        CK(hipMemset(dw, 0, (size_t)I * J * 4)); CK(hipMemset(dbias, 0, I * 4));
+        float* scratch = nullptr;
+        if (variant == 1) CK(hipMalloc(&scratch, wgrad_planes_g_scratch_floats(5, 5, ncb, ncb, 7) * 4));
+        if (variant == 2) CK(hipMalloc(&scratch, wgrad_planes_g_scratch_floats(7, 5, ncb, ncb, 7) * 4));
+        int rc;
+        if (variant < 2) rc = launch_wgrad_planes_g<5, 5, 8>(da, ncb, db_, ncb, rows, I, J + 1, EpiAtomicWB{dw, J, dbias, J}, 7, st, scratch);
+        else rc = launch_wgrad_planes_g<7, 5, 8>(da, ncb, db_, ncb, rows, I, J + 1, EpiAtomicWB{dw, J, dbias, J}, 7, st, scratch);
+        if (rc != NRL_OK) return 1;
+        CK(hipStreamSynchronize(st));
+        std::vector<float> hw8((size_t)I * J), hb8(I);
+        CK(hipMemcpy(hw8.data(), dw, hw8.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hb8.data(), dbias, hb8.size() * 4, hipMemcpyDeviceToHost));
+        double d8 = 0, mx = 0;
+        for (size_t i = 0; i < hw.size(); ++i) { d8 = std::max(d8, (double)fabs(hw[i] - hw8[i])); mx = std::max(mx, (double)fabs(hw[i])); }
+        for (size_t i = 0; i < hb.size(); ++i) d8 = std::max(d8, (double)fabs(hb[i] - hb8[i]));
+        printf("generic, 8-wave workgroup <%d, 5>%s vs 4-wave <5, 5>: max |difference| %.3e (|dW| max %.3e)\n", variant < 2 ? 5 : 7,
+               variant ? " two-step reduce" : " atomics", d8, mx);
+      }
     }
     {
       const int64_t rows = 211200, n_mb = rows / 16;
@@ -225,6 +263,27 @@ int main() {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("generic 300 x 301 over 211200 rows, 160 x 160 tiles, %3d splits: %.3f ms\n", nsplit, ms / 20);
+        auto fn8 = [&] { launch_wgrad_planes_g<5, 5, 8>(da, ncb, db_, ncb, rows, I, J + 1, EpiAtomicWB{dw, J, dbias, J}, nsplit, st); };
+        for (int i = 0; i < 5; ++i) fn8();
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 20; ++i) fn8();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("   ... 8-wave workgroups:                                  %3d splits: %.3f ms\n", nsplit, ms / 20);
+        auto fn7 = [&] { launch_wgrad_planes_g<7, 5>(da, ncb, db_, ncb, rows, 200, J + 1, EpiAtomicWB{dw, J, dbias, J}, nsplit, st); };
+        auto fn78 = [&] { launch_wgrad_planes_g<7, 5, 8>(da, ncb, db_, ncb, rows, 200, J + 1, EpiAtomicWB{dw, J, dbias, J}, nsplit, st); };
+        for (int i = 0; i < 5; ++i) fn7();
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 20; ++i) fn7();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        float ms7 = ms / 20;
+        for (int i = 0; i < 5; ++i) fn78();
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 20; ++i) fn78();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("   ... 224 x 160 tiles <7, 5> (13 of 19 A block columns):  %3d splits: %.3f ms, 8-wave %.3f ms\n", nsplit, ms7, ms / 20);
       }
     }
   }
