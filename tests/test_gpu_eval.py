@@ -369,3 +369,23 @@ def test_news_vector_cache_and_epoch_hooks_use_the_token_table():
             assert torch.equal(s1, mod.forward(batch))
     finally:
         del os.environ["NRL_TOKEN_TABLE"]
+
+
+def test_token_table_under_inference_mode(monkeypatch):
+    """Lightning runs validation / test steps under ``torch.inference_mode()`` by default: the table route (key built from the
+    parameters' version counters, buffers allocated as inference tensors and reused later under ``no_grad``) must work there."""
+    from newsreclib_amd import _lib
+    _lib.set_gemm_engine("bf16x3")
+    rng = np.random.default_rng(11)
+    enc, _ = _text_encoder(777, seed=6)
+    ids = _title_ids(rng, 40, 777, 30).cuda()
+    monkeypatch.setenv("NRL_TOKEN_TABLE", "0")
+    with torch.no_grad():
+        plain = enc(ids)
+    monkeypatch.delenv("NRL_TOKEN_TABLE")
+    with torch.inference_mode():
+        with enc.token_table():
+            a = enc(ids)
+    with torch.no_grad(), enc.token_table():                 # the buffer built under inference mode serves the next epoch too
+        b = enc(ids)
+    assert torch.equal(a, plain) and torch.equal(b, plain)
