@@ -300,6 +300,31 @@ def test_conv_weight_gradient_from_planes_equals_the_fp32_fed_kernel(shape, tmp_
         # (one flipped gate touches three rows of a 500-row table = 0.6 % of its entries, one filter's 900 of the 270 k weight
         #  gradients = 0.33 %, one of the 300 bias gradients)
         assert off <= 2e-2 and float(d.max()) <= 0.05 * scale, (k, off, float(d.max()), scale)
+    # ... and the ReLU-gate argument is CHECKED, not assumed (round-5 advisor): the pre-activations are restated on the host in fp64
+    # under the product's dropout draw; every filter whose weight-gradient row differs beyond rounding between the two k orders must
+    # have a pre-activation within 1e-4 of zero (relative to the largest) somewhere in the batch -- a mismatch on a filter with no
+    # such gate would be a real ordering bug, and fails here.
+    N, L, D, F, W, Q = shape
+    if N * L * F * W * D <= 6e9:
+        from oracle.nrms_oracle import dropout_multiplier
+        rng = np.random.default_rng(N + L)                                   # (the script's draws, in its order)
+        t64 = lambda *s, scale: (rng.standard_normal(s) * scale).astype(np.float32).astype(np.float64)  # noqa: E731
+        emb, wc, bc = t64(500, D, scale=0.3), t64(F, 1, W, D, scale=(W * D) ** -0.5), t64(F, scale=0.05)
+        t64(Q, F, scale=F ** -0.5), t64(Q, scale=0.05), t64(Q, scale=0.1)
+        ids = rng.integers(0, 500, (N, L))
+        ids[::3, L - 3:] = 0
+        x = emb[ids] * dropout_multiplier(11, 2, 0.2, (N, L, D)).numpy().astype(np.float64)
+        xp = np.pad(x, ((0, 0), (1, 1), (0, 0)))
+        pre = bc[None, None, :] + sum(xp[:, w:w + L, :] @ wc[:, 0, w, :].T for w in range(W))      # (N, L, F)
+        # (two k orders of a 900-term fp32 accumulation differ by ~sqrt(900) * 6e-8 * |partial sums| ~ 2e-6: a gate can only flip inside
+        #  a band of that size; 1e-5 of the largest pre-activation leaves a factor of a few.  How many filters have such a gate is
+        #  printed: the check has teeth only while that is a minority of the filters)
+        near = (np.abs(pre) <= 1e-5 * max(1.0, float(np.abs(pre).max()))).any(axis=(0, 1))         # filters with a gate at the edge
+        scale1 = max(1.0, float(np.abs(a["g1"]).max()))
+        rows_off = (np.abs(a["g1"] - c["g1"]).reshape(F, -1).max(axis=1) > 2e-5 * scale1)
+        print(f"conv planes vs rows {shape}: {int(rows_off.sum())} of {F} filter rows differ beyond rounding; "
+              f"{int(near.sum())} filters have a pre-activation within 1e-5 of zero")
+        assert not (rows_off & ~near).any(), (int(rows_off.sum()), int(near.sum()), np.nonzero(rows_off & ~near)[0][:8])
     for k in ("g1", "g2"):                                                   # conv weight (F, 1, W, D), conv bias
         scale = max(1.0, float(np.abs(a[k]).max()))
         assert float(np.abs(a[k] - b[k]).max()) <= 2e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
