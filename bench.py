@@ -560,6 +560,26 @@ def main():
                                                            "(outside the timed groups: the first untimed forward builds it), "
                                                            "gathered per position; news vectors torch.equal to the table-less forward"},
                                    "without_token_table_ms": round(plain_ms, 4)}
+        unforked_ms = None
+        if world == 1 and not args.no_extras:
+            # the one-GPU step as a rank of an N > 1 job runs it: `news_fork` off (trainer.NRMSTrainer switches it off on more than one
+            # rank, so that all three weight gradients stay in the window the gradient exchange hides in) -- the compute term of
+            # `multi_gpu_prediction`
+            was = bool((lib.nrl_get_options() >> _lib.OPTION_NAMES.index("news_fork")) & 1)
+            _lib.set_option("news_fork", False)
+            try:
+                for i in range(5):
+                    trainer.step(batches[i % N_BATCHES], batches[(i + 1) % N_BATCHES])
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
+                torch.cuda.synchronize()
+                ev[0].record()
+                for i in range(30):
+                    trainer.step(batches[i % N_BATCHES], batches[(i + 1) % N_BATCHES])
+                    ev[i + 1].record()
+                torch.cuda.synchronize()
+                unforked_ms = statistics.median(ev[i].elapsed_time(ev[i + 1]) for i in range(30))
+            finally:
+                _lib.set_option("news_fork", was)
         if world == 1 and args.engine != "f32" and not args.no_extras:
             # the exact-fp32 projection engine on the same workload (extra key, outside the timed region), with its own
             # roofline: the in-projection GEMM with the fused gather, against the fp32 MFMA peak
@@ -608,7 +628,10 @@ def main():
             # rounds 4-5 saw once inside the evaluation loop that used to follow it -- tools/eval_idle_probe.py:
             # 9 stalls in 33 processes with this host work in front of the loop, 0 in 21 (+ 24 rounds inside one) without it; DESIGN section 5
             try:
-                out["multi_gpu_prediction"] = predict_multi_gpu(median_ms)
+                out["multi_gpu_prediction"] = predict_multi_gpu(unforked_ms or median_ms)
+                out["multi_gpu_prediction"]["compute_basis"] = (
+                    "median of 30 one-GPU steps with news_fork OFF, as ranks of an N > 1 job run (%.4f ms; this run's own step with the "
+                    "fork: %.4f ms)" % (unforked_ms, median_ms)) if unforked_ms else "this run's one-GPU step"
             except Exception as e:                         # an extra must never cost the headline line
                 out["multi_gpu_prediction"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:

@@ -119,7 +119,7 @@ int nrl_get_gemm_engine(void);
  *  11 "news_tail_bwd"   additive-attention backward of that path in ONE kernel that recomputes tanh from the y planes
  *  12 "user_fork"       (default OFF, measured slower) user-encoder backward: the in-projection dgrad and the three weight gradients side by side on two
  *                       library-internal streams (forked from and joined back into the caller's stream inside the call)
- *  13 "news_fork"       news-encoder backward: the additive-attention and out-projection weight gradients on a
+ *  13 "news_fork"       (default ON since ABI v16; off before) news-encoder backward: the additive-attention and out-projection weight gradients on a
  *                       library-internal stream beside the activation-gradient chain of phase 1 (forked after the tail
  *                       backward, joined before the phase-1 call returns; a phase-2 call then runs only the in-projection one)
  *  14 "news_qkv_planes" token-attention backward of the fused news path: q|k|v / d_o split once into (hi, lo) bf16 planes in LDS, operand

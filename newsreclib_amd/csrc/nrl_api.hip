@@ -32,8 +32,10 @@ static const char* const kOptEnv[O_COUNT] = {"NRL_NEWS_FUSED", "NRL_NEWS_FUSED_B
 std::atomic<uint32_t> g_opt_default{[] {
   uint32_t m = 0;
   for (int i = 0; i < O_COUNT; ++i) {
-    // (off: the measured losers; news_fused_bwd and news_tail_od are retired bits, see opt_retired)
-    const bool dflt = i != O_NEWS_FUSED_BWD && i != O_USER_FORK && i != O_NEWS_FORK && i != O_NEWS_TAIL_OD;
+    // (off: the measured losers; news_fused_bwd and news_tail_od are retired bits, see opt_retired.  news_fork: neutral in rounds 3-5
+    //  (3.02 vs 3.03 ms), ON since round 6 -- with the back-half weight gradients as 8-wave workgroups running them beside the
+    //  out-projection dgrad / token-attention backward chain is worth 37-41 us of the B = 128 step, profiles/r06_ab.txt)
+    const bool dflt = i != O_NEWS_FUSED_BWD && i != O_USER_FORK && i != O_NEWS_TAIL_OD;
     const char* e = getenv(kOptEnv[i]);
     bool v = e == nullptr ? dflt : (dflt ? e[0] != '0' : e[0] == '1');
     if (opt_retired(i)) v = false;           // (bits kept for the mask's layout; their kernels left the library in ABI v14)
@@ -393,6 +395,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
   // caller evaluates the same predicate and skips them)
   sb_.forked = news_fork_on(sb_);
   SideFork side;
+  hipEvent_t side_in_join = nullptr;
   if (phase != 2) {
     if (sb_.forked) {
       ForkSet* fs = nullptr;
@@ -407,6 +410,18 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
       a.heads = s.heads; a.scale = s.geom.scale; a.hpw = 1; a.planes = planes ? 1 : 0;
       if (planes && opt(O_NEWS_QKV_PLANES)) NRL_TRY(launch_news_attn_bwd_p(a, st));   // operands split once, into LDS planes
       else NRL_TRY(launch_news_attn_bwd(a, st));
+      if (news_fork_in_on(sb_, planes)) {
+        // dqkv is complete: the in-projection weight gradient leaves for the second internal stream, beside the live-row dgrad and
+        // the table gradient below (joined before this call returns; a phase-2 call evaluates the same predicate and skips it)
+        ForkSet* fs = nullptr;
+        NRL_TRY(fork_set(&fs));
+        const int si = news_fork_in_mode() == 2 ? 0 : 1;
+        NRL_HIP(hipEventRecord(fs->fork, st));
+        NRL_HIP(hipStreamWaitEvent(fs->s[si], fs->fork, 0));
+        NRL_TRY(block_wgrad_in_planes(g, w.x, sb_, w, fs->s[si]));
+        NRL_HIP(hipEventRecord(fs->join[1], fs->s[si]));
+        side_in_join = fs->join[1];
+      }
     }
     // dx = dqkv W_in, times dropout1, added into the table rows (embedding_dense_backward)
     const KCSlab dq_hp{w.dqkv, s.M};
@@ -440,6 +455,7 @@ int nrl_news_encoder_bwd(const NrlBlockParams* p, const NrlBlockGrads* g, const 
     }
   }
   if (phase != 2 && sb_.forked) NRL_HIP(hipStreamWaitEvent(st, side.join, 0));   // the side stream's work is part of this call
+  if (side_in_join != nullptr) NRL_HIP(hipStreamWaitEvent(st, side_in_join, 0));
   if (phase != 1) NRL_TRY(block_bwd_phase2(g, w.x, sb_, w, st, slabs, planes));
   return NRL_OK;
 }

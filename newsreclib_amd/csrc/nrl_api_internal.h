@@ -125,7 +125,7 @@ static inline bool engine_field_ok(int v) { return v >= 0 && v <= 2; }
 //                                          side by side on two internal streams instead of one after the other -- measured
 //                                          SLOWER on one box (3.36-3.40 vs 3.31 ms per step at B = 128): the cross-stream
 //                                          event waits cost more than the ~75 us of small launches they overlap
-//   news_fork       NRL_NEWS_FORK=1        the two back-half weight gradients of the fused news path (additive attention,
+//   news_fork       NRL_NEWS_FORK=0        (default ON since round 6) the two back-half weight gradients of the fused news path (additive attention,
 //                                          out-projection) on an internal side stream beside the HBM-write-bound chain
 //                                          out-projection dgrad -> token-attention backward -> in-projection dgrad -> table
 //                                          gradient of phase 1, joined before the call returns
@@ -736,6 +736,31 @@ static int block_bwd_phase1(const NrlBlockParams* P, const NrlBlockGrads* G, con
   return NRL_OK;
 }
 
+// The in-projection weight gradient of the fused news path from planes (dW_in += dqkv^T x): its own function because, under
+// news_fork, it too is issued from phase 1 -- as soon as the token-attention backward has produced dqkv, on the internal stream
+// that carries the two back-half weight gradients (behind them), beside the live-row dgrad and the table gradient: with it ALL
+// weight gradients of the news encoder run beside its activation-gradient chain.  Measured on one box (profiles/r06_ab.txt, three
+// alternating runs each): phase 2 (NRL_NEWS_FORK_IN=0) 2.712 ms, its own second stream (=1) 2.681, behind the back-half ones
+// (=2, the default) 2.673.  Partial tiles go to the q|k|v slabs, dead once the attention backward has run.
+static inline int news_fork_in_mode() {     // 0: phase 2 (off); 1: its own internal stream; 2: behind the back-half weight gradients on theirs
+  static const int v = [] { const char* e = getenv("NRL_NEWS_FORK_IN"); return e != nullptr ? atoi(e) : 2; }();
+  return v;
+}
+static inline bool news_fork_in_on(const BlockShape& s, bool bf16_planes) {
+  return news_fork_in_mode() != 0 && bf16_planes && news_fork_on(s) && s.forked;
+}
+static int block_wgrad_in_planes(const NrlBlockGrads* G, const float* x_rows, const BlockShape& s, const BlockWs& w, hipStream_t st) {
+  const int D = s.D;
+  const size_t scratch_avail = opt(O_WGRAD_2STEP) ? qkv_elems(s.M, s.D, s.heads, s.pad_rows) : 0;
+  static const int wp_splits = [] { const char* e = getenv("NRL_WGRAD_PLANES_SPLITS"); return e ? atoi(e) : 32; }();
+  const EpiAtomicWBHeads epi_w{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh};
+  float* const sc_w = wgrad_planes_scratch_floats(s.heads, 20, wp_splits) <= scratch_avail ? w.qkv : nullptr;
+  // round 6: two waves per SIMD over the same tile (8-wave workgroups): 0.37 -> 0.33-0.34 ms at B = 128 (tools/wp_probe.hip,
+  // profiles/r06_wgrad_planes_probe.txt); NRL_WGRAD_PLANES_WAVES=4 restores the one-wave-per-SIMD shape (A/B runs)
+  if (wgrad_planes_waves() == 4) return launch_wgrad_planes<0, 4>(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1, epi_w, wp_splits, st, sc_w);
+  return launch_wgrad_planes<0, 8>(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1, epi_w, wp_splits, st, sc_w);
+}
+
 static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const BlockShape& s, const BlockWs& w,
                             hipStream_t st, bool dqkv_head_planes = false, bool bf16_planes = false) {
   const int D = s.D, Q = s.Q;
@@ -773,14 +798,8 @@ static int block_bwd_phase2(const NrlBlockGrads* G, const float* x_rows, const B
   // dW_in += dqkv^T x ; db_in += colsum(dqkv)
   if (bf16_planes) {
     // both operands pre-split by their producers: pure DMA + transpose-read + MFMA kernel (nrl_wgrad_planes.h)
-    static const int wp_splits = [] { const char* e = getenv("NRL_WGRAD_PLANES_SPLITS"); return e ? atoi(e) : 32; }();
-    // round 6: two waves per SIMD over the same tile (8-wave workgroups): 0.37 -> 0.33-0.34 ms at B = 128 (tools/wp_probe.hip,
-    // profiles/r06_wgrad_planes_probe.txt); NRL_WGRAD_PLANES_WAVES=4 restores the one-wave-per-SIMD shape (A/B runs)
-    const int wp_waves = wgrad_planes_waves();
-    const EpiAtomicWBHeads epi_w{G->in_proj_weight, D, G->in_proj_bias, D, s.heads, s.dh};
-    float* const sc_w = scratch_for(wgrad_planes_scratch_floats(s.heads, 20, wp_splits));
-    if (wp_waves == 4) return launch_wgrad_planes<0, 4>(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1, epi_w, wp_splits, st, sc_w);
-    return launch_wgrad_planes<0, 8>(w.dqkv, x_rows, s.pool_groups, s.heads, 20, D + 1, epi_w, wp_splits, st, sc_w);
+    if (news_fork_in_on(s, bf16_planes)) return NRL_OK;     // issued from phase 1, beside the live-row dgrad (nrl_news_encoder_bwd)
+    return block_wgrad_in_planes(G, x_rows, s, w, st);
   }
   if (dqkv_head_planes) {
     // dqkv in head planes (news_attn_bwd_kernel): 64 output rows per head, remapped to [Wq; Wk; Wv] rows on the way out

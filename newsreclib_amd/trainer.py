@@ -14,7 +14,7 @@ from typing import Dict, Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 
 
 class FlatParams:
@@ -927,6 +927,13 @@ class NRMSTrainer:
         self._dense_ranges = [(0, self.flat.numel)]
         self._in_step = False
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if world > 1 and dev.type == "cuda" and "NRL_NEWS_FORK" not in os.environ:
+            # N > 1: the weight-gradient phase of the news-encoder backward is the window the gradient exchange hides in (it starts when
+            # the table gradient is complete).  `news_fork` (default on since round 6: -40 ... -95 us of the one-GPU step) moves two of
+            # its three GEMMs OUT of that window, beside the activation-gradient chain: 0.60 -> 0.37 ms of window at B = 128.  With
+            # 87 MB to exchange per step the window is worth more than the fork: keep the three weight gradients behind the table
+            # gradient on more than one rank (NRL_NEWS_FORK=0|1 in the environment decides instead, for A/B runs on real nodes).
+            _lib.set_option("news_fork", False)
         if lazy_adam is None:
             lazy_adam = os.environ.get("NRL_LAZY_ADAM", "1") not in ("", "0")
         # world > 1: under the touched-row exchange the gathered ids name the rows; under the dense all-reduce (and `auto`) the
