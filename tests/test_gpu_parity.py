@@ -301,7 +301,7 @@ def test_news_path_format_switches_agree(N, L, option):
     ids = torch.randint(0, 97, (N, L), generator=gen)
     d_out = torch.randn(N, 300, generator=gen)
     res = []
-    was = bool((_lib.load().nrl_get_options() >> _lib.OPTION_NAMES.index(option)) & 1)     # (news_fork is off by default)
+    was = bool((_lib.load().nrl_get_options() >> _lib.OPTION_NAMES.index(option)) & 1)     # (the process default is restored afterwards)
     for on in (True, False):
         _lib.set_option(option, on)
         try:
