@@ -929,8 +929,8 @@ class NRMSTrainer:
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if world > 1 and dev.type == "cuda" and "NRL_NEWS_FORK" not in os.environ:
             # N > 1: the weight-gradient phase of the news-encoder backward is the window the gradient exchange hides in (it starts when
-            # the table gradient is complete).  `news_fork` (default on since round 6: -40 ... -95 us of the one-GPU step) moves two of
-            # its three GEMMs OUT of that window, beside the activation-gradient chain: 0.60 -> 0.37 ms of window at B = 128.  With
+            # the table gradient is complete).  `news_fork` (default on since round 6: -70 ... -130 us of the one-GPU step) moves its
+            # three GEMMs OUT of that window, beside the activation-gradient chain: 0.60 ms of window at B = 128 -> none.  With
             # 87 MB to exchange per step the window is worth more than the fork: keep the three weight gradients behind the table
             # gradient on more than one rank (NRL_NEWS_FORK=0|1 in the environment decides instead, for A/B runs on real nodes).
             _lib.set_option("news_fork", False)
