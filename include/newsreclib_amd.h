@@ -362,7 +362,10 @@ typedef struct NrlCnnGrads { /* accumulators, kernels ADD */
 /* CNNAddAtt.forward, text.py:163-176: ids (N, L) int64 -> out (N, F).
  * x = dropout(emb[ids]) (stream0, flat index over (N, L, D)); c = dropout(relu(conv(x))) (stream0 + 1,
  * flat index over (N, L, F)); out = additive attention over the L tokens.  The convolution runs as
- * ONE GEMM with K = W*D over overlapping rows of x (no im2col buffer). */
+ * ONE GEMM with K = W*D over overlapping rows of x (no im2col buffer).
+ * save_for_backward != 0: the workspace then holds everything nrl_cnn_encoder_bwd reads (including, under the
+ * bf16x3 engine at F % 16 == 12, F <= 304, Q <= 224, the (hi, lo) planes of c its additive-attention weight gradient is
+ * fed from); a backward after a forward with save_for_backward == 0 is undefined. */
 size_t nrl_cnn_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t embed_dim,
                                        int32_t num_filters, int32_t window, int32_t query_dim);
 int nrl_cnn_encoder_fwd(const NrlCnnParams* p, const float* emb_table, int64_t vocab,

@@ -36,6 +36,7 @@ struct CnnWs {
   uint16_t* rp;  // row-panel weight images (nrl_rowpanel.h)
   unsigned char *xpl, *dpl;   // x / dc as fragment-block planes over 32 padded rows per news (conv weight gradient), or null
   float* wsc;                 // its split-K partial tiles
+  unsigned char *cpl, *tpl;   // c (+ its ones column) / d_pre as fragment-block planes over the real rows (cnn_aa_planes), or null
 };
 
 // The convolution weight gradient from planes (wgrad_planes_conv_kernel, nrl_wgrad_planes.h): window 3, a news inside one
@@ -73,6 +74,22 @@ static bool cnn_dc_planes_on(const CnnShape& s) {
   static const bool live = [] { const char* e = getenv("NRL_LIVE_ROWS"); return !(e != nullptr && e[0] == '0'); }();
   return on && live && cnn_x_planes_on(s);
 }
+
+// Round 6, the additive attention of the convolution encoder on planes, as the NRMS block has had it since round 3 (news_aa_planes):
+// the convolution's epilogue writes c ALSO as (hi, lo) planes over the real rows with a ones column (EpiLinearPlanes), the pooling
+// backward writes d_pre ONLY as planes; the tanh projection and the additive-attention dgrad read their A operand from them without
+// a split, and the weight gradient dW_a += d_pre^T c (+ the bias from the ones column) is the DMA-fed planes kernel
+// (wgrad_planes_g<7, 5>, 8-wave workgroups) instead of the fp32-fed gemm_bf16x3_dma_tn (263 us per call at B = 128, the planes kernel
+// 86 us on the same shape in the NRMS step).  Widths as there: F % 16 == 12 (room for the ones column), Q <= 224.  Forward and
+// backward evaluate the same predicate; a backward without sorted positions (no dc planes) is refused the planes.
+// NRL_CNN_AA_PLANES=0: the fp32 operands (A/B runs).
+static bool cnn_aa_planes_on(const CnnShape& s) {
+  static const bool on = [] { const char* e = getenv("NRL_CNN_AA_PLANES"); return !(e != nullptr && e[0] == '0'); }();
+  return on && cnn_dc_planes_on(s) && (s.F & 15) == 12 && s.F <= 304 && s.Q <= 224 && s.Q % 4 == 0 && opt(O_NEWS_AA_PLANES);
+}
+static int cnn_ncb_c(const CnnShape& s) { return (s.F + 16) / 16; }
+static int cnn_ncb_q(const CnnShape& s) { return (s.Q + 15) / 16; }
+static size_t cnn_row_planes_bytes(int64_t M, int ncb) { return (size_t)((M + 31) / 32) * 2 * ncb * 1024; }
 
 // conv forward / dgrad and additive-attention forward / dgrad on the row-panel kernel (bf16x3, widths <= 320)
 struct CnnRp {
@@ -149,6 +166,8 @@ static size_t cnn_ws_floats(const CnnShape& s) {
   if (cnn_conv_planes_ok(s)) {
     n += al(planes_from_rows_bytes(s.N, cnn_ncb_x(s), 2 * cnn_conv_kt(s)) / 4) + al(planes_from_rows_bytes(s.N, cnn_ncb_dc(s), 2 * cnn_conv_kt(s)) / 4);
     n += al(wgrad_planes_conv_scratch_floats(5, 2, cnn_ncb_dc(s), cnn_ncb_x(s), cnn_conv_planes_splits()));
+    if ((s.F & 15) == 12 && s.F <= 304 && s.Q <= 224)      // (sized by shape alone: the switches are read per call)
+      n += al(cnn_row_planes_bytes(s.M, cnn_ncb_c(s)) / 4) + al(cnn_row_planes_bytes(s.M, cnn_ncb_q(s)) / 4);
   }
   return n;
 }
@@ -174,10 +193,15 @@ static int cnn_carve(void* ws, size_t ws_bytes, const CnnShape& s, CnnWs* o) {
   o->rp = reinterpret_cast<uint16_t*>(take((cnn_rp_elems(s) + 1) / 2));
   o->xpl = o->dpl = nullptr;
   o->wsc = nullptr;
+  o->cpl = o->tpl = nullptr;
   if (cnn_conv_planes_ok(s)) {
     o->xpl = reinterpret_cast<unsigned char*>(take(planes_from_rows_bytes(s.N, cnn_ncb_x(s), 2 * cnn_conv_kt(s)) / 4));
     o->dpl = reinterpret_cast<unsigned char*>(take(planes_from_rows_bytes(s.N, cnn_ncb_dc(s), 2 * cnn_conv_kt(s)) / 4));
     o->wsc = take(wgrad_planes_conv_scratch_floats(5, 2, cnn_ncb_dc(s), cnn_ncb_x(s), cnn_conv_planes_splits()));
+    if ((s.F & 15) == 12 && s.F <= 304 && s.Q <= 224) {
+      o->cpl = reinterpret_cast<unsigned char*>(take(cnn_row_planes_bytes(s.M, cnn_ncb_c(s)) / 4));
+      o->tpl = reinterpret_cast<unsigned char*>(take(cnn_row_planes_bytes(s.M, cnn_ncb_q(s)) / 4));
+    }
   }
   return NRL_OK;
 }
@@ -349,7 +373,7 @@ size_t nrl_cnn_encoder_workspace_bytes(int64_t n_news, int32_t seq_len, int32_t 
 int nrl_cnn_encoder_fwd(const NrlCnnParams* p, const float* emb_table, int64_t vocab, const int64_t* ids,
                         int64_t n_news, int32_t seq_len, double p_drop, uint64_t seed, uint32_t stream0,
                         int32_t save_for_backward, float* out, void* ws, size_t ws_bytes, void* stream) {
-  (void)vocab; (void)save_for_backward;
+  (void)vocab;
   CnnShape s;
   NRL_TRY(cnn_check(p, n_news, seq_len, &s));
   NRL_REQUIRE(emb_table && ids && out, "cnn_encoder_fwd: null argument");
@@ -374,7 +398,19 @@ int nrl_cnn_encoder_fwd(const NrlCnnParams* p, const float* emb_table, int64_t v
     NRL_REQUIRE(s.M * (int64_t)s.D < (1LL << 32), "dropout index space is 32-bit");
     NRL_TRY(launch_embedding_rows_planes(emb_table, ids, s.N, s.L, s.D, ncb_x, nrb, drop1, w.xpl, st));
     const KCWindowPlanes a{w.xpl, s.M, s.L, nrb, ncb_x, s.W, s.pad};
-    NRL_TRY(rp_dispatch(a, rp.conv_f, EpiLinear{w.c, s.F, p->conv_bias, 2, drop2, s.F}, s.M, s.F, s.W * 16 * ncb_x, st));
+    const EpiLinear epi_c{w.c, s.F, p->conv_bias, 2, drop2, s.F};
+    if (save_for_backward != 0 && cnn_aa_planes_on(s) && w.cpl != nullptr) {   // (an evaluation forward has no use for the planes)
+      // c as fp32 rows (the pooling kernels, the ReLU gate of the backward) AND as planes with the ones column
+      const int ncb_c = cnn_ncb_c(s);
+      if (s.M % 32 != 0)   // rows past M in the last 32-row k-tile of the weight gradient
+        NRL_HIP(hipMemsetAsync(w.cpl + (s.M / 32) * 2 * ncb_c * 1024, 0, (size_t)2 * ncb_c * 1024, st));
+      NRL_TRY(rp_dispatch(a, rp.conv_f, EpiLinearPlanes{epi_c, w.cpl, ncb_c}, s.M, s.F, s.W * 16 * ncb_x, st));
+      // t = tanh(c W_a^T + b_a) from the planes
+      NRL_TRY(rp_dispatch(KCPlanesG{w.cpl, s.M, ncb_c}, rp.att_f, EpiLinear{w.t, s.Q, p->att_bias, 1, nodrop, s.Q}, s.M, s.Q, s.F, st));
+      NRL_TRY(pool_fwd(w.t, p->att_query, w.c, s.N, s.L, s.Q, s.F, w.w, out, st));
+      return NRL_OK;
+    }
+    NRL_TRY(rp_dispatch(a, rp.conv_f, epi_c, s.M, s.F, s.W * 16 * ncb_x, st));
   } else {
   // x = dropout(emb[ids])                                  (text.py:165-166)
   NRL_TRY(embedding_rows_fwd(emb_table, ids, s.M, s.D, drop1, 0, w.x, st));
@@ -416,21 +452,38 @@ int nrl_cnn_encoder_bwd(const NrlCnnParams* p, const NrlCnnGrads* g, float* d_em
   const SplitWeight sa = planes_view(w.planes_att, s.Q, s.F);
   CnnRp rp;
   NRL_TRY(cnn_rp_images(p, s, w, false, &rp, st));        // built by the forward; weights unchanged since
-  // additive attention backward: t -> d_pre in place, dq_a
-  NRL_TRY(pool_bwd_pre(d_out, w.c, w.w, w.t, p->att_query, g->att_query, s.N, s.L, s.Q, s.F, st));
-  // dc = (d_pre W_a + w * d_out) * dropout2 * [c > 0]       (pre-ReLU gradient)
   const bool x_pl = cnn_x_planes_on(s) && rp.on && w.xpl != nullptr;
   const bool dc_pl = x_pl && cnn_dc_planes_on(s) && sorted_positions != nullptr && w.dpl != nullptr;
+  // (the forward wrote the c planes under cnn_aa_planes_on alone; a backward that cannot use them still has c and t as fp32)
+  const bool aa_pl = dc_pl && cnn_aa_planes_on(s) && w.cpl != nullptr && w.tpl != nullptr;
+  const int ncb_q = cnn_ncb_q(s);
+  // additive attention backward: t -> d_pre (in place, or as planes only), dq_a
+  if (aa_pl && s.M % 32 != 0) NRL_HIP(hipMemsetAsync(w.tpl + (s.M / 32) * 2 * ncb_q * 1024, 0, (size_t)2 * ncb_q * 1024, st));
+  NRL_TRY(pool_bwd_pre(d_out, w.c, w.w, w.t, p->att_query, g->att_query, s.N, s.L, s.Q, s.F, st, aa_pl ? w.tpl : nullptr));
+  // dc = (d_pre W_a + w * d_out) * dropout2 * [c > 0]       (pre-ReLU gradient)
   if (dc_pl) {
     const EpiPoolBwdNewsPlanes epi{EpiPoolBwd{nullptr, s.F, w.w, d_out, s.L, drop2, w.c}, w.dpl, cnn_ncb_dc(s), 2 * cnn_conv_kt(s), s.L, s.F};
     NRL_TRY(launch_planes_zero_pad_rows(w.dpl, s.N, s.L, cnn_ncb_dc(s), 2 * cnn_conv_kt(s), st));
+    if (aa_pl) NRL_TRY(rp_dispatch(KCPlanesG{w.tpl, s.M, ncb_q}, rp.att_d, epi, s.M, s.F, s.Q, st));
+    else
     NRL_TRY(rp_dispatch(KCPlain{w.t, s.Q, s.M}, rp.att_d, epi, s.M, s.F, s.Q, st));
   } else {
   NRL_TRY(gemm_dgrad(w.t, p->att_weight, sa, EpiPoolBwd{w.dc, s.F, w.w, d_out, s.L, drop2, w.c}, s.M, s.Q, s.F, st,
                      rp.on ? &rp.att_d : nullptr));
   }
   // dW_a += d_pre^T c ; db_a += colsum(d_pre)
+  if (aa_pl) {
+    // both operands as planes over the same rows (the ones column of the c planes gives the bias gradient); split-K partial tiles
+    // in the fp32 dc buffer, which the planes path never writes
+    static const int sp = [] { const char* e = getenv("NRL_WGRAD_PLANES_AA_SPLITS"); return e ? atoi(e) : 128; }();
+    const int ncb_c = cnn_ncb_c(s);
+    const size_t need = wgrad_planes_g_scratch_floats(7, 5, ncb_q, ncb_c, sp);
+    float* const sc = opt(O_WGRAD_2STEP) && need <= (size_t)s.M * s.F ? w.dc : nullptr;
+    NRL_TRY((wgrad_planes_g_dispatch<7, 5>(w.tpl, ncb_q, w.cpl, ncb_c, (s.M + 31) / 32 * 32, s.Q, s.F + 1,
+                                         EpiAtomicWB{g->att_weight, s.F, g->att_bias, s.F}, sp, st, sc)));
+  } else {
   NRL_TRY(gemm_wgrad(w.t, s.Q, w.c, s.F, g->att_weight, g->att_bias, s.M, st));
+  }
   NRL_TRY(cnn_conv_wgrad(s, w, w.dc, w.x, s.F, g->conv_weight, g->conv_bias, st, x_pl, dc_pl));
   // dx[m, d] = dropout1 * sum_{t', f} dc[m + t' - pad', f] Wc[f, (W-1-t')*D + d]
   {

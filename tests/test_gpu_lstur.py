@@ -278,12 +278,24 @@ def test_conv_weight_gradient_from_planes_equals_the_fp32_fed_kernel(shape, tmp_
     res = {}
     # "0": fp32 rows everywhere; "1x": x as fp32 rows, converted for the planes weight gradient (round 4); "1": x ONLY as planes,
     # written by the lookup and read by the convolution forward through KCWindowPlanes too (round 5)
-    for flag, xp in (("0", "0"), ("1x", "0"), ("1", "1")):
+    # "1f": as "1" with the additive attention fed from fp32 rows (NRL_CNN_AA_PLANES=0, rounds 4-5); "1" has it on planes (round 6)
+    for flag, xp in (("0", "0"), ("1x", "0"), ("1", "1"), ("1f", "1")):
         f = str(tmp_path / ("g%s.npz" % flag))
-        env = dict(os.environ, NRL_CONV_WGRAD_PLANES=flag[0], NRL_CONV_X_PLANES=xp)
+        env = dict(os.environ, NRL_CONV_WGRAD_PLANES=flag[0], NRL_CONV_X_PLANES=xp, NRL_CNN_AA_PLANES="0" if flag == "1f" else "1")
         subprocess.run([sys.executable, "-c", _CONV_WGRAD_SCRIPT, root, f] + [str(v) for v in shape], check=True, env=env,
                        timeout=600)
         res[flag] = np.load(f)
+    # additive attention on planes (c planes from the convolution's epilogue, d_pre planes from the pooling backward) against the
+    # fp32-fed form: the planes hold the very (hi, lo) split the row-panel kernel makes of the fp32 rows, so the tanh projection, the
+    # output, dc, the convolution's gradients and the table gradient are EQUAL; the additive attention's own weight / bias gradient
+    # comes from another kernel (summation order), its query gradient from atomics in both runs
+    p1, f1 = res["1"], res["1f"]
+    assert np.array_equal(p1["out"], f1["out"])
+    for k in ("g0", "g1", "g2"):
+        assert np.array_equal(p1[k], f1[k]), k
+    for k in ("g3", "g4", "g5"):
+        scale = max(1.0, float(np.abs(f1[k]).max()))
+        assert float(np.abs(p1[k] - f1[k]).max()) <= 2e-5 * scale, (k, float(np.abs(p1[k] - f1[k]).max()), scale)
     a, b = res["0"], res["1x"]
     assert np.array_equal(a["out"], b["out"])
     assert np.array_equal(a["g0"], b["g0"])                                  # table gradient: sorted segments, fixed order
