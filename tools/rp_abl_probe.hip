@@ -31,8 +31,8 @@ using namespace nrl;
     }                                                        \
   } while (0)
 
-template <int NBLK, int WAVES, int RB, int ABL>
-__global__ void __launch_bounds__(WAVES * 64, 2)
+template <int NBLK, int WAVES, int RB, int ABL, int OCC = 2>
+__global__ void __launch_bounds__(WAVES * 64, OCC)
     rp_probe_kernel(const KCPlain A, const uint16_t* __restrict__ img_base, const EpiStore epi, const int64_t M, const int N, const int K,
                     const int kblocks, const int64_t panel_elems, const int panels, const int panel_group, const int64_t row_blocks) {
   int64_t rb_idx = blockIdx.x;
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2)
   store_accumulators<RB, NBLK>(epi, acc, m0, n_panel0, wave, 0, l15, g, M, N);
 }
 
-template <int NBLK, int ABL>
+template <int NBLK, int ABL, int OCC = 2>
 static float run(const float* a, const uint16_t* img, float* c, int64_t M, int N, int K, int panels, hipStream_t st) {
   const int kb = rp_kblocks(K, false);
   const int64_t blocks = (M + 127) / 128;
@@ -204,10 +204,10 @@ static float run(const float* a, const uint16_t* img, float* c, int64_t M, int N
     CK(hipEventRecord(e0, st));
     if (group > 0) {
       const int64_t rx = (blocks + 7) / 8, groups = (panels + group - 1) / group;
-      hipLaunchKernelGGL((rp_probe_kernel<NBLK, 4, 2, ABL>), dim3((unsigned)(8 * rx * group * groups)), dim3(256), 0, st, KCPlain{a, K, M}, img,
+      hipLaunchKernelGGL((rp_probe_kernel<NBLK, 4, 2, ABL, OCC>), dim3((unsigned)(8 * rx * group * groups)), dim3(256), 0, st, KCPlain{a, K, M}, img,
                          EpiStore{c, N}, M, N, K, kb, (int64_t)rp_image_elems(NBLK, kb), panels, group, blocks);
     } else {
-      hipLaunchKernelGGL((rp_probe_kernel<NBLK, 4, 2, ABL>), dim3((unsigned)blocks, (unsigned)panels), dim3(256), 0, st, KCPlain{a, K, M}, img,
+      hipLaunchKernelGGL((rp_probe_kernel<NBLK, 4, 2, ABL, OCC>), dim3((unsigned)blocks, (unsigned)panels), dim3(256), 0, st, KCPlain{a, K, M}, img,
                          EpiStore{c, N}, M, N, K, kb, (int64_t)rp_image_elems(NBLK, kb), panels, 0, blocks);
     }
     CK(hipEventRecord(e1, st));
@@ -267,9 +267,44 @@ static void shape(const char* name, int64_t M, int N, int K, hipStream_t st) {
   CK(hipFree(a)); CK(hipFree(w)); CK(hipFree(c)); CK(hipFree(img));
 }
 
+// another panel width at another occupancy (NBLK = 12: 192-column panels, 48 KB of LDS, three workgroups per CU: 168 VGPRs, 20 B of scratch).
+// ALL-ZERO operands here: the same launches run 11-14 % faster than over random data (0.121 vs 0.136 ms, 0.417 vs 0.475) -- the part's
+// clocks follow the data's switching activity -- so compare inside this block only
+template <int NBLK, int OCC>
+static void occ_shape(const char* name, int64_t M, int N, int K, hipStream_t st) {
+  const int panels = (N + 16 * NBLK - 1) / (16 * NBLK), kb = rp_kblocks(K, false);
+  float *a, *w, *c;
+  uint16_t* img;
+  CK(hipMalloc(&a, (size_t)M * K * 4));
+  CK(hipMalloc(&w, (size_t)N * K * 4));
+  CK(hipMalloc(&c, (size_t)M * N * 4));
+  CK(hipMalloc(&img, (size_t)panels * rp_image_elems(NBLK, kb) * 2));
+  CK(hipMemset(a, 0, (size_t)M * K * 4));
+  CK(hipMemset(w, 0, (size_t)N * K * 4));
+  RpImageJobs jobs;
+  rp_jobs_init(&jobs);
+  const int pw = 16 * NBLK;
+  for (int p = 0; p < panels; ++p)
+    rp_jobs_add(&jobs, w + (int64_t)p * pw * K, K, 1, N - p * pw < pw ? N - p * pw : pw, K, nullptr, img + (size_t)p * rp_image_elems(NBLK, kb), NBLK);
+  if (rp_jobs_launch(jobs, st) != NRL_OK) exit(1);
+  CK(hipStreamSynchronize(st));
+  const double gf = 2.0 * M * (double)N * K * 3 / 1e9;
+  const float t = run<NBLK, 0, OCC>(a, img, c, M, N, K, panels, st);
+  printf("%s: M=%lld N=%d K=%d  NBLK=%d (%d panels), %d workgroups per CU asked: %.3f ms (%4.0f TF-bf16/s of useful work)\n", name, (long long)M, N, K, NBLK, panels, OCC, t, gf / t);
+  fflush(stdout);
+  CK(hipFree(a)); CK(hipFree(w)); CK(hipFree(c)); CK(hipFree(img));
+}
+
 int main() {
   hipStream_t st;
   CK(hipStreamCreate(&st));
+  occ_shape<16, 2>("768 x 768", 38400, 768, 768, st);
+  occ_shape<12, 2>("768 x 768", 38400, 768, 768, st);
+  occ_shape<12, 3>("768 x 768", 38400, 768, 768, st);
+  occ_shape<16, 2>("768 x 3072", 38400, 768, 3072, st);
+  occ_shape<12, 2>("768 x 3072", 38400, 768, 3072, st);
+  occ_shape<12, 3>("768 x 3072", 38400, 768, 3072, st);
+  occ_shape<16, 2>("3072 x 768", 38400, 3072, 768, st);
   shape<16>("config-4 projection", 38400, 768, 768, st);
   shape<16>("config-4 feed-forward 2", 38400, 768, 3072, st);
   shape<19>("NRMS out-projection shape", 211200, 300, 300, st);
